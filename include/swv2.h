@@ -1,0 +1,195 @@
+/* swv2 -- C ABI of the MI355X-native SwinV2 weather hot path (libswv2.so).
+ *
+ * The reference (NERSC/swin_v2_weather, 100 % Python) has no FFI boundary: its hot path is the PyTorch op sequence
+ * inside networks/swinv2_global.py.  This header is the boundary a maintainer binds instead (ctypes stub in
+ * INTEGRATION.md): each entry point replaces the op sequence cited next to it.
+ *
+ * Conventions
+ *  - plain C: raw DEVICE pointers, explicit sizes, no torch types.  `stream` is a hipStream_t passed as void*
+ *    (0 = the null stream); every call only enqueues work on that stream and returns.
+ *  - every function returns SWV2_OK (0) or a negative error code and never throws; `swv2_last_error()` returns a
+ *    thread-local message for the last failure on the calling thread.
+ *  - no entry point allocates, frees or synchronises: the caller owns all memory, including workspaces, so every
+ *    call can be captured in a hipGraph.
+ *  - no hidden global device state: re-entrant from autograd worker threads.
+ *  - dtypes: activations that cross kernels are bf16 (uint16 storage) unless stated; the residual stream, LayerNorm
+ *    statistics, log-sum-exp and all parameter gradients are fp32.  MFMA products take bf16 operands and
+ *    accumulate in fp32.
+ */
+#ifndef SWV2_H
+#define SWV2_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SWV2_VERSION 100 /* round 1 */
+
+enum {
+    SWV2_OK = 0,
+    SWV2_ERR_INVALID = -1,     /* bad argument (null pointer, size, alignment) */
+    SWV2_ERR_UNSUPPORTED = -2, /* shape outside the compiled kernel set */
+    SWV2_ERR_LAUNCH = -3       /* HIP launch failure */
+};
+
+int swv2_version(void);
+const char* swv2_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Window-ordered, head-major attention layout (produced by swv2_linear with SWV2_EPI_QKV_HEADS):
+ *   qkvh  [Bw][heads][3][Lp][DP] bf16   s=0: q/max(|q|,1e-12)  s=1: k/max(|k|,1e-12)  s=2: v ; zero padded
+ *   rnorm [Bw][heads][2][Lp]     fp32   1/max(|q|,1e-12), 1/max(|k|,1e-12)
+ *   oh    [Bw][heads][Lp][DP]    bf16   attention output, heads not yet merged
+ *   lse   [Bw][heads][Lp]        fp32   log2-domain log-sum-exp of the scaled, biased, masked scores
+ * Bw = B * windows per sample, window index = b*nW + wi*nww + wj, token index t = r*ww + c
+ * (reference: window_partition, swinv2_global.py:89-101).  Lp, DP: swv2_attn_geometry().
+ * ------------------------------------------------------------------------------------------------------------ */
+int swv2_attn_geometry(int L, int head_dim, int* Lp, int* DP);
+
+typedef struct swv2_attn_args {
+    const void* qkvh;         /* in  */
+    const float* logit_scale; /* in  [heads] raw tau; sigma = exp(min(tau, ln 100))   (swinv2_global.py:305) */
+    const float* bias;        /* in  [heads][L][L] continuous position bias (swinv2_global.py:274-287) or NULL */
+    void* oh;                 /* fwd: out; bwd: in */
+    float* lse;               /* fwd: out; bwd: in */
+    const void* doh;          /* bwd in : grad of oh, same layout */
+    const float* rnorm;       /* bwd in */
+    void* dqkvh;              /* bwd out: grads w.r.t. the un-normalised q, k, v, layout of qkvh */
+    float* dlogit_scale;      /* bwd out: [heads], ACCUMULATED (caller zeroes) */
+    float* dbias;             /* bwd out: [heads][L][L], ACCUMULATED (caller zeroes); NULL iff bias is NULL */
+    int Bw, heads, L, head_dim;
+    int nwh, nww;             /* windows per sample along H and W */
+    int mask_thr;             /* shift mask (swinv2_global.py:403-424) in closed form: in the last window row
+                                 (wi == nwh-1) tokens t >= mask_thr are region 1, others region 0; pairs from
+                                 different regions get -100.  (wh - sh) * ww for a block shifted by sh > 0 rows;
+                                 0 = no mask. */
+    int max_chunks;           /* workgroups per head (each loops over windows); 64 is a good default */
+} swv2_attn_args;
+
+/* cosine window attention core, forward: swinv2_global.py:304-318 (q,k normalisation is in the QKV epilogue) */
+int swv2_attn_fwd(const swv2_attn_args* a, void* stream);
+/* backward of the same, including the backward of the L2 normalisation of q and k */
+int swv2_attn_bwd(const swv2_attn_args* a, void* stream);
+
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Linear layers: C[M][N] = A[M][K] . W[N][K]^T on bf16 MFMA with fp32 accumulation.
+ * The A operand is described by a "loader" (what PyTorch does as separate passes in the reference is folded into
+ * the load), the output by an "epilogue".  W is always bf16 [N][K] row-major, produced by swv2_prep_weight.
+ * Replaces: nn.Linear / nn.Conv2d(k=s=4) + the layout ops around them in swinv2_global.py (qkv :300-301, proj :319,
+ * Mlp fc1/fc2 :381-386, PatchEmbed.proj :537,544, PatchMerging :519-523, head + un-patchify :767,784-792).
+ * ------------------------------------------------------------------------------------------------------------ */
+enum swv2_operand_kind {
+    SWV2_OP_F32 = 0,       /* fp32 rows [rows][ld]; optional rowidx gather (roll + window partition, :457,89-101)   */
+    SWV2_OP_BF16 = 1,      /* bf16 rows [rows][ld]; optional rowidx gather                                          */
+    SWV2_OP_BF16_GELU = 2, /* bf16 rows, erf-GELU applied on load (timm Mlp act)                                     */
+    SWV2_OP_HEADS = 3,     /* head-major window layout [Bw][h][S][Lp][DP]: row = bw*Lp + t, col = (part*h+head)*DP+j
+                              p[0]=heads p[2]=Lp p[3]=DP, ld = S                                                     */
+    SWV2_OP_PATCH = 4,     /* im2col of x[B][Cin][H][W] fp32 for the 4x4/stride-4 conv: row=(b,i,j), col=cin*16+p*4+q
+                              p[0]=Cin p[1]=H p[2]=W                                                                 */
+    SWV2_OP_MERGE_LN = 5   /* 2x2 PatchMerging gather of x[B][H][W][C] fp32 + LayerNorm(4C) on load:
+                              p[0]=H p[1]=W p[2]=C, aux0=mean aux1=rstd (swv2_merge_stats) aux2=gamma aux3=beta     */
+};
+
+typedef struct swv2_operand {
+    int kind;              /* enum swv2_operand_kind */
+    const void* ptr;
+    const int32_t* rowidx; /* optional: logical row -> source row, negative = all-zero row */
+    const float* aux0;
+    const float* aux1;
+    const float* aux2;
+    const float* aux3;
+    long ld;               /* row pitch in elements (or S for SWV2_OP_HEADS) */
+    int rows, cols;        /* logical M and K */
+    int p[4];
+} swv2_operand;
+
+enum swv2_epilogue_kind {
+    SWV2_EPI_BF16 = 0,      /* out bf16 [M][ld] = acc + bias ; optional rowidx scatter                               */
+    SWV2_EPI_F32 = 1,       /* out fp32 [M][ld] = acc + bias (+ aux fp32, same shape, added at the destination
+                               row: the residual gradient) ; optional rowidx scatter                                 */
+    SWV2_EPI_QKV_HEADS = 2, /* out = qkvh, aux_out = rnorm: + bias, split heads, L2-normalise q and k (:300-304)
+                               p[0]=heads p[2]=Lp p[3]=DP p[4]=L ; N = 3*heads*DP, bias padded alike                 */
+    SWV2_EPI_GELU_GRAD = 3, /* out bf16 = acc * GELU'(aux) ; aux = bf16 pre-activation, same shape/pitch as out     */
+    SWV2_EPI_UNPATCH = 4,   /* out fp32 y[B][Cout][H][W] (+ aux skip[B][Cs][H][W]) ; N = Cout*16 with columns ordered
+                               c*16+p*4+q ; p[0]=Cout p[1]=H p[2]=W p[3]=Cs (0 = no skip)   (:784-802)               */
+    SWV2_EPI_HEADS = 5,     /* out = [Bw][h][Lp][DP] bf16 split heads, no normalisation ; p as QKV_HEADS, N=heads*DP */
+    SWV2_EPI_F32_ACC = 6    /* out fp32 [M][ld] += acc ; optional rowidx scatter                                     */
+};
+
+typedef struct swv2_epilogue {
+    int kind;              /* enum swv2_epilogue_kind */
+    void* out;
+    const float* bias;     /* [N] or NULL */
+    const void* aux;
+    float* aux_out;
+    const int32_t* rowidx; /* optional: logical row -> destination row, negative = skip */
+    long ld;               /* output row pitch in elements */
+    int p[5];
+} swv2_epilogue;
+
+int swv2_linear(const swv2_operand* a, const void* w_bf16, const swv2_epilogue* e, int N, void* stream);
+
+/* Weight gradient: dW[nmap(n)][kmap(k)] += sum_m dY[m][n] X[m][k], db[nmap(n)] += sum_m dY[m][n]   (fp32 atomics;
+ * caller zeroes; db may be NULL).  dW has row pitch ldw; nmap/kmap (NULL = identity, negative = drop) undo the head
+ * padding of the SWV2_OP_HEADS layouts.  `splits` = number of row slices processed by different workgroups. */
+int swv2_linear_wgrad(const swv2_operand* dy, const swv2_operand* x, float* dW, float* db, const int32_t* nmap,
+                      const int32_t* kmap, int ldw, int splits, void* stream);
+
+/* out_bf16[i][j] = W'[row_map ? row_map[i] : i][col_map ? col_map[j] : j] (0 where a map entry is negative),
+ * W' = transpose ? w^T : w, w fp32 [rows][cols].  Casts, transposes, permutes and pads a parameter once per step. */
+int swv2_prep_weight(const float* w, int rows, int cols, int transpose, const int32_t* row_map, int out_rows,
+                     const int32_t* col_map, int out_cols, void* out_bf16, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Fused LayerNorm + drop-path + residual add, with the window_reverse + reverse cyclic roll folded into the row
+ * scatter:  y[dst] = res[res_mod ? dst % res_mod : dst] + scale[dst / rows_per_sample] * (LN(a[m])*gamma + beta),
+ * dst = rowidx ? rowidx[m] : m (negative = padded row, skipped).
+ * Replaces  x + drop_path(norm(branch))  (swinv2_global.py:490,496), window_reverse + roll (:468-476) and
+ * PatchEmbed's norm + pos_embed add (:545,780 with res = pos_embed as [T][C], res_mod = T).
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct swv2_ln_args {
+    const void* a;         /* bf16 [M][C] branch output                                   */
+    const float* res;      /* fwd: fp32 residual rows (NULL = 0)                           */
+    const float* gamma;    /* [C] */
+    const float* beta;     /* [C] (fwd) */
+    const float* scale;    /* [B] drop-path factor per sample or NULL                     */
+    const int32_t* rowidx; /* [M] or NULL                                                  */
+    float* y;              /* fwd out: fp32 rows                                           */
+    float* mean;           /* [M] fwd: out, bwd: in */
+    float* rstd;           /* [M] fwd: out, bwd: in */
+    const float* dy;       /* bwd in : fp32 grad of y (destination rows)                  */
+    void* da;              /* bwd out: bf16 [M][C] grad of a (zeros on padded rows)       */
+    float* dgamma;         /* bwd out: [C] ACCUMULATED */
+    float* dbeta;          /* bwd out: [C] ACCUMULATED */
+    int M, C, res_mod, rows_per_sample;
+    float eps;
+} swv2_ln_args;
+
+int swv2_ln_residual_fwd(const swv2_ln_args* a, void* stream);
+int swv2_ln_residual_bwd(const swv2_ln_args* a, void* stream);
+
+/* out[i] (+)= sum_b in[b][i], i < n (n % 4 == 0): pos_embed gradient */
+int swv2_batch_sum(const float* in, float* out, int B, long n, int accumulate, void* stream);
+
+/* PatchMerging (swinv2_global.py:500-523; never instantiated by swinv2net but part of the model file) */
+int swv2_merge_stats(const float* x, float* mean, float* rstd, int B, int H, int W, int C, float eps, void* stream);
+int swv2_merge_ln_bwd(const float* x, const void* dn_bf16, const float* gamma, const float* mean, const float* rstd,
+                      float* dx, float* dgamma, float* dbeta, int B, int H, int W, int C, void* stream);
+
+/* Geometric l2 loss (utils/losses.py:188-232, utils/grids.py:115-117): one pass produces, per (b,c) plane,
+ * sums[2*bc] += sum q[h](prd-tar)^2 and sums[2*bc+1] += sum q[h] tar^2 (caller zeroes sums);
+ * the backward is dprd = coef[bc] * q[h] * (prd - tar) with coef from the chain rule of the chosen variant. */
+int swv2_loss_sums(const float* prd, const float* tar, const float* quad_w, float* sums, int BC, int H, int W, void* stream);
+int swv2_loss_grad(const float* prd, const float* tar, const float* quad_w, const float* coef, float* dprd, int BC, int H,
+                   int W, void* stream);
+
+/* torch.optim.Adam step (train.py:176) over one flat fp32 buffer; step >= 1; grads are multiplied by grad_inv_scale */
+int swv2_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                   int step, float grad_inv_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SWV2_H */

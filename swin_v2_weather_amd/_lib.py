@@ -1,0 +1,127 @@
+"""ctypes binding of libswv2.so (the C ABI declared in include/swv2.h).
+
+There is NO fallback: if the shared library is missing or a call fails this module raises.  The library is built
+in-tree by `build_library()` (hipcc, --offload-arch=gfx950), which `__graft_entry__.build()` calls.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import threading
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(HERE, "libswv2.so")
+SOURCES = ["capi.hip", "attn.hip", "gemm.hip", "rowops.hip"]
+
+_lib = None
+_lock = threading.Lock()
+
+
+class Swv2Error(RuntimeError):
+    pass
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into swin_v2_weather_amd/libswv2.so (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "swv2.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs, procs = [], []
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    for s in srcs:
+        o = os.path.join(HERE, "build", os.path.basename(s) + ".o")
+        objs.append(o)
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o]
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for cmd, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise Swv2Error("hipcc failed: %s\n%s" % (" ".join(cmd), out.decode()))
+        if verbose and out:
+            print(out.decode())
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise Swv2Error("link failed: %s\n%s" % (" ".join(cmd), r.stdout.decode()))
+    return LIB_PATH
+
+
+# ---- structures (mirror include/swv2.h) ---------------------------------------------------------------------
+class AttnArgs(C.Structure):
+    _fields_ = [("qkvh", C.c_void_p), ("logit_scale", C.c_void_p), ("bias", C.c_void_p), ("oh", C.c_void_p),
+                ("lse", C.c_void_p), ("doh", C.c_void_p), ("rnorm", C.c_void_p), ("dqkvh", C.c_void_p),
+                ("dlogit_scale", C.c_void_p), ("dbias", C.c_void_p),
+                ("Bw", C.c_int), ("heads", C.c_int), ("L", C.c_int), ("head_dim", C.c_int),
+                ("nwh", C.c_int), ("nww", C.c_int), ("mask_thr", C.c_int), ("max_chunks", C.c_int)]
+
+
+class Operand(C.Structure):
+    _fields_ = [("kind", C.c_int), ("ptr", C.c_void_p), ("rowidx", C.c_void_p), ("aux0", C.c_void_p),
+                ("aux1", C.c_void_p), ("aux2", C.c_void_p), ("aux3", C.c_void_p), ("ld", C.c_long),
+                ("rows", C.c_int), ("cols", C.c_int), ("p", C.c_int * 4)]
+
+
+class Epilogue(C.Structure):
+    _fields_ = [("kind", C.c_int), ("out", C.c_void_p), ("bias", C.c_void_p), ("aux", C.c_void_p),
+                ("aux_out", C.c_void_p), ("rowidx", C.c_void_p), ("ld", C.c_long), ("p", C.c_int * 5)]
+
+
+class LnArgs(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("res", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("scale", C.c_void_p), ("rowidx", C.c_void_p), ("y", C.c_void_p), ("mean", C.c_void_p),
+                ("rstd", C.c_void_p), ("dy", C.c_void_p), ("da", C.c_void_p), ("dgamma", C.c_void_p),
+                ("dbeta", C.c_void_p), ("M", C.c_int), ("C", C.c_int), ("res_mod", C.c_int),
+                ("rows_per_sample", C.c_int), ("eps", C.c_float)]
+
+
+OP_F32, OP_BF16, OP_BF16_GELU, OP_HEADS, OP_PATCH, OP_MERGE_LN = range(6)
+EPI_BF16, EPI_F32, EPI_QKV_HEADS, EPI_GELU_GRAD, EPI_UNPATCH, EPI_HEADS, EPI_F32_ACC = range(7)
+
+# every symbol include/swv2.h declares: (name, restype, argtypes)
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_long, C.c_float
+SYMBOLS = {
+    "swv2_version": (_I, []),
+    "swv2_last_error": (C.c_char_p, []),
+    "swv2_attn_geometry": (_I, [_I, _I, C.POINTER(_I), C.POINTER(_I)]),
+    "swv2_attn_fwd": (_I, [C.POINTER(AttnArgs), _P]),
+    "swv2_attn_bwd": (_I, [C.POINTER(AttnArgs), _P]),
+    "swv2_linear": (_I, [C.POINTER(Operand), _P, C.POINTER(Epilogue), _I, _P]),
+    "swv2_linear_wgrad": (_I, [C.POINTER(Operand), C.POINTER(Operand), _P, _P, _P, _P, _I, _I, _P]),
+    "swv2_prep_weight": (_I, [_P, _I, _I, _I, _P, _I, _P, _I, _P, _P]),
+    "swv2_ln_residual_fwd": (_I, [C.POINTER(LnArgs), _P]),
+    "swv2_ln_residual_bwd": (_I, [C.POINTER(LnArgs), _P]),
+    "swv2_batch_sum": (_I, [_P, _P, _I, _L, _I, _P]),
+    "swv2_merge_stats": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "swv2_merge_ln_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "swv2_loss_sums": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "swv2_loss_grad": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "swv2_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P]),
+}
+
+
+def load() -> C.CDLL:
+    """Load libswv2.so; raises Swv2Error when it has not been built (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise Swv2Error(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                "(the HIP library is required; there is no fallback path)")
+            lib = C.CDLL(LIB_PATH)
+            for name, (res, args) in SYMBOLS.items():
+                fn = getattr(lib, name)            # AttributeError if a declared symbol is missing
+                fn.restype, fn.argtypes = res, args
+            _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().swv2_last_error()
+        raise Swv2Error(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")

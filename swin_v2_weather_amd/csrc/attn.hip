@@ -1,0 +1,473 @@
+// Cosine window attention core for SwinV2 (forward + backward), gfx950 / CDNA4.
+//
+// Semantics: reference networks/swinv2_global.py:298-318 (WindowMultiHeadAttention.forward) and :170-198 (NoPos):
+//   S = sigma_h * qn kn^T + Bias_h + Mask ; P = softmax(S) ; O = P v
+// with qn, kn already L2-normalised (done by the qkv GEMM epilogue, see gemm.hip), sigma_h = exp(min(tau_h, ln 100)).
+//
+// Data layout (window-ordered, head-major, zero padded; produced by the qkv GEMM epilogue):
+//   qkvh [Bw][h][3][Lp][DP] bf16   (s = 0 qn, 1 kn, 2 v),  Lp = 16*LT >= L,  DP = 16*DK >= d
+//   oh   [Bw][h][Lp][DP]    bf16
+//   lse  [Bw][h][Lp]        fp32   log2-domain log-sum-exp of the scaled scores
+// One (window, head) block is one contiguous slab, so every global access of these kernels is a fully coalesced
+// 512-byte wave access.  roll/partition never appear here: they are folded into the qkv GEMM's row gather and the
+// proj GEMM's row scatter.
+//
+// Work decomposition: one workgroup = (head, chunk of windows); LT waves, wave w owns one 16-row tile:
+//   forward : wave = query tile, "swapped" product S^T = K Q^T so a lane owns one query column: the softmax row
+//             reductions are in-lane + 2 cross-lane steps, and S^T accumulators are directly the B operand of
+//             O^T = V^T P^T (k16 MFMA, natural k order).  The CPB bias rows of (head, q-tile) live in registers for
+//             the lifetime of the workgroup (loaded once), pre-multiplied by log2(e); padded keys carry -1e30.
+//   backward: wave = key tile, product S = Q K^T so P / dS accumulators are directly the B operands of
+//             dV^T = dO^T P and dK^T = Q^T dS; dK, dV need no cross-wave reduction, the bias gradient of
+//             (head, key-tile) accumulates in registers across all windows of the workgroup, and only dQ crosses
+//             waves (LDS float atomics, one 16x16 tile per step).
+#include "common.h"
+
+namespace {
+
+template <int LT, int DK>
+struct AttnCfg {
+    static constexpr int Lp = 16 * LT;
+    static constexpr int DP = 16 * DK;
+    static constexpr int NT = 64 * LT;          // threads per workgroup
+    static constexpr int SLAB = Lp * DP;        // elements of one [Lp][DP] slab
+};
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <int LT, int DK, bool HAS_BIAS>
+__global__ __launch_bounds__(64 * LT) void attn_fwd_kernel(
+    const uint16_t* __restrict__ qkvh, const float* __restrict__ logit_scale, const float* __restrict__ bias,
+    uint16_t* __restrict__ oh, float* __restrict__ lse, int Bw, int h, int L, int nW, int nww, int nwh, int mask_thr) {
+    using C = AttnCfg<LT, DK>;
+    constexpr int Lp = C::Lp, DP = C::DP, SLAB = C::SLAB;
+    __shared__ __attribute__((aligned(16))) uint16_t smem[2 * 2 * SLAB];   // [buf][K|V][Lp][DP]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int qt = tid >> 6;                 // this wave's query tile
+    const int fr = lane & 15, g = lane >> 4;
+    const int hd = blockIdx.y;
+    const int q = 16 * qt + fr;              // this lane's query (token index in the window)
+
+    const float sc2 = __expf(fminf(logit_scale[hd], SWV2_LN100)) * SWV2_LOG2E;
+
+    // CPB bias rows of this (head, q-tile), log2 domain, -1e30 on padded keys
+    float biasr[LT][4];
+    if (HAS_BIAS) {
+#pragma unroll
+        for (int t = 0; t < LT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = 16 * t + 4 * g + r;
+                float v = SWV2_NEG_BIG;
+                if (key < L) v = (q < L) ? bias[((size_t)hd * L + q) * L + key] * SWV2_LOG2E : 0.f;
+                biasr[t][r] = v;
+            }
+    }
+
+    constexpr int CHUNKS_PER_T = 2 * DK;     // 16-byte chunks each thread stages per window (K then V)
+    uint4 stage[CHUNKS_PER_T];
+    auto issue_loads = [&](int bw) {
+        const uint16_t* base = qkvh + ((size_t)bw * h + hd) * 3 * SLAB + SLAB;   // K slab, V slab follows
+#pragma unroll
+        for (int j = 0; j < CHUNKS_PER_T; ++j) stage[j] = *(const uint4*)(base + (size_t)(tid + j * C::NT) * 8);
+    };
+    auto write_stage = [&](int buf) {
+        uint16_t* dst = smem + buf * 2 * SLAB;
+#pragma unroll
+        for (int j = 0; j < CHUNKS_PER_T; ++j) *(uint4*)(dst + (size_t)(tid + j * C::NT) * 8) = stage[j];
+    };
+
+    int bw = blockIdx.x;
+    if (bw >= Bw) return;
+    issue_loads(bw);
+    write_stage(0);
+    __syncthreads();
+
+    for (int it = 0; bw < Bw; bw += gridDim.x, ++it) {
+        const int buf = it & 1;
+        const int bw_next = bw + gridDim.x;
+        if (bw_next < Bw) issue_loads(bw_next);
+
+        const uint16_t* Ks = smem + buf * 2 * SLAB;
+        const uint16_t* Vs = Ks + SLAB;
+        const size_t slab0 = ((size_t)bw * h + hd) * 3 * SLAB;
+
+        // Q fragment (B operand: B[k = d 4g+j][n = query fr]) straight from global: 512 B contiguous per wave
+        bf16x4 qf[DK];
+#pragma unroll
+        for (int kk = 0; kk < DK; ++kk) qf[kk] = *(const bf16x4*)(qkvh + slab0 + (size_t)q * DP + 16 * kk + 4 * g);
+
+        // S^T tiles: rows = keys 16t + 4g + r, column = query fr
+        f32x4 acc[LT];
+#pragma unroll
+        for (int t = 0; t < LT; ++t) {
+            acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < DK; ++kk) {
+                const bf16x4 kf = *(const bf16x4*)(Ks + (16 * t + fr) * DP + 16 * kk + 4 * g);
+                acc[t] = mfma16(kf, qf[kk], acc[t]);
+            }
+        }
+
+        const bool do_mask = (mask_thr > 0) && (((bw % nW) / nww) == nwh - 1);
+        const bool qid = q >= mask_thr;
+        float mx = SWV2_NEG_BIG;
+#pragma unroll
+        for (int t = 0; t < LT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = 16 * t + 4 * g + r;
+                float s;
+                if (HAS_BIAS) {
+                    s = fmaf(acc[t][r], sc2, biasr[t][r]);
+                } else {
+                    s = acc[t][r] * sc2;
+                    if (16 * t + 16 > L) s = (key < L) ? s : SWV2_NEG_BIG;
+                }
+                if (do_mask) s += ((key >= mask_thr) != qid) ? (-100.f * SWV2_LOG2E) : 0.f;
+                acc[t][r] = s;
+                mx = fmaxf(mx, s);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < LT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __builtin_amdgcn_exp2f(acc[t][r] - mx);
+                acc[t][r] = p;
+                sum += p;
+            }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+
+        // O^T[d][q] = sum_keys V^T[d][key] P^T[key][q]
+        f32x4 o[DK];
+#pragma unroll
+        for (int dt = 0; dt < DK; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < LT; ++t) {
+            const bf16x4 pb = f2bf4(acc[t]);
+#pragma unroll
+            for (int dt = 0; dt < DK; ++dt) {
+                const bf16x4 vf = lds_tr_read(Vs + (16 * t + 4 * g + (fr >> 2)) * DP + 16 * dt + (fr & 3) * 4);
+                o[dt] = mfma16(vf, pb, o[dt]);
+            }
+        }
+        const float inv = (q < L) ? 1.f / sum : 0.f;
+        uint16_t* orow = oh + ((size_t)bw * h + hd) * SLAB + (size_t)q * DP;
+#pragma unroll
+        for (int dt = 0; dt < DK; ++dt) {
+            f32x4 v = o[dt];
+            v[0] *= inv; v[1] *= inv; v[2] *= inv; v[3] *= inv;
+            *(bf16x4*)(orow + 16 * dt + 4 * g) = f2bf4(v);
+        }
+        if (g == 0) lse[((size_t)bw * h + hd) * Lp + q] = (q < L) ? mx + __log2f(sum) : 0.f;
+
+        if (bw_next < Bw) write_stage(buf ^ 1);
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------
+template <int LT, int DK, bool HAS_BIAS>
+__global__ __launch_bounds__(64 * LT) void attn_bwd_kernel(
+    const uint16_t* __restrict__ qkvh, const float* __restrict__ logit_scale, const float* __restrict__ bias,
+    const uint16_t* __restrict__ oh, const uint16_t* __restrict__ doh, const float* __restrict__ lse,
+    const float* __restrict__ rnorm,       // [Bw][h][2][Lp]  1/max(|q|,eps), 1/max(|k|,eps)
+    uint16_t* __restrict__ dqkvh,          // [Bw][h][3][Lp][DP]  grads w.r.t. the UN-normalised q, k and v
+    float* __restrict__ dlogit,            // [h]      (atomically accumulated)
+    float* __restrict__ dbias,             // [h][L][L] (atomically accumulated) or null
+    int Bw, int h, int L, int nW, int nww, int nwh, int mask_thr) {
+    using C = AttnCfg<LT, DK>;
+    constexpr int Lp = C::Lp, DP = C::DP, SLAB = C::SLAB, NT = C::NT;
+    constexpr int LpP = Lp + 4;              // dQ^T accumulator row pitch (floats): (4*LpP) % 32 == 16
+    __shared__ __attribute__((aligned(16))) uint16_t Qs[SLAB];
+    __shared__ __attribute__((aligned(16))) uint16_t Ks[SLAB];
+    __shared__ __attribute__((aligned(16))) uint16_t dOs[SLAB];
+    __shared__ __attribute__((aligned(16))) uint16_t scr[LT * 256];    // per-wave 16x16 bf16 transpose tile
+    __shared__ __attribute__((aligned(16))) float dQT[DP * LpP];        // [d][q]
+    __shared__ __attribute__((aligned(16))) float LSEs[Lp];
+    __shared__ __attribute__((aligned(16))) float DLs[Lp];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int tw = tid >> 6;                 // this wave's key tile
+    const int fr = lane & 15, g = lane >> 4;
+    const int hd = blockIdx.y;
+    const int key = 16 * tw + fr;            // this lane's key
+    uint16_t* myscr = scr + tw * 256;
+
+    const float tau = logit_scale[hd];
+    const float sigma = __expf(fminf(tau, SWV2_LN100));
+    const float sc2 = sigma * SWV2_LOG2E;
+
+    f32x4 biasr[LT];
+    f32x4 dbr[LT];
+    if (HAS_BIAS) {
+#pragma unroll
+        for (int qt = 0; qt < LT; ++qt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = 16 * qt + 4 * g + r;
+                float v = SWV2_NEG_BIG;
+                if (key < L) v = (q < L) ? bias[((size_t)hd * L + q) * L + key] * SWV2_LOG2E : 0.f;
+                biasr[qt][r] = v;
+                dbr[qt][r] = 0.f;
+            }
+    }
+    float dsig = 0.f;
+
+    for (int bw = blockIdx.x; bw < Bw; bw += gridDim.x) {
+        const size_t slab0 = ((size_t)bw * h + hd) * 3 * SLAB;
+        const size_t oslab = ((size_t)bw * h + hd) * SLAB;
+        // ---- stage Q, K, dO (16-byte chunks), LSE; zero the dQ accumulator
+        constexpr int CH = SLAB / 8;         // chunks per slab = 32*LT*DK
+        for (int c = tid; c < CH; c += NT) {
+            *(uint4*)(Qs + c * 8) = *(const uint4*)(qkvh + slab0 + (size_t)c * 8);
+            *(uint4*)(Ks + c * 8) = *(const uint4*)(qkvh + slab0 + SLAB + (size_t)c * 8);
+            *(uint4*)(dOs + c * 8) = *(const uint4*)(doh + oslab + (size_t)c * 8);
+        }
+        for (int i = tid; i < DP * LpP; i += NT) dQT[i] = 0.f;
+        if (tid < Lp) LSEs[tid] = (tid < L) ? lse[((size_t)bw * h + hd) * Lp + tid] : 1.0e30f;
+        __syncthreads();
+        // ---- delta[q] = sum_d dO[q][d] O[q][d]
+        if (tid < Lp) {
+            float dl = 0.f;
+#pragma unroll
+            for (int c = 0; c < 2 * DK; ++c) {
+                const bf16x8 a = *(const bf16x8*)(dOs + tid * DP + 8 * c);
+                const bf16x8 b = *(const bf16x8*)(oh + oslab + (size_t)tid * DP + 8 * c);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dl = fmaf(bf2f(a[j]), bf2f(b[j]), dl);
+            }
+            DLs[tid] = dl;
+        }
+        // ---- this wave's K and V tile as B operands (B[k = d 4g+j][n = key fr]) and K^T as A operand
+        bf16x4 kf[DK], vf[DK], kT[DK];
+#pragma unroll
+        for (int kk = 0; kk < DK; ++kk) {
+            kf[kk] = *(const bf16x4*)(Ks + key * DP + 16 * kk + 4 * g);
+            vf[kk] = *(const bf16x4*)(qkvh + slab0 + 2 * SLAB + (size_t)key * DP + 16 * kk + 4 * g);
+            kT[kk] = lds_tr_read(Ks + (16 * tw + 4 * g + (fr >> 2)) * DP + 16 * kk + (fr & 3) * 4);
+        }
+        __syncthreads();
+
+        const bool do_mask = (mask_thr > 0) && (((bw % nW) / nww) == nwh - 1);
+        const bool kid = key >= mask_thr;
+        f32x4 dk[DK], dv[DK];
+#pragma unroll
+        for (int dt = 0; dt < DK; ++dt) {
+            dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+
+        // one q-tile step; `br` / `dbrow` are this lane's bias row and bias-gradient row of the tile (registers)
+        auto step = [&](const int qt, const f32x4 br, f32x4& dbrow) {
+            // S = Q K^T and dP = dO V^T : rows q = 16qt + 4g + r, column = key fr
+            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < DK; ++kk) {
+                const bf16x4 qa = *(const bf16x4*)(Qs + (16 * qt + fr) * DP + 16 * kk + 4 * g);
+                const bf16x4 da = *(const bf16x4*)(dOs + (16 * qt + fr) * DP + 16 * kk + 4 * g);
+                s = mfma16(qa, kf[kk], s);
+                dp = mfma16(da, vf[kk], dp);
+            }
+            const f32x4 l4 = *(const f32x4*)(LSEs + 16 * qt + 4 * g);
+            const f32x4 d4 = *(const f32x4*)(DLs + 16 * qt + 4 * g);
+            f32x4 p, ds;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = 16 * qt + 4 * g + r;
+                float x;
+                if (HAS_BIAS) {
+                    x = fmaf(s[r], sc2, br[r]);
+                } else {
+                    x = s[r] * sc2;
+                    if (16 * tw + 16 > L) x = (key < L) ? x : SWV2_NEG_BIG;
+                }
+                if (do_mask) x += ((q >= mask_thr) != kid) ? (-100.f * SWV2_LOG2E) : 0.f;
+                const float pr = __builtin_amdgcn_exp2f(x - l4[r]);
+                const float dsr = pr * (dp[r] - d4[r]);
+                p[r] = pr;
+                ds[r] = dsr * sigma;                      // d(cos) = sigma * dS
+                dsig = fmaf(dsr, s[r], dsig);
+                if (HAS_BIAS) dbrow[r] += dsr;
+            }
+            const bf16x4 pb = f2bf4(p);
+            const bf16x4 dsb = f2bf4(ds);
+            // dV^T += dO^T P ; dK^T += Q^T dcos     (A operands: transposed reads of the staged dO / Q tiles)
+#pragma unroll
+            for (int dt = 0; dt < DK; ++dt) {
+                const int off = (16 * qt + 4 * g + (fr >> 2)) * DP + 16 * dt + (fr & 3) * 4;
+                dv[dt] = mfma16(lds_tr_read(dOs + off), pb, dv[dt]);
+                dk[dt] = mfma16(lds_tr_read(Qs + off), dsb, dk[dt]);
+            }
+            // dQ^T[d][q] += K^T[d][key] dcos^T[key][q] : transpose the 16x16 dcos tile through the wave's scratch
+            *(bf16x4*)(myscr + fr * 16 + 4 * g) = dsb;                      // image [key][q]
+            const bf16x4 dsT = lds_tr_read(myscr + (4 * g + (fr >> 2)) * 16 + (fr & 3) * 4);
+#pragma unroll
+            for (int dt = 0; dt < DK; ++dt) {
+                f32x4 dq = mfma16(kT[dt], dsT, (f32x4){0.f, 0.f, 0.f, 0.f});   // rows d = 16dt+4g+r, col q = fr
+#pragma unroll
+                for (int r = 0; r < 4; ++r) atomicAdd(&dQT[(16 * dt + 4 * g + r) * LpP + 16 * qt + fr], dq[r]);
+            }
+        };
+        if constexpr (HAS_BIAS) {
+            // fully unrolled so the bias / bias-gradient rows are statically indexed registers; the scheduling
+            // barrier keeps the compiler from hoisting the next tiles' LDS reads (register pressure)
+#pragma unroll
+            for (int qt = 0; qt < LT; ++qt) {
+                step(qt, biasr[qt], dbr[qt]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            f32x4 dummy = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int qt = 0; qt < LT; ++qt) step(qt, dummy, dummy);
+        }
+
+        // ---- dK (through the L2-normalisation) and dV of this wave's key tile
+        {
+            const float rk = rnorm[(((size_t)bw * h + hd) * 2 + 1) * Lp + key];
+            float dot = 0.f;
+#pragma unroll
+            for (int dt = 0; dt < DK; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dot = fmaf(dk[dt][r], bf2f(kf[dt][r]), dot);
+            dot += __shfl_xor(dot, 16);
+            dot += __shfl_xor(dot, 32);
+#pragma unroll
+            for (int dt = 0; dt < DK; ++dt) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = rk * (dk[dt][r] - bf2f(kf[dt][r]) * dot);
+                *(bf16x4*)(dqkvh + slab0 + SLAB + (size_t)key * DP + 16 * dt + 4 * g) = f2bf4(v);
+                *(bf16x4*)(dqkvh + slab0 + 2 * SLAB + (size_t)key * DP + 16 * dt + 4 * g) = f2bf4(dv[dt]);
+            }
+        }
+        __syncthreads();
+        // ---- dQ rows (through the L2-normalisation): one thread per query row
+        if (tid < Lp) {
+            const float rq = rnorm[(((size_t)bw * h + hd) * 2 + 0) * Lp + tid];
+            float dot = 0.f;
+#pragma unroll
+            for (int d = 0; d < DP; ++d) dot = fmaf(dQT[d * LpP + tid], bf2f(Qs[tid * DP + d]), dot);
+#pragma unroll
+            for (int c = 0; c < DP / 4; ++c) {
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    v[j] = rq * (dQT[(4 * c + j) * LpP + tid] - bf2f(Qs[tid * DP + 4 * c + j]) * dot);
+                *(bf16x4*)(dqkvh + slab0 + (size_t)tid * DP + 4 * c) = f2bf4(v);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- flush the per-workgroup reductions
+    dsig = wave_sum(dsig);
+    if (lane == 0 && tau <= SWV2_LN100) atomicAdd(dlogit + hd, dsig * sigma);
+    if (HAS_BIAS && key < L) {
+#pragma unroll
+        for (int qt = 0; qt < LT; ++qt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = 16 * qt + 4 * g + r;
+                if (q < L) atomicAdd(dbias + ((size_t)hd * L + q) * L + key, dbr[qt][r]);
+            }
+    }
+}
+
+template <int LT, int DK>
+int launch_fwd(const swv2_attn_args* a, hipStream_t st) {
+    const int nchunk = a->Bw < a->max_chunks ? a->Bw : a->max_chunks;
+    dim3 grid(nchunk, a->heads), block(64 * LT);
+    const int nW = a->nwh * a->nww;
+    if (a->bias)
+        hipLaunchKernelGGL((attn_fwd_kernel<LT, DK, true>), grid, block, 0, st, (const uint16_t*)a->qkvh, a->logit_scale,
+                           a->bias, (uint16_t*)a->oh, a->lse, a->Bw, a->heads, a->L, nW, a->nww, a->nwh, a->mask_thr);
+    else
+        hipLaunchKernelGGL((attn_fwd_kernel<LT, DK, false>), grid, block, 0, st, (const uint16_t*)a->qkvh,
+                           a->logit_scale, a->bias, (uint16_t*)a->oh, a->lse, a->Bw, a->heads, a->L, nW, a->nww,
+                           a->nwh, a->mask_thr);
+    SWV2_CHECK_LAUNCH("swv2_attn_fwd");
+    return SWV2_OK;
+}
+
+template <int LT, int DK>
+int launch_bwd(const swv2_attn_args* a, hipStream_t st) {
+    const int nchunk = a->Bw < a->max_chunks ? a->Bw : a->max_chunks;
+    dim3 grid(nchunk, a->heads), block(64 * LT);
+    const int nW = a->nwh * a->nww;
+    if (a->bias)
+        hipLaunchKernelGGL((attn_bwd_kernel<LT, DK, true>), grid, block, 0, st, (const uint16_t*)a->qkvh, a->logit_scale,
+                           a->bias, (const uint16_t*)a->oh, (const uint16_t*)a->doh, a->lse, a->rnorm,
+                           (uint16_t*)a->dqkvh, a->dlogit_scale, a->dbias, a->Bw, a->heads, a->L, nW, a->nww, a->nwh,
+                           a->mask_thr);
+    else
+        hipLaunchKernelGGL((attn_bwd_kernel<LT, DK, false>), grid, block, 0, st, (const uint16_t*)a->qkvh,
+                           a->logit_scale, a->bias, (const uint16_t*)a->oh, (const uint16_t*)a->doh, a->lse, a->rnorm,
+                           (uint16_t*)a->dqkvh, a->dlogit_scale, a->dbias, a->Bw, a->heads, a->L, nW, a->nww, a->nwh,
+                           a->mask_thr);
+    SWV2_CHECK_LAUNCH("swv2_attn_bwd");
+    return SWV2_OK;
+}
+
+int check_args(const swv2_attn_args* a, bool bwd) {
+    SWV2_CHECK_ARG(a != nullptr, "attn: null args");
+    SWV2_CHECK_ARG(a->qkvh && a->oh && a->lse && a->logit_scale, "attn: null tensor pointer");
+    SWV2_CHECK_ARG(a->Bw > 0 && a->heads > 0 && a->L > 0 && a->head_dim > 0, "attn: non-positive size");
+    SWV2_CHECK_ARG(a->head_dim % 4 == 0, "attn: head_dim %d must be a multiple of 4", a->head_dim);
+    SWV2_CHECK_ARG(a->nwh > 0 && a->nww > 0 && a->Bw % (a->nwh * a->nww) == 0,
+                   "attn: Bw=%d is not a multiple of the %dx%d windows per sample", a->Bw, a->nwh, a->nww);
+    SWV2_CHECK_ARG(a->mask_thr >= 0 && a->mask_thr < a->L, "attn: mask_thr out of range");
+    SWV2_CHECK_ARG(a->max_chunks > 0, "attn: max_chunks must be positive");
+    if (bwd) SWV2_CHECK_ARG(a->doh && a->rnorm && a->dqkvh && a->dlogit_scale && (!a->bias || a->dbias),
+                            "attn_bwd: null gradient pointer");
+    return SWV2_OK;
+}
+
+}  // namespace
+
+// tile geometry shared with the host side (gemm epilogue, python wrappers)
+extern "C" int swv2_attn_geometry(int L, int head_dim, int* Lp, int* DP) {
+    int LT = 0, DK = 0;
+    if (L <= 64) LT = 4; else if (L <= 176) LT = 11;
+    if (head_dim <= 16) DK = 1; else if (head_dim <= 32) DK = 2;
+    SWV2_CHECK_ARG(LT && DK, "attention: unsupported window area L=%d (<=176) or head_dim=%d (<=32)", L, head_dim);
+    if (Lp) *Lp = 16 * LT;
+    if (DP) *DP = 16 * DK;
+    return SWV2_OK;
+}
+
+#define SWV2_ATTN_DISPATCH(FN)                                                         \
+    int Lp, DP;                                                                        \
+    int rc = swv2_attn_geometry(a->L, a->head_dim, &Lp, &DP);                          \
+    if (rc) return rc;                                                                 \
+    hipStream_t st = (hipStream_t)stream;                                              \
+    if (Lp == 64 && DP == 16) return FN<4, 1>(a, st);                                  \
+    if (Lp == 64 && DP == 32) return FN<4, 2>(a, st);                                  \
+    if (Lp == 176 && DP == 16) return FN<11, 1>(a, st);                                \
+    if (Lp == 176 && DP == 32) return FN<11, 2>(a, st);                                \
+    swv2_set_error("attention: no kernel for Lp=%d DP=%d", Lp, DP);                    \
+    return SWV2_ERR_UNSUPPORTED;
+
+extern "C" int swv2_attn_fwd(const swv2_attn_args* a, void* stream) {
+    int rc0 = check_args(a, false);
+    if (rc0) return rc0;
+    SWV2_ATTN_DISPATCH(launch_fwd)
+}
+
+extern "C" int swv2_attn_bwd(const swv2_attn_args* a, void* stream) {
+    int rc0 = check_args(a, true);
+    if (rc0) return rc0;
+    SWV2_ATTN_DISPATCH(launch_bwd)
+}

@@ -1,0 +1,71 @@
+// Shared device/host helpers for the swv2 HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/swv2.h"
+
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define SWV2_LOG2E 1.4426950408889634f
+#define SWV2_LN100 4.605170185988092f
+#define SWV2_NEG_BIG (-1.0e30f)
+
+// ---- bf16 <-> f32 -------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ float bf2f(short v) { return __uint_as_float(((uint32_t)(uint16_t)v) << 16); }
+// plain casts: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN-preserving) on gfx950
+__device__ __forceinline__ uint16_t f2bf(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+__device__ __forceinline__ bf16x4 f2bf4(f32x4 v) { return __builtin_bit_cast(bf16x4, __builtin_convertvector(v, bf4_t)); }
+__device__ __forceinline__ uint32_t f2bf2(float lo, float hi) {
+    f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf2_t));
+}
+
+// ---- MFMA wrappers (wave64) ---------------------------------------------------------------
+// v_mfma_f32_16x16x16_bf16: A[i=l&15][k=4*(l>>4)+j], B[k=4*(l>>4)+j][n=l&15], C[row=4*(l>>4)+r][col=l&15]
+__device__ __forceinline__ f32x4 mfma16(bf16x4 a, bf16x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+// v_mfma_f32_16x16x32_bf16: A[i=l&15][k=8*(l>>4)+j], B[k=8*(l>>4)+j][n=l&15], same C map
+__device__ __forceinline__ f32x4 mfma32(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+// ds_read_b64_tr_b16: per 16-lane group, lane 4q+p supplies the address of row q / cols 4p..4p+3 of a 4x16 block of
+// 16-bit elements; lane i receives column i of the 4 rows (row q in element q).
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+__device__ __forceinline__ bf16x4 lds_tr_read(const uint16_t* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)p);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ---- host side ----------------------------------------------------------------------------
+void swv2_set_error(const char* fmt, ...);
+#define SWV2_CHECK_ARG(cond, ...)                 \
+    do {                                          \
+        if (!(cond)) {                            \
+            swv2_set_error(__VA_ARGS__);          \
+            return SWV2_ERR_INVALID;              \
+        }                                         \
+    } while (0)
+#define SWV2_CHECK_LAUNCH(name)                                                      \
+    do {                                                                             \
+        hipError_t e_ = hipGetLastError();                                           \
+        if (e_ != hipSuccess) {                                                      \
+            swv2_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));    \
+            return SWV2_ERR_LAUNCH;                                                  \
+        }                                                                            \
+    } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,651 @@
+// bf16 MFMA GEMM engine for the tall-skinny products of the SwinV2 hot path (gfx950 / CDNA4).
+//
+//   NT:  C[M][N]  = A[M][K] . W[N][K]^T          forward linears, dX = dY . W  (W pre-transposed by swv2_cast_weights)
+//   TN:  dW[N][K] = sum_m dY[m][N]^T . X[m][K]    weight gradients (+ bias gradient = column sums of dY)
+//
+// M is the token count (10^5 .. 10^6), N and K are channel counts (96 .. 1232), so every product is
+// HBM-bound on the A / C streams.  The engine therefore spends its structure on the memory side:
+//   * A "loader" functor maps (row, 8-element k-chunk) -> 16 bytes of bf16; it folds into the load what PyTorch does
+//     as separate passes in the reference: fp32->bf16 conversion, the cyclic roll + window partition gather
+//     (swinv2_global.py:457,89-101), the 4x4 patch im2col of PatchEmbed (:537), the 2x2 PatchMerging gather (:519),
+//     un-merging of attention heads (:318), GELU (timm Mlp) and LayerNorm-on-load.
+//   * An "epilogue" functor receives 16x64 fp32 sub-tiles staged in wave-private LDS and writes them out in
+//     whatever layout the consumer wants, always as full 16-byte, row-contiguous stores: bias, the head-major
+//     window-ordered q/k/v layout with the L2 normalisation of q and k (:304), GELU', un-patchify + skip (:784-802).
+//   * One workgroup owns a 128-row panel of A and walks all N tiles itself, so the panel's re-reads hit its own
+//     XCD's L2 instead of crossing XCDs.
+// Tile: 128x128x64, 256 threads = 4 waves in a 2x2 grid of 64x64 wave tiles (16 accumulators of 16x16),
+// v_mfma_f32_16x16x32_bf16, double-buffered LDS with register-staged prefetch (issue loads for step s+1, compute
+// step s, write LDS after), XOR-swizzled 128-byte LDS rows for conflict-free ds_read_b128 fragments.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int KCH = BK / 8;                 // 16-byte chunks per tile row
+constexpr int NTHREADS = 256;
+
+// swizzled element offset of chunk kc of row r in a [rows][64] bf16 tile (128-byte rows)
+__device__ __forceinline__ int swz(int r, int kc) { return r * BK + ((kc ^ ((r >> 1) & 7)) << 3); }
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+__device__ __forceinline__ uint4 pack8(const float* v) {
+    uint4 r;
+    r.x = f2bf2(v[0], v[1]); r.y = f2bf2(v[2], v[3]); r.z = f2bf2(v[4], v[5]); r.w = f2bf2(v[6], v[7]);
+    return r;
+}
+__device__ __forceinline__ void unpack8(uint4 c, float* v) {
+    const uint32_t w[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = __uint_as_float(w[i] << 16);
+        v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// A loaders: chunk(m, k0) returns 8 bf16 (k0 multiple of 8) of logical row m; zeros outside [0,M)x[0,K)
+// ------------------------------------------------------------------------------------------------
+struct LoadDesc {           // plain-data description shared by all loader kinds (filled by the host)
+    const void* ptr;        // primary source
+    const int32_t* rowidx;  // optional gather table: logical row -> source row, <0 = zero row
+    const float* aux0;      // LN-on-load: mean[M] ; patch: unused
+    const float* aux1;      // LN-on-load: rstd[M]
+    const float* aux2;      // LN-on-load: gamma[K]
+    const float* aux3;      // LN-on-load: beta[K]
+    long ld;                // source row pitch in elements
+    int M, K;
+    int p0, p1, p2, p3;     // kind-specific ints (see loaders)
+};
+
+template <int KIND> struct ALoad;
+
+enum { A_F32 = 0, A_BF16 = 1, A_BF16_GELU = 2, A_HEADS = 3, A_PATCH = 4, A_MERGE_LN = 5 };
+
+// fp32 rows (optionally gathered): the residual stream x[B*T][C]
+template <> struct ALoad<A_F32> {
+    static constexpr bool ROW_FASTEST = false;
+    LoadDesc d;
+    __device__ __forceinline__ uint4 chunk(int m, int k0) const {
+        if (m >= d.M || k0 >= d.K) return make_uint4(0, 0, 0, 0);
+        long r = m;
+        if (d.rowidx) { r = d.rowidx[m]; if (r < 0) return make_uint4(0, 0, 0, 0); }
+        const float* p = (const float*)d.ptr + r * d.ld + k0;
+        const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+        uint4 o;
+        o.x = f2bf2(a[0], a[1]); o.y = f2bf2(a[2], a[3]); o.z = f2bf2(b[0], b[1]); o.w = f2bf2(b[2], b[3]);
+        return o;
+    }
+};
+// bf16 rows (optionally gathered)
+template <> struct ALoad<A_BF16> {
+    static constexpr bool ROW_FASTEST = false;
+    LoadDesc d;
+    __device__ __forceinline__ uint4 chunk(int m, int k0) const {
+        if (m >= d.M || k0 >= d.K) return make_uint4(0, 0, 0, 0);
+        long r = m;
+        if (d.rowidx) { r = d.rowidx[m]; if (r < 0) return make_uint4(0, 0, 0, 0); }
+        return *(const uint4*)((const uint16_t*)d.ptr + r * d.ld + k0);
+    }
+};
+// bf16 rows through GELU (fc2 input = GELU(fc1 output); the pre-activation is what is kept for backward)
+template <> struct ALoad<A_BF16_GELU> {
+    static constexpr bool ROW_FASTEST = false;
+    LoadDesc d;
+    __device__ __forceinline__ uint4 chunk(int m, int k0) const {
+        if (m >= d.M || k0 >= d.K) return make_uint4(0, 0, 0, 0);
+        float v[8];
+        unpack8(*(const uint4*)((const uint16_t*)d.ptr + (long)m * d.ld + k0), v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = gelu_f(v[i]);
+        return pack8(v);
+    }
+};
+// head-major window layout [Bw][h][S][Lp][DP] -> logical row m = bw*Lp + t, logical k = (part*h + head)*DP + j
+// (head dim padded to DP; the matching weights are padded by swv2_prep_weight).
+// p0 = heads, p2 = Lp, p3 = DP ; ld = number of parts S (1 for oh, 3 for dqkvh)
+template <> struct ALoad<A_HEADS> {
+    static constexpr bool ROW_FASTEST = false;
+    LoadDesc d;
+    __device__ __forceinline__ uint4 chunk(int m, int k0) const {
+        if (m >= d.M || k0 >= d.K) return make_uint4(0, 0, 0, 0);
+        const int h = d.p0, Lp = d.p2, DP = d.p3, S = (int)d.ld;
+        const int bw = m / Lp, t = m - bw * Lp;
+        const int ph = k0 / DP, j = k0 - ph * DP, part = ph / h, hd = ph - part * h;
+        return *(const uint4*)((const uint16_t*)d.ptr + ((((long)bw * h + hd) * S + part) * Lp + t) * DP + j);
+    }
+};
+// PatchEmbed im2col: x[B][Cin][H][W] fp32, row m = (b, i, j) patch, k = cin*16 + p*4 + q (conv weight order)
+// p0 = Cin, p1 = H, p2 = W ; patch = 4.  Adjacent rows are adjacent 16-byte groups -> row-fastest thread map.
+template <> struct ALoad<A_PATCH> {
+    static constexpr bool ROW_FASTEST = true;
+    LoadDesc d;
+    __device__ __forceinline__ uint4 chunk(int m, int k0) const {
+        if (m >= d.M || k0 >= d.K) return make_uint4(0, 0, 0, 0);
+        const int Cin = d.p0, H = d.p1, W = d.p2, gw = W >> 2, gh = H >> 2;
+        const int b = m / (gh * gw), ij = m - b * gh * gw, i = ij / gw, j = ij - i * gw;
+        const int cin = k0 >> 4, p = (k0 >> 2) & 3;                 // p in {0, 2}
+        const float* src = (const float*)d.ptr + (((long)b * Cin + cin) * H + 4 * i + p) * W + 4 * j;
+        const f32x4 a = *(const f32x4*)src, c = *(const f32x4*)(src + W);
+        uint4 o;
+        o.x = f2bf2(a[0], a[1]); o.y = f2bf2(a[2], a[3]); o.z = f2bf2(c[0], c[1]); o.w = f2bf2(c[2], c[3]);
+        return o;
+    }
+};
+// PatchMerging gather + LayerNorm(4C) on load: x[B][H][W][C] fp32, row m = (b, i, j) on the half grid,
+// k = (wp*2 + hp)*C + c  (swinv2_global.py:520) ; p0 = H, p1 = W, p2 = C ; aux = mean, rstd, gamma, beta
+template <> struct ALoad<A_MERGE_LN> {
+    static constexpr bool ROW_FASTEST = false;
+    LoadDesc d;
+    __device__ __forceinline__ uint4 chunk(int m, int k0) const {
+        if (m >= d.M || k0 >= d.K) return make_uint4(0, 0, 0, 0);
+        const int H = d.p0, W = d.p1, C = d.p2, h2 = H >> 1, w2 = W >> 1;
+        const int b = m / (h2 * w2), ij = m - b * h2 * w2, i = ij / w2, j = ij - i * w2;
+        const float mu = d.aux0[m], rs = d.aux1[m];
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = k0 + e, blk = k / C, c = k - blk * C, wp = blk >> 1, hp = blk & 1;
+            const float x = ((const float*)d.ptr)[(((long)b * H + 2 * i + hp) * W + 2 * j + wp) * C + c];
+            v[e] = (x - mu) * rs * d.aux2[k] + d.aux3[k];
+        }
+        return pack8(v);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Epilogues: tile(stage, m0, n0, lane) consumes a 16-row x 64-col fp32 sub-tile held in wave-private LDS
+// (pitch EP floats): rows m0..m0+15, cols n0..n0+63 of C.
+// ------------------------------------------------------------------------------------------------
+constexpr int EP = 68;     // staging pitch in floats
+
+struct EpiDesc {
+    void* out;              // primary output
+    const float* bias;      // [N] or null
+    const void* aux;        // kind specific (pre-activation for GELU', skip input, ...)
+    float* aux_out;         // kind specific second output (rnorm)
+    const int32_t* rowidx;  // optional scatter table: logical row -> destination row, <0 = skip
+    long ld;                // output row pitch (elements)
+    int M, N;
+    int p0, p1, p2, p3, p4;
+};
+
+enum { E_BF16 = 0, E_F32 = 1, E_QKV_HEADS = 2, E_GELU_GRAD = 3, E_UNPATCH = 4, E_HEADS = 5, E_F32_ACC = 6 };
+
+template <int KIND> struct Epi;
+
+// row-major bf16 store (+bias): lane -> (row = lane/4, 16 columns)
+template <> struct Epi<E_BF16> {
+    EpiDesc d;
+    __device__ __forceinline__ void tile(const float* st, int m0, int n0, int lane) const {
+        const int r = lane >> 2, c0 = (lane & 3) * 16, m = m0 + r, n = n0 + c0;
+        if (m >= d.M || n >= d.N) return;
+        long dst = m;
+        if (d.rowidx) { dst = d.rowidx[m]; if (dst < 0) return; }
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(f32x4*)(v + 4 * i) = *(const f32x4*)(st + r * EP + c0 + 4 * i);
+        if (d.bias) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] += (n + i < d.N) ? d.bias[n + i] : 0.f;
+        }
+        uint16_t* o = (uint16_t*)d.out + dst * d.ld + n;
+        if (n + 16 <= d.N) {
+            *(uint4*)o = pack8(v);
+            *(uint4*)(o + 8) = pack8(v + 8);
+        } else {
+            for (int i = 0; i < 16 && n + i < d.N; ++i) o[i] = f2bf(v[i]);
+        }
+    }
+};
+// row-major fp32 store (+bias) (+aux: an fp32 tensor of the output's shape added at the destination row, e.g. the
+// gradient that arrives over the residual connection)
+template <> struct Epi<E_F32> {
+    EpiDesc d;
+    __device__ __forceinline__ void tile(const float* st, int m0, int n0, int lane) const {
+        const int r = lane >> 2, c0 = (lane & 3) * 16, m = m0 + r, n = n0 + c0;
+        if (m >= d.M || n >= d.N) return;
+        long dst = m;
+        if (d.rowidx) { dst = d.rowidx[m]; if (dst < 0) return; }
+        float* o = (float*)d.out + dst * d.ld + n;
+        const float* ax = d.aux ? (const float*)d.aux + dst * d.ld + n : nullptr;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 v = *(const f32x4*)(st + r * EP + c0 + 4 * i);
+            if (n + 4 * i + 4 <= d.N) {
+                if (d.bias) v += *(const f32x4*)(d.bias + n + 4 * i);
+                if (ax) v += *(const f32x4*)(ax + 4 * i);
+                *(f32x4*)(o + 4 * i) = v;
+            } else {
+                for (int j = 0; j < 4 && n + 4 * i + j < d.N; ++j)
+                    o[4 * i + j] = v[j] + (d.bias ? d.bias[n + 4 * i + j] : 0.f) + (ax ? ax[4 * i + j] : 0.f);
+            }
+        }
+    }
+};
+// fp32 accumulate into the destination (dx of the second branch summed into the first), no bias
+template <> struct Epi<E_F32_ACC> {
+    EpiDesc d;
+    __device__ __forceinline__ void tile(const float* st, int m0, int n0, int lane) const {
+        const int r = lane >> 2, c0 = (lane & 3) * 16, m = m0 + r, n = n0 + c0;
+        if (m >= d.M || n >= d.N) return;
+        long dst = m;
+        if (d.rowidx) { dst = d.rowidx[m]; if (dst < 0) return; }
+        float* o = (float*)d.out + dst * d.ld + n;
+        for (int i = 0; i < 16 && n + i < d.N; ++i) o[i] += st[r * EP + c0 + i];
+    }
+};
+// q/k/v split into the head-major window layout with L2-normalised q and k (swinv2_global.py:300-304).
+// logical col n = (part*h + head)*DP + j (head dim padded to DP by swv2_prep_weight, padded columns are exact zeros);
+// logical row m = bw*Lp + t (rows t >= L are padding and are written as zeros).
+// p0 = heads, p2 = Lp, p3 = DP, p4 = L ; out = qkvh ; aux_out = rnorm [Bw][h][2][Lp] ; bias is padded like n.
+// PARTS = 3 with normalisation of parts 0 and 1 (E_QKV_HEADS) or 1 without (E_HEADS).
+template <int DPc, bool NORM>
+__device__ __forceinline__ void heads_item(const EpiDesc& d, const float* st, int m0, int n0, int lane) {
+    const int h = d.p0, Lp = d.p2, L = d.p4, S = NORM ? 3 : 1;
+    constexpr int SLOTS = 64 / DPc;                   // heads per 64-column sub-tile
+    for (int it = lane; it < 16 * SLOTS; it += 64) {
+        const int r = it & 15, slot = it >> 4;
+        const int nb = n0 + slot * DPc, m = m0 + r;
+        if (m >= d.M || nb >= d.N) continue;
+        const int ph = nb / DPc, part = ph / h, hd = ph - part * h;
+        const int bw = m / Lp, t = m - bw * Lp;
+        const bool valid = t < L;
+        float v[DPc];
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < DPc; ++j) {
+            float x = 0.f;
+            if (valid) x = st[r * EP + slot * DPc + j] + (d.bias ? d.bias[nb + j] : 0.f);
+            v[j] = x;
+            ss = fmaf(x, x, ss);
+        }
+        float rn = 1.f;
+        if (NORM && part < 2) {
+            rn = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+            d.aux_out[(((long)bw * h + hd) * 2 + part) * Lp + t] = valid ? rn : 0.f;
+        }
+        uint16_t* o = (uint16_t*)d.out + ((((long)bw * h + hd) * S + part) * Lp + t) * DPc;
+#pragma unroll
+        for (int j = 0; j < DPc; j += 8) {
+            float w[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w[e] = v[j + e] * rn;
+            *(uint4*)(o + j) = pack8(w);
+        }
+    }
+}
+template <> struct Epi<E_QKV_HEADS> {
+    EpiDesc d;
+    __device__ __forceinline__ void tile(const float* st, int m0, int n0, int lane) const {
+        if (d.p3 == 16) heads_item<16, true>(d, st, m0, n0, lane); else heads_item<32, true>(d, st, m0, n0, lane);
+    }
+};
+// heads split without normalisation: [Bw][h][1][Lp][DP] (gradient of the merged attention output)
+template <> struct Epi<E_HEADS> {
+    EpiDesc d;
+    __device__ __forceinline__ void tile(const float* st, int m0, int n0, int lane) const {
+        if (d.p3 == 16) heads_item<16, false>(d, st, m0, n0, lane); else heads_item<32, false>(d, st, m0, n0, lane);
+    }
+};
+// dh = (acc) * GELU'(pre-activation) ; aux = pre-activation bf16 [M][N] row-major, same pitch as out
+template <> struct Epi<E_GELU_GRAD> {
+    EpiDesc d;
+    __device__ __forceinline__ void tile(const float* st, int m0, int n0, int lane) const {
+        const int r = lane >> 2, c0 = (lane & 3) * 16, m = m0 + r, n = n0 + c0;
+        if (m >= d.M || n >= d.N) return;
+        const uint16_t* pre = (const uint16_t*)d.aux + (long)m * d.ld + n;
+        uint16_t* o = (uint16_t*)d.out + (long)m * d.ld + n;
+        float v[16], hv[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(f32x4*)(v + 4 * i) = *(const f32x4*)(st + r * EP + c0 + 4 * i);
+        if (n + 16 <= d.N) {
+            unpack8(*(const uint4*)pre, hv);
+            unpack8(*(const uint4*)(pre + 8), hv + 8);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] *= gelu_grad_f(hv[i]);
+            *(uint4*)o = pack8(v);
+            *(uint4*)(o + 8) = pack8(v + 8);
+        } else {
+            for (int i = 0; i < 16 && n + i < d.N; ++i) o[i] = f2bf(v[i] * gelu_grad_f(bf2f(pre[i])));
+        }
+    }
+};
+// head Linear + un-patchify (+ residual skip), swinv2_global.py:784-802.  The bf16 head weight is stored with its
+// rows permuted to n' = c*16 + p*4 + q (swv2_cast_weights), so 16 consecutive columns are one channel's 4x4 patch:
+//   y[b][c][4i+p][4j+q] = acc[m=(b,i,j)][c*16 + p*4 + q] (+ skip[b][c][4i+p][4j+q])
+// p0 = Cout, p1 = H, p2 = W, p3 = Cskip (channels of the skip tensor, 0 = no skip) ; aux = skip ; out = y
+template <> struct Epi<E_UNPATCH> {
+    EpiDesc d;
+    __device__ __forceinline__ void tile(const float* st, int m0, int n0, int lane) const {
+        const int Cout = d.p0, H = d.p1, W = d.p2, Cs = d.p3, gw = W >> 2, gh = H >> 2;
+        // 16 rows x 4 channels x 4 p = 256 float4 items; lane -> row fastest so stores run along W
+        for (int it = lane; it < 256; it += 64) {
+            const int r = it & 15, cp = it >> 4, cl = cp >> 2, p = cp & 3;
+            const int m = m0 + r, c = (n0 >> 4) + cl;
+            if (m >= d.M || c >= Cout) continue;
+            const int b = m / (gh * gw), ij = m - b * gh * gw, i = ij / gw, j = ij - i * gw;
+            f32x4 v = *(const f32x4*)(st + r * EP + cl * 16 + p * 4);
+            if (Cs) v += *(const f32x4*)((const float*)d.aux + (((long)b * Cs + c) * H + 4 * i + p) * W + 4 * j);
+            *(f32x4*)((float*)d.out + (((long)b * Cout + c) * H + 4 * i + p) * W + 4 * j) = v;
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// NT kernel
+// ------------------------------------------------------------------------------------------------
+template <int AK, int EK>
+__global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(ALoad<AK> al, const uint16_t* __restrict__ Wb, Epi<EK> ep,
+                                                           int M, int N, int K) {
+    __shared__ __attribute__((aligned(16))) uint16_t smem[2 * (BM + BN) * BK];   // [buf][A | B] = 64 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, g = lane >> 4;
+    const int wr = wave >> 1, wc = wave & 1;              // 2 x 2 waves, 64 x 64 each
+    const int m_base = blockIdx.x * BM;
+    const int ntiles = (N + BN - 1) / BN, ksteps = (K + BK - 1) / BK, steps = ntiles * ksteps;
+
+    uint4 ra[4], rb[4];
+    auto issue = [&](int s) {
+        const int nt = s / ksteps, ks = s - nt * ksteps;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + i * NTHREADS;
+            int r, kc;
+            if (ALoad<AK>::ROW_FASTEST) { r = c & (BM - 1); kc = c >> 7; } else { r = c >> 3; kc = c & 7; }
+            ra[i] = al.chunk(m_base + r, ks * BK + kc * 8);
+            const int rn = c >> 3, kcb = c & 7, n = nt * BN + rn, k0 = ks * BK + kcb * 8;
+            rb[i] = (n < N && k0 < K) ? *(const uint4*)(Wb + (long)n * K + k0) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto commit = [&](int buf) {
+        uint16_t* As = smem + buf * (BM + BN) * BK;
+        uint16_t* Bs = As + BM * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + i * NTHREADS;
+            int r, kc;
+            if (ALoad<AK>::ROW_FASTEST) { r = c & (BM - 1); kc = c >> 7; } else { r = c >> 3; kc = c & 7; }
+            *(uint4*)(As + swz(r, kc)) = ra[i];
+            *(uint4*)(Bs + swz(c >> 3, c & 7)) = rb[i];
+        }
+    };
+
+    f32x4 acc[4][4];
+    issue(0);
+    for (int s = 0; s < steps; ++s) {
+        const int nt = s / ksteps, ks = s - nt * ksteps, buf = s & 1;
+        if (ks == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        commit(buf);
+        __syncthreads();
+        if (s + 1 < steps) issue(s + 1);
+        const uint16_t* As = smem + buf * (BM + BN) * BK;
+        const uint16_t* Bs = As + BM * BK;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = *(const bf16x8*)(As + swz(wr * 64 + i * 16 + fr, kk * 4 + g));
+                bf[i] = *(const bf16x8*)(Bs + swz(wc * 64 + i * 16 + fr, kk * 4 + g));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
+        }
+        if (ks == ksteps - 1) {
+            __syncthreads();                               // every wave is done reading buf -> reuse it as staging
+            float* st = (float*)(smem + buf * (BM + BN) * BK) + wave * 16 * EP;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) st[(4 * g + r) * EP + 16 * j + fr] = acc[i][j][r];
+                ep.tile(st, m_base + wr * 64 + i * 16, nt * BN + wc * 64, lane);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// TN kernel: dW[N][K] (+)= sum over a slice of rows of dY^T X ; optional db[N] = column sums of dY
+// grid = (ntiles_n * ntiles_k, splits).  Output accumulated with fp32 atomics (caller zeroes dW / db).
+// ------------------------------------------------------------------------------------------------
+constexpr int TM = 32;                      // rows per step
+constexpr int TP = 136;                     // LDS row pitch (elements) of the [TM][128] tiles: 272 B
+
+template <int YK, int XK>
+__global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(ALoad<YK> yl, ALoad<XK> xl, float* __restrict__ dW,
+                                                           float* __restrict__ db, const int32_t* __restrict__ nmap,
+                                                           const int32_t* __restrict__ kmap, int ldw, int M, int N,
+                                                           int K, int ntk, int rows_per_split) {
+    __shared__ __attribute__((aligned(16))) uint16_t smem[2 * 2 * TM * TP];      // [buf][Y | X][TM][TP]
+    __shared__ float dbs[BN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, g = lane >> 4;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int tn = blockIdx.x / ntk, tk = blockIdx.x - tn * ntk;
+    const int n_base = tn * BN, k_base = tk * BN;
+    const int m_lo = blockIdx.y * rows_per_split;
+    const int m_hi = min(M, m_lo + rows_per_split);
+    const int steps = (m_hi - m_lo + TM - 1) / TM;
+    if (steps <= 0) return;
+    const bool want_db = (db != nullptr) && (tk == 0);
+    if (tid < BN) dbs[tid] = 0.f;
+
+    // staging: each tile is TM x 16 chunks = 512 chunks -> 2 per thread per operand; thread keeps a fixed chunk column
+    const int srow = tid >> 4, scol = tid & 15;          // rows srow, srow + 16
+    uint4 ry[2], rx[2];
+    float colsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto issue = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m_lo + s * TM + srow + 16 * i;
+            const bool ok = m < m_hi;
+            ry[i] = ok ? yl.chunk(m, n_base + scol * 8) : make_uint4(0, 0, 0, 0);
+            rx[i] = ok ? xl.chunk(m, k_base + scol * 8) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto commit = [&](int buf) {
+        uint16_t* Ys = smem + buf * 2 * TM * TP;
+        uint16_t* Xs = Ys + TM * TP;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *(uint4*)(Ys + (srow + 16 * i) * TP + scol * 8) = ry[i];
+            *(uint4*)(Xs + (srow + 16 * i) * TP + scol * 8) = rx[i];
+            if (want_db) {
+                float v[8];
+                unpack8(ry[i], v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) colsum[e] += v[e];
+            }
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    issue(0);
+    for (int s = 0; s < steps; ++s) {
+        const int buf = s & 1;
+        commit(buf);
+        __syncthreads();
+        if (s + 1 < steps) issue(s + 1);
+        const uint16_t* Ys = smem + buf * 2 * TM * TP;
+        const uint16_t* Xs = Ys + TM * TP;
+        // A operand = dY^T (rows n, k = m), B operand = X (k = m, cols k'): both are transposed reads of row-major tiles
+        bf16x8 af[4], bf[4];
+        const int r0 = 8 * g + (fr >> 2), cc = (fr & 3) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bf16x4 a0 = lds_tr_read(Ys + r0 * TP + wr * 64 + i * 16 + cc);
+            const bf16x4 a1 = lds_tr_read(Ys + (r0 + 4) * TP + wr * 64 + i * 16 + cc);
+            const bf16x4 b0 = lds_tr_read(Xs + r0 * TP + wc * 64 + i * 16 + cc);
+            const bf16x4 b1 = lds_tr_read(Xs + (r0 + 4) * TP + wc * 64 + i * 16 + cc);
+            af[i] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+            bf[i] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
+    }
+    // accumulate the tile: rows n = n_base + wr*64 + 16i + 4g + r, cols k = k_base + wc*64 + 16j + fr
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int n = n_base + wr * 64 + 16 * i + 4 * g + r, k = k_base + wc * 64 + 16 * j + fr;
+                if (n >= N || k >= K) continue;
+                if (nmap) n = nmap[n];
+                if (kmap) k = kmap[k];
+                if (n >= 0 && k >= 0) atomicAdd(dW + (long)n * ldw + k, acc[i][j][r]);
+            }
+    if (want_db) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicAdd(&dbs[scol * 8 + e], colsum[e]);
+        __syncthreads();
+        if (tid < BN && n_base + tid < N) {
+            const int n = nmap ? nmap[n_base + tid] : n_base + tid;
+            if (n >= 0) atomicAdd(db + n, dbs[tid]);
+        }
+    }
+}
+
+template <int AK>
+ALoad<AK> make_loader(const swv2_operand* o) {
+    ALoad<AK> l;
+    l.d.ptr = o->ptr; l.d.rowidx = o->rowidx; l.d.aux0 = o->aux0; l.d.aux1 = o->aux1; l.d.aux2 = o->aux2;
+    l.d.aux3 = o->aux3; l.d.ld = o->ld; l.d.M = o->rows; l.d.K = o->cols;
+    l.d.p0 = o->p[0]; l.d.p1 = o->p[1]; l.d.p2 = o->p[2]; l.d.p3 = o->p[3];
+    return l;
+}
+
+template <int AK, int EK>
+int launch_nt2(const swv2_operand* a, const void* w, const swv2_epilogue* e, int M, int N, int K, hipStream_t st) {
+    Epi<EK> ep;
+    ep.d.out = e->out; ep.d.bias = e->bias; ep.d.aux = e->aux; ep.d.aux_out = e->aux_out; ep.d.rowidx = e->rowidx;
+    ep.d.ld = e->ld; ep.d.M = M; ep.d.N = N;
+    ep.d.p0 = e->p[0]; ep.d.p1 = e->p[1]; ep.d.p2 = e->p[2]; ep.d.p3 = e->p[3]; ep.d.p4 = e->p[4];
+    hipLaunchKernelGGL((gemm_nt_kernel<AK, EK>), dim3(cdiv(M, BM)), dim3(NTHREADS), 0, st, make_loader<AK>(a),
+                       (const uint16_t*)w, ep, M, N, K);
+    SWV2_CHECK_LAUNCH("swv2_linear");
+    return SWV2_OK;
+}
+
+template <int AK>
+int launch_nt1(const swv2_operand* a, const void* w, const swv2_epilogue* e, int M, int N, int K, hipStream_t st) {
+    switch (e->kind) {
+        case SWV2_EPI_BF16: return launch_nt2<AK, E_BF16>(a, w, e, M, N, K, st);
+        case SWV2_EPI_F32: return launch_nt2<AK, E_F32>(a, w, e, M, N, K, st);
+        case SWV2_EPI_F32_ACC: return launch_nt2<AK, E_F32_ACC>(a, w, e, M, N, K, st);
+        case SWV2_EPI_QKV_HEADS: return launch_nt2<AK, E_QKV_HEADS>(a, w, e, M, N, K, st);
+        case SWV2_EPI_HEADS: return launch_nt2<AK, E_HEADS>(a, w, e, M, N, K, st);
+        case SWV2_EPI_GELU_GRAD: return launch_nt2<AK, E_GELU_GRAD>(a, w, e, M, N, K, st);
+        case SWV2_EPI_UNPATCH: return launch_nt2<AK, E_UNPATCH>(a, w, e, M, N, K, st);
+    }
+    swv2_set_error("swv2_linear: unknown epilogue kind %d", e->kind);
+    return SWV2_ERR_INVALID;
+}
+
+template <int YK>
+int launch_tn1(const swv2_operand* y, const swv2_operand* x, float* dW, float* db, const int32_t* nmap,
+               const int32_t* kmap, int ldw, int M, int N, int K, int splits, hipStream_t st) {
+    const int ntn = cdiv(N, BN), ntk = cdiv(K, BN);
+    int rows = cdiv(M, splits);
+    rows = cdiv(rows, TM) * TM;
+    dim3 grid(ntn * ntk, cdiv(M, rows));
+#define TN_CASE(XK)                                                                                              \
+    hipLaunchKernelGGL((gemm_tn_kernel<YK, XK>), grid, dim3(NTHREADS), 0, st, make_loader<YK>(y), make_loader<XK>(x), \
+                       dW, db, nmap, kmap, ldw, M, N, K, ntk, rows)
+    switch (x->kind) {
+        case SWV2_OP_F32: TN_CASE(A_F32); break;
+        case SWV2_OP_BF16: TN_CASE(A_BF16); break;
+        case SWV2_OP_BF16_GELU: TN_CASE(A_BF16_GELU); break;
+        case SWV2_OP_HEADS: TN_CASE(A_HEADS); break;
+        case SWV2_OP_PATCH: TN_CASE(A_PATCH); break;
+        case SWV2_OP_MERGE_LN: TN_CASE(A_MERGE_LN); break;
+        default: swv2_set_error("swv2_linear_wgrad: unknown X operand kind %d", x->kind); return SWV2_ERR_INVALID;
+    }
+#undef TN_CASE
+    SWV2_CHECK_LAUNCH("swv2_linear_wgrad");
+    return SWV2_OK;
+}
+
+int check_operand(const swv2_operand* o, const char* who) {
+    SWV2_CHECK_ARG(o && o->ptr, "%s: null operand", who);
+    SWV2_CHECK_ARG(o->rows > 0 && o->cols > 0, "%s: empty operand", who);
+    SWV2_CHECK_ARG(o->cols % 8 == 0, "%s: operand width %d must be a multiple of 8", who, o->cols);
+    SWV2_CHECK_ARG(((uintptr_t)o->ptr & 15) == 0, "%s: operand pointer must be 16-byte aligned", who);
+    if (o->kind == SWV2_OP_F32 || o->kind == SWV2_OP_BF16 || o->kind == SWV2_OP_BF16_GELU)
+        SWV2_CHECK_ARG(o->ld % 8 == 0 && o->ld >= o->cols, "%s: row pitch %ld must be a multiple of 8 and >= cols", who, o->ld);
+    if (o->kind == SWV2_OP_PATCH)
+        SWV2_CHECK_ARG(o->p[1] % 4 == 0 && o->p[2] % 4 == 0 && o->cols == o->p[0] * 16, "%s: bad patch geometry", who);
+    if (o->kind == SWV2_OP_MERGE_LN)
+        SWV2_CHECK_ARG(o->aux0 && o->aux1 && o->aux2 && o->aux3 && o->cols == 4 * o->p[2], "%s: bad merge operand", who);
+    return SWV2_OK;
+}
+
+}  // namespace
+
+extern "C" int swv2_linear(const swv2_operand* a, const void* w_bf16, const swv2_epilogue* e, int N, void* stream) {
+    int rc = check_operand(a, "swv2_linear");
+    if (rc) return rc;
+    SWV2_CHECK_ARG(w_bf16 && e && e->out && N > 0, "swv2_linear: null weight / epilogue / N");
+    SWV2_CHECK_ARG(((uintptr_t)w_bf16 & 15) == 0 && ((uintptr_t)e->out & 15) == 0, "swv2_linear: unaligned pointer");
+    if (e->kind == SWV2_EPI_BF16 || e->kind == SWV2_EPI_GELU_GRAD)
+        SWV2_CHECK_ARG(e->ld % 8 == 0 && e->ld >= N, "swv2_linear: output pitch %ld must be a multiple of 8 and >= N", e->ld);
+    if (e->kind == SWV2_EPI_F32 || e->kind == SWV2_EPI_F32_ACC)
+        SWV2_CHECK_ARG(e->ld % 4 == 0 && e->ld >= N, "swv2_linear: output pitch %ld must be a multiple of 4 and >= N", e->ld);
+    if (e->kind == SWV2_EPI_QKV_HEADS || e->kind == SWV2_EPI_HEADS)
+        SWV2_CHECK_ARG((e->p[3] == 16 || e->p[3] == 32) && N % e->p[3] == 0 && e->p[0] > 0 && e->p[2] > 0,
+                       "swv2_linear: head-split epilogue needs DP in {16,32} and N a multiple of DP (DP=%d N=%d)", e->p[3], N);
+    if (e->kind == SWV2_EPI_UNPATCH) SWV2_CHECK_ARG(N == e->p[0] * 16, "swv2_linear: un-patchify needs N == Cout*16");
+    const int M = a->rows, K = a->cols;
+    hipStream_t st = (hipStream_t)stream;
+    switch (a->kind) {
+        case SWV2_OP_F32: return launch_nt1<A_F32>(a, w_bf16, e, M, N, K, st);
+        case SWV2_OP_BF16: return launch_nt1<A_BF16>(a, w_bf16, e, M, N, K, st);
+        case SWV2_OP_BF16_GELU: return launch_nt1<A_BF16_GELU>(a, w_bf16, e, M, N, K, st);
+        case SWV2_OP_HEADS: return launch_nt1<A_HEADS>(a, w_bf16, e, M, N, K, st);
+        case SWV2_OP_PATCH: return launch_nt1<A_PATCH>(a, w_bf16, e, M, N, K, st);
+        case SWV2_OP_MERGE_LN: return launch_nt1<A_MERGE_LN>(a, w_bf16, e, M, N, K, st);
+    }
+    swv2_set_error("swv2_linear: unknown operand kind %d", a->kind);
+    return SWV2_ERR_INVALID;
+}
+
+extern "C" int swv2_linear_wgrad(const swv2_operand* dy, const swv2_operand* x, float* dW, float* db,
+                                 const int32_t* nmap, const int32_t* kmap, int ldw, int splits, void* stream) {
+    int rc = check_operand(dy, "swv2_linear_wgrad(dy)");
+    if (rc) return rc;
+    rc = check_operand(x, "swv2_linear_wgrad(x)");
+    if (rc) return rc;
+    SWV2_CHECK_ARG(dW && splits > 0 && ldw > 0, "swv2_linear_wgrad: null dW, bad splits or bad pitch");
+    SWV2_CHECK_ARG(dy->rows == x->rows, "swv2_linear_wgrad: row counts differ (%d vs %d)", dy->rows, x->rows);
+    const int M = dy->rows, N = dy->cols, K = x->cols;
+    hipStream_t st = (hipStream_t)stream;
+    switch (dy->kind) {
+        case SWV2_OP_F32: return launch_tn1<A_F32>(dy, x, dW, db, nmap, kmap, ldw, M, N, K, splits, st);
+        case SWV2_OP_BF16: return launch_tn1<A_BF16>(dy, x, dW, db, nmap, kmap, ldw, M, N, K, splits, st);
+        case SWV2_OP_HEADS: return launch_tn1<A_HEADS>(dy, x, dW, db, nmap, kmap, ldw, M, N, K, splits, st);
+    }
+    swv2_set_error("swv2_linear_wgrad: unsupported dY operand kind %d", dy->kind);
+    return SWV2_ERR_INVALID;
+}

@@ -1,0 +1,460 @@
+// Row-wise (HBM-bound) kernels of the SwinV2 hot path: fused LayerNorm + drop-path + residual (+ window reverse /
+// un-roll scatter), its backward, weight preparation, batch sums, the geometric l2 loss, fused Adam.
+// All of them stream rows with 16-byte accesses; G lanes cooperate on one row (G = 16/32/64 by channel count).
+#include "common.h"
+
+namespace {
+
+constexpr int LN_BLOCK = 256;
+
+__device__ __forceinline__ void unpack8f(uint4 c, float* v) {
+    const uint32_t w[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = __uint_as_float(w[i] << 16);
+        v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ uint4 pack8f(const float* v) {
+    uint4 r;
+    r.x = f2bf2(v[0], v[1]); r.y = f2bf2(v[2], v[3]); r.z = f2bf2(v[4], v[5]); r.w = f2bf2(v[6], v[7]);
+    return r;
+}
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// y[dst] = res[rsrc] + scale[b] * (LN(a[m]) * gamma + beta)
+//   a     : [M][C] bf16 branch output (proj or fc2 or patch conv), logical rows m
+//   dst   : rowidx ? rowidx[m] : m   (window reverse + un-roll folded into the scatter; <0 = padded row, skipped)
+//   res   : fp32 rows; row = res_mod ? dst % res_mod : dst  (res_mod = T broadcasts pos_embed over the batch)
+//   scale : per-sample drop-path factor, b = dst / rows_per_sample ; null = 1
+// saves mean / rstd per logical row for the backward.  CH = chunks (of 8 channels) per lane.
+// reference: x + drop_path(norm(branch(x)))  swinv2_global.py:490,496 ; PatchEmbed norm + pos_embed :545,780
+// ------------------------------------------------------------------------------------------------
+template <int G, int CH>
+__global__ __launch_bounds__(LN_BLOCK) void ln_residual_fwd_kernel(
+    const uint16_t* __restrict__ a, const float* __restrict__ res, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ scale, const int32_t* __restrict__ rowidx,
+    float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, int M, int C, int res_mod,
+    int rows_per_sample, float eps) {
+    const int gl = threadIdx.x % G;
+    const int rows_per_block = LN_BLOCK / G;
+    for (long m = (long)blockIdx.x * rows_per_block + threadIdx.x / G; m < M; m += (long)gridDim.x * rows_per_block) {
+        long dst = m;
+        if (rowidx) dst = rowidx[m];
+        float v[CH][8];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int c0 = (gl + i * G) * 8;
+            if (c0 < C) {
+                unpack8f(*(const uint4*)(a + m * C + c0), v[i]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += v[i][e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+            }
+        }
+        const float mu = group_sum<G>(s) / C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+            if ((gl + i * G) * 8 < C) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mu; q = fmaf(d, d, q); }
+            }
+        const float rs = rsqrtf(group_sum<G>(q) / C + eps);
+        if (gl == 0) { mean[m] = mu; rstd[m] = rs; }
+        if (dst < 0) continue;
+        const float sc = scale ? scale[dst / rows_per_sample] : 1.f;
+        const long rrow = res_mod ? dst % res_mod : dst;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int c0 = (gl + i * G) * 8;
+            if (c0 >= C) continue;
+#pragma unroll
+            for (int hlf = 0; hlf < 2; ++hlf) {
+                const f32x4 gm = *(const f32x4*)(gamma + c0 + 4 * hlf), bt = *(const f32x4*)(beta + c0 + 4 * hlf);
+                f32x4 r = res ? *(const f32x4*)(res + rrow * C + c0 + 4 * hlf) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[e] += sc * ((v[i][4 * hlf + e] - mu) * rs * gm[e] + bt[e]);
+                *(f32x4*)(y + dst * C + c0 + 4 * hlf) = r;
+            }
+        }
+    }
+}
+
+// backward of the above w.r.t. the branch output a, gamma, beta.  dy is the gradient of y (fp32, destination rows);
+// the gradient w.r.t. `res` is dy itself (the caller owns that accumulation).
+//   da[m] = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)),  g = scale * dy[dst] * gamma   (zeros for padded rows)
+//   dgamma += sum_rows scale * dy * xhat ; dbeta += sum_rows scale * dy      (fp32 atomics, one per column per block)
+template <int G, int CH>
+__global__ __launch_bounds__(LN_BLOCK) void ln_residual_bwd_kernel(
+    const uint16_t* __restrict__ a, const float* __restrict__ dy, const float* __restrict__ gamma,
+    const float* __restrict__ scale, const int32_t* __restrict__ rowidx, const float* __restrict__ mean,
+    const float* __restrict__ rstd, uint16_t* __restrict__ da, float* __restrict__ dgamma, float* __restrict__ dbeta,
+    int M, int C, int rows_per_sample) {
+    const int gl = threadIdx.x % G;
+    const int rows_per_block = LN_BLOCK / G;
+    float dg[CH][8], dbt[CH][8];
+#pragma unroll
+    for (int i = 0; i < CH; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { dg[i][e] = 0.f; dbt[i][e] = 0.f; }
+
+    for (long m = (long)blockIdx.x * rows_per_block + threadIdx.x / G; m < M; m += (long)gridDim.x * rows_per_block) {
+        long dst = m;
+        if (rowidx) dst = rowidx[m];
+        if (dst < 0) {                               // padded row: zero gradient
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int c0 = (gl + i * G) * 8;
+                if (c0 < C) *(uint4*)(da + m * C + c0) = make_uint4(0, 0, 0, 0);
+            }
+            continue;
+        }
+        const float mu = mean[m], rs = rstd[m];
+        const float sc = scale ? scale[dst / rows_per_sample] : 1.f;
+        float xh[CH][8], gg[CH][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int c0 = (gl + i * G) * 8;
+            if (c0 < C) {
+                float av[8];
+                unpack8f(*(const uint4*)(a + m * C + c0), av);
+#pragma unroll
+                for (int hlf = 0; hlf < 2; ++hlf) {
+                    const f32x4 d4 = *(const f32x4*)(dy + dst * C + c0 + 4 * hlf);
+                    const f32x4 gm = *(const f32x4*)(gamma + c0 + 4 * hlf);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = 4 * hlf + e;
+                        const float d = sc * d4[e];
+                        xh[i][k] = (av[k] - mu) * rs;
+                        gg[i][k] = d * gm[e];
+                        dg[i][k] = fmaf(d, xh[i][k], dg[i][k]);
+                        dbt[i][k] += d;
+                        s1 += gg[i][k];
+                        s2 = fmaf(gg[i][k], xh[i][k], s2);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { xh[i][e] = 0.f; gg[i][e] = 0.f; }
+            }
+        }
+        s1 = group_sum<G>(s1) / C;
+        s2 = group_sum<G>(s2) / C;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int c0 = (gl + i * G) * 8;
+            if (c0 >= C) continue;
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = rs * (gg[i][e] - s1 - xh[i][e] * s2);
+            *(uint4*)(da + m * C + c0) = pack8f(o);
+        }
+    }
+    // block reduction of dgamma / dbeta: rows_per_block partial sums per column
+    __shared__ float sg[LN_BLOCK * 8], sb[LN_BLOCK * 8];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int c0 = (gl + i * G) * 8;
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sg[threadIdx.x * 8 + e] = dg[i][e]; sb[threadIdx.x * 8 + e] = dbt[i][e]; }
+        __syncthreads();
+        if (threadIdx.x < G && c0 < C) {             // first row-group's lanes sum over the row groups
+            float tg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int r = 0; r < rows_per_block; ++r)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    tg[e] += sg[(r * G + gl) * 8 + e];
+                    tb[e] += sb[(r * G + gl) * 8 + e];
+                }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                atomicAdd(dgamma + c0 + e, tg[e]);
+                atomicAdd(dbeta + c0 + e, tb[e]);
+            }
+        }
+    }
+}
+
+// out_bf16[i][j] = W'[rmap ? rmap[i] : i][cmap ? cmap[j] : j]  (0 where a map entry is < 0), W' = transpose ? w^T : w
+__global__ void prep_weight_kernel(const float* __restrict__ w, int rows, int cols, int transpose,
+                                   const int32_t* __restrict__ rmap, int out_rows, const int32_t* __restrict__ cmap,
+                                   int out_cols, uint16_t* __restrict__ out) {
+    const long n = (long)out_rows * out_cols;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
+        const int i = idx / out_cols, j = idx - (long)i * out_cols;
+        const int r = rmap ? rmap[i] : i, c = cmap ? cmap[j] : j;
+        float v = 0.f;
+        if (r >= 0 && c >= 0) v = transpose ? w[(long)c * cols + r] : w[(long)r * cols + c];
+        out[idx] = f2bf(v);
+    }
+}
+
+// out[i] (+)= sum_b in[b][i]
+__global__ void batch_sum_kernel(const float* __restrict__ in, float* __restrict__ out, int B, long n, int accumulate) {
+    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long)gridDim.x * blockDim.x * 4) {
+        f32x4 s = accumulate ? *(const f32x4*)(out + i) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < B; ++b) s += *(const f32x4*)(in + (long)b * n + i);
+        *(f32x4*)(out + i) = s;
+    }
+}
+
+// per-row mean / rstd of the 2x2-merged rows (PatchMerging LayerNorm(4C), swinv2_global.py:521)
+__global__ void merge_stats_kernel(const float* __restrict__ x, float* __restrict__ mean, float* __restrict__ rstd,
+                                   int B, int H, int W, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int h2 = H >> 1, w2 = W >> 1;
+    const long M = (long)B * h2 * w2;
+    for (long m = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); m < M; m += (long)gridDim.x * (blockDim.x >> 6)) {
+        const int b = m / (h2 * w2), ij = m - (long)b * h2 * w2, i = ij / w2, j = ij - i * w2;
+        float s = 0.f, q = 0.f;
+        for (int k = lane; k < 4 * C; k += 64) {
+            const int blk = k / C, c = k - blk * C, wp = blk >> 1, hp = blk & 1;
+            const float v = x[(((long)b * H + 2 * i + hp) * W + 2 * j + wp) * C + c];
+            s += v;
+            q = fmaf(v, v, q);
+        }
+        s = wave_sum(s);
+        q = wave_sum(q);
+        const float mu = s / (4 * C);
+        const float var = fmaxf(q / (4 * C) - mu * mu, 0.f);
+        if (lane == 0) { mean[m] = mu; rstd[m] = rsqrtf(var + eps); }
+    }
+}
+
+// backward of the PatchMerging LayerNorm + gather: dn [M][4C] bf16 (grad of the normalised rows) -> dx [B][H][W][C]
+// fp32 (every x element belongs to exactly one merged row), dgamma / dbeta [4C] via atomics.
+__global__ void merge_ln_bwd_kernel(const float* __restrict__ x, const uint16_t* __restrict__ dn,
+                                    const float* __restrict__ gamma, const float* __restrict__ mean,
+                                    const float* __restrict__ rstd, float* __restrict__ dx, float* __restrict__ dgamma,
+                                    float* __restrict__ dbeta, int B, int H, int W, int C) {
+    const int lane = threadIdx.x & 63;
+    const int h2 = H >> 1, w2 = W >> 1, K = 4 * C;
+    const long M = (long)B * h2 * w2;
+    for (long m = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); m < M; m += (long)gridDim.x * (blockDim.x >> 6)) {
+        const int b = m / (h2 * w2), ij = m - (long)b * h2 * w2, i = ij / w2, j = ij - i * w2;
+        const float mu = mean[m], rs = rstd[m];
+        float s1 = 0.f, s2 = 0.f;
+        for (int k = lane; k < K; k += 64) {
+            const int blk = k / C, c = k - blk * C, wp = blk >> 1, hp = blk & 1;
+            const float xh = (x[(((long)b * H + 2 * i + hp) * W + 2 * j + wp) * C + c] - mu) * rs;
+            const float d = bf2f(dn[m * K + k]);
+            const float gg = d * gamma[k];
+            s1 += gg;
+            s2 = fmaf(gg, xh, s2);
+            atomicAdd(dgamma + k, d * xh);
+            atomicAdd(dbeta + k, d);
+        }
+        s1 = wave_sum(s1) / K;
+        s2 = wave_sum(s2) / K;
+        for (int k = lane; k < K; k += 64) {
+            const int blk = k / C, c = k - blk * C, wp = blk >> 1, hp = blk & 1;
+            const long xi = (((long)b * H + 2 * i + hp) * W + 2 * j + wp) * C + c;
+            const float xh = (x[xi] - mu) * rs;
+            const float gg = bf2f(dn[m * K + k]) * gamma[k];
+            dx[xi] = rs * (gg - s1 - xh * s2);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// geometric l2 loss (losses.py:188-232, grids.py:115-117): per (b, c) quadrature sums in one pass
+//   sums[(b*C + c)*2 + 0] = sum_{h,w} q[h] (prd - tar)^2 ; [..+1] = sum_{h,w} q[h] tar^2
+// and the backward  dprd = coef[b][c] * q[h] * (prd - tar)   (coef from the host: chain rule of the chosen l2 variant)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void loss_sums_kernel(const float* __restrict__ prd, const float* __restrict__ tar,
+                                                        const float* __restrict__ qw, float* __restrict__ sums,
+                                                        int H, int W, int slices) {
+    const int bc = blockIdx.x / slices, sl = blockIdx.x - bc * slices;
+    const long plane = (long)H * W;
+    const long lo = plane * sl / slices / 4 * 4, hi = (sl + 1 == slices) ? plane : plane * (sl + 1) / slices / 4 * 4;
+    const float* p = prd + bc * plane;
+    const float* t = tar + bc * plane;
+    float s0 = 0.f, s1 = 0.f;
+    for (long i = lo + threadIdx.x * 4; i < hi; i += 256 * 4) {
+        const f32x4 a = *(const f32x4*)(p + i), b = *(const f32x4*)(t + i);
+        const float q = qw[i / W];                 // W % 4 == 0: the 4 elements share a latitude row
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = a[e] - b[e];
+            s0 = fmaf(q * d, d, s0);
+            s1 = fmaf(q * b[e], b[e], s1);
+        }
+    }
+    s0 = wave_sum(s0);
+    s1 = wave_sum(s1);
+    __shared__ float r0[4], r1[4];
+    if ((threadIdx.x & 63) == 0) { r0[threadIdx.x >> 6] = s0; r1[threadIdx.x >> 6] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(sums + bc * 2, r0[0] + r0[1] + r0[2] + r0[3]);
+        atomicAdd(sums + bc * 2 + 1, r1[0] + r1[1] + r1[2] + r1[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict__ prd, const float* __restrict__ tar,
+                                                        const float* __restrict__ qw, const float* __restrict__ coef,
+                                                        const float* __restrict__ coef_tar, float* __restrict__ dprd,
+                                                        int H, int W, long total) {
+    const long plane = (long)H * W;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (long)gridDim.x * 256 * 4) {
+        const long bc = i / plane;
+        const float q = qw[(i - bc * plane) / W];
+        const float c = coef[bc] * q;
+        const f32x4 a = *(const f32x4*)(prd + i), b = *(const f32x4*)(tar + i);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = c * (a[e] - b[e]);
+        (void)coef_tar;
+        *(f32x4*)(dprd + i) = o;
+    }
+}
+
+// fused Adam over one flat fp32 buffer (torch.optim.Adam semantics, train.py:176: betas (0.9, 0.95), eps 1e-8,
+// no weight decay, bias correction).  step_size = lr / (1 - b1^t), bc2_sqrt = sqrt(1 - b2^t); inv_scale un-scales grads.
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long n, float b1, float b2, float eps, float step_size,
+                            float bc2_sqrt, float inv_scale) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * inv_scale;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= step_size * mi / (sqrtf(vi) / bc2_sqrt + eps);
+    }
+}
+
+template <int G, int CH>
+void launch_ln_fwd(const swv2_ln_args* a, hipStream_t st) {
+    const int rows_per_block = LN_BLOCK / G;
+    const int grid = min(cdiv(a->M, rows_per_block), 256 * 16);
+    hipLaunchKernelGGL((ln_residual_fwd_kernel<G, CH>), dim3(grid), dim3(LN_BLOCK), 0, st, (const uint16_t*)a->a, a->res,
+                       a->gamma, a->beta, a->scale, a->rowidx, a->y, a->mean, a->rstd, a->M, a->C, a->res_mod,
+                       a->rows_per_sample, a->eps);
+}
+template <int G, int CH>
+void launch_ln_bwd(const swv2_ln_args* a, hipStream_t st) {
+    const int rows_per_block = LN_BLOCK / G;
+    const int grid = min(cdiv(a->M, rows_per_block), 256 * 4);
+    hipLaunchKernelGGL((ln_residual_bwd_kernel<G, CH>), dim3(grid), dim3(LN_BLOCK), 0, st, (const uint16_t*)a->a, a->dy,
+                       a->gamma, a->scale, a->rowidx, a->mean, a->rstd, (uint16_t*)a->da, a->dgamma, a->dbeta, a->M,
+                       a->C, a->rows_per_sample);
+}
+
+int ln_check(const swv2_ln_args* a, bool bwd) {
+    SWV2_CHECK_ARG(a && a->a && a->gamma && a->mean && a->rstd, "ln_residual: null pointer");
+    SWV2_CHECK_ARG(a->M > 0 && a->C > 0 && a->C % 8 == 0 && a->C <= 1024, "ln_residual: C=%d must be a multiple of 8, <= 1024", a->C);
+    SWV2_CHECK_ARG(a->rows_per_sample > 0, "ln_residual: rows_per_sample must be positive");
+    if (bwd) SWV2_CHECK_ARG(a->dy && a->da && a->dgamma && a->dbeta, "ln_residual_bwd: null gradient pointer");
+    else SWV2_CHECK_ARG(a->y && a->beta, "ln_residual_fwd: null output pointer");
+    return SWV2_OK;
+}
+
+}  // namespace
+
+#define LN_DISPATCH(FN)                                              \
+    const int chunks = a->C / 8;                                     \
+    if (chunks <= 16) FN<16, 1>(a, st);                              \
+    else if (chunks <= 32) FN<32, 1>(a, st);                         \
+    else if (chunks <= 64) FN<64, 1>(a, st);                         \
+    else FN<64, 2>(a, st);
+
+extern "C" int swv2_ln_residual_fwd(const swv2_ln_args* a, void* stream) {
+    int rc = ln_check(a, false);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    LN_DISPATCH(launch_ln_fwd)
+    SWV2_CHECK_LAUNCH("swv2_ln_residual_fwd");
+    return SWV2_OK;
+}
+
+extern "C" int swv2_ln_residual_bwd(const swv2_ln_args* a, void* stream) {
+    int rc = ln_check(a, true);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    LN_DISPATCH(launch_ln_bwd)
+    SWV2_CHECK_LAUNCH("swv2_ln_residual_bwd");
+    return SWV2_OK;
+}
+
+extern "C" int swv2_prep_weight(const float* w, int rows, int cols, int transpose, const int32_t* row_map, int out_rows,
+                                const int32_t* col_map, int out_cols, void* out_bf16, void* stream) {
+    SWV2_CHECK_ARG(w && out_bf16 && rows > 0 && cols > 0 && out_rows > 0 && out_cols > 0, "prep_weight: bad argument");
+    const long n = (long)out_rows * out_cols;
+    hipLaunchKernelGGL(prep_weight_kernel, dim3(min(cdiv(n, 256), 4096)), dim3(256), 0, (hipStream_t)stream, w, rows, cols,
+                       transpose, row_map, out_rows, col_map, out_cols, (uint16_t*)out_bf16);
+    SWV2_CHECK_LAUNCH("swv2_prep_weight");
+    return SWV2_OK;
+}
+
+extern "C" int swv2_batch_sum(const float* in, float* out, int B, long n, int accumulate, void* stream) {
+    SWV2_CHECK_ARG(in && out && B > 0 && n > 0 && n % 4 == 0, "batch_sum: bad argument (n must be a multiple of 4)");
+    hipLaunchKernelGGL(batch_sum_kernel, dim3(min(cdiv(n / 4, 256), 8192)), dim3(256), 0, (hipStream_t)stream, in, out, B, n,
+                       accumulate);
+    SWV2_CHECK_LAUNCH("swv2_batch_sum");
+    return SWV2_OK;
+}
+
+extern "C" int swv2_merge_stats(const float* x, float* mean, float* rstd, int B, int H, int W, int C, float eps,
+                                void* stream) {
+    SWV2_CHECK_ARG(x && mean && rstd && B > 0 && H % 2 == 0 && W % 2 == 0 && C > 0, "merge_stats: bad argument");
+    const long M = (long)B * (H / 2) * (W / 2);
+    hipLaunchKernelGGL(merge_stats_kernel, dim3(min(cdiv(M, 4), 4096)), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, B, H,
+                       W, C, eps);
+    SWV2_CHECK_LAUNCH("swv2_merge_stats");
+    return SWV2_OK;
+}
+
+extern "C" int swv2_merge_ln_bwd(const float* x, const void* dn_bf16, const float* gamma, const float* mean,
+                                 const float* rstd, float* dx, float* dgamma, float* dbeta, int B, int H, int W, int C,
+                                 void* stream) {
+    SWV2_CHECK_ARG(x && dn_bf16 && gamma && mean && rstd && dx && dgamma && dbeta, "merge_ln_bwd: null pointer");
+    const long M = (long)B * (H / 2) * (W / 2);
+    hipLaunchKernelGGL(merge_ln_bwd_kernel, dim3(min(cdiv(M, 4), 4096)), dim3(256), 0, (hipStream_t)stream, x,
+                       (const uint16_t*)dn_bf16, gamma, mean, rstd, dx, dgamma, dbeta, B, H, W, C);
+    SWV2_CHECK_LAUNCH("swv2_merge_ln_bwd");
+    return SWV2_OK;
+}
+
+extern "C" int swv2_loss_sums(const float* prd, const float* tar, const float* quad_w, float* sums, int BC, int H, int W,
+                              void* stream) {
+    SWV2_CHECK_ARG(prd && tar && quad_w && sums && BC > 0 && H > 0 && W > 0 && W % 4 == 0, "loss_sums: bad argument (W % 4)");
+    const int slices = BC >= 2048 ? 1 : cdiv(2048, BC);
+    hipLaunchKernelGGL(loss_sums_kernel, dim3(BC * slices), dim3(256), 0, (hipStream_t)stream, prd, tar, quad_w, sums, H, W,
+                       slices);
+    SWV2_CHECK_LAUNCH("swv2_loss_sums");
+    return SWV2_OK;
+}
+
+extern "C" int swv2_loss_grad(const float* prd, const float* tar, const float* quad_w, const float* coef, float* dprd,
+                              int BC, int H, int W, void* stream) {
+    SWV2_CHECK_ARG(prd && tar && quad_w && coef && dprd && BC > 0 && W % 4 == 0, "loss_grad: bad argument (W % 4)");
+    const long total = (long)BC * H * W;
+    hipLaunchKernelGGL(loss_grad_kernel, dim3(min(cdiv(total / 4, 256), 8192)), dim3(256), 0, (hipStream_t)stream, prd, tar,
+                       quad_w, coef, nullptr, dprd, H, W, total);
+    SWV2_CHECK_LAUNCH("swv2_loss_grad");
+    return SWV2_OK;
+}
+
+extern "C" int swv2_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                              float eps, int step, float grad_inv_scale, void* stream) {
+    SWV2_CHECK_ARG(p && g && m && v && n > 0 && step > 0, "adam_step: bad argument");
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(min(cdiv(n, 256), 8192)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, beta1,
+                       beta2, eps, lr / bc1, sqrtf(bc2), grad_inv_scale);
+    SWV2_CHECK_LAUNCH("swv2_adam_step");
+    return SWV2_OK;
+}

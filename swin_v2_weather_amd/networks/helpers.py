@@ -1,0 +1,56 @@
+"""Model wrappers and factory with the reference's surface (networks/helpers.py:1-55)."""
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from .swinv2_global import swinv2net
+
+
+class SingleStepWrapper(nn.Module):
+    """One step into the future; `coszen` is accepted and ignored (helpers.py:7-15)."""
+
+    def __init__(self, params, model_handle):
+        super().__init__()
+        self.model = model_handle(params)
+
+    def forward(self, inp, coszen=None):
+        return self.model(inp)
+
+
+class MultiStepWrapper(nn.Module):
+    """Autoregressive rollout over n_future + 1 steps with shared weights (helpers.py:18-41): the prediction is fed
+    back, the next step's cos-zenith channel and the trailing invariant channels are re-appended, all step outputs are
+    concatenated along the channel dimension."""
+
+    def __init__(self, params, model_handle):
+        super().__init__()
+        self.model = model_handle(params)
+        self.n_future = params.n_future
+        self.invar = 1 * params.add_orography + 2 * params.add_landmask
+
+    def forward(self, inp, coszen=None):
+        result = []
+        inpt = inp
+        invars = inp[:, -self.invar:, :, :] if self.invar else None
+        for step in range(self.n_future + 1):
+            pred = self.model(inpt)
+            result.append(pred)
+            if step == self.n_future:
+                break
+            inpt = pred
+            if coszen is not None:
+                inpt = torch.cat([inpt, coszen[:, step:step + 1, :, :]], dim=1)
+            if self.invar:
+                inpt = torch.cat([inpt, invars], dim=1)
+        return torch.cat(result, dim=1)
+
+
+def get_model(params):
+    if params.nettype == 'swin':
+        model = partial(swinv2net)
+    else:
+        raise Exception(f"model type {params.nettype} not implemented")
+    if params.n_future > 0:
+        return MultiStepWrapper(params, model)
+    return SingleStepWrapper(params, model)

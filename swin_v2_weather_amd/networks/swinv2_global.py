@@ -1,0 +1,707 @@
+"""MI355X-native SwinV2 (global weather) model behind the reference's module surface.
+
+Same constructors, attribute / state_dict names and call signatures as the reference
+`networks/swinv2_global.py` (swinv2net :57-74, SwinTransformerV2Cr :657-803, Stage :549-655, Block :324-497,
+WindowMultiHeadAttention{,NoPos} :122-321, PatchEmbed :526-546, PatchMerging :500-523), so checkpoints and
+`get_model(params)` are drop-in.  The modules here are only parameter containers + autograd glue: every
+forward / backward arithmetic op is a HIP kernel from libswv2.so (see ops.py, include/swv2.h):
+
+  block forward  = 7 launches   x --[gather roll+partition | qkv GEMM | split heads + L2-norm]--> qkvh
+                                  --[cosine window attention (MFMA), CPB bias, closed-form shift mask]--> oh
+                                  --[merge heads | proj GEMM]--> a1 --[LN + drop-path + residual, reverse+un-roll scatter]--> x1
+                                  --[fc1 GEMM]--> h --[GELU on load | fc2 GEMM]--> a2 --[LN + drop-path + residual]--> x2
+
+The module constructors draw their initial parameters in the same order as the reference's, so the same
+`torch.manual_seed` gives the same initial weights.  There is no CPU / eager fallback: forward raises if the input is
+not on a GPU or libswv2.so is not built.
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+from typing import Any, List, Optional, Tuple, Type, Union
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.utils.checkpoint import checkpoint
+
+from .. import _lib as L
+from .. import ops
+
+BF16 = torch.bfloat16
+
+
+def to_2tuple(x):
+    return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+
+
+def bchw_to_bhwc(x: torch.Tensor) -> torch.Tensor:
+    return x.permute(0, 2, 3, 1)
+
+
+def bhwc_to_bchw(x: torch.Tensor) -> torch.Tensor:
+    return x.permute(0, 3, 1, 2)
+
+
+def _need_gpu(x: torch.Tensor, who: str):
+    if not x.is_cuda:
+        raise L.Swv2Error(f"{who}: the swv2 hot path runs on an MI355X only (got a {x.device} tensor); there is no "
+                          "CPU fallback")
+
+
+class _WeightCache:
+    """bf16 (cast / transposed / permuted / padded) copies of the fp32 parameters, rebuilt when a parameter changes
+    (optimizer steps bump `Tensor._version`)."""
+
+    def __init__(self):
+        self._c = {}
+
+    def get(self, key, params, builder):
+        ver = tuple((p.data_ptr(), p._version) for p in params)
+        hit = self._c.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        with torch.no_grad():
+            val = builder()
+        self._c[key] = (ver, val)
+        return val
+
+
+# ================================================================================================
+# window helpers kept for API parity (reference :89-119); roll + partition as one gather kernel-side
+# ================================================================================================
+def window_partition(x, window_size: Tuple[int, int]):
+    """(B, H, W, C) -> (num_windows*B, wh, ww, C); pure view/copy helper kept for API compatibility."""
+    B, H, W, C = x.shape
+    x = x.view(B, H // window_size[0], window_size[0], W // window_size[1], window_size[1], C)
+    return x.permute(0, 1, 3, 2, 4, 5).contiguous().view(-1, window_size[0], window_size[1], C)
+
+
+def window_reverse(windows, window_size: Tuple[int, int], img_size: Tuple[int, int]):
+    H, W = img_size
+    C = windows.shape[-1]
+    x = windows.view(-1, H // window_size[0], W // window_size[1], window_size[0], window_size[1], C)
+    return x.permute(0, 1, 3, 2, 4, 5).contiguous().view(-1, H, W, C)
+
+
+# ================================================================================================
+# block: one autograd node, 7 forward launches
+# ================================================================================================
+class _BlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bias, dp1, dp2, logit_scale, qkv_w, qkv_b, proj_w, proj_b, n1_w, n1_b, fc1_w, fc1_b, fc2_w,
+                fc2_b, n2_w, n2_b, blk):
+        B, gh, gw, Cc = x.shape
+        plan = blk._plan(B, x.device)
+        wc = blk._wcache
+        h, Lp, DP, Bw, T = plan.heads, plan.Lp, plan.DP, plan.Bw, plan.T
+        dev = x.device
+        x = x.contiguous()
+        x2d = x.view(B * T, Cc)
+        M_w = Bw * Lp
+        hid = fc1_w.shape[0]
+
+        w_qkv = wc.get("qkv", (qkv_w,), lambda: ops.prep_weight(qkv_w, row_map=plan.qkv_map, out_rows=3 * h * DP))
+        b_qkv = wc.get("qkv_b", (qkv_b,), lambda: torch.where(plan.qkv_map >= 0, qkv_b[plan.qkv_map.clamp(min=0).long()],
+                                                              torch.zeros((), device=dev)).contiguous())
+        w_proj = wc.get("proj", (proj_w,), lambda: ops.prep_weight(proj_w, col_map=plan.proj_map, out_cols=h * DP))
+        w_fc1 = wc.get("fc1", (fc1_w,), lambda: ops.prep_weight(fc1_w))
+        w_fc2 = wc.get("fc2", (fc2_w,), lambda: ops.prep_weight(fc2_w))
+
+        # 1. roll + partition gather | qkv GEMM | + bias, split heads, L2-normalise q, k
+        qkvh = torch.empty(Bw * h * 3 * Lp * DP, dtype=BF16, device=dev)
+        rnorm = torch.empty(Bw * h * 2 * Lp, dtype=torch.float32, device=dev)
+        ops.linear(ops.op_f32(x2d, rows=M_w, rowidx=plan.rowidx), w_qkv,
+                   ops.epilogue(L.EPI_QKV_HEADS, qkvh, bias=b_qkv, aux_out=rnorm, p=(h, 0, Lp, DP, plan.L)), 3 * h * DP)
+        # 2. cosine attention core
+        oh = torch.empty(Bw * h * Lp * DP, dtype=BF16, device=dev)
+        lse = torch.empty(Bw * h * Lp, dtype=torch.float32, device=dev)
+        bias_c = None if bias is None else bias.detach().float().contiguous()
+        ops.attn_fwd(ops.attn_args(qkvh, logit_scale.detach(), bias_c, oh, lse, Bw, h, plan.L, plan.d, plan.nwh, plan.nww,
+                                   plan.mask_thr))
+        # 3. merge heads | proj GEMM
+        a1 = torch.empty(M_w, Cc, dtype=BF16, device=dev)
+        ops.linear(ops.op_heads(oh, Bw, h, 1, Lp, DP), w_proj, ops.epilogue(L.EPI_BF16, a1, ld=Cc, bias=proj_b.detach()), Cc)
+        # 4. LN1 + drop-path + residual, scattered back through reverse + un-roll
+        x1 = torch.empty(B * T, Cc, dtype=torch.float32, device=dev)
+        mean1 = torch.empty(M_w, dtype=torch.float32, device=dev)
+        rstd1 = torch.empty(M_w, dtype=torch.float32, device=dev)
+        ops.ln_residual_fwd(a1, x2d, n1_w.detach(), n1_b.detach(), dp1, plan.rowidx, x1, mean1, rstd1, M_w, Cc, 0, T)
+        # 5. fc1 (pre-activation kept), 6. GELU-on-load | fc2
+        hpre = torch.empty(B * T, hid, dtype=BF16, device=dev)
+        ops.linear(ops.op_f32(x1), w_fc1, ops.epilogue(L.EPI_BF16, hpre, ld=hid, bias=fc1_b.detach()), hid)
+        a2 = torch.empty(B * T, Cc, dtype=BF16, device=dev)
+        ops.linear(ops.op_bf16(hpre, gelu=True), w_fc2, ops.epilogue(L.EPI_BF16, a2, ld=Cc, bias=fc2_b.detach()), Cc)
+        # 7. LN2 + drop-path + residual
+        x2 = torch.empty(B * T, Cc, dtype=torch.float32, device=dev)
+        mean2 = torch.empty(B * T, dtype=torch.float32, device=dev)
+        rstd2 = torch.empty(B * T, dtype=torch.float32, device=dev)
+        ops.ln_residual_fwd(a2, x1, n2_w.detach(), n2_b.detach(), dp2, None, x2, mean2, rstd2, B * T, Cc, 0, T)
+
+        ctx.blk, ctx.plan, ctx.has_bias = blk, plan, bias is not None
+        ctx.save_for_backward(x2d, bias_c if bias is not None else x2d.new_empty(0), dp1 if dp1 is not None else x2d.new_empty(0),
+                              dp2 if dp2 is not None else x2d.new_empty(0), logit_scale, qkv_w, proj_w, n1_w, fc1_w, fc2_w, n2_w,
+                              qkvh, rnorm, oh, lse, a1, mean1, rstd1, x1, hpre, a2, mean2, rstd2)
+        return x2.view(B, gh, gw, Cc)
+
+    @staticmethod
+    def backward(ctx, dx2):
+        (x2d, bias_c, dp1, dp2, logit_scale, qkv_w, proj_w, n1_w, fc1_w, fc2_w, n2_w, qkvh, rnorm, oh, lse, a1, mean1,
+         rstd1, x1, hpre, a2, mean2, rstd2) = ctx.saved_tensors
+        blk, plan = ctx.blk, ctx.plan
+        wc = blk._wcache
+        h, Lp, DP, Bw, T, B = plan.heads, plan.Lp, plan.DP, plan.Bw, plan.T, plan.B
+        dev = x2d.device
+        Cc = x2d.shape[1]
+        hid = fc1_w.shape[0]
+        M_w = Bw * Lp
+        dp1 = dp1 if dp1.numel() else None
+        dp2 = dp2 if dp2.numel() else None
+        dx2 = dx2.contiguous().view(B * T, Cc).float()
+        f32 = dict(dtype=torch.float32, device=dev)
+
+        w_fc2t = wc.get("fc2t", (fc2_w,), lambda: ops.prep_weight(fc2_w, transpose=True))
+        w_fc1t = wc.get("fc1t", (fc1_w,), lambda: ops.prep_weight(fc1_w, transpose=True))
+        w_projt = wc.get("projt", (proj_w,), lambda: ops.prep_weight(proj_w, transpose=True, row_map=plan.proj_map, out_rows=h * DP))
+        w_qkvt = wc.get("qkvt", (qkv_w,), lambda: ops.prep_weight(qkv_w, transpose=True, col_map=plan.qkv_map, out_cols=3 * h * DP))
+
+        # 7'. LN2 backward
+        da2 = torch.empty(B * T, Cc, dtype=BF16, device=dev)
+        dn2w, dn2b = torch.zeros(Cc, **f32), torch.zeros(Cc, **f32)
+        ops.ln_residual_bwd(a2, dx2, n2_w, dp2, None, mean2, rstd2, da2, dn2w, dn2b, B * T, Cc, T)
+        # 6'. fc2: dW = da2^T GELU(h), dh = (da2 W2) * GELU'(h)
+        dfc2w, dfc2b = torch.zeros(Cc, hid, **f32), torch.zeros(Cc, **f32)
+        ops.linear_wgrad(ops.op_bf16(da2), ops.op_bf16(hpre, gelu=True), dfc2w, dfc2b)
+        dh = torch.empty(B * T, hid, dtype=BF16, device=dev)
+        ops.linear(ops.op_bf16(da2), w_fc2t, ops.epilogue(L.EPI_GELU_GRAD, dh, ld=hid, aux=hpre), hid)
+        # 5'. fc1: dW = dh^T x1 ; dx1 = dx2 + dh W1
+        dfc1w, dfc1b = torch.zeros(hid, Cc, **f32), torch.zeros(hid, **f32)
+        ops.linear_wgrad(ops.op_bf16(dh), ops.op_f32(x1), dfc1w, dfc1b)
+        dx1 = torch.empty(B * T, Cc, **f32)
+        ops.linear(ops.op_bf16(dh), w_fc1t, ops.epilogue(L.EPI_F32, dx1, ld=Cc, aux=dx2), Cc)
+        del dh
+        # 4'. LN1 backward (gathers dx1 rows through the window table; padded rows -> 0)
+        da1 = torch.empty(M_w, Cc, dtype=BF16, device=dev)
+        dn1w, dn1b = torch.zeros(Cc, **f32), torch.zeros(Cc, **f32)
+        ops.ln_residual_bwd(a1, dx1, n1_w, dp1, plan.rowidx, mean1, rstd1, da1, dn1w, dn1b, M_w, Cc, T)
+        # 3'. proj: dW = da1^T merge(oh) ; d(oh) = split(da1 Wp)
+        dprojw, dprojb = torch.zeros(Cc, Cc, **f32), torch.zeros(Cc, **f32)
+        ops.linear_wgrad(ops.op_bf16(da1), ops.op_heads(oh, Bw, h, 1, Lp, DP), dprojw, dprojb, kmap=plan.proj_map)
+        doh = torch.empty(Bw * h * Lp * DP, dtype=BF16, device=dev)
+        ops.linear(ops.op_bf16(da1), w_projt, ops.epilogue(L.EPI_HEADS, doh, p=(h, 0, Lp, DP, plan.L)), h * DP)
+        # 2'. attention backward (incl. the backward of the q / k normalisation)
+        dqkvh = torch.empty(Bw * h * 3 * Lp * DP, dtype=BF16, device=dev)
+        dlogit = torch.zeros(h, **f32)
+        dbias = torch.zeros_like(bias_c) if ctx.has_bias else None
+        ops.attn_bwd(ops.attn_args(qkvh, logit_scale, bias_c if ctx.has_bias else None, oh, lse, Bw, h, plan.L, plan.d,
+                                   plan.nwh, plan.nww, plan.mask_thr, doh=doh, rnorm=rnorm, dqkvh=dqkvh, dlogit=dlogit,
+                                   dbias=dbias))
+        # 1'. qkv: dW = dqkv^T gather(x) ; dx = dx1 + scatter(dqkv Wqkv)
+        dqkvw, dqkvb = torch.zeros(3 * Cc, Cc, **f32), torch.zeros(3 * Cc, **f32)
+        ops.linear_wgrad(ops.op_heads(dqkvh, Bw, h, 3, Lp, DP), ops.op_f32(x2d, rows=M_w, rowidx=plan.rowidx), dqkvw, dqkvb,
+                         nmap=plan.qkv_map)
+        dx = torch.empty(B * T, Cc, **f32)
+        ops.linear(ops.op_heads(dqkvh, Bw, h, 3, Lp, DP), w_qkvt,
+                   ops.epilogue(L.EPI_F32, dx, ld=Cc, aux=dx1, rowidx=plan.rowidx), Cc)
+        return (dx.view(B, plan.gh, plan.gw, Cc), dbias, None, None, dlogit, dqkvw, dqkvb, dprojw, dprojb, dn1w, dn1b,
+                dfc1w, dfc1b, dfc2w, dfc2b, dn2w, dn2b, None)
+
+
+class Mlp(nn.Module):
+    """Parameter container with timm.layers.Mlp's attribute names (fc1, fc2); the arithmetic lives in the block kernels
+    (GELU variant) or, for the tiny 2->384->heads meta network (ReLU + Dropout), in `WindowMultiHeadAttention`."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        drops = drop if isinstance(drop, (tuple, list)) else (drop, drop)
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.drop1 = nn.Dropout(drops[0])
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.drop2 = nn.Dropout(drops[1])
+
+
+class DropPath(nn.Module):
+    """Per-sample stochastic depth (timm semantics): produces the [B] scale vector the LN+residual kernel consumes."""
+
+    def __init__(self, drop_prob: float = 0.0):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def scale(self, x: torch.Tensor) -> Optional[torch.Tensor]:
+        if self.drop_prob == 0.0 or not self.training:
+            return None
+        keep = 1.0 - self.drop_prob
+        m = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)   # same RNG draw as the reference
+        if keep > 0.0:
+            m.div_(keep)
+        return m.reshape(-1).float().contiguous()
+
+
+class WindowMultiHeadAttentionNoPos(nn.Module):
+    """Parameter container (reference :122-201).  `forward` on already partitioned windows is provided for API
+    compatibility and runs the same kernels through a 1-window-row plan."""
+
+    rel_pos = False
+
+    def __init__(self, dim: int, num_heads: int, window_size: Tuple[int, int], drop_attn: float = 0.0,
+                 drop_proj: float = 0.0, sequential_attn: bool = False) -> None:
+        super().__init__()
+        assert dim % num_heads == 0, \
+            "The number of input features (in_features) are not divisible by the number of heads (num_heads)."
+        assert drop_attn == 0.0 and drop_proj == 0.0, "attention / projection dropout is 0 in every reference config"
+        self.in_features, self.window_size, self.num_heads = dim, tuple(window_size), num_heads
+        self.sequential_attn = sequential_attn
+        self.qkv = nn.Linear(in_features=dim, out_features=dim * 3, bias=True)
+        self.proj = nn.Linear(in_features=dim, out_features=dim, bias=True)
+        self._extra_init()
+        self.logit_scale = nn.Parameter(torch.log(10 * torch.ones(num_heads)))
+
+    def _extra_init(self):
+        pass
+
+    def position_bias(self) -> Optional[torch.Tensor]:
+        return None
+
+    def update_input_size(self, new_window_size, **kwargs: Any) -> None:
+        self.window_size = tuple(new_window_size)
+
+
+class WindowMultiHeadAttention(WindowMultiHeadAttentionNoPos):
+    """+ log-spaced continuous position bias from the 2 -> 384 -> heads meta MLP (reference :204-321)."""
+
+    rel_pos = True
+
+    def __init__(self, dim, num_heads, window_size, drop_attn=0.0, drop_proj=0.0, meta_hidden_dim: int = 384,
+                 sequential_attn: bool = False) -> None:
+        self._meta_hidden = meta_hidden_dim
+        super().__init__(dim, num_heads, window_size, drop_attn, drop_proj, sequential_attn)
+        self._make_pair_wise_relative_positions()
+
+    def _extra_init(self):
+        self.meta_mlp = Mlp(2, hidden_features=self._meta_hidden, out_features=self.num_heads, act_layer=nn.ReLU,
+                            drop=(0.125, 0.0))
+
+    def _make_pair_wise_relative_positions(self) -> None:
+        wh, ww = self.window_size
+        dev = self.logit_scale.device
+        r = torch.arange(wh, device=dev).view(-1, 1).expand(wh, ww).reshape(-1)
+        c = torch.arange(ww, device=dev).view(1, -1).expand(wh, ww).reshape(-1)
+        d = torch.stack([r.view(-1, 1) - r.view(1, -1), c.view(-1, 1) - c.view(1, -1)], dim=-1).reshape(-1, 2).float()
+        self.register_buffer("relative_coordinates_log", torch.sign(d) * torch.log(1.0 + d.abs()), persistent=False)
+
+    def update_input_size(self, new_window_size, **kwargs: Any) -> None:
+        self.window_size = tuple(new_window_size)
+        self._make_pair_wise_relative_positions()
+
+    def position_bias(self) -> torch.Tensor:
+        """[heads, L, L] bias table (reference :274-287).  A 26k x 2 -> 384 -> heads MLP: host-side torch ops so
+        that the hard-coded Dropout(0.125) consumes the torch RNG stream exactly like the reference."""
+        L_ = self.window_size[0] * self.window_size[1]
+        m = self.meta_mlp
+        hdn = F.dropout(F.relu(F.linear(self.relative_coordinates_log, m.fc1.weight, m.fc1.bias)), 0.125, self.training)
+        o = F.linear(hdn, m.fc2.weight, m.fc2.bias)
+        return o.transpose(1, 0).reshape(self.num_heads, L_, L_)
+
+
+class SwinTransformerV2CrBlock(nn.Module):
+    """Post-norm Swin block (reference :324-497) as one fused autograd node."""
+
+    def __init__(self, dim: int, num_heads: int, feat_size: Tuple[int, int], window_size: Tuple[int, int],
+                 shift_size: Tuple[int, int] = (0, 0), mlp_ratio: float = 4.0, init_values: Optional[float] = 0,
+                 proj_drop: float = 0.0, drop_attn: float = 0.0, drop_path: float = 0.0, extra_norm: bool = False,
+                 sequential_attn: bool = False, norm_layer: Type[nn.Module] = nn.LayerNorm, rel_pos: bool = True) -> None:
+        super().__init__()
+        assert proj_drop == 0.0, "projection dropout is 0 in every reference config"
+        self.dim = dim
+        self.feat_size = tuple(feat_size)
+        self.target_shift_size = to_2tuple(shift_size)
+        self.window_size, self.shift_size = self._calc_window_shift(to_2tuple(window_size))
+        self.window_area = self.window_size[0] * self.window_size[1]
+        self.init_values = init_values
+        attn_cls = WindowMultiHeadAttention if rel_pos else WindowMultiHeadAttentionNoPos
+        self.attn = attn_cls(dim=dim, num_heads=num_heads, window_size=self.window_size, drop_attn=drop_attn,
+                             drop_proj=proj_drop, sequential_attn=sequential_attn)
+        self.norm1 = norm_layer(dim)
+        self.drop_path1 = DropPath(drop_prob=drop_path) if drop_path > 0.0 else nn.Identity()
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), drop=proj_drop, out_features=dim)
+        self.norm2 = norm_layer(dim)
+        self.drop_path2 = DropPath(drop_prob=drop_path) if drop_path > 0.0 else nn.Identity()
+        self.norm3 = nn.Identity()
+        self._wcache = _WeightCache()
+        self.init_weights()
+
+    def _calc_window_shift(self, target_window_size):
+        window_size = [f if f <= w else w for f, w in zip(self.feat_size, target_window_size)]
+        shift_size = [0 if f <= w else s for f, w, s in zip(self.feat_size, window_size, self.target_shift_size)]
+        return tuple(window_size), tuple(shift_size)
+
+    @property
+    def attn_mask(self) -> Optional[torch.Tensor]:
+        """Dense [nW, L, L] mask (reference buffer :403-424), materialised only for inspection / tests: the kernels
+        use the closed form (one threshold) and never read it."""
+        if not any(self.shift_size):
+            return None
+        gh, gw = self.feat_size
+        wh, ww = self.window_size
+        sh, _ = self.shift_size
+        nwh, nww = gh // wh, gw // ww
+        rows = torch.arange(nwh).view(-1, 1) * wh + torch.arange(wh).view(1, -1)
+        rid = (rows >= gh - sh).float() if sh > 0 else torch.zeros(nwh, wh)
+        tok = rid.view(nwh, 1, wh, 1).expand(nwh, nww, wh, ww).reshape(nwh * nww, wh * ww)
+        diff = tok.unsqueeze(1) - tok.unsqueeze(2)
+        return torch.where(diff != 0, torch.full_like(diff, -100.0), torch.zeros_like(diff))
+
+    def init_weights(self):
+        if self.init_values is not None:
+            nn.init.constant_(self.norm1.weight, self.init_values)
+            nn.init.constant_(self.norm2.weight, self.init_values)
+
+    def update_input_size(self, new_window_size: Tuple[int, int], new_feat_size: Tuple[int, int]) -> None:
+        self.feat_size = tuple(new_feat_size)
+        self.window_size, self.shift_size = self._calc_window_shift(to_2tuple(new_window_size))
+        self.window_area = self.window_size[0] * self.window_size[1]
+        self.attn.update_input_size(new_window_size=self.window_size)
+
+    def _plan(self, B: int, device) -> ops.WindowPlan:
+        gh, gw = self.feat_size
+        return ops.window_plan(B, gh, gw, self.window_size[0], self.window_size[1], self.shift_size[0], self.shift_size[1],
+                               self.attn.num_heads, self.dim // self.attn.num_heads, device.index or 0)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x: [B, H, W, C] fp32 -> [B, H, W, C]"""
+        _need_gpu(x, "SwinTransformerV2CrBlock")
+        if tuple(x.shape[1:3]) != self.feat_size:
+            raise L.Swv2Error(f"block built for feature size {self.feat_size}, got {tuple(x.shape[1:3])}")
+        bias = self.attn.position_bias()
+        dp1 = self.drop_path1.scale(x) if isinstance(self.drop_path1, DropPath) else None
+        dp2 = self.drop_path2.scale(x) if isinstance(self.drop_path2, DropPath) else None
+        a, m = self.attn, self.mlp
+        return _BlockFn.apply(x.float(), bias, dp1, dp2, a.logit_scale, a.qkv.weight, a.qkv.bias, a.proj.weight,
+                              a.proj.bias, self.norm1.weight, self.norm1.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight,
+                              m.fc2.bias, self.norm2.weight, self.norm2.bias, self)
+
+
+# ================================================================================================
+# PatchEmbed (+ pos_embed), PatchMerging, head + un-patchify
+# ================================================================================================
+class _PatchEmbedFn(torch.autograd.Function):
+    """x[B,Cin,H,W] -> LN(conv4x4s4(x) + b) * g + beta (+ pos) as [B,gh,gw,C] fp32: im2col-on-load GEMM + fused LN."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, g, beta, pos, mod):
+        B, Cin, H, W = x.shape
+        Cc = w.shape[0]
+        gh, gw = H // 4, W // 4
+        T, dev = gh * gw, x.device
+        x = x.contiguous().float()
+        wb = mod._wcache.get("pe", (w,), lambda: ops.prep_weight(w))
+        a0 = torch.empty(B * T, Cc, dtype=BF16, device=dev)
+        ops.linear(ops.op_patch(x), wb, ops.epilogue(L.EPI_BF16, a0, ld=Cc, bias=b.detach()), Cc)
+        pos_t = None
+        if pos is not None:   # [1,C,gh,gw] -> [T][C] rows, broadcast over the batch by the kernel (res_mod = T)
+            pos_t = mod._wcache.get("pos", (pos,), lambda: pos.detach().permute(0, 2, 3, 1).reshape(T, Cc).contiguous())
+        e = torch.empty(B * T, Cc, dtype=torch.float32, device=dev)
+        mean = torch.empty(B * T, dtype=torch.float32, device=dev)
+        rstd = torch.empty(B * T, dtype=torch.float32, device=dev)
+        ops.ln_residual_fwd(a0, pos_t, g.detach(), beta.detach(), None, None, e, mean, rstd, B * T, Cc, T if pos is not None else 0, T)
+        ctx.mod, ctx.shape, ctx.has_pos = mod, (B, Cin, H, W, Cc), pos is not None
+        ctx.save_for_backward(x, w, g, a0, mean, rstd)
+        return e.view(B, gh, gw, Cc)
+
+    @staticmethod
+    def backward(ctx, de):
+        x, w, g, a0, mean, rstd = ctx.saved_tensors
+        B, Cin, H, W, Cc = ctx.shape
+        T, dev = (H // 4) * (W // 4), x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        de = de.contiguous().view(B * T, Cc).float()
+        da0 = torch.empty(B * T, Cc, dtype=BF16, device=dev)
+        dg, dbeta = torch.zeros(Cc, **f32), torch.zeros(Cc, **f32)
+        ops.ln_residual_bwd(a0, de, g, None, None, mean, rstd, da0, dg, dbeta, B * T, Cc, T)
+        dw, db = torch.zeros(Cc, Cin * 16, **f32), torch.zeros(Cc, **f32)
+        ops.linear_wgrad(ops.op_bf16(da0), ops.op_patch(x), dw, db)
+        dpos = None
+        if ctx.has_pos:
+            s = torch.empty(T, Cc, **f32)
+            ops.batch_sum(de.view(B, T * Cc), s.view(-1))
+            dpos = s.view(1, H // 4, W // 4, Cc).permute(0, 3, 1, 2)
+        dx = None
+        if ctx.needs_input_grad[0]:      # only the multi-step rollout differentiates through the input
+            wt = ctx.mod._wcache.get("pet", (w,), lambda: ops.prep_weight(w, transpose=True))
+            dx = torch.empty(B, Cin, H, W, **f32)
+            ops.linear(ops.op_bf16(da0), wt, ops.epilogue(L.EPI_UNPATCH, dx, p=(Cin, H, W, 0, 0)), Cin * 16)
+        return dx, dw.view(Cc, Cin, 4, 4), db, dg, dbeta, dpos, None
+
+
+class PatchEmbed(nn.Module):
+    """2D image to patch embedding (reference :526-546).  `forward` returns [B, C, gh, gw] like the reference (a BCHW
+    view of BHWC memory); the model uses `forward_bhwc` and never makes that round trip."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768, norm_layer=None):
+        super().__init__()
+        img_size, patch_size = to_2tuple(img_size), to_2tuple(patch_size)
+        if patch_size != (4, 4):
+            raise L.Swv2Error("the swv2 patch-embed kernel is specialised for patch_size 4 (all reference configs)")
+        self.img_size, self.patch_size = img_size, patch_size
+        self.grid_size = (img_size[0] // patch_size[0], img_size[1] // patch_size[1])
+        self.num_patches = self.grid_size[0] * self.grid_size[1]
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+        self.norm = norm_layer(embed_dim) if norm_layer else nn.Identity()
+        self._wcache = _WeightCache()
+
+    def forward_bhwc(self, x, pos_embed=None):
+        B, Cin, H, W = x.shape
+        assert H == self.img_size[0], f"Input image height ({H}) doesn't match model ({self.img_size[0]})."
+        assert W == self.img_size[1], f"Input image width ({W}) doesn't match model ({self.img_size[1]})."
+        _need_gpu(x, "PatchEmbed")
+        if not isinstance(self.norm, nn.LayerNorm):
+            raise L.Swv2Error("PatchEmbed without LayerNorm is not used by the reference model")
+        return _PatchEmbedFn.apply(x, self.proj.weight, self.proj.bias, self.norm.weight, self.norm.bias, pos_embed, self)
+
+    def forward(self, x):
+        return self.forward_bhwc(x).permute(0, 3, 1, 2)
+
+
+class _PatchMergingFn(torch.autograd.Function):
+    """[B,H,W,C] -> Linear_{4C->2C}(LN_{4C}(2x2 gather)) (reference :519-523): gather + LN folded into the GEMM's load."""
+
+    @staticmethod
+    def forward(ctx, x, g, beta, w, mod):
+        B, H, W, Cc = x.shape
+        dev = x.device
+        x = x.contiguous().float()
+        M = B * (H // 2) * (W // 2)
+        mean = torch.empty(M, dtype=torch.float32, device=dev)
+        rstd = torch.empty(M, dtype=torch.float32, device=dev)
+        ops.merge_stats(x, mean, rstd)
+        wb = mod._wcache.get("red", (w,), lambda: ops.prep_weight(w))
+        y = torch.empty(M, 2 * Cc, dtype=torch.float32, device=dev)
+        ops.linear(ops.op_merge_ln(x, mean, rstd, g.detach(), beta.detach()), wb, ops.epilogue(L.EPI_F32, y, ld=2 * Cc), 2 * Cc)
+        ctx.mod = mod
+        ctx.save_for_backward(x, g, beta, w, mean, rstd)
+        return y.view(B, H // 2, W // 2, 2 * Cc)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g, beta, w, mean, rstd = ctx.saved_tensors
+        B, H, W, Cc = x.shape
+        dev = x.device
+        M = B * (H // 2) * (W // 2)
+        f32 = dict(dtype=torch.float32, device=dev)
+        dy = dy.contiguous().view(M, 2 * Cc).float()
+        dw = torch.zeros(2 * Cc, 4 * Cc, **f32)
+        ops.linear_wgrad(ops.op_f32(dy), ops.op_merge_ln(x, mean, rstd, g, beta), dw, None)
+        wt = ctx.mod._wcache.get("redt", (w,), lambda: ops.prep_weight(w, transpose=True))
+        dn = torch.empty(M, 4 * Cc, dtype=BF16, device=dev)
+        ops.linear(ops.op_f32(dy), wt, ops.epilogue(L.EPI_BF16, dn, ld=4 * Cc), 4 * Cc)
+        dx = torch.empty_like(x)
+        dg, dbeta = torch.zeros(4 * Cc, **f32), torch.zeros(4 * Cc, **f32)
+        ops.merge_ln_bwd(x, dn, g, mean, rstd, dx, dg, dbeta)
+        return dx, dg, dbeta, dw, None
+
+
+class PatchMerging(nn.Module):
+    """Patch merging (reference :500-523); never instantiated by `swinv2net` (downscale=False) but part of the file."""
+
+    def __init__(self, dim: int, norm_layer: Type[nn.Module] = nn.LayerNorm) -> None:
+        super().__init__()
+        self.norm = norm_layer(4 * dim)
+        self.reduction = nn.Linear(in_features=4 * dim, out_features=2 * dim, bias=False)
+        self._wcache = _WeightCache()
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        _need_gpu(x, "PatchMerging")
+        return _PatchMergingFn.apply(x, self.norm.weight, self.norm.bias, self.reduction.weight, self)
+
+
+class _HeadFn(torch.autograd.Function):
+    """e[B,gh,gw,C] -> y[B,Cout,H,W] = un-patchify(e W_head^T) (+ skip[:, :Cout]) (reference :784-802): one GEMM whose
+    epilogue writes NCHW rows directly (head weight rows permuted to channel-major)."""
+
+    @staticmethod
+    def forward(ctx, e, w, skip, mod):
+        B, gh, gw, Cc = e.shape
+        Cout = mod.out_chans
+        H, W = gh * 4, gw * 4
+        dev = e.device
+        e2d = e.contiguous().view(B * gh * gw, Cc).float()
+        perm = mod._head_perm(dev)
+        wb = mod._wcache.get("head", (w,), lambda: ops.prep_weight(w, row_map=perm))
+        y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=dev)
+        Cs = 0
+        if skip is not None:
+            skip = skip.contiguous().float()
+            Cs = skip.shape[1]
+        ops.linear(ops.op_f32(e2d), wb, ops.epilogue(L.EPI_UNPATCH, y, aux=skip, p=(Cout, H, W, Cs, 0)), Cout * 16)
+        ctx.mod, ctx.has_skip, ctx.Cs = mod, skip is not None, Cs
+        ctx.save_for_backward(e2d, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        e2d, w = ctx.saved_tensors
+        mod = ctx.mod
+        B, Cout, H, W = dy.shape
+        Cc, dev = e2d.shape[1], e2d.device
+        dy = dy.contiguous().float()
+        perm = mod._head_perm(dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        dw = torch.zeros(Cout * 16, Cc, **f32)
+        ops.linear_wgrad(ops.op_patch(dy), ops.op_f32(e2d), dw, None, nmap=perm)
+        wt = mod._wcache.get("headt", (w,), lambda: ops.prep_weight(w, transpose=True, col_map=perm))
+        de = torch.empty(B * (H // 4) * (W // 4), Cc, **f32)
+        ops.linear(ops.op_patch(dy), wt, ops.epilogue(L.EPI_F32, de, ld=Cc), Cc)
+        dskip = None
+        if ctx.has_skip and ctx.needs_input_grad[2]:
+            dskip = torch.zeros(B, ctx.Cs, H, W, **f32)
+            dskip[:, :Cout] = dy
+        return de.view(B, H // 4, W // 4, Cc), dw, dskip, None
+
+
+# ================================================================================================
+# stage / model
+# ================================================================================================
+class SwinTransformerV2CrStage(nn.Module):
+    """Stage (reference :549-655).  Works on BHWC internally; `forward` keeps the reference's BCHW in/out contract,
+    `forward_bhwc` avoids the two permutes."""
+
+    def __init__(self, embed_dim: int, depth: int, downscale: bool, num_heads: int, feat_size: Tuple[int, int],
+                 window_size: Tuple[int, int], mlp_ratio: float = 4.0, init_values: Optional[float] = 0.0,
+                 proj_drop: float = 0.0, drop_attn: float = 0.0, drop_path: Union[List[float], float] = 0.0,
+                 norm_layer: Type[nn.Module] = nn.LayerNorm, extra_norm_period: int = 0, extra_norm_stage: bool = False,
+                 sequential_attn: bool = False, rel_pos: bool = True, grad_checkpointing: bool = False) -> None:
+        super().__init__()
+        self.downscale = downscale
+        self.feat_size = (feat_size[0] // 2, feat_size[1] // 2) if downscale else tuple(feat_size)
+        self.grad_checkpointing = grad_checkpointing
+        if downscale:
+            self.downsample = PatchMerging(embed_dim, norm_layer=norm_layer)
+            embed_dim = embed_dim * 2
+        else:
+            self.downsample = nn.Identity()
+        self.blocks = nn.Sequential(*[
+            SwinTransformerV2CrBlock(
+                dim=embed_dim, num_heads=num_heads, feat_size=self.feat_size, window_size=window_size,
+                shift_size=tuple([0 if ((index % 2) == 0) else w // 2 for w in window_size]), mlp_ratio=mlp_ratio,
+                init_values=init_values, proj_drop=proj_drop, drop_attn=drop_attn,
+                drop_path=drop_path[index] if isinstance(drop_path, list) else drop_path,
+                sequential_attn=sequential_attn, norm_layer=norm_layer, rel_pos=rel_pos)
+            for index in range(depth)])
+
+    def update_input_size(self, new_window_size, new_feat_size: Tuple[int, int]) -> None:
+        self.feat_size = (new_feat_size[0] // 2, new_feat_size[1] // 2) if self.downscale else tuple(new_feat_size)
+        for block in self.blocks:
+            block.update_input_size(new_window_size=new_window_size, new_feat_size=self.feat_size)
+
+    def forward_bhwc(self, x: torch.Tensor) -> torch.Tensor:
+        x = self.downsample(x)
+        for block in self.blocks:
+            if self.grad_checkpointing and torch.is_grad_enabled():
+                x = checkpoint(block, x, use_reentrant=False)
+            else:
+                x = block(x)
+        return x
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return bhwc_to_bchw(self.forward_bhwc(bchw_to_bhwc(x)))
+
+
+class SwinTransformerV2Cr(nn.Module):
+    """Swin Transformer V2 for global weather fields (reference :657-803)."""
+
+    def __init__(self, img_size: Tuple[int, int] = (224, 224), patch_size: int = 4, window_size: Optional[int] = None,
+                 img_window_ratio: int = 32, in_chans: int = 3, out_chans: int = 3, embed_dim: int = 96,
+                 depths: Tuple[int, ...] = (2, 2, 6, 2), num_heads: Tuple[int, ...] = (3, 6, 12, 24),
+                 mlp_ratio: float = 4.0, init_values: Optional[float] = 0., drop_rate: float = 0.0,
+                 proj_drop_rate: float = 0.0, attn_drop_rate: float = 0.0, drop_path_rate: float = 0.0,
+                 norm_layer: Type[nn.Module] = nn.LayerNorm, extra_norm_period: int = 0, extra_norm_stage: bool = False,
+                 sequential_attn: bool = False, global_pool: str = 'avg', weight_init='skip', full_pos_embed: bool = False,
+                 rel_pos: bool = True, checkpoint_stages: bool = False, residual: bool = False, **kwargs: Any) -> None:
+        super().__init__()
+        img_size = to_2tuple(img_size)
+        window_size = tuple([s // img_window_ratio for s in img_size]) if window_size is None else to_2tuple(window_size)
+        if weight_init != 'skip':
+            raise L.Swv2Error("weight_init != 'skip' is broken in the reference (undefined named_apply, :774-775)")
+        self.patch_size, self.img_size, self.window_size = patch_size, img_size, window_size
+        self.num_features, self.out_chans = int(embed_dim), out_chans
+        self.feature_info = []
+        self.full_pos_embed, self.checkpoint_stages, self.residual = full_pos_embed, checkpoint_stages, residual
+        self.depth = len(depths)
+        self.patch_embed = PatchEmbed(img_size=img_size, patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim,
+                                      norm_layer=norm_layer)
+        grid = self.patch_embed.grid_size
+        dpr = [x.tolist() for x in torch.linspace(0, drop_path_rate, sum(depths)).split(depths)]
+        stages = []
+        in_dim, in_scale = embed_dim, 1
+        for stage_idx, (depth, heads) in enumerate(zip(depths, num_heads)):
+            stages += [SwinTransformerV2CrStage(
+                embed_dim=in_dim, depth=depth, downscale=False, feat_size=(grid[0] // in_scale, grid[1] // in_scale),
+                num_heads=heads, window_size=window_size, mlp_ratio=mlp_ratio, init_values=init_values,
+                proj_drop=proj_drop_rate, drop_attn=attn_drop_rate, drop_path=dpr[stage_idx],
+                extra_norm_period=extra_norm_period, extra_norm_stage=extra_norm_stage or (stage_idx + 1) == len(depths),
+                sequential_attn=sequential_attn, norm_layer=norm_layer, rel_pos=rel_pos,
+                grad_checkpointing=self.checkpoint_stages)]
+            self.feature_info += [dict(num_chs=in_dim, reduction=4 * in_scale, module=f'stages.{stage_idx}')]
+        self.stages = nn.Sequential(*stages)
+        self.head = nn.Linear(embed_dim, self.out_chans * self.patch_size * self.patch_size, bias=False)
+        if self.full_pos_embed:
+            self.pos_embed = nn.Parameter(torch.randn(1, embed_dim, grid[0], grid[1]) * .02)
+        self._wcache = _WeightCache()
+        self._perm = None
+
+    def _head_perm(self, device) -> torch.Tensor:
+        """row map of the head weight: n' = c*16 + p*4 + q  <-  n = (p*4 + q)*Cout + c   (un-patchify order, :789-791)"""
+        if self._perm is None or self._perm.device != device:
+            c = torch.arange(self.out_chans).view(-1, 1)
+            pq = torch.arange(16).view(1, -1)
+            self._perm = (pq * self.out_chans + c).reshape(-1).to(torch.int32).to(device)
+        return self._perm
+
+    def forward_features(self, x: torch.Tensor) -> torch.Tensor:
+        """-> [B, C, gh, gw] (BCHW view, as the reference)."""
+        return bhwc_to_bchw(self._features_bhwc(x))
+
+    def _features_bhwc(self, x):
+        e = self.patch_embed.forward_bhwc(x, self.pos_embed if self.full_pos_embed else None)
+        for stage in self.stages:
+            e = stage.forward_bhwc(e)
+        return e
+
+    def forward_head(self, x: torch.Tensor, skip: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return _HeadFn.apply(bchw_to_bhwc(x), self.head.weight, skip, self)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        _need_gpu(x, "SwinTransformerV2Cr")
+        e = self._features_bhwc(x)
+        return _HeadFn.apply(e, self.head.weight, x if self.residual else None, self)
+
+    def update_input_size(self, new_img_size=None, new_window_size=None, img_window_ratio: int = 32) -> None:
+        raise L.Swv2Error("update_input_size is broken in the reference itself (wrong kwarg, :829-832); rebuild the model")
+
+    @torch.jit.ignore
+    def set_grad_checkpointing(self, enable=True):
+        for s in self.stages:
+            s.grad_checkpointing = enable
+
+
+def swinv2net(params, checkpoint_stages=False):
+    """Factory with the reference's param -> ctor mapping (swinv2_global.py:57-74)."""
+    act_ckpt = checkpoint_stages or params.activation_ckpt
+    return SwinTransformerV2Cr(img_size=params.img_size, patch_size=params.patch_size, depths=(params.depth,),
+                               num_heads=(params.num_heads,), in_chans=params.n_in_channels,
+                               out_chans=params.n_out_channels, embed_dim=params.embed_dim,
+                               img_window_ratio=params.window_ratio, drop_path_rate=params.drop_path_rate,
+                               full_pos_embed=params.full_pos_embed, rel_pos=params.rel_pos, mlp_ratio=params.mlp_ratio,
+                               checkpoint_stages=act_ckpt, residual=params.residual)
+
+
+def swin_from_yaml(fname, checkpoint_stages=False):
+    """Build from a flat yaml of hyper-parameters (reference :47-54; PyYAML instead of the absent ruamel)."""
+    import yaml
+    with open(fname) as f:
+        hparams = yaml.safe_load(f)
+    return swinv2net(SimpleNamespace(**hparams), checkpoint_stages=checkpoint_stages)

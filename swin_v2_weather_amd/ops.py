@@ -1,0 +1,218 @@
+"""Thin tensor-level wrappers over the C ABI (include/swv2.h).
+
+PyTorch is used for device memory, streams and autograd bookkeeping only; every arithmetic op of the hot path is a
+HIP kernel in libswv2.so.  All wrappers enqueue on torch's current stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import functools
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+BF16 = torch.bfloat16
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: torch.Tensor, dtype, name: str):
+    if t.dtype != dtype or not t.is_contiguous() or not t.is_cuda:
+        raise L.Swv2Error(f"{name}: expected a contiguous CUDA {dtype} tensor, got {t.dtype} "
+                          f"contiguous={t.is_contiguous()} device={t.device}")
+    return t
+
+
+def attn_geometry(Lwin: int, head_dim: int):
+    lp, dp = C.c_int(), C.c_int()
+    L.check(L.load().swv2_attn_geometry(Lwin, head_dim, C.byref(lp), C.byref(dp)), "swv2_attn_geometry")
+    return lp.value, dp.value
+
+
+# ---- operand / epilogue builders ---------------------------------------------------------------------------
+def operand(kind, t, rows, cols, ld=0, rowidx=None, aux=(None, None, None, None), p=(0, 0, 0, 0)) -> L.Operand:
+    o = L.Operand()
+    o.kind, o.ptr, o.rowidx = kind, _p(t), _p(rowidx)
+    o.aux0, o.aux1, o.aux2, o.aux3 = (_p(a) for a in aux)
+    o.ld, o.rows, o.cols = ld, rows, cols
+    o.p = (C.c_int * 4)(*p)
+    o._keep = (t, rowidx, aux)
+    return o
+
+
+def op_f32(x2d: torch.Tensor, rows=None, rowidx=None):
+    _chk(x2d, torch.float32, "op_f32")
+    return operand(L.OP_F32, x2d, rows if rows is not None else x2d.shape[0], x2d.shape[1], x2d.shape[1], rowidx)
+
+
+def op_bf16(x2d: torch.Tensor, rows=None, rowidx=None, gelu=False):
+    _chk(x2d, BF16, "op_bf16")
+    return operand(L.OP_BF16_GELU if gelu else L.OP_BF16, x2d, rows if rows is not None else x2d.shape[0],
+                   x2d.shape[1], x2d.shape[1], rowidx)
+
+
+def op_heads(t: torch.Tensor, Bw, heads, parts, Lp, DP):
+    _chk(t, BF16, "op_heads")
+    return operand(L.OP_HEADS, t, Bw * Lp, parts * heads * DP, parts, p=(heads, 0, Lp, DP))
+
+
+def op_patch(x4d: torch.Tensor):
+    _chk(x4d, torch.float32, "op_patch")
+    B, Cin, H, W = x4d.shape
+    return operand(L.OP_PATCH, x4d, B * (H // 4) * (W // 4), Cin * 16, 0, p=(Cin, H, W, 0))
+
+
+def op_merge_ln(x4d, mean, rstd, gamma, beta):
+    B, H, W, Cc = x4d.shape
+    return operand(L.OP_MERGE_LN, x4d, B * (H // 2) * (W // 2), 4 * Cc, 0, aux=(mean, rstd, gamma, beta), p=(H, W, Cc, 0))
+
+
+def epilogue(kind, out, ld=0, bias=None, aux=None, aux_out=None, rowidx=None, p=(0, 0, 0, 0, 0)) -> L.Epilogue:
+    e = L.Epilogue()
+    e.kind, e.out, e.bias, e.aux, e.aux_out, e.rowidx, e.ld = kind, _p(out), _p(bias), _p(aux), _p(aux_out), _p(rowidx), ld
+    e.p = (C.c_int * 5)(*p)
+    e._keep = (out, bias, aux, aux_out, rowidx)
+    return e
+
+
+def linear(a: L.Operand, w_bf16: torch.Tensor, e: L.Epilogue, N: int):
+    _chk(w_bf16, BF16, "linear weight")
+    if w_bf16.shape[0] != N or w_bf16.shape[1] != a.cols:
+        raise L.Swv2Error(f"linear: weight {tuple(w_bf16.shape)} does not match N={N} K={a.cols}")
+    L.check(L.load().swv2_linear(C.byref(a), _p(w_bf16), C.byref(e), N, _stream()), "swv2_linear")
+
+
+def linear_wgrad(dy: L.Operand, x: L.Operand, dW: torch.Tensor, db: Optional[torch.Tensor], nmap=None, kmap=None,
+                 splits: int = 64):
+    _chk(dW, torch.float32, "dW")
+    ldw = dW.shape[-1] if dW.dim() == 2 else dW[0].numel()
+    L.check(L.load().swv2_linear_wgrad(C.byref(dy), C.byref(x), _p(dW), _p(db), _p(nmap), _p(kmap), ldw, splits,
+                                       _stream()), "swv2_linear_wgrad")
+
+
+def prep_weight(w: torch.Tensor, transpose=False, row_map=None, out_rows=None, col_map=None, out_cols=None):
+    """fp32 [rows][cols] parameter -> bf16 [out_rows][out_cols] (cast / transpose / permute / zero-pad)."""
+    w2 = w.detach().reshape(w.shape[0], -1)
+    _chk(w2, torch.float32, "prep_weight")
+    rows, cols = w2.shape
+    r_t, c_t = (cols, rows) if transpose else (rows, cols)
+    out_rows = out_rows if out_rows is not None else r_t
+    out_cols = out_cols if out_cols is not None else c_t
+    out = torch.empty(out_rows, out_cols, dtype=BF16, device=w.device)
+    L.check(L.load().swv2_prep_weight(_p(w2), rows, cols, int(transpose), _p(row_map), out_rows, _p(col_map), out_cols,
+                                      _p(out), _stream()), "swv2_prep_weight")
+    return out
+
+
+def ln_residual_fwd(a, res, gamma, beta, scale, rowidx, y, mean, rstd, M, Cc, res_mod, rows_per_sample, eps=1e-5):
+    g = L.LnArgs()
+    g.a, g.res, g.gamma, g.beta, g.scale, g.rowidx = _p(a), _p(res), _p(gamma), _p(beta), _p(scale), _p(rowidx)
+    g.y, g.mean, g.rstd = _p(y), _p(mean), _p(rstd)
+    g.M, g.C, g.res_mod, g.rows_per_sample, g.eps = M, Cc, res_mod, rows_per_sample, eps
+    L.check(L.load().swv2_ln_residual_fwd(C.byref(g), _stream()), "swv2_ln_residual_fwd")
+
+
+def ln_residual_bwd(a, dy, gamma, scale, rowidx, mean, rstd, da, dgamma, dbeta, M, Cc, rows_per_sample):
+    g = L.LnArgs()
+    g.a, g.dy, g.gamma, g.scale, g.rowidx = _p(a), _p(dy), _p(gamma), _p(scale), _p(rowidx)
+    g.mean, g.rstd, g.da, g.dgamma, g.dbeta = _p(mean), _p(rstd), _p(da), _p(dgamma), _p(dbeta)
+    g.M, g.C, g.res_mod, g.rows_per_sample, g.eps = M, Cc, 0, rows_per_sample, 1e-5
+    L.check(L.load().swv2_ln_residual_bwd(C.byref(g), _stream()), "swv2_ln_residual_bwd")
+
+
+def attn_args(qkvh, logit_scale, bias, oh, lse, Bw, heads, Lwin, head_dim, nwh, nww, mask_thr, doh=None, rnorm=None,
+              dqkvh=None, dlogit=None, dbias=None, max_chunks=64) -> L.AttnArgs:
+    a = L.AttnArgs()
+    a.qkvh, a.logit_scale, a.bias, a.oh, a.lse = _p(qkvh), _p(logit_scale), _p(bias), _p(oh), _p(lse)
+    a.doh, a.rnorm, a.dqkvh, a.dlogit_scale, a.dbias = _p(doh), _p(rnorm), _p(dqkvh), _p(dlogit), _p(dbias)
+    a.Bw, a.heads, a.L, a.head_dim, a.nwh, a.nww, a.mask_thr, a.max_chunks = Bw, heads, Lwin, head_dim, nwh, nww, mask_thr, max_chunks
+    return a
+
+
+def attn_fwd(a: L.AttnArgs):
+    L.check(L.load().swv2_attn_fwd(C.byref(a), _stream()), "swv2_attn_fwd")
+
+
+def attn_bwd(a: L.AttnArgs):
+    L.check(L.load().swv2_attn_bwd(C.byref(a), _stream()), "swv2_attn_bwd")
+
+
+def batch_sum(inp: torch.Tensor, out: torch.Tensor, accumulate=False):
+    B = inp.shape[0]
+    n = inp[0].numel()
+    L.check(L.load().swv2_batch_sum(_p(inp), _p(out), B, n, int(accumulate), _stream()), "swv2_batch_sum")
+
+
+def merge_stats(x, mean, rstd, eps=1e-5):
+    B, H, W, Cc = x.shape
+    L.check(L.load().swv2_merge_stats(_p(x), _p(mean), _p(rstd), B, H, W, Cc, eps, _stream()), "swv2_merge_stats")
+
+
+def merge_ln_bwd(x, dn, gamma, mean, rstd, dx, dgamma, dbeta):
+    B, H, W, Cc = x.shape
+    L.check(L.load().swv2_merge_ln_bwd(_p(x), _p(dn), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dgamma), _p(dbeta),
+                                       B, H, W, Cc, _stream()), "swv2_merge_ln_bwd")
+
+
+def loss_sums(prd, tar, qw, sums):
+    B, Cc, H, W = prd.shape
+    L.check(L.load().swv2_loss_sums(_p(prd), _p(tar), _p(qw), _p(sums), B * Cc, H, W, _stream()), "swv2_loss_sums")
+
+
+def loss_grad(prd, tar, qw, coef, dprd):
+    B, Cc, H, W = prd.shape
+    L.check(L.load().swv2_loss_grad(_p(prd), _p(tar), _p(qw), _p(coef), _p(dprd), B * Cc, H, W, _stream()), "swv2_loss_grad")
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_inv_scale=1.0):
+    L.check(L.load().swv2_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, step, grad_inv_scale,
+                                    _stream()), "swv2_adam_step")
+
+
+# ---- per-geometry index tables ------------------------------------------------------------------------------
+class WindowPlan:
+    """Index tables for one (batch, grid, window, shift, heads) geometry: the cyclic roll, the window partition, its
+    inverse and the attention mask are all reduced to one int32 row table + one threshold."""
+
+    def __init__(self, B, gh, gw, wh, ww, sh, sw, heads, head_dim, device):
+        self.B, self.gh, self.gw, self.wh, self.ww, self.sh, self.sw = B, gh, gw, wh, ww, sh, sw
+        self.heads, self.d = heads, head_dim
+        self.L = wh * ww
+        self.Lp, self.DP = attn_geometry(self.L, head_dim)
+        self.nwh, self.nww = gh // wh, gw // ww
+        self.nW = self.nwh * self.nww
+        self.Bw = B * self.nW
+        self.T = gh * gw
+        if gh % wh or gw % ww:
+            raise L.Swv2Error(f"window {wh}x{ww} does not divide the patch grid {gh}x{gw}")
+        # swinv2_global.py:403-424 closed form: only a row shift produces a (non-zero) mask
+        self.mask_thr = (wh - sh) * ww if sh > 0 else 0
+        wi = torch.arange(self.nwh).view(-1, 1, 1, 1)
+        wj = torch.arange(self.nww).view(1, -1, 1, 1)
+        r = torch.arange(wh).view(1, 1, -1, 1)
+        c = torch.arange(ww).view(1, 1, 1, -1)
+        src = (((wi * wh + r + sh) % gh) * gw + (wj * ww + c + sw) % gw).reshape(self.nW, self.L)
+        tab = torch.full((B, self.nW, self.Lp), -1, dtype=torch.int64)
+        tab[:, :, :self.L] = src.unsqueeze(0) + (torch.arange(B) * self.T).view(B, 1, 1)
+        self.rowidx = tab.reshape(-1).to(torch.int32).to(device)
+        # head padding maps: padded feature (part*h + head)*DP + j -> part*C + head*d + j (or -1)
+        Cc = heads * head_dim
+        j = torch.arange(self.DP)
+        hd = torch.arange(heads).view(-1, 1)
+        one = torch.where(j.view(1, -1) < head_dim, hd * head_dim + j.view(1, -1), torch.full((1, 1), -1)).reshape(-1)
+        self.proj_map = one.to(torch.int32).to(device)                          # [h*DP]
+        three = torch.cat([torch.where(one >= 0, one + part * Cc, one) for part in range(3)])
+        self.qkv_map = three.to(torch.int32).to(device)                         # [3*h*DP]
+
+
+@functools.lru_cache(maxsize=64)
+def window_plan(B, gh, gw, wh, ww, sh, sw, heads, head_dim, device_index) -> WindowPlan:
+    return WindowPlan(B, gh, gw, wh, ww, sh, sw, heads, head_dim, torch.device("cuda", device_index))

@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Headline benchmark: ERA5 samples/sec of the swin_73var depth-12 training step on N MI355X (BASELINE.json).
+
+    python bench.py [--gpus N --steps K --warmup W]        # N > 1: launched by torch.distributed.run, one rank / GPU
+
+A "step" is one full optimisation step of the reference's loop (train.py:275-289) on synthetic N(0,1) fields already
+resident in HBM: zero_grad -> forward -> geometric l2 loss -> backward (+ RCCL gradient all-reduce under DDP) -> Adam.
+Workload at every N: swin_73var, depth 12, embed_dim 128, 8 heads, 73 x 720 x 1440 (the 721-row grid cropped like
+data_loader_era5.py:163), local batch 2 per GPU (weak scaling), bf16 MFMA with fp32 accumulation.
+Rank 0 prints ONE JSON line (see README / DESIGN.md for the fields).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+T_TOK, L_WIN, PATCH = 180 * 360, 162, 4
+
+
+def model_params(a):
+    return SimpleNamespace(nettype="swin", img_size=[a.height, a.width], patch_size=4, depth=a.depth, num_heads=a.heads,
+                           n_in_channels=73, n_out_channels=73, embed_dim=a.embed_dim, window_ratio=a.window_ratio,
+                           drop_path_rate=a.drop_path_rate, full_pos_embed=True, rel_pos=bool(a.rel_pos), mlp_ratio=4,
+                           activation_ckpt=False, residual=False, n_future=0, add_orography=False, add_landmask=False)
+
+
+def train_flops_per_sample(a):
+    """F_fwd = 2 T P^2 C (Cin + Cout) + depth T (24 C^2 + 4 L C); F_train = 3 F_fwd"""
+    T = (a.height // 4) * (a.width // 4)
+    Lw = (a.height // a.window_ratio) * (a.width // a.window_ratio)
+    C = a.embed_dim
+    return 3.0 * (2.0 * T * 16 * C * (73 + 73) + a.depth * T * (24.0 * C * C + 4.0 * Lw * C))
+
+
+def cpu_baseline(a):
+    """Oracle (oracle/swin_oracle.py, fp32 torch on the host cores) on a bounded sample of the same workload: one
+    sample at the full 73 x H x W shape through patch-embed + ONE block + head, forward + backward, and the same with
+    zero blocks; the per-sample time for depth D is extrapolated as t0 + D * (t1 - t0)."""
+    from oracle import swin_oracle as O
+    from swin_v2_weather_amd.networks.helpers import get_model
+    torch.manual_seed(0)
+    times = {}
+    threads = torch.get_num_threads()
+    for depth in (0, 1):
+        p = model_params(a)
+        p.depth = max(depth, 1)
+        ref = get_model(p)                                  # parameter container only (CPU); never run on CPU
+        sd = {k: v.detach().clone() for k, v in ref.state_dict().items()}
+        for k in sd:                                        # LN weights are 0 at init: blocks would be the identity
+            if k.endswith("norm1.weight") or k.endswith("norm2.weight"):
+                sd[k].fill_(1.0)
+        cfg = O.SwinCfg.from_params(p)
+        cfg.depth = depth
+        net = O.OracleNet(cfg, sd)
+        x = torch.randn(1, 73, a.height, a.width)
+        t0 = time.time()
+        y = net(x)
+        y.square().mean().backward()
+        times[depth] = time.time() - t0
+        del net, y
+    per_sample = times[0] + a.depth * (times[1] - times[0])
+    return {"value": 1.0 / per_sample, "unit": "samples/sec", "cores": threads, "kind": "port",
+            "sample": f"oracle fp32 fwd+bwd of 1 sample 73x{a.height}x{a.width}: embed+head {times[0]:.1f}s, +1 block "
+                      f"{times[1] - times[0]:.1f}s, extrapolated to depth {a.depth} ({per_sample:.0f}s/sample); optimizer excluded"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--local-batch", type=int, default=2)
+    ap.add_argument("--depth", type=int, default=12)
+    ap.add_argument("--embed-dim", type=int, default=128)
+    ap.add_argument("--heads", type=int, default=8)
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--width", type=int, default=1440)
+    ap.add_argument("--window-ratio", type=int, default=80)
+    ap.add_argument("--rel-pos", type=int, default=0, help="0 = yaml default of swin_73var (rel_pos: false)")
+    ap.add_argument("--drop-path-rate", type=float, default=0.1)
+    ap.add_argument("--pool", type=int, default=2, help="device-resident synthetic batches that are cycled")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--roofline-kernel", default="attn_bwd")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", init_method="env://")
+
+    from swin_v2_weather_amd import ops
+    from swin_v2_weather_amd.networks.helpers import get_model
+    from swin_v2_weather_amd.utils.losses import LossHandler
+
+    torch.manual_seed(333)                                   # same initial weights on every rank
+    p = model_params(a)
+    model = get_model(p).to(dev)
+    model.train()
+    lp = SimpleNamespace(n_future=0, img_shape_x=a.height, img_shape_y=a.width, loss="l2", channel_weights="none",
+                         n_out_channels=73, model_grid_type="equiangular")
+    loss_obj = LossHandler(lp).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.95), fused=True)
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], output_device=local_rank,
+                                                        broadcast_buffers=False, gradient_as_bucket_view=True)
+    g = torch.Generator(device=dev).manual_seed(333 + rank)
+    B = a.local_batch
+    pool = [(torch.randn(B, 73, a.height, a.width, device=dev, generator=g),
+             torch.randn(B, 73, a.height, a.width, device=dev, generator=g)) for _ in range(a.pool)]
+
+    def step(i):
+        inp, tar = pool[i % len(pool)]
+        net.zero_grad()
+        gen = net(inp)
+        loss = loss_obj(gen, tar, inp)
+        loss.backward()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    fence()
+    ops.start_kernel_timing([a.roofline_kernel])
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        loss = step(a.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    ktimes = ops.stop_kernel_timing()
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    if rank == 0:
+        value = world * B * a.steps / dt
+        flops = train_flops_per_sample(a)
+        T = (a.height // 4) * (a.width // 4)
+        Lw = (a.height // a.window_ratio) * (a.width // a.window_ratio)
+        n_l, k_ms = ktimes.get(a.roofline_kernel, (0, 0.0))
+        # algorithmic bytes per attention-core launch: fwd 8 T C, bwd 16 T C bytes per sample
+        per_sample = {"attn_fwd": 8.0, "attn_bwd": 16.0}.get(a.roofline_kernel, 0.0) * T * a.embed_dim
+        alg = per_sample * B
+        achieved = alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        out = {
+            "metric": "ERA5 samples/sec (73x721x1440) swin_73var depth12", "value": value, "unit": "samples/sec",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"swin_73var depth{a.depth} embed{a.embed_dim} heads{a.heads} 73x{a.height}x{a.width} "
+                                   f"window{a.height // a.window_ratio}x{a.width // a.window_ratio} rel_pos={bool(a.rel_pos)} "
+                                   f"full train step (fwd+loss+bwd+Adam)",
+                       "local_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                       "final_loss": float(loss)},
+            "model_tflops_per_gpu": value * flops / world / 1e12,
+            "mfma_frac_end_to_end": value * flops / world / 2.5e15,
+            "roofline": {"kernel": a.roofline_kernel, "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": None, "launches_timed": n_l, "avg_ms": k_ms,
+                         "algorithmic_bytes_per_launch": alg,
+                         "flops_per_launch": {"attn_fwd": 4.0, "attn_bwd": 8.0}.get(a.roofline_kernel, 0.0) * T * Lw * a.embed_dim * B},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -65,6 +65,7 @@ typedef struct swv2_attn_args {
                                  different regions get -100.  (wh - sh) * ww for a block shifted by sh > 0 rows;
                                  0 = no mask. */
     int max_chunks;           /* workgroups per head (each loops over windows); 64 is a good default */
+    int dbg;                  /* must be 0 (kernel-ablation switches used by tests/perf_probe.py only) */
 } swv2_attn_args;
 
 /* cosine window attention core, forward: swinv2_global.py:304-318 (q,k normalisation is in the QKV epilogue) */
@@ -115,7 +116,9 @@ enum swv2_epilogue_kind {
     SWV2_EPI_UNPATCH = 4,   /* out fp32 y[B][Cout][H][W] (+ aux skip[B][Cs][H][W]) ; N = Cout*16 with columns ordered
                                c*16+p*4+q ; p[0]=Cout p[1]=H p[2]=W p[3]=Cs (0 = no skip)   (:784-802)               */
     SWV2_EPI_HEADS = 5,     /* out = [Bw][h][Lp][DP] bf16 split heads, no normalisation ; p as QKV_HEADS, N=heads*DP */
-    SWV2_EPI_F32_ACC = 6    /* out fp32 [M][ld] += acc ; optional rowidx scatter                                     */
+    SWV2_EPI_F32_ACC = 6,   /* out fp32 [M][ld] += acc ; optional rowidx scatter                                     */
+    SWV2_EPI_BF16_GELU = 7  /* out bf16 = acc + bias (pre-activation, kept for backward), aux_out bf16 = erf-GELU of it,
+                               both [M][ld] (fc1 of the timm Mlp, swinv2_global.py:381-386)                         */
 };
 
 typedef struct swv2_epilogue {
@@ -149,6 +152,7 @@ int swv2_prep_weight(const float* w, int rows, int cols, int transpose, const in
  * Replaces  x + drop_path(norm(branch))  (swinv2_global.py:490,496), window_reverse + roll (:468-476) and
  * PatchEmbed's norm + pos_embed add (:545,780 with res = pos_embed as [T][C], res_mod = T).
  * ------------------------------------------------------------------------------------------------------------ */
+#define SWV2_LN_BWD_MAX_BLOCKS 512
 typedef struct swv2_ln_args {
     const void* a;         /* bf16 [M][C] branch output                                   */
     const float* res;      /* fwd: fp32 residual rows (NULL = 0)                           */
@@ -163,6 +167,7 @@ typedef struct swv2_ln_args {
     void* da;              /* bwd out: bf16 [M][C] grad of a (zeros on padded rows)       */
     float* dgamma;         /* bwd out: [C] ACCUMULATED */
     float* dbeta;          /* bwd out: [C] ACCUMULATED */
+    float* ws;             /* bwd: workspace of SWV2_LN_BWD_MAX_BLOCKS * 2 * C floats (per-block partial sums) */
     int M, C, res_mod, rows_per_sample;
     float eps;
 } swv2_ln_args;

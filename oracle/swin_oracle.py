@@ -34,6 +34,27 @@ import torch
 import torch.nn.functional as F
 
 Tensor = torch.Tensor
+
+# Optional rounding emulation (tests only): when set to a callable, it is applied at exactly the points where the HIP
+# path stores a value as bf16 (GEMM operands, normalised q/k, v, softmax probabilities, branch outputs).  The default
+# (None) is the exact fp32/fp64 restatement of the reference.  Gradients pass straight through the rounding.
+_ROUND = None
+
+
+def set_rounding(fn) -> None:
+    global _ROUND
+    _ROUND = fn
+
+
+def bf16_round(x: Tensor) -> Tensor:
+    """straight-through bf16 rounding: value of x.bfloat16(), gradient of identity"""
+    return x + (x.detach().to(torch.bfloat16).to(x.dtype) - x.detach())
+
+
+def _r(x: Tensor) -> Tensor:
+    return x if _ROUND is None else _ROUND(x)
+
+
 LN_EPS = 1e-5               # torch.nn.LayerNorm default (swinv2_global.py:376,387 use nn.LayerNorm)
 LOGIT_MAX = math.log(100.0)  # swinv2_global.py:305  clamp(max=log(1/0.01))
 
@@ -182,7 +203,10 @@ def cpb_bias(p: Dict[str, Tensor], pre: str, wh: int, ww: int, heads: int,
     hdn = torch.relu(R @ p[pre + "meta_mlp.fc1.weight"].T + p[pre + "meta_mlp.fc1.bias"])
     hdn = F.dropout(hdn, drop_p, training)
     o = hdn @ p[pre + "meta_mlp.fc2.weight"].T + p[pre + "meta_mlp.fc2.bias"]     # [L*L, h]
-    return o.T.reshape(heads, L, L)
+    o = o.T.reshape(heads, L, L)
+    if _ROUND is not None:      # the kernels hold the bias table in the log2 domain as bf16
+        o = _r(o * 1.4426950408889634) / 1.4426950408889634
+    return o
 
 
 def attention_core(qkv: Tensor, logit_scale: Tensor, heads: int,
@@ -195,8 +219,9 @@ def attention_core(qkv: Tensor, logit_scale: Tensor, heads: int,
     C = C3 // 3
     d = C // heads
     q, k, v = qkv.reshape(Bw, L, 3, heads, d).permute(2, 0, 3, 1, 4)        # each [Bw, h, L, d]
-    qn = q / q.norm(dim=-1, keepdim=True).clamp_min(1e-12)
-    kn = k / k.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    qn = _r(q / q.norm(dim=-1, keepdim=True).clamp_min(1e-12))
+    kn = _r(k / k.norm(dim=-1, keepdim=True).clamp_min(1e-12))
+    v = _r(v)
     S = torch.einsum("bhqd,bhkd->bhqk", qn, kn)
     S = S * torch.exp(torch.clamp(logit_scale, max=LOGIT_MAX)).view(1, heads, 1, 1)
     if bias is not None:
@@ -204,16 +229,20 @@ def attention_core(qkv: Tensor, logit_scale: Tensor, heads: int,
     if mask is not None:
         nW = mask.shape[0]
         S = (S.reshape(Bw // nW, nW, heads, L, L) + mask.view(1, nW, 1, L, L)).reshape(Bw, heads, L, L)
-    P = torch.softmax(S, dim=-1)
-    return torch.einsum("bhqk,bhkd->bqhd", P, v).reshape(Bw, L, C)
+    if _ROUND is None:
+        P = torch.softmax(S, dim=-1)
+        return torch.einsum("bhqk,bhkd->bqhd", P, v).reshape(Bw, L, C)
+    # HIP path: un-normalised exp rounded to bf16 for the P.V product, fp32 row sum, one division at the end
+    E = torch.exp(S - S.max(dim=-1, keepdim=True).values)
+    return _r(torch.einsum("bhqk,bhkd->bqhd", _r(E), v) / E.sum(-1).permute(0, 2, 1).unsqueeze(-1)).reshape(Bw, L, C)
 
 
 def window_attention(xw: Tensor, p: Dict[str, Tensor], pre: str, heads: int,
                      bias: Optional[Tensor], mask: Optional[Tensor]) -> Tensor:
     """qkv Linear -> attention_core -> proj Linear on [Bw, L, C] windows."""
-    qkv = xw @ p[pre + "qkv.weight"].T + p[pre + "qkv.bias"]
+    qkv = _r(xw) @ _r(p[pre + "qkv.weight"]).T + p[pre + "qkv.bias"]
     o = attention_core(qkv, p[pre + "logit_scale"], heads, bias, mask)
-    return o @ p[pre + "proj.weight"].T + p[pre + "proj.bias"]
+    return _r(o @ _r(p[pre + "proj.weight"]).T + p[pre + "proj.bias"])
 
 
 def drop_path_scale(B: int, prob: float, training: bool, like: Tensor) -> Optional[Tensor]:
@@ -244,8 +273,8 @@ def block_forward(x: Tensor, p: Dict[str, Tensor], pre: str, cfg: SwinCfg, index
     dp = cfg.drop_path(index)
     s1 = drop_path_scale(B, dp, training, x)
     x = x + (a if s1 is None else a * s1.view(B, 1, 1, 1))
-    m = gelu_erf(x @ p[pre + "mlp.fc1.weight"].T + p[pre + "mlp.fc1.bias"])
-    m = m @ p[pre + "mlp.fc2.weight"].T + p[pre + "mlp.fc2.bias"]
+    m = _r(gelu_erf(_r(_r(x) @ _r(p[pre + "mlp.fc1.weight"]).T + p[pre + "mlp.fc1.bias"])))
+    m = _r(m @ _r(p[pre + "mlp.fc2.weight"]).T + p[pre + "mlp.fc2.bias"])
     m = layer_norm(m, p[pre + "norm2.weight"], p[pre + "norm2.bias"])
     s2 = drop_path_scale(B, dp, training, x)
     return x + (m if s2 is None else m * s2.view(B, 1, 1, 1))
@@ -257,7 +286,7 @@ def patch_embed(x: Tensor, p: Dict[str, Tensor], pre: str, P: int) -> Tensor:
     gh, gw = H // P, W // P
     w = p[pre + "proj.weight"]                                   # [C, Cin, P, P]
     patches = x.reshape(B, Cin, gh, P, gw, P).permute(0, 2, 4, 1, 3, 5).reshape(B, gh, gw, Cin * P * P)
-    e = patches @ w.reshape(w.shape[0], -1).T + p[pre + "proj.bias"]
+    e = _r(_r(patches) @ _r(w.reshape(w.shape[0], -1)).T + p[pre + "proj.bias"])
     return layer_norm(e, p[pre + "norm.weight"], p[pre + "norm.bias"])
 
 
@@ -267,14 +296,14 @@ def patch_merging(x: Tensor, p: Dict[str, Tensor], pre: str) -> Tensor:
     parts = [x[:, hp::2, wp::2, :] for wp in (0, 1) for hp in (0, 1)]
     m = torch.cat(parts, dim=-1)
     m = layer_norm(m, p[pre + "norm.weight"], p[pre + "norm.bias"])
-    return m @ p[pre + "reduction.weight"].T
+    return _r(m) @ _r(p[pre + "reduction.weight"]).T
 
 
 def head_unpatchify(e: Tensor, w_head: Tensor, P: int, out_chans: int,
                     skip: Optional[Tensor]) -> Tensor:
     """[B,gh,gw,C] -> [B,Cout,H,W]: y[b,c,P*i+p,P*j+q] = (e W^T)[b,i,j,(p*P+q)*Cout+c] (+skip) (:784-802)."""
     B, gh, gw, C = e.shape
-    z = (e @ w_head.T).reshape(B, gh, gw, P, P, out_chans)
+    z = (_r(e) @ _r(w_head).T).reshape(B, gh, gw, P, P, out_chans)
     y = z.permute(0, 5, 1, 3, 2, 4).reshape(B, out_chans, gh * P, gw * P)
     if skip is not None:
         y = y + skip[:, :out_chans]

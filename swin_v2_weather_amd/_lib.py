@@ -56,7 +56,7 @@ class AttnArgs(C.Structure):
                 ("lse", C.c_void_p), ("doh", C.c_void_p), ("rnorm", C.c_void_p), ("dqkvh", C.c_void_p),
                 ("dlogit_scale", C.c_void_p), ("dbias", C.c_void_p),
                 ("Bw", C.c_int), ("heads", C.c_int), ("L", C.c_int), ("head_dim", C.c_int),
-                ("nwh", C.c_int), ("nww", C.c_int), ("mask_thr", C.c_int), ("max_chunks", C.c_int)]
+                ("nwh", C.c_int), ("nww", C.c_int), ("mask_thr", C.c_int), ("max_chunks", C.c_int), ("dbg", C.c_int)]
 
 
 class Operand(C.Structure):
@@ -74,12 +74,13 @@ class LnArgs(C.Structure):
     _fields_ = [("a", C.c_void_p), ("res", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
                 ("scale", C.c_void_p), ("rowidx", C.c_void_p), ("y", C.c_void_p), ("mean", C.c_void_p),
                 ("rstd", C.c_void_p), ("dy", C.c_void_p), ("da", C.c_void_p), ("dgamma", C.c_void_p),
-                ("dbeta", C.c_void_p), ("M", C.c_int), ("C", C.c_int), ("res_mod", C.c_int),
+                ("dbeta", C.c_void_p), ("ws", C.c_void_p), ("M", C.c_int), ("C", C.c_int), ("res_mod", C.c_int),
                 ("rows_per_sample", C.c_int), ("eps", C.c_float)]
 
 
+LN_BWD_MAX_BLOCKS = 512
 OP_F32, OP_BF16, OP_BF16_GELU, OP_HEADS, OP_PATCH, OP_MERGE_LN = range(6)
-EPI_BF16, EPI_F32, EPI_QKV_HEADS, EPI_GELU_GRAD, EPI_UNPATCH, EPI_HEADS, EPI_F32_ACC = range(7)
+EPI_BF16, EPI_F32, EPI_QKV_HEADS, EPI_GELU_GRAD, EPI_UNPATCH, EPI_HEADS, EPI_F32_ACC, EPI_BF16_GELU = range(8)
 
 # every symbol include/swv2.h declares: (name, restype, argtypes)
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_long, C.c_float

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(64 * LT) void attn_fwd_kernel(
                 const int key = 16 * t + 4 * g + r;
                 float v = SWV2_NEG_BIG;
                 if (key < L) v = (q < L) ? bias[((size_t)hd * L + q) * L + key] * SWV2_LOG2E : 0.f;
-                biasr[t][r] = v;
+                biasr[t][r] = bf2f(f2bf(v));     // bf16 like the backward's LDS image: identical P in both passes
             }
     }
 
@@ -177,6 +177,16 @@ __global__ __launch_bounds__(64 * LT) void attn_fwd_kernel(
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
+// Per window, three barrier-separated phases:
+//   stage  : q, k, dO slabs -> LDS (16-byte chunks, prefetched into registers during the previous window),
+//            delta[q] = sum_d dO O computed by the staging threads themselves (shuffle over the row's chunks)
+//   phase 1: wave = key tile.  S = Q K^T, dP = dO V^T (MFMA), P = exp2(S' - LSE'), dS = P (dP - delta);
+//            dV^T += dO^T P, dK^T += Q^T dcos with the accumulators used directly as B operands; the bf16 dcos tile is
+//            written to an LDS image [key][q] (8-byte writes); dK, dV leave through the L2-normalisation backward.
+//   phase 2: wave = query tile.  dQ^T = sum_t K_t^T dcos_t^T with both operands as transposed LDS reads -- no atomics,
+//            no cross-wave reduction -- then the normalisation backward and a coalesced store.
+// The CPB bias (log2 domain, bf16, [key][q]) of the workgroup's head sits in LDS when it fits (BIAS_LDS), its
+// gradient accumulates in registers (wave = key tile owns 16 x Lp entries) across all windows of the workgroup.
 template <int LT, int DK, bool HAS_BIAS>
 __global__ __launch_bounds__(64 * LT) void attn_bwd_kernel(
     const uint16_t* __restrict__ qkvh, const float* __restrict__ logit_scale, const float* __restrict__ bias,
@@ -185,81 +195,122 @@ __global__ __launch_bounds__(64 * LT) void attn_bwd_kernel(
     uint16_t* __restrict__ dqkvh,          // [Bw][h][3][Lp][DP]  grads w.r.t. the UN-normalised q, k and v
     float* __restrict__ dlogit,            // [h]      (atomically accumulated)
     float* __restrict__ dbias,             // [h][L][L] (atomically accumulated) or null
-    int Bw, int h, int L, int nW, int nww, int nwh, int mask_thr) {
+    int Bw, int h, int L, int nW, int nww, int nwh, int mask_thr, int dbg) {
     using C = AttnCfg<LT, DK>;
     constexpr int Lp = C::Lp, DP = C::DP, SLAB = C::SLAB, NT = C::NT;
-    constexpr int LpP = Lp + 4;              // dQ^T accumulator row pitch (floats): (4*LpP) % 32 == 16
+    constexpr int DSP = Lp + 4;                              // row pitch (elements) of the [key][q] bf16 images
+    constexpr bool BIAS_LDS = HAS_BIAS && (LT * DK <= 11);   // 145 KB at LT=11, DK=1
+    constexpr int CH = SLAB / 8;                             // 16-byte chunks per slab
+    constexpr int CPT = (CH + NT - 1) / NT;                  // chunks per thread (1 for DK <= 2)
+    constexpr int CPR = 2 * DK;                              // chunks per row
     __shared__ __attribute__((aligned(16))) uint16_t Qs[SLAB];
     __shared__ __attribute__((aligned(16))) uint16_t Ks[SLAB];
     __shared__ __attribute__((aligned(16))) uint16_t dOs[SLAB];
-    __shared__ __attribute__((aligned(16))) uint16_t scr[LT * 256];    // per-wave 16x16 bf16 transpose tile
-    __shared__ __attribute__((aligned(16))) float dQT[DP * LpP];        // [d][q]
+    __shared__ __attribute__((aligned(16))) uint16_t dSb[Lp * DSP];
+    __shared__ __attribute__((aligned(16))) uint16_t biasS[BIAS_LDS ? Lp * DSP : 8];
     __shared__ __attribute__((aligned(16))) float LSEs[Lp];
     __shared__ __attribute__((aligned(16))) float DLs[Lp];
+    __shared__ float red[LT];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int tw = tid >> 6;                 // this wave's key tile
+    const int tw = tid >> 6;                 // this wave's tile (key tile in phase 1, query tile in phase 2)
     const int fr = lane & 15, g = lane >> 4;
     const int hd = blockIdx.y;
-    const int key = 16 * tw + fr;            // this lane's key
-    uint16_t* myscr = scr + tw * 256;
+    const int key = 16 * tw + fr;            // phase 1: this lane's key
 
     const float tau = logit_scale[hd];
     const float sigma = __expf(fminf(tau, SWV2_LN100));
     const float sc2 = sigma * SWV2_LOG2E;
 
-    f32x4 biasr[LT];
+    // bias rows: registers (fallback) or LDS image biasS[key][q]; gradient rows always in registers
+    f32x4 biasr[BIAS_LDS ? 1 : LT];
     f32x4 dbr[LT];
     if (HAS_BIAS) {
 #pragma unroll
-        for (int qt = 0; qt < LT; ++qt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int q = 16 * qt + 4 * g + r;
+        for (int qt = 0; qt < LT; ++qt) dbr[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (BIAS_LDS) {
+            for (int i = tid; i < Lp * Lp; i += NT) {
+                const int q = i / Lp, k = i - q * Lp;       // k fastest: coalesced global reads
                 float v = SWV2_NEG_BIG;
-                if (key < L) v = (q < L) ? bias[((size_t)hd * L + q) * L + key] * SWV2_LOG2E : 0.f;
-                biasr[qt][r] = v;
-                dbr[qt][r] = 0.f;
+                if (k < L) v = (q < L) ? bias[((size_t)hd * L + q) * L + k] * SWV2_LOG2E : 0.f;
+                biasS[k * DSP + q] = f2bf(v);
             }
+        } else {
+#pragma unroll
+            for (int qt = 0; qt < (BIAS_LDS ? 1 : LT); ++qt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = 16 * qt + 4 * g + r;
+                    float v = SWV2_NEG_BIG;
+                    if (key < L) v = (q < L) ? bias[((size_t)hd * L + q) * L + key] * SWV2_LOG2E : 0.f;
+                    biasr[qt][r] = bf2f(f2bf(v));           // bf16-rounded like the LDS image and the forward
+                }
+        }
     }
     float dsig = 0.f;
 
-    for (int bw = blockIdx.x; bw < Bw; bw += gridDim.x) {
-        const size_t slab0 = ((size_t)bw * h + hd) * 3 * SLAB;
-        const size_t oslab = ((size_t)bw * h + hd) * SLAB;
-        // ---- stage Q, K, dO (16-byte chunks), LSE; zero the dQ accumulator
-        constexpr int CH = SLAB / 8;         // chunks per slab = 32*LT*DK
-        for (int c = tid; c < CH; c += NT) {
-            *(uint4*)(Qs + c * 8) = *(const uint4*)(qkvh + slab0 + (size_t)c * 8);
-            *(uint4*)(Ks + c * 8) = *(const uint4*)(qkvh + slab0 + SLAB + (size_t)c * 8);
-            *(uint4*)(dOs + c * 8) = *(const uint4*)(doh + oslab + (size_t)c * 8);
-        }
-        for (int i = tid; i < DP * LpP; i += NT) dQT[i] = 0.f;
-        if (tid < Lp) LSEs[tid] = (tid < L) ? lse[((size_t)bw * h + hd) * Lp + tid] : 1.0e30f;
-        __syncthreads();
-        // ---- delta[q] = sum_d dO[q][d] O[q][d]
-        if (tid < Lp) {
-            float dl = 0.f;
+    // ---- staging registers: chunk c = tid + j*NT of the q, k, dO, o slabs
+    uint4 sq[CPT], sk[CPT], sdo[CPT], so[CPT];
+    float slse = 0.f;
+    auto issue = [&](int bw) {
+        const size_t slab0 = ((size_t)bw * h + hd) * 3 * SLAB, oslab = ((size_t)bw * h + hd) * SLAB;
 #pragma unroll
-            for (int c = 0; c < 2 * DK; ++c) {
-                const bf16x8 a = *(const bf16x8*)(dOs + tid * DP + 8 * c);
-                const bf16x8 b = *(const bf16x8*)(oh + oslab + (size_t)tid * DP + 8 * c);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) dl = fmaf(bf2f(a[j]), bf2f(b[j]), dl);
+        for (int j = 0; j < CPT; ++j) {
+            const int c = tid + j * NT;
+            if (c < CH) {
+                sq[j] = *(const uint4*)(qkvh + slab0 + (size_t)c * 8);
+                sk[j] = *(const uint4*)(qkvh + slab0 + SLAB + (size_t)c * 8);
+                sdo[j] = *(const uint4*)(doh + oslab + (size_t)c * 8);
+                so[j] = *(const uint4*)(oh + oslab + (size_t)c * 8);
             }
-            DLs[tid] = dl;
         }
-        // ---- this wave's K and V tile as B operands (B[k = d 4g+j][n = key fr]) and K^T as A operand
-        bf16x4 kf[DK], vf[DK], kT[DK];
+        if (tid < Lp) slse = (tid < L) ? lse[((size_t)bw * h + hd) * Lp + tid] : 1.0e30f;
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int c = tid + j * NT;
+            if (c < CH) {
+                *(uint4*)(Qs + c * 8) = sq[j];
+                *(uint4*)(Ks + c * 8) = sk[j];
+                *(uint4*)(dOs + c * 8) = sdo[j];
+            }
+            // delta partial over this chunk's 8 channels, reduced over the CPR chunks of the row (adjacent lanes)
+            float dl = 0.f;
+            if (c < CH) {
+                const uint32_t a[4] = {sdo[j].x, sdo[j].y, sdo[j].z, sdo[j].w}, b[4] = {so[j].x, so[j].y, so[j].z, so[j].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    dl = fmaf(__uint_as_float(a[e] << 16), __uint_as_float(b[e] << 16), dl);
+                    dl = fmaf(__uint_as_float(a[e] & 0xffff0000u), __uint_as_float(b[e] & 0xffff0000u), dl);
+                }
+            }
+#pragma unroll
+            for (int o = 1; o < CPR; o <<= 1) dl += __shfl_xor(dl, o);
+            if (c < CH && (c % CPR) == 0) DLs[c / CPR] = dl;
+        }
+        if (tid < Lp) LSEs[tid] = slse;
+    };
+
+    int bw = blockIdx.x;
+    if (bw >= Bw) return;
+    issue(bw);
+    commit();
+    __syncthreads();
+
+    for (; bw < Bw; bw += gridDim.x) {
+        const size_t slab0 = ((size_t)bw * h + hd) * 3 * SLAB;
+        const int bw_next = bw + gridDim.x;
+        if (bw_next < Bw) issue(bw_next);
+
+        // ================= phase 1: wave = key tile =================
+        bf16x4 kf[DK], vf[DK];
 #pragma unroll
         for (int kk = 0; kk < DK; ++kk) {
             kf[kk] = *(const bf16x4*)(Ks + key * DP + 16 * kk + 4 * g);
             vf[kk] = *(const bf16x4*)(qkvh + slab0 + 2 * SLAB + (size_t)key * DP + 16 * kk + 4 * g);
-            kT[kk] = lds_tr_read(Ks + (16 * tw + 4 * g + (fr >> 2)) * DP + 16 * kk + (fr & 3) * 4);
         }
-        __syncthreads();
-
         const bool do_mask = (mask_thr > 0) && (((bw % nW) / nww) == nwh - 1);
         const bool kid = key >= mask_thr;
         f32x4 dk[DK], dv[DK];
@@ -268,8 +319,7 @@ __global__ __launch_bounds__(64 * LT) void attn_bwd_kernel(
             dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-
-        // one q-tile step; `br` / `dbrow` are this lane's bias row and bias-gradient row of the tile (registers)
+        // one q-tile step; `br` / `dbrow`: this lane's bias row / bias-gradient row of the tile
         auto step = [&](const int qt, const f32x4 br, f32x4& dbrow) {
             // S = Q K^T and dP = dO V^T : rows q = 16qt + 4g + r, column = key fr
             f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
@@ -303,6 +353,7 @@ __global__ __launch_bounds__(64 * LT) void attn_bwd_kernel(
             }
             const bf16x4 pb = f2bf4(p);
             const bf16x4 dsb = f2bf4(ds);
+            *(bf16x4*)(dSb + key * DSP + 16 * qt + 4 * g) = dsb;            // image [key][q] for phase 2
             // dV^T += dO^T P ; dK^T += Q^T dcos     (A operands: transposed reads of the staged dO / Q tiles)
 #pragma unroll
             for (int dt = 0; dt < DK; ++dt) {
@@ -310,30 +361,35 @@ __global__ __launch_bounds__(64 * LT) void attn_bwd_kernel(
                 dv[dt] = mfma16(lds_tr_read(dOs + off), pb, dv[dt]);
                 dk[dt] = mfma16(lds_tr_read(Qs + off), dsb, dk[dt]);
             }
-            // dQ^T[d][q] += K^T[d][key] dcos^T[key][q] : transpose the 16x16 dcos tile through the wave's scratch
-            *(bf16x4*)(myscr + fr * 16 + 4 * g) = dsb;                      // image [key][q]
-            const bf16x4 dsT = lds_tr_read(myscr + (4 * g + (fr >> 2)) * 16 + (fr & 3) * 4);
-#pragma unroll
-            for (int dt = 0; dt < DK; ++dt) {
-                f32x4 dq = mfma16(kT[dt], dsT, (f32x4){0.f, 0.f, 0.f, 0.f});   // rows d = 16dt+4g+r, col q = fr
-#pragma unroll
-                for (int r = 0; r < 4; ++r) atomicAdd(&dQT[(16 * dt + 4 * g + r) * LpP + 16 * qt + fr], dq[r]);
-            }
         };
         if constexpr (HAS_BIAS) {
-            // fully unrolled so the bias / bias-gradient rows are statically indexed registers; the scheduling
-            // barrier keeps the compiler from hoisting the next tiles' LDS reads (register pressure)
-#pragma unroll
+            // rolled loop; the bias-gradient rows stay statically indexed registers through a (scalar, wave-uniform)
+            // switch on the tile index -- full unrolling costs > 100 extra VGPRs and spills
+#pragma unroll 1
             for (int qt = 0; qt < LT; ++qt) {
-                step(qt, biasr[qt], dbr[qt]);
-                __builtin_amdgcn_sched_barrier(0);
+                f32x4 br;
+                if constexpr (BIAS_LDS) {
+                    const bf16x4 b4 = *(const bf16x4*)(biasS + key * DSP + 16 * qt + 4 * g);
+                    br = (f32x4){bf2f(b4[0]), bf2f(b4[1]), bf2f(b4[2]), bf2f(b4[3])};
+                } else {
+                    br = (f32x4){0.f, 0.f, 0.f, 0.f};
+#define SWV2_CASE(I) case I: if (I < LT) br = biasr[BIAS_LDS ? 0 : (I < LT ? I : 0)]; break;
+                    switch (qt) { SWV2_CASE(0) SWV2_CASE(1) SWV2_CASE(2) SWV2_CASE(3) SWV2_CASE(4) SWV2_CASE(5)
+                                  SWV2_CASE(6) SWV2_CASE(7) SWV2_CASE(8) SWV2_CASE(9) SWV2_CASE(10) }
+#undef SWV2_CASE
+                }
+                f32x4 dsrow = {0.f, 0.f, 0.f, 0.f};
+                step(qt, br, dsrow);
+#define SWV2_CASE(I) case I: if (I < LT) dbr[I < LT ? I : 0] += dsrow; break;
+                switch (qt) { SWV2_CASE(0) SWV2_CASE(1) SWV2_CASE(2) SWV2_CASE(3) SWV2_CASE(4) SWV2_CASE(5)
+                              SWV2_CASE(6) SWV2_CASE(7) SWV2_CASE(8) SWV2_CASE(9) SWV2_CASE(10) }
+#undef SWV2_CASE
             }
         } else {
             f32x4 dummy = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
             for (int qt = 0; qt < LT; ++qt) step(qt, dummy, dummy);
         }
-
         // ---- dK (through the L2-normalisation) and dV of this wave's key tile
         {
             const float rk = rnorm[(((size_t)bw * h + hd) * 2 + 1) * Lp + key];
@@ -354,27 +410,55 @@ __global__ __launch_bounds__(64 * LT) void attn_bwd_kernel(
             }
         }
         __syncthreads();
-        // ---- dQ rows (through the L2-normalisation): one thread per query row
-        if (tid < Lp) {
-            const float rq = rnorm[(((size_t)bw * h + hd) * 2 + 0) * Lp + tid];
+
+        // ================= phase 2: wave = query tile =================
+        if (!(dbg & 1)) {
+            const int q = 16 * tw + fr;
+            f32x4 dq[DK];
+#pragma unroll
+            for (int dt = 0; dt < DK; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < LT; ++t) {
+                const int row = 16 * t + 4 * g + (fr >> 2);
+                const bf16x4 dsT = lds_tr_read(dSb + row * DSP + 16 * tw + (fr & 3) * 4);   // B[k = key][n = q]
+#pragma unroll
+                for (int dt = 0; dt < DK; ++dt)
+                    dq[dt] = mfma16(lds_tr_read(Ks + row * DP + 16 * dt + (fr & 3) * 4), dsT, dq[dt]);   // rows d, col q
+            }
+            const float rq = rnorm[(((size_t)bw * h + hd) * 2 + 0) * Lp + q];
+            bf16x4 qn[DK];
             float dot = 0.f;
 #pragma unroll
-            for (int d = 0; d < DP; ++d) dot = fmaf(dQT[d * LpP + tid], bf2f(Qs[tid * DP + d]), dot);
+            for (int dt = 0; dt < DK; ++dt) {
+                qn[dt] = *(const bf16x4*)(Qs + q * DP + 16 * dt + 4 * g);
 #pragma unroll
-            for (int c = 0; c < DP / 4; ++c) {
+                for (int r = 0; r < 4; ++r) dot = fmaf(dq[dt][r], bf2f(qn[dt][r]), dot);
+            }
+            dot += __shfl_xor(dot, 16);
+            dot += __shfl_xor(dot, 32);
+#pragma unroll
+            for (int dt = 0; dt < DK; ++dt) {
                 f32x4 v;
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    v[j] = rq * (dQT[(4 * c + j) * LpP + tid] - bf2f(Qs[tid * DP + 4 * c + j]) * dot);
-                *(bf16x4*)(dqkvh + slab0 + (size_t)tid * DP + 4 * c) = f2bf4(v);
+                for (int r = 0; r < 4; ++r) v[r] = rq * (dq[dt][r] - bf2f(qn[dt][r]) * dot);
+                *(bf16x4*)(dqkvh + slab0 + (size_t)q * DP + 16 * dt + 4 * g) = f2bf4(v);
             }
         }
         __syncthreads();
+        if (bw_next < Bw) commit();
+        __syncthreads();
     }
 
-    // ---- flush the per-workgroup reductions
+    // ---- flush the per-workgroup reductions: one atomic per workgroup for the logit scale
     dsig = wave_sum(dsig);
-    if (lane == 0 && tau <= SWV2_LN100) atomicAdd(dlogit + hd, dsig * sigma);
+    if (lane == 0) red[tw] = dsig;
+    __syncthreads();
+    if (tid == 0 && tau <= SWV2_LN100) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < LT; ++i) t += red[i];
+        atomicAdd(dlogit + hd, t * sigma);
+    }
     if (HAS_BIAS && key < L) {
 #pragma unroll
         for (int qt = 0; qt < LT; ++qt)
@@ -411,12 +495,12 @@ int launch_bwd(const swv2_attn_args* a, hipStream_t st) {
         hipLaunchKernelGGL((attn_bwd_kernel<LT, DK, true>), grid, block, 0, st, (const uint16_t*)a->qkvh, a->logit_scale,
                            a->bias, (const uint16_t*)a->oh, (const uint16_t*)a->doh, a->lse, a->rnorm,
                            (uint16_t*)a->dqkvh, a->dlogit_scale, a->dbias, a->Bw, a->heads, a->L, nW, a->nww, a->nwh,
-                           a->mask_thr);
+                           a->mask_thr, a->dbg);
     else
         hipLaunchKernelGGL((attn_bwd_kernel<LT, DK, false>), grid, block, 0, st, (const uint16_t*)a->qkvh,
                            a->logit_scale, a->bias, (const uint16_t*)a->oh, (const uint16_t*)a->doh, a->lse, a->rnorm,
                            (uint16_t*)a->dqkvh, a->dlogit_scale, a->dbias, a->Bw, a->heads, a->L, nW, a->nww, a->nwh,
-                           a->mask_thr);
+                           a->mask_thr, a->dbg);
     SWV2_CHECK_LAUNCH("swv2_attn_bwd");
     return SWV2_OK;
 }

@@ -28,9 +28,25 @@ constexpr int NTHREADS = 256;
 // swizzled element offset of chunk kc of row r in a [rows][64] bf16 tile (128-byte rows)
 __device__ __forceinline__ int swz(int r, int kc) { return r * BK + ((kc ^ ((r >> 1) & 7)) << 3); }
 
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+// erf-GELU (timm Mlp act = nn.GELU) with the Abramowitz-Stegun 7.1.26 rational erf (|err| < 1.5e-7, far below the
+// bf16 storage precision): one v_rcp + one v_exp + a few FMAs instead of the ~40-instruction erff().
+__device__ __forceinline__ void erf_parts(float x, float& erf_v, float& gauss) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
+    gauss = __expf(-z * z);                                    // exp(-x^2 / 2)
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    const float e = fmaf(-poly, gauss, 1.f);
+    erf_v = copysignf(e, x);
+}
+__device__ __forceinline__ float gelu_f(float x) {
+    float e, gs;
+    erf_parts(x, e, gs);
+    return 0.5f * x * (1.f + e);
+}
 __device__ __forceinline__ float gelu_grad_f(float x) {
-    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+    float e, gs;
+    erf_parts(x, e, gs);
+    return fmaf(x * 0.3989422804014327f, gs, 0.5f * (1.f + e));
 }
 
 __device__ __forceinline__ uint4 pack8(const float* v) {
@@ -174,7 +190,7 @@ struct EpiDesc {
     int p0, p1, p2, p3, p4;
 };
 
-enum { E_BF16 = 0, E_F32 = 1, E_QKV_HEADS = 2, E_GELU_GRAD = 3, E_UNPATCH = 4, E_HEADS = 5, E_F32_ACC = 6 };
+enum { E_BF16 = 0, E_F32 = 1, E_QKV_HEADS = 2, E_GELU_GRAD = 3, E_UNPATCH = 4, E_HEADS = 5, E_F32_ACC = 6, E_BF16_GELU = 7 };
 
 template <int KIND> struct Epi;
 
@@ -190,8 +206,16 @@ template <> struct Epi<E_BF16> {
 #pragma unroll
         for (int i = 0; i < 4; ++i) *(f32x4*)(v + 4 * i) = *(const f32x4*)(st + r * EP + c0 + 4 * i);
         if (d.bias) {
+            if (n + 16 <= d.N) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] += (n + i < d.N) ? d.bias[n + i] : 0.f;
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 b4 = *(const f32x4*)(d.bias + n + 4 * i);
+                    v[4 * i] += b4[0]; v[4 * i + 1] += b4[1]; v[4 * i + 2] += b4[2]; v[4 * i + 3] += b4[3];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] += (n + i < d.N) ? d.bias[n + i] : 0.f;
+            }
         }
         uint16_t* o = (uint16_t*)d.out + dst * d.ld + n;
         if (n + 16 <= d.N) {
@@ -199,6 +223,32 @@ template <> struct Epi<E_BF16> {
             *(uint4*)(o + 8) = pack8(v + 8);
         } else {
             for (int i = 0; i < 16 && n + i < d.N; ++i) o[i] = f2bf(v[i]);
+        }
+    }
+};
+// fc1 of the Mlp: out = acc + bias (bf16 pre-activation), aux_out = GELU(out) (bf16), same row-major layout
+template <> struct Epi<E_BF16_GELU> {
+    EpiDesc d;
+    __device__ __forceinline__ void tile(const float* st, int m0, int n0, int lane) const {
+        const int r = lane >> 2, c0 = (lane & 3) * 16, m = m0 + r, n = n0 + c0;
+        if (m >= d.M || n >= d.N) return;
+        float v[16], gl[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(f32x4*)(v + 4 * i) = *(const f32x4*)(st + r * EP + c0 + 4 * i);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (d.bias) v[i] += (n + i < d.N) ? d.bias[n + i] : 0.f;
+            gl[i] = gelu_f(bf2f(f2bf(v[i])));      // GELU of the stored (bf16) pre-activation: what the backward sees
+        }
+        uint16_t* o = (uint16_t*)d.out + (long)m * d.ld + n;
+        uint16_t* o2 = (uint16_t*)d.aux_out + (long)m * d.ld + n;
+        if (n + 16 <= d.N) {
+            *(uint4*)o = pack8(v);
+            *(uint4*)(o + 8) = pack8(v + 8);
+            *(uint4*)o2 = pack8(gl);
+            *(uint4*)(o2 + 8) = pack8(gl + 8);
+        } else {
+            for (int i = 0; i < 16 && n + i < d.N; ++i) { o[i] = f2bf(v[i]); o2[i] = f2bf(gl[i]); }
         }
     }
 };
@@ -258,11 +308,14 @@ __device__ __forceinline__ void heads_item(const EpiDesc& d, const float* st, in
         float v[DPc];
         float ss = 0.f;
 #pragma unroll
-        for (int j = 0; j < DPc; ++j) {
-            float x = 0.f;
-            if (valid) x = st[r * EP + slot * DPc + j] + (d.bias ? d.bias[nb + j] : 0.f);
-            v[j] = x;
-            ss = fmaf(x, x, ss);
+        for (int j = 0; j < DPc; j += 4) {
+            f32x4 x = *(const f32x4*)(st + r * EP + slot * DPc + j);
+            if (d.bias) x += *(const f32x4*)(d.bias + nb + j);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[j + e] = valid ? x[e] : 0.f;
+                ss = fmaf(v[j + e], v[j + e], ss);
+            }
         }
         float rn = 1.f;
         if (NORM && part < 2) {
@@ -559,6 +612,7 @@ int launch_nt1(const swv2_operand* a, const void* w, const swv2_epilogue* e, int
         case SWV2_EPI_HEADS: return launch_nt2<AK, E_HEADS>(a, w, e, M, N, K, st);
         case SWV2_EPI_GELU_GRAD: return launch_nt2<AK, E_GELU_GRAD>(a, w, e, M, N, K, st);
         case SWV2_EPI_UNPATCH: return launch_nt2<AK, E_UNPATCH>(a, w, e, M, N, K, st);
+        case SWV2_EPI_BF16_GELU: return launch_nt2<AK, E_BF16_GELU>(a, w, e, M, N, K, st);
     }
     swv2_set_error("swv2_linear: unknown epilogue kind %d", e->kind);
     return SWV2_ERR_INVALID;
@@ -609,7 +663,8 @@ extern "C" int swv2_linear(const swv2_operand* a, const void* w_bf16, const swv2
     if (rc) return rc;
     SWV2_CHECK_ARG(w_bf16 && e && e->out && N > 0, "swv2_linear: null weight / epilogue / N");
     SWV2_CHECK_ARG(((uintptr_t)w_bf16 & 15) == 0 && ((uintptr_t)e->out & 15) == 0, "swv2_linear: unaligned pointer");
-    if (e->kind == SWV2_EPI_BF16 || e->kind == SWV2_EPI_GELU_GRAD)
+    if (e->kind == SWV2_EPI_BF16_GELU) SWV2_CHECK_ARG(e->aux_out != nullptr, "swv2_linear: GELU epilogue needs aux_out");
+    if (e->kind == SWV2_EPI_BF16 || e->kind == SWV2_EPI_GELU_GRAD || e->kind == SWV2_EPI_BF16_GELU)
         SWV2_CHECK_ARG(e->ld % 8 == 0 && e->ld >= N, "swv2_linear: output pitch %ld must be a multiple of 8 and >= N", e->ld);
     if (e->kind == SWV2_EPI_F32 || e->kind == SWV2_EPI_F32_ACC)
         SWV2_CHECK_ARG(e->ld % 4 == 0 && e->ld >= N, "swv2_linear: output pitch %ld must be a multiple of 4 and >= N", e->ld);
@@ -645,6 +700,7 @@ extern "C" int swv2_linear_wgrad(const swv2_operand* dy, const swv2_operand* x, 
         case SWV2_OP_F32: return launch_tn1<A_F32>(dy, x, dW, db, nmap, kmap, ldw, M, N, K, splits, st);
         case SWV2_OP_BF16: return launch_tn1<A_BF16>(dy, x, dW, db, nmap, kmap, ldw, M, N, K, splits, st);
         case SWV2_OP_HEADS: return launch_tn1<A_HEADS>(dy, x, dW, db, nmap, kmap, ldw, M, N, K, splits, st);
+        case SWV2_OP_PATCH: return launch_tn1<A_PATCH>(dy, x, dW, db, nmap, kmap, ldw, M, N, K, splits, st);
     }
     swv2_set_error("swv2_linear_wgrad: unsupported dY operand kind %d", dy->kind);
     return SWV2_ERR_INVALID;

@@ -72,8 +72,8 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_residual_fwd_kernel(
         const float rs = rsqrtf(group_sum<G>(q) / C + eps);
         if (gl == 0) { mean[m] = mu; rstd[m] = rs; }
         if (dst < 0) continue;
-        const float sc = scale ? scale[dst / rows_per_sample] : 1.f;
-        const long rrow = res_mod ? dst % res_mod : dst;
+        const float sc = scale ? scale[(int)dst / rows_per_sample] : 1.f;
+        const long rrow = res_mod ? (long)((int)dst % res_mod) : dst;
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
             const int c0 = (gl + i * G) * 8;
@@ -98,8 +98,8 @@ template <int G, int CH>
 __global__ __launch_bounds__(LN_BLOCK) void ln_residual_bwd_kernel(
     const uint16_t* __restrict__ a, const float* __restrict__ dy, const float* __restrict__ gamma,
     const float* __restrict__ scale, const int32_t* __restrict__ rowidx, const float* __restrict__ mean,
-    const float* __restrict__ rstd, uint16_t* __restrict__ da, float* __restrict__ dgamma, float* __restrict__ dbeta,
-    int M, int C, int rows_per_sample) {
+    const float* __restrict__ rstd, uint16_t* __restrict__ da, float* __restrict__ ws, int M, int C,
+    int rows_per_sample) {
     const int gl = threadIdx.x % G;
     const int rows_per_block = LN_BLOCK / G;
     float dg[CH][8], dbt[CH][8];
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_residual_bwd_kernel(
             continue;
         }
         const float mu = mean[m], rs = rstd[m];
-        const float sc = scale ? scale[dst / rows_per_sample] : 1.f;
+        const float sc = scale ? scale[(int)dst / rows_per_sample] : 1.f;
         float xh[CH][8], gg[CH][8];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -179,12 +179,34 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_residual_bwd_kernel(
                     tg[e] += sg[(r * G + gl) * 8 + e];
                     tb[e] += sb[(r * G + gl) * 8 + e];
                 }
+            // per-block partial sums (plain stores); ln_partials_reduce_kernel folds them: thousands of same-address
+            // float atomics serialise at the memory side (measured: 7x the kernel's streaming time)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                atomicAdd(dgamma + c0 + e, tg[e]);
-                atomicAdd(dbeta + c0 + e, tb[e]);
+                ws[((size_t)blockIdx.x * 2 + 0) * C + c0 + e] = tg[e];
+                ws[((size_t)blockIdx.x * 2 + 1) * C + c0 + e] = tb[e];
             }
         }
+    }
+}
+
+// dgamma[j] += sum_b ws[b][0][j], dbeta[j] += sum_b ws[b][1][j] : 32 columns x 8 slices of blocks per workgroup
+__global__ __launch_bounds__(256) void ln_partials_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dgamma,
+                                                                 float* __restrict__ dbeta, int nblocks, int C) {
+    __shared__ float part[8][32];
+    const int col = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int j = blockIdx.x * 32 + col;
+    float s = 0.f;
+    if (j < 2 * C) {
+#pragma unroll 8
+        for (int b = sl; b < nblocks; b += 8) s += ws[(size_t)b * 2 * C + j];
+    }
+    part[sl][col] = s;
+    __syncthreads();
+    if (sl == 0 && j < 2 * C) {
+#pragma unroll
+        for (int i = 1; i < 8; ++i) s += part[i][col];
+        if (j < C) dgamma[j] += s; else dbeta[j - C] += s;
     }
 }
 
@@ -348,17 +370,19 @@ void launch_ln_fwd(const swv2_ln_args* a, hipStream_t st) {
 template <int G, int CH>
 void launch_ln_bwd(const swv2_ln_args* a, hipStream_t st) {
     const int rows_per_block = LN_BLOCK / G;
-    const int grid = min(cdiv(a->M, rows_per_block), 256 * 4);
+    const int grid = min(cdiv(a->M, rows_per_block), SWV2_LN_BWD_MAX_BLOCKS);
     hipLaunchKernelGGL((ln_residual_bwd_kernel<G, CH>), dim3(grid), dim3(LN_BLOCK), 0, st, (const uint16_t*)a->a, a->dy,
-                       a->gamma, a->scale, a->rowidx, a->mean, a->rstd, (uint16_t*)a->da, a->dgamma, a->dbeta, a->M,
-                       a->C, a->rows_per_sample);
+                       a->gamma, a->scale, a->rowidx, a->mean, a->rstd, (uint16_t*)a->da, a->ws, a->M, a->C,
+                       a->rows_per_sample);
+    hipLaunchKernelGGL(ln_partials_reduce_kernel, dim3(cdiv(2 * a->C, 32)), dim3(256), 0, st, a->ws, a->dgamma, a->dbeta,
+                       grid, a->C);
 }
 
 int ln_check(const swv2_ln_args* a, bool bwd) {
     SWV2_CHECK_ARG(a && a->a && a->gamma && a->mean && a->rstd, "ln_residual: null pointer");
     SWV2_CHECK_ARG(a->M > 0 && a->C > 0 && a->C % 8 == 0 && a->C <= 1024, "ln_residual: C=%d must be a multiple of 8, <= 1024", a->C);
     SWV2_CHECK_ARG(a->rows_per_sample > 0, "ln_residual: rows_per_sample must be positive");
-    if (bwd) SWV2_CHECK_ARG(a->dy && a->da && a->dgamma && a->dbeta, "ln_residual_bwd: null gradient pointer");
+    if (bwd) SWV2_CHECK_ARG(a->dy && a->da && a->dgamma && a->dbeta && a->ws, "ln_residual_bwd: null gradient / workspace pointer");
     else SWV2_CHECK_ARG(a->y && a->beta, "ln_residual_fwd: null output pointer");
     return SWV2_OK;
 }

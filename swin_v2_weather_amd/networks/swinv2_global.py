@@ -9,7 +9,7 @@ forward / backward arithmetic op is a HIP kernel from libswv2.so (see ops.py, in
   block forward  = 7 launches   x --[gather roll+partition | qkv GEMM | split heads + L2-norm]--> qkvh
                                   --[cosine window attention (MFMA), CPB bias, closed-form shift mask]--> oh
                                   --[merge heads | proj GEMM]--> a1 --[LN + drop-path + residual, reverse+un-roll scatter]--> x1
-                                  --[fc1 GEMM]--> h --[GELU on load | fc2 GEMM]--> a2 --[LN + drop-path + residual]--> x2
+                                  --[fc1 GEMM | + bias, GELU]--> h, g --[fc2 GEMM]--> a2 --[LN + drop-path + residual]--> x2
 
 The module constructors draw their initial parameters in the same order as the reference's, so the same
 `torch.manual_seed` gives the same initial weights.  There is no CPU / eager fallback: forward raises if the input is
@@ -128,11 +128,12 @@ class _BlockFn(torch.autograd.Function):
         mean1 = torch.empty(M_w, dtype=torch.float32, device=dev)
         rstd1 = torch.empty(M_w, dtype=torch.float32, device=dev)
         ops.ln_residual_fwd(a1, x2d, n1_w.detach(), n1_b.detach(), dp1, plan.rowidx, x1, mean1, rstd1, M_w, Cc, 0, T)
-        # 5. fc1 (pre-activation kept), 6. GELU-on-load | fc2
+        # 5. fc1: pre-activation (kept for GELU') and activation, 6. fc2
         hpre = torch.empty(B * T, hid, dtype=BF16, device=dev)
-        ops.linear(ops.op_f32(x1), w_fc1, ops.epilogue(L.EPI_BF16, hpre, ld=hid, bias=fc1_b.detach()), hid)
+        hact = torch.empty(B * T, hid, dtype=BF16, device=dev)
+        ops.linear(ops.op_f32(x1), w_fc1, ops.epilogue(L.EPI_BF16_GELU, hpre, ld=hid, bias=fc1_b.detach(), aux_out=hact), hid)
         a2 = torch.empty(B * T, Cc, dtype=BF16, device=dev)
-        ops.linear(ops.op_bf16(hpre, gelu=True), w_fc2, ops.epilogue(L.EPI_BF16, a2, ld=Cc, bias=fc2_b.detach()), Cc)
+        ops.linear(ops.op_bf16(hact), w_fc2, ops.epilogue(L.EPI_BF16, a2, ld=Cc, bias=fc2_b.detach()), Cc)
         # 7. LN2 + drop-path + residual
         x2 = torch.empty(B * T, Cc, dtype=torch.float32, device=dev)
         mean2 = torch.empty(B * T, dtype=torch.float32, device=dev)
@@ -142,13 +143,13 @@ class _BlockFn(torch.autograd.Function):
         ctx.blk, ctx.plan, ctx.has_bias = blk, plan, bias is not None
         ctx.save_for_backward(x2d, bias_c if bias is not None else x2d.new_empty(0), dp1 if dp1 is not None else x2d.new_empty(0),
                               dp2 if dp2 is not None else x2d.new_empty(0), logit_scale, qkv_w, proj_w, n1_w, fc1_w, fc2_w, n2_w,
-                              qkvh, rnorm, oh, lse, a1, mean1, rstd1, x1, hpre, a2, mean2, rstd2)
+                              qkvh, rnorm, oh, lse, a1, mean1, rstd1, x1, hpre, hact, a2, mean2, rstd2)
         return x2.view(B, gh, gw, Cc)
 
     @staticmethod
     def backward(ctx, dx2):
         (x2d, bias_c, dp1, dp2, logit_scale, qkv_w, proj_w, n1_w, fc1_w, fc2_w, n2_w, qkvh, rnorm, oh, lse, a1, mean1,
-         rstd1, x1, hpre, a2, mean2, rstd2) = ctx.saved_tensors
+         rstd1, x1, hpre, hact, a2, mean2, rstd2) = ctx.saved_tensors
         blk, plan = ctx.blk, ctx.plan
         wc = blk._wcache
         h, Lp, DP, Bw, T, B = plan.heads, plan.Lp, plan.DP, plan.Bw, plan.T, plan.B
@@ -172,7 +173,7 @@ class _BlockFn(torch.autograd.Function):
         ops.ln_residual_bwd(a2, dx2, n2_w, dp2, None, mean2, rstd2, da2, dn2w, dn2b, B * T, Cc, T)
         # 6'. fc2: dW = da2^T GELU(h), dh = (da2 W2) * GELU'(h)
         dfc2w, dfc2b = torch.zeros(Cc, hid, **f32), torch.zeros(Cc, **f32)
-        ops.linear_wgrad(ops.op_bf16(da2), ops.op_bf16(hpre, gelu=True), dfc2w, dfc2b)
+        ops.linear_wgrad(ops.op_bf16(da2), ops.op_bf16(hact), dfc2w, dfc2b)
         dh = torch.empty(B * T, hid, dtype=BF16, device=dev)
         ops.linear(ops.op_bf16(da2), w_fc2t, ops.epilogue(L.EPI_GELU_GRAD, dh, ld=hid, aux=hpre), hid)
         # 5'. fc1: dW = dh^T x1 ; dx1 = dx2 + dh W1

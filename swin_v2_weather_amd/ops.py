@@ -24,6 +24,35 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# ---- optional per-kernel event timing (bench.py): HIP events on the launch stream around selected entry points ----
+_TIMED = None          # None or dict name -> list of (start_event, end_event)
+
+
+def start_kernel_timing(names):
+    global _TIMED
+    _TIMED = {n: [] for n in names}
+
+
+def stop_kernel_timing():
+    """-> {name: (launches, mean_ms)}; synchronises."""
+    global _TIMED
+    rec, _TIMED = _TIMED, None
+    torch.cuda.synchronize()
+    return {n: (len(ev), sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)) for n, ev in (rec or {}).items()}
+
+
+def _timed(name, fn, *args):
+    rec = _TIMED
+    if rec is None or name not in rec:
+        return fn(*args)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    r = fn(*args)
+    b.record()
+    rec[name].append((a, b))
+    return r
+
+
 def _chk(t: torch.Tensor, dtype, name: str):
     if t.dtype != dtype or not t.is_contiguous() or not t.is_cuda:
         raise L.Swv2Error(f"{name}: expected a contiguous CUDA {dtype} tensor, got {t.dtype} "
@@ -83,11 +112,11 @@ def epilogue(kind, out, ld=0, bias=None, aux=None, aux_out=None, rowidx=None, p=
     return e
 
 
-def linear(a: L.Operand, w_bf16: torch.Tensor, e: L.Epilogue, N: int):
+def linear(a: L.Operand, w_bf16: torch.Tensor, e: L.Epilogue, N: int, tag: str = "linear"):
     _chk(w_bf16, BF16, "linear weight")
     if w_bf16.shape[0] != N or w_bf16.shape[1] != a.cols:
         raise L.Swv2Error(f"linear: weight {tuple(w_bf16.shape)} does not match N={N} K={a.cols}")
-    L.check(L.load().swv2_linear(C.byref(a), _p(w_bf16), C.byref(e), N, _stream()), "swv2_linear")
+    L.check(_timed(tag, L.load().swv2_linear, C.byref(a), _p(w_bf16), C.byref(e), N, _stream()), "swv2_linear")
 
 
 def linear_wgrad(dy: L.Operand, x: L.Operand, dW: torch.Tensor, db: Optional[torch.Tensor], nmap=None, kmap=None,
@@ -124,6 +153,8 @@ def ln_residual_bwd(a, dy, gamma, scale, rowidx, mean, rstd, da, dgamma, dbeta, 
     g = L.LnArgs()
     g.a, g.dy, g.gamma, g.scale, g.rowidx = _p(a), _p(dy), _p(gamma), _p(scale), _p(rowidx)
     g.mean, g.rstd, g.da, g.dgamma, g.dbeta = _p(mean), _p(rstd), _p(da), _p(dgamma), _p(dbeta)
+    ws = torch.empty(L.LN_BWD_MAX_BLOCKS * 2 * Cc, dtype=torch.float32, device=a.device)
+    g.ws = _p(ws)
     g.M, g.C, g.res_mod, g.rows_per_sample, g.eps = M, Cc, 0, rows_per_sample, 1e-5
     L.check(L.load().swv2_ln_residual_bwd(C.byref(g), _stream()), "swv2_ln_residual_bwd")
 
@@ -138,11 +169,11 @@ def attn_args(qkvh, logit_scale, bias, oh, lse, Bw, heads, Lwin, head_dim, nwh, 
 
 
 def attn_fwd(a: L.AttnArgs):
-    L.check(L.load().swv2_attn_fwd(C.byref(a), _stream()), "swv2_attn_fwd")
+    L.check(_timed("attn_fwd", L.load().swv2_attn_fwd, C.byref(a), _stream()), "swv2_attn_fwd")
 
 
 def attn_bwd(a: L.AttnArgs):
-    L.check(L.load().swv2_attn_bwd(C.byref(a), _stream()), "swv2_attn_bwd")
+    L.check(_timed("attn_bwd", L.load().swv2_attn_bwd, C.byref(a), _stream()), "swv2_attn_bwd")
 
 
 def batch_sum(inp: torch.Tensor, out: torch.Tensor, accumulate=False):

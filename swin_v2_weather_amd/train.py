@@ -1,0 +1,317 @@
+"""Trainer with the reference's surface (train.py:1-415): same CLI flags, same `Trainer` methods, same step order,
+same checkpoint dictionary and experiment-directory layout -- driving the HIP-backed model.
+
+    python -m swin_v2_weather_amd.train --yaml_config swin_v2_weather_amd/config/swin.yaml --config swin_73var --run_num 00
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m swin_v2_weather_amd.train ...
+
+Differences that are deliberate (reference quirks):
+  * single-process runs work (the reference calls dist.get_world_size() without a group, train.py:294);
+  * wandb / apex / ruamel are optional: absent here, so logging goes to screen/file and `optimizer_type: FusedLAMB`
+    raises; hyperparams.yaml is written with PyYAML;
+  * --enable_amp is accepted for CLI compatibility.  The HIP path always computes its GEMMs and attention on bf16 MFMA
+    with fp32 accumulation, fp32 LayerNorm / softmax / residual stream (what autocast does in the reference), and bf16
+    needs no GradScaler, so the flag only sets params.enable_amp;
+  * DDP: broadcast_buffers=False (the model has no persistent buffers; the reference re-broadcasts ~250 MB of constant
+    masks every forward), gradient_as_bucket_view=True; backend nccl (= RCCL over xGMI) on GPUs.
+"""
+import argparse
+import logging
+import os
+import time
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import yaml
+from torch.nn.parallel import DistributedDataParallel
+
+from .networks.helpers import get_model
+from .utils import get_data_loader_distributed, logging_utils
+from .utils.YParams import YParams
+from .utils.losses import LossHandler
+from .utils.preprocess_utils import PreProcessor
+from .utils.weighted_acc_rmse import weighted_rmse_torch
+
+try:  # optional observability (absent in this image)
+    import wandb
+except Exception:  # pragma: no cover
+    wandb = None
+
+
+class Trainer():
+    def count_parameters(self):
+        return sum(p.numel() for p in self.model.parameters() if p.requires_grad)
+
+    def __init__(self, params, args, model_factory=None, device=None):
+        """`model_factory(params) -> nn.Module` and `device` are test hooks (CPU/gloo plumbing tests inject the oracle
+        model); the product path always builds `get_model(params)` on an MI355X."""
+        self.sweep_id = args.sweep_id
+        self.root_dir = params['exp_dir']
+        self.config = args.config
+        params['enable_amp'] = args.enable_amp
+        self._model_factory = model_factory or get_model
+
+        self.world_size = int(os.environ.get('WORLD_SIZE', 1))
+        self.local_rank = 0
+        self.world_rank = 0
+        use_cuda = torch.cuda.is_available() and (device is None or torch.device(device).type == 'cuda')
+        if self.world_size > 1:
+            if not dist.is_initialized():
+                dist.init_process_group(backend='nccl' if use_cuda else 'gloo', init_method='env://')
+            self.world_rank = dist.get_rank()
+            self.local_rank = int(os.environ.get("LOCAL_RANK", 0))
+        if use_cuda:
+            torch.cuda.set_device(self.local_rank)
+            self.device = torch.device('cuda', self.local_rank)
+        elif device is not None:
+            self.device = torch.device(device)
+        else:
+            raise RuntimeError("no MI355X visible: the swv2 hot path has no CPU fallback")
+
+        self.log_to_screen = params.log_to_screen and self.world_rank == 0
+        self.log_to_wandb = params.log_to_wandb and self.world_rank == 0 and wandb is not None
+        self.params = params
+        self.params['name'] = args.config + '_' + str(args.run_num)
+        self.params['group'] = args.config
+        self.params['data_num_shards'] = self.world_size
+        self.params['data_shard_id'] = self.world_rank
+        self.run_num = args.run_num
+
+    def build_and_launch(self):
+        params = self.params
+        params['in_channels'] = np.array(params['in_channels'])
+        params['out_channels'] = np.array(params['out_channels'])
+        params['n_in_channels'] = len(params['in_channels'])
+        params['n_out_channels'] = len(params['out_channels'])
+        if params.add_zenith:
+            params.n_in_channels += 1
+        if params.add_landmask:
+            params.n_in_channels += 2
+        if params.add_orography:
+            params.n_in_channels += 1
+
+        if self.sweep_id:
+            raise RuntimeError("wandb sweeps are not available in this build")
+        exp_dir = os.path.join(*[self.root_dir, self.config, self.run_num])
+        if self.world_rank == 0:
+            os.makedirs(os.path.join(exp_dir, 'training_checkpoints/'), exist_ok=True)
+            os.makedirs(os.path.join(exp_dir, 'wandb/'), exist_ok=True)
+        params['experiment_dir'] = os.path.abspath(exp_dir)
+        params['checkpoint_path'] = os.path.join(exp_dir, 'training_checkpoints/ckpt.tar')
+        params['best_checkpoint_path'] = os.path.join(exp_dir, 'training_checkpoints/best_ckpt.tar')
+        params['resuming'] = True if os.path.isfile(params.checkpoint_path) else False
+        if self.log_to_wandb:
+            wandb.init(dir=os.path.join(exp_dir, "wandb"), config=params.params, name=params.name, group=params.group,
+                       project=params.project, entity=params.entity, resume=params.resuming)
+        if self.world_rank == 0:
+            logging_utils.log_to_file(logger_name=None, log_filename=os.path.join(exp_dir, 'out.log'))
+            logging_utils.log_versions()
+            params.log()
+
+        params['global_batch_size'] = params.batch_size
+        params['local_batch_size'] = int(params.batch_size // self.world_size)
+
+        self.train_data_loader, self.train_dataset, self.train_sampler = get_data_loader_distributed(
+            params, params.train_data_path, dist.is_initialized(), train=True)
+        self.valid_data_loader, self.valid_dataset = get_data_loader_distributed(
+            params, params.valid_data_path, dist.is_initialized(), train=False)
+        params['img_shape_x'] = self.train_dataset.img_shape_x
+        params['img_shape_y'] = self.train_dataset.img_shape_y
+
+        if self.world_rank == 0:
+            hparams = {str(k): (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in params.params.items()}
+            with open(os.path.join(params['experiment_dir'], 'hyperparams.yaml'), 'w') as hpfile:
+                yaml.safe_dump(hparams, hpfile)
+
+        self.loss_obj = LossHandler(params).to(self.device)
+        self.model = self._model_factory(params).to(self.device)
+        self.preprocessor = PreProcessor(params, self.device).to(self.device)
+
+        if params.optimizer_type == 'adam':
+            self.optimizer = torch.optim.Adam(self.model.parameters(), lr=params.lr, betas=(0.9, 0.95),
+                                              fused=self.device.type == 'cuda')
+        elif params.optimizer_type == 'FusedLAMB':
+            raise Exception("optimizer type FusedLAMB needs apex, which is not available in this build")
+        else:
+            raise Exception(f"optimizer type {params.optimizer_type} not implemented")
+
+        if dist.is_initialized():
+            ddp_kw = dict(broadcast_buffers=False, gradient_as_bucket_view=True,
+                          bucket_cap_mb=params['ddp_bucket_cap_mb'] if 'ddp_bucket_cap_mb' in params else 25,
+                          static_graph=bool(params['checkpointing']) if 'checkpointing' in params else False)
+            if self.device.type == 'cuda':
+                self.model = DistributedDataParallel(self.model, device_ids=[self.local_rank], output_device=self.local_rank, **ddp_kw)
+            else:
+                self.model = DistributedDataParallel(self.model, **ddp_kw)
+
+        self.iters = 0
+        self.startEpoch = 0
+        if params.finetune and not params.resuming:
+            assert params['pretrained_checkpoint_path'] is not None, "error, please specify a valid pretrained checkpoint path"
+            if self.log_to_screen:
+                logging.info("Loading checkpoint %s" % params.pretrained_checkpoint_path)
+            self.restore_checkpoint(params.pretrained_checkpoint_path)
+        if params.resuming:
+            if self.log_to_screen:
+                logging.info("Loading checkpoint %s" % params.checkpoint_path)
+            self.restore_checkpoint(params.checkpoint_path)
+        self.epoch = self.startEpoch
+
+        if params.scheduler == 'ReduceLROnPlateau':
+            self.scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, factor=0.2, patience=5, mode='min')
+        elif params.scheduler == 'CosineAnnealingLR':
+            for group in self.optimizer.param_groups:
+                group.setdefault('initial_lr', group['lr'])
+            self.scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(self.optimizer, T_max=params.max_epochs,
+                                                                        last_epoch=self.startEpoch - 1)
+        else:
+            self.scheduler = None
+
+        if self.log_to_screen:
+            logging.info("Number of parameters = {}".format(self.count_parameters()))
+        self.train()
+
+    def train(self):
+        if self.log_to_screen:
+            logging.info("Starting Training Loop...")
+        best_valid_loss = 1.e6
+        for epoch in range(self.startEpoch, self.params.max_epochs):
+            if dist.is_initialized() and (self.train_sampler is not None):
+                self.train_sampler.set_epoch(epoch)
+            start = time.time()
+            tr_time, data_time, train_logs = self.train_one_epoch()
+            valid_time, valid_logs = self.validate_one_epoch()
+            if self.params.scheduler == 'ReduceLROnPlateau':
+                self.scheduler.step(valid_logs['valid_loss'])
+            elif self.params.scheduler == 'CosineAnnealingLR':
+                self.scheduler.step()
+            if self.log_to_wandb:
+                wandb.log({'lr': self.optimizer.param_groups[-1]['lr']})
+            if self.world_rank == 0 and self.params.save_checkpoint:
+                self.save_checkpoint(self.params.checkpoint_path)
+                if valid_logs['valid_loss'] <= best_valid_loss:
+                    self.save_checkpoint(self.params.best_checkpoint_path)
+                    best_valid_loss = valid_logs['valid_loss']
+            if self.log_to_screen:
+                logging.info('Time taken for epoch {} is {} sec'.format(epoch + 1, time.time() - start))
+                logging.info('Training time = {}, Valid time = {}'.format(tr_time, valid_time))
+                logging.info('Train loss: {}. Valid loss: {}'.format(train_logs['loss'], valid_logs['valid_loss']))
+                if 'samples_per_sec' in train_logs:
+                    logging.info('Train throughput: {:.3f} samples/sec'.format(train_logs['samples_per_sec']))
+
+    def train_step(self, data):
+        """One optimisation step in the reference's order (train.py:275-289); returns the (detached) local loss."""
+        inp, tar, coszen = self.preprocessor(data)
+        self.model.zero_grad()
+        gen = self.model(inp, coszen=coszen).to(self.device, dtype=torch.float)
+        loss = self.loss_obj(gen, tar, inp)
+        loss.backward()
+        self.optimizer.step()
+        return loss.detach()
+
+    def train_one_epoch(self):
+        self.epoch += 1
+        tr_time = 0
+        data_time = 0
+        tr_loss = []
+        self.model.train()
+        n_samples = 0
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        for i, data in enumerate(self.train_data_loader, 0):
+            tr_start = time.time()
+            loss = self.train_step(data)
+            if dist.is_initialized():
+                dist.all_reduce(loss)
+            tr_loss.append(loss.item() / world)        # host sync per step, as the reference (train.py:294)
+            self.iters += 1
+            n_samples += self.params.local_batch_size * world
+            tr_time += time.time() - tr_start
+        logs = {'loss': np.mean(tr_loss), 'samples_per_sec': n_samples / max(tr_time, 1e-9)}
+        if self.log_to_wandb:
+            wandb.log(logs, step=self.epoch)
+        return tr_time, data_time, logs
+
+    def validate_one_epoch(self):
+        self.model.eval()
+        if 'global_stds_path' in self.params and os.path.isfile(str(self.params.global_stds_path)):
+            mult = torch.as_tensor(np.load(self.params.global_stds_path)[0, self.params.out_channels, 0, 0]).to(self.device)
+        else:
+            mult = torch.ones(self.params.n_out_channels, device=self.device)      # synthetic fields: unit stds
+        valid_buff = torch.zeros((3), dtype=torch.float32, device=self.device)
+        valid_loss = valid_buff[0].view(-1)
+        valid_steps = valid_buff[2].view(-1)
+        valid_weighted_rmse = torch.zeros((self.params.n_out_channels), dtype=torch.float32, device=self.device)
+        valid_start = time.time()
+        with torch.no_grad():
+            for i, data in enumerate(self.valid_data_loader, 0):
+                inp, tar, coszen = self.preprocessor(data)
+                gen = self.model(inp, coszen=coszen).to(self.device, dtype=torch.float)
+                valid_loss += self.loss_obj(gen, tar, inp)
+                valid_steps += 1.
+                tar = tar[:, -self.params.n_out_channels:]
+                gen = gen[:, -self.params.n_out_channels:]
+                valid_weighted_rmse += weighted_rmse_torch(gen, tar)
+        if dist.is_initialized():
+            dist.all_reduce(valid_buff)
+            dist.all_reduce(valid_weighted_rmse)
+        valid_buff[0:2] = valid_buff[0:2] / valid_buff[2]
+        valid_weighted_rmse = valid_weighted_rmse / valid_buff[2]
+        valid_weighted_rmse *= mult
+        valid_buff_cpu = valid_buff.detach().cpu().numpy()
+        valid_weighted_rmse_cpu = valid_weighted_rmse.detach().cpu().numpy()
+        valid_time = time.time() - valid_start
+        logs = {'valid_loss': valid_buff_cpu[0]}
+        if 'track_channels' in self.params:
+            idxes = [self.params.channel_names.index(v) for v in self.params.track_channels]
+            track_channels = self.params.track_channels
+        else:
+            track_channels, idxes = ['u10m', 'v10m'], [0, 1]
+        for idx, var in zip(idxes, track_channels):
+            if idx < len(valid_weighted_rmse_cpu):
+                logs.update({f'valid_rmse_{var}': valid_weighted_rmse_cpu[idx]})
+        if self.log_to_wandb:
+            wandb.log(logs, step=self.epoch)
+        return valid_time, logs
+
+    def save_checkpoint(self, checkpoint_path, model=None):
+        if not model:
+            model = self.model
+        torch.save({'iters': self.iters, 'epoch': self.epoch, 'model_state': model.state_dict(),
+                    'optimizer_state_dict': self.optimizer.state_dict()}, checkpoint_path)
+
+    def restore_checkpoint(self, checkpoint_path):
+        checkpoint = torch.load(checkpoint_path, map_location=self.device, weights_only=False)
+        try:
+            self.model.load_state_dict(checkpoint['model_state'])
+        except Exception:
+            # checkpoints saved under DDP carry a leading 'module.' (train.py:382-389)
+            new_state_dict = OrderedDict()
+            for key, val in checkpoint['model_state'].items():
+                new_state_dict[key[7:] if key.startswith('module.') else 'module.' + key] = val
+            self.model.load_state_dict(new_state_dict)
+        if self.params.resuming:
+            self.iters = checkpoint['iters']
+            self.startEpoch = checkpoint['epoch']
+            self.optimizer.load_state_dict(checkpoint['optimizer_state_dict'])
+
+
+def main(argv=None):
+    logging_utils.config_logger()
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--run_num", default='00', type=str)
+    parser.add_argument("--yaml_config", default=os.path.join(os.path.dirname(__file__), 'config', 'swin.yaml'), type=str)
+    parser.add_argument("--config", default='swin_73var', type=str)
+    parser.add_argument("--enable_amp", action='store_true')
+    parser.add_argument("--sweep_id", default=None, type=str, help='wandb sweeps are not supported in this build')
+    args = parser.parse_args(argv)
+    params = YParams(os.path.abspath(args.yaml_config), args.config)
+    trainer = Trainer(params, args)
+    trainer.build_and_launch()
+    if dist.is_initialized():
+        dist.barrier()
+    logging.info('DONE')
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,143 @@
+"""ERA5 loader surface of the reference (utils/data_loader_era5.py:21-181) feeding SYNTHETIC Gaussian fields.
+
+`get_data_loader(params, files_pattern, distributed, train)` returns `(loader, dataset, sampler)` for training and
+`(loader, dataset)` otherwise, with the reference's tensor contract:
+    inp [B, n_in, H, W], tar [B, n_out*(n_future+1), H, W]  (+ zen_inp [B,1,H,W], zen_tar [B,n_future+1,H,W] if add_zenith)
+and the reference's dataset index arithmetic (year / local index, year-boundary wrap :158-160, target slab :164-165).
+There is no HDF5 here (no h5py, no ERA5 files): each "year file" is a virtual array fields[N, 73, 721, 1440] of iid
+N(0,1) values that is a pure function of (seed, year, time index), cropped to img_size like :163-165 and normalised with
+means 0 / stds 1.  Two ways to consume it:
+  * torch DataLoader over `GetDataset` (CPU generation; plumbing / tests), or
+  * `DevicePoolLoader` (params.synthetic_device_pool > 0, default for GPU runs): a pool of K batches generated ON THE
+    DEVICE once and cycled, so the timed loop has no host RNG and no H2D copy (605 MB / sample would otherwise bind the
+    step to PCIe).
+"""
+import logging
+import math
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader, Dataset
+from torch.utils.data.distributed import DistributedSampler
+
+
+def worker_init(wrk_id):
+    np.random.seed(torch.utils.data.get_worker_info().seed % (2 ** 32 - 1))
+
+
+def is_leap_year(yr):
+    return (yr % 4 == 0)
+
+
+def _get(params, key, default):
+    return params[key] if key in params else default
+
+
+def cos_zenith(year: int, hours: float, H: int, W: int) -> torch.Tensor:
+    """Smooth stand-in for modulus' cos_zenith_angle (absent): textbook declination / hour-angle formula on the
+    0.25-degree grid (lat 90..-90, lon 0..360), [H, W] float32 in [-1, 1]."""
+    lat = torch.deg2rad(torch.linspace(90.0, -90.0, 721)[:H]).view(-1, 1)
+    lon = torch.deg2rad(torch.arange(0, 360, 0.25)[:W]).view(1, -1)
+    day = hours / 24.0
+    dec = math.radians(-23.44) * math.cos(2 * math.pi * (day + 10.0) / 365.25)
+    hour_angle = 2 * math.pi * ((hours % 24.0) / 24.0) + lon - math.pi
+    return (torch.sin(lat) * math.sin(dec) + torch.cos(lat) * math.cos(dec) * torch.cos(hour_angle)).float()
+
+
+class GetDataset(Dataset):
+    def __init__(self, params, location, train):
+        self.params, self.location, self.train = params, location, train
+        self.dt = params.dt
+        self.in_channels = np.asarray(params.in_channels)
+        self.out_channels = np.asarray(params.out_channels)
+        self.n_in_channels = params.n_in_channels
+        self.n_out_channels = params.n_out_channels
+        self.n_future = params.n_future
+        self.seed = _get(params, 'seed', None) or 333          # data_loader_era5_dali.py:100 default
+        self.n_years = _get(params, 'synthetic_n_years', 2)
+        self.years = [1979 + i for i in range(self.n_years)] if train else [2016 + i for i in range(self.n_years)]
+        self.n_samples_per_year = _get(params, 'synthetic_samples_per_year', 1460)
+        self.img_shape_x, self.img_shape_y = params.img_size[0], params.img_size[1]
+        assert self.img_shape_x <= 721 and self.img_shape_y <= 1440, 'image shapes are greater than dataset image shapes'
+        self.n_samples_total = self.n_years * self.n_samples_per_year
+        logging.info("Synthetic ERA5: {} virtual years x {} samples, image {} x {} x {}".format(
+            self.n_years, self.n_samples_per_year, self.img_shape_x, self.img_shape_y, self.n_in_channels))
+
+    def __len__(self):
+        return self.n_samples_total
+
+    def _fields(self, year_idx, t, channels):
+        """rows `channels` of the virtual fields[t] of year `year_idx`, cropped: [len(channels), H, W] N(0,1)"""
+        g = torch.Generator().manual_seed((self.seed * 1000003 + self.years[year_idx]) * 10007 + int(t))
+        full = torch.randn(73, self.img_shape_x, self.img_shape_y, generator=g)
+        return full[torch.as_tensor(channels)]
+
+    def index(self, global_idx):
+        """year / local index with the reference's boundary handling (:149-160)"""
+        year_idx = int(global_idx / self.n_samples_per_year)
+        local_idx = int(global_idx % self.n_samples_per_year)
+        step = self.dt
+        local_idx = local_idx % (self.n_samples_per_year - step * (self.n_future + 1))
+        if local_idx < step:
+            local_idx += step
+        return year_idx, local_idx
+
+    def __getitem__(self, global_idx):
+        year_idx, local_idx = self.index(global_idx)
+        step = self.dt
+        inp = self._fields(year_idx, local_idx, self.in_channels)
+        tar = torch.stack([self._fields(year_idx, t, self.out_channels)
+                           for t in range(local_idx + step, local_idx + step * (self.n_future + 1) + 1, step)], 0)
+        tar = tar.reshape(self.n_out_channels * (self.n_future + 1), self.img_shape_x, self.img_shape_y)
+        if self.params.add_zenith:
+            H, W = self.img_shape_x, self.img_shape_y
+            zi = cos_zenith(self.years[year_idx], 6.0 * local_idx, H, W).unsqueeze(0)
+            zt = torch.stack([cos_zenith(self.years[year_idx], 6.0 * t, H, W)
+                              for t in range(local_idx + step, local_idx + step * (self.n_future + 1) + 1, step)], 0)
+            return inp, tar, zi, zt
+        return inp, tar
+
+
+class DevicePoolLoader:
+    """K device-resident batches, generated once with the device RNG (seed = base seed + rank) and cycled."""
+
+    def __init__(self, params, dataset, device, train, pool, steps_per_epoch):
+        self.dataset, self.steps, self.batches = dataset, steps_per_epoch, []
+        B, H, W = int(params.local_batch_size), dataset.img_shape_x, dataset.img_shape_y
+        n_in = len(dataset.in_channels)
+        n_tar = dataset.n_out_channels * (dataset.n_future + 1)
+        g = torch.Generator(device=device).manual_seed(dataset.seed + 7919 * _get(params, 'data_shard_id', 0) + (0 if train else 1))
+        for k in range(pool):
+            inp = torch.randn(B, n_in, H, W, device=device, generator=g)
+            tar = torch.randn(B, n_tar, H, W, device=device, generator=g)
+            if params.add_zenith:
+                zi = cos_zenith(dataset.years[0], 6.0 * k, H, W).to(device).expand(B, 1, H, W).contiguous()
+                zt = torch.stack([cos_zenith(dataset.years[0], 6.0 * (k + 1 + s), H, W) for s in range(dataset.n_future + 1)],
+                                 0).to(device).unsqueeze(0).expand(B, -1, H, W).contiguous()
+                self.batches.append((inp, tar, zi, zt))
+            else:
+                self.batches.append((inp, tar))
+
+    def __len__(self):
+        return self.steps
+
+    def __iter__(self):
+        for i in range(self.steps):
+            yield self.batches[i % len(self.batches)]
+
+
+def get_data_loader(params, files_pattern, distributed, train):
+    dataset = GetDataset(params, files_pattern, train)
+    pool = _get(params, 'synthetic_device_pool', 0)
+    if pool:
+        device = torch.device('cuda', torch.cuda.current_device())
+        shards = _get(params, 'data_num_shards', 1)
+        steps = _get(params, 'synthetic_steps_per_epoch', max(1, len(dataset) // (int(params.local_batch_size) * shards)))
+        loader = DevicePoolLoader(params, dataset, device, train, pool, steps)
+        return (loader, dataset, None) if train else (loader, dataset)
+    sampler = DistributedSampler(dataset, shuffle=train, num_replicas=params.data_num_shards,
+                                 rank=params.data_shard_id) if distributed else None
+    dataloader = DataLoader(dataset, batch_size=int(params.local_batch_size), num_workers=params.num_data_workers,
+                            shuffle=(sampler is None), sampler=sampler, worker_init_fn=worker_init, drop_last=True,
+                            pin_memory=torch.cuda.is_available())
+    return (dataloader, dataset, sampler) if train else (dataloader, dataset)

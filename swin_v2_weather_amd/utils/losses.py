@@ -1,0 +1,107 @@
+"""LossHandler with the reference's surface and semantics (utils/losses.py:30-232) on the fused quadrature kernels.
+
+The O(B*C*H*W) work -- the latitude-weighted sums of (prd - tar)^2 and tar^2 per (sample, channel) plane and the
+gradient d loss / d prd -- is two HIP kernels (swv2_loss_sums / swv2_loss_grad); the remaining arithmetic is on
+[B, C] tensors.  Supported: the 'l2' family used by every entry of config/swin.yaml ('l2', 'squared geometric l2',
+'weighted absolute|relative temp-std squared geometric l2').  l1 / geometric h1 are not selected by any config.
+"""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import ops
+from .grids import naive_quadrature_weights
+
+
+class _QuadSums(torch.autograd.Function):
+    """sums[b, c] = (sum_hw q[h] (prd - tar)^2, sum_hw q[h] tar^2); backward: dprd = 2 dS0[b,c] q[h] (prd - tar)"""
+
+    @staticmethod
+    def forward(ctx, prd, tar, qw):
+        prd, tar = prd.contiguous().float(), tar.contiguous().float()
+        B, C = prd.shape[:2]
+        sums = torch.zeros(B, C, 2, dtype=torch.float32, device=prd.device)
+        ops.loss_sums(prd, tar, qw, sums)
+        ctx.save_for_backward(prd, tar, qw)
+        return sums
+
+    @staticmethod
+    def backward(ctx, dsums):
+        prd, tar, qw = ctx.saved_tensors
+        coef = (2.0 * dsums[..., 0]).contiguous().float()
+        dprd = torch.empty_like(prd)
+        ops.loss_grad(prd, tar, qw, coef, dprd)
+        return dprd, None, None
+
+
+def auto_channel_weights(channel_names, n_out):
+    """losses.py:57-68"""
+    w = torch.ones(n_out, dtype=torch.float32)
+    for c, chn in enumerate(channel_names):
+        if chn in ['u10m', 'v10m', 'u100m', 'v100m', 'tp', 'sp', 'msl', 'tcwv']:
+            w[c] = 0.1
+        elif chn in ['t2m', '2d']:
+            w[c] = 1.0
+        elif chn[0] in ['z', 'u', 'v', 't', 'r', 'q']:
+            w[c] = 0.001 * float(chn[1:])
+        else:
+            w[c] = 0.01
+    return w
+
+
+class LossHandler(nn.Module):
+    """Wrapper class that handles computing losses: `LossHandler(params)(prd, tar, inp)` (losses.py:30-150)."""
+
+    def __init__(self, params):
+        super().__init__()
+        self.n_future = params.n_future
+        self.img_shape = (params.img_shape_x, params.img_shape_y)
+        self.loss_type = params.loss
+        flags = set(params.loss.split())
+        if 'pole-masked' in flags:
+            raise ValueError("pole-masked losses hit an undefined name in the reference (grids.py:97-99)")
+        if 'l2' not in flags:
+            raise ValueError(f"Unknown / unsupported loss function: {self.loss_type} (l2 family only)")
+        if 'weighted' in flags:
+            if params.channel_weights == 'auto':
+                cw = auto_channel_weights(params.channel_names, params.n_out_channels)
+            else:
+                cw = torch.Tensor(params.channel_weights).float()
+        else:
+            cw = torch.ones(params.n_out_channels, dtype=torch.float32)
+        cw = cw.reshape(1, -1, 1, 1)
+        cw = cw / torch.sum(cw)
+        self.absolute = 'absolute' in flags
+        # plain 'l2' never forwards `squared` (losses.py:112-113), and is sphere-weighted all the same (quirk 9)
+        self.squared = ('squared' in flags) and ('geometric' in flags)
+        if 'temp-std' in flags:
+            eps = 1e-6
+            oc = np.asarray(params.out_channels)
+            gstd = torch.from_numpy(np.load(params.global_stds_path)).reshape(1, -1, 1, 1)[:, oc]
+            tstd = np.sqrt(params.dt) * torch.from_numpy(np.load(params.time_diff_stds_path)).reshape(1, -1, 1, 1)[:, oc]
+            tvw = gstd / (tstd + eps)
+            if 'squared' in flags:
+                tvw = tvw ** 2
+            cw = cw * tvw
+        self.register_buffer('channel_weights', cw.float())
+        if getattr(params, 'model_grid_type', 'equiangular') == 'legendre_gauss':
+            raise ValueError("legendre-gauss quadrature needs torch_harmonics (not used by config/swin.yaml)")
+        self.register_buffer('quad_rows', naive_quadrature_weights(self.img_shape[0], self.img_shape[1], True).contiguous())
+        ms = torch.ones(self.n_future + 1, dtype=torch.float32) / float(self.n_future + 1)
+        self.register_buffer('multistep_weight', ms.reshape(-1, 1, 1, 1))
+
+    def forward(self, prd: torch.Tensor, tar: torch.Tensor, inp: torch.Tensor = None):
+        chw = self.channel_weights
+        if self.training:
+            chw = (chw * self.multistep_weight).reshape(1, -1)
+        else:
+            chw = chw.reshape(1, -1)
+        sums = _QuadSums.apply(prd, tar, self.quad_rows)
+        norms = sums[..., 0]
+        if not self.absolute:
+            norms = norms / sums[..., 1]
+        if not self.squared:
+            norms = torch.sqrt(norms)
+        return torch.sum(chw * norms)

@@ -45,8 +45,10 @@ def npz(name, **arrs):
     print(f"  wrote {name}: {os.path.getsize(path) / 1024:.0f} KB")
 
 
-def randomize(module, seed):
-    """Randomise the parameters that are degenerate at init (LN weights = 0, logit_scale const)."""
+def randomize(module, seed, clamp_head=True):
+    """Randomise the parameters that are degenerate at init (LN weights = 0, logit_scale const).  `clamp_head` pushes the
+    last head above the ln(100) clamp (operator-level fixtures); the whole-model fixtures keep tau near its ln(10) init,
+    because a sigma = 100 head makes the softmax an arg-max whose fp32-vs-bf16 comparison is ill-conditioned."""
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
         for n, p in module.named_parameters():
@@ -56,8 +58,9 @@ def randomize(module, seed):
                 p.copy_(0.1 * torch.randn(p.shape, generator=g))
             elif n.endswith("logit_scale"):
                 # spread around ln(10); last head above the ln(100) clamp to exercise it
-                v = torch.log(torch.tensor(10.0)) + 0.5 * torch.randn(p.shape, generator=g)
-                v[-1] = 5.0
+                v = torch.log(torch.tensor(10.0)) + (0.5 if clamp_head else 0.25) * torch.randn(p.shape, generator=g)
+                if clamp_head:
+                    v[-1] = 5.0
                 p.copy_(v)
 
 
@@ -196,7 +199,7 @@ def tiny_model(relpos, residual, in_chans=5, out_chans=5, depth=2, C=32, h=2, im
     m = sw.SwinTransformerV2Cr(img_size=img, patch_size=4, depths=(depth,), num_heads=(h,), in_chans=in_chans,
                                out_chans=out_chans, embed_dim=C, img_window_ratio=ratio, drop_path_rate=dp,
                                full_pos_embed=True, rel_pos=relpos, mlp_ratio=4, residual=residual)
-    randomize(m, seed)
+    randomize(m, seed, clamp_head=False)
     cfg = O.SwinCfg(img_size=img, patch_size=4, depth=depth, num_heads=h, in_chans=in_chans, out_chans=out_chans,
                     embed_dim=C, window_ratio=ratio, drop_path_rate=dp, full_pos_embed=True, rel_pos=relpos,
                     residual=residual)
@@ -326,7 +329,7 @@ def fx_multistep():
                          add_orography=True, add_landmask=True)
     torch.manual_seed(seed)
     m = hp.get_model(params)
-    randomize(m, seed)
+    randomize(m, seed, clamp_head=False)
     m.eval()
     inp = torch.randn(2, 9, 48, 72, requires_grad=True)
     coszen = torch.rand(2, 2, 48, 72) * 2 - 1

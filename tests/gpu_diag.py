@@ -261,6 +261,32 @@ def cmp_grads(module, fx, what):
     say(f"   {what}: worst param-grad rel {worst:.3e}")
 
 
+def emu_block(fx, tag, relpos, dims):
+    """oracle forward/backward of a block fixture with bf16 rounding emulated at the HIP path's storage points"""
+    gh, gw, wh, ww, sh, sw, Cc, h = dims
+    cfg = O.SwinCfg(img_size=(gh * 4, gw * 4), patch_size=4, depth=2, num_heads=h, in_chans=1, out_chans=1, embed_dim=Cc,
+                    window_ratio=1, rel_pos=relpos)
+
+    class _C(O.SwinCfg):
+        window = property(lambda s_: (wh, ww))
+
+        def shift(s_, i):
+            return (sh, sw)
+
+        def drop_path(s_, i):
+            return 0.0
+    cfg.__class__ = _C
+    p = {"b." + k[2:]: torch.from_numpy(fx[k]).clone().requires_grad_(True) for k in fx.files if k.startswith("p:")}
+    x = torch.from_numpy(fx["x"]).clone().requires_grad_(True)
+    O.set_rounding(O.bf16_round)
+    try:
+        y = O.block_forward(x, p, "b.", cfg, 1, training=False)
+        y.backward(torch.from_numpy(fx["gy"]))
+    finally:
+        O.set_rounding(None)
+    return y.detach(), x.grad, {k[2:]: v.grad for k, v in p.items()}
+
+
 def t_block():
     for tag in ["nopos_noshift_eval", "relpos_shift_eval", "nopos_shift_3x3_eval"]:
         fx = np.load(os.path.join(GOLD, f"block_{tag}.npz"))
@@ -272,9 +298,21 @@ def t_block():
         x = torch.from_numpy(fx["x"]).to(dev).requires_grad_(True)
         y = blk(x)
         y.backward(torch.from_numpy(fx["gy"]).to(dev))
-        say(f"block[{tag}]: y rel {rel(y, torch.from_numpy(fx['y'])):.3e} max {mx(y, torch.from_numpy(fx['y'])):.3e}  "
-            f"gx rel {rel(x.grad, torch.from_numpy(fx['gx'])):.3e}")
-        cmp_grads(blk, fx, f"block[{tag}]")
+        say(f"block[{tag}] vs fp32 reference fixture: y rel {rel(y, torch.from_numpy(fx['y'])):.3e} max "
+            f"{mx(y, torch.from_numpy(fx['y'])):.3e}  gx rel {rel(x.grad, torch.from_numpy(fx['gx'])):.3e}")
+        cmp_grads(blk, fx, f"block[{tag}] vs fixture")
+        ye, gxe, ge = emu_block(fx, tag, "relpos" in tag, (gh, gw, wh, ww, sh, sw, Cc, h))
+        say(f"block[{tag}] vs bf16-emulating oracle: y rel {rel(y, ye):.3e} max {mx(y, ye):.3e} gx rel {rel(x.grad, gxe):.3e}")
+        worst = 0.0
+        for n, p_ in blk.named_parameters():
+            if ge.get(n) is None or p_.grad is None:
+                continue
+            r = rel(p_.grad, ge[n])
+            if float(ge[n].abs().max()) > 1e-3:
+                worst = max(worst, r)
+            if r > 2e-2:
+                say(f"      emu grad {n}: rel {r:.3e} |ref| {float(ge[n].abs().max()):.3e}")
+        say(f"   block[{tag}] vs emu: worst param-grad rel {worst:.3e}")
 
 
 def t_patch_modules():
@@ -310,9 +348,30 @@ def t_model():
         x = torch.from_numpy(fx["x"]).to(dev).requires_grad_(True)
         y = m(x)
         y.backward(torch.from_numpy(fx["gy"]).to(dev))
-        say(f"model[{tag}]: y rel {rel(y, torch.from_numpy(fx['y'])):.3e} max {mx(y, torch.from_numpy(fx['y'])):.3e} "
+        say(f"model[{tag}] vs fp32 fixture: y rel {rel(y, torch.from_numpy(fx['y'])):.3e} max {mx(y, torch.from_numpy(fx['y'])):.3e} "
             f"gx rel {rel(x.grad, torch.from_numpy(fx['gx'])) if x.grad is not None else 'none'}")
-        cmp_grads(m, fx, f"model[{tag}]")
+        # bf16-emulating oracle
+        cfg = O.SwinCfg(img_size=(H, W), patch_size=4, depth=depth, num_heads=h, in_chans=cin, out_chans=cout, embed_dim=Cc,
+                        window_ratio=ratio, rel_pos=bool(relpos), residual=bool(residual))
+        p = {k[2:]: torch.from_numpy(fx[k]).clone().requires_grad_(True) for k in fx.files if k.startswith("p:")}
+        xo = torch.from_numpy(fx["x"]).clone().requires_grad_(True)
+        O.set_rounding(O.bf16_round)
+        try:
+            yo = O.model_forward(xo, p, cfg, training=False)
+            yo.backward(torch.from_numpy(fx["gy"]))
+        finally:
+            O.set_rounding(None)
+        say(f"model[{tag}] vs bf16-emulating oracle: y rel {rel(y, yo):.3e} max {mx(y, yo):.3e} gx rel {rel(x.grad, xo.grad):.3e}")
+        worst = 0.0
+        for n, p_ in m.named_parameters():
+            if p[n].grad is None or p_.grad is None:
+                continue
+            r = rel(p_.grad, p[n].grad)
+            if float(p[n].grad.abs().max()) > 1e-3:
+                worst = max(worst, r)
+            if r > 3e-2:
+                say(f"      emu grad {n}: rel {r:.3e} |ref| {float(p[n].grad.abs().max()):.3e}")
+        say(f"   model[{tag}] vs emu: worst param-grad rel {worst:.3e}")
 
 
 TESTS = [

@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Per-kernel timing probe at the benchmark shape (GPU box): python tests/perf_probe.py [filter]"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from swin_v2_weather_amd import _lib as L, ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+BF = torch.bfloat16
+OUT = []
+
+
+def say(*a):
+    s = " ".join(str(x) for x in a)
+    print(s, flush=True)
+    OUT.append(s)
+
+
+def timeit(fn, n=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3   # us
+
+
+def probe_attn(B=2, rel_pos=False):
+    plan = ops.window_plan(B, 180, 360, 9, 18, 4, 9, 8, 16, 0)
+    Bw, h, Lp, DP, Lw = plan.Bw, 8, plan.Lp, plan.DP, plan.L
+    qkvh = (torch.randn(Bw, h, 3, Lp, DP, device=dev) * 0.25).to(BF)
+    qkvh[:, :, :, Lw:] = 0
+    rnorm = torch.rand(Bw, h, 2, Lp, device=dev) + 0.5
+    oh = torch.empty(Bw, h, Lp, DP, dtype=BF, device=dev)
+    lse = torch.empty(Bw, h, Lp, device=dev)
+    ls = torch.full((h,), 2.3, device=dev)
+    bias = torch.randn(h, Lw, Lw, device=dev) if rel_pos else None
+    doh = (torch.randn(Bw, h, Lp, DP, device=dev)).to(BF)
+    dq = torch.empty(Bw, h, 3, Lp, DP, dtype=BF, device=dev)
+    dls = torch.zeros(h, device=dev)
+    dbias = torch.zeros(h, Lw, Lw, device=dev) if rel_pos else None
+    for chunks in (32, 64, 128):
+        a = ops.attn_args(qkvh, ls, bias, oh, lse, Bw, h, Lw, 16, plan.nwh, plan.nww, plan.mask_thr, max_chunks=chunks)
+        say(f"attn_fwd  B={B} bias={rel_pos} chunks={chunks}: {timeit(lambda: ops.attn_fwd(a)):.1f} us")
+    for chunks in (32, 64, 128):
+        for dbg in (0, 1, 2, 4, 5):
+            a = ops.attn_args(qkvh, ls, bias, oh, lse, Bw, h, Lw, 16, plan.nwh, plan.nww, plan.mask_thr, doh=doh, rnorm=rnorm,
+                              dqkvh=dq, dlogit=dls, dbias=dbias, max_chunks=chunks)
+            a.dbg = dbg
+            say(f"attn_bwd  B={B} bias={rel_pos} chunks={chunks} dbg={dbg}: {timeit(lambda: ops.attn_bwd(a)):.1f} us")
+
+
+def probe_gemm(B=2):
+    T, Cc = 64800, 128
+    M = B * T
+    x = torch.randn(M, Cc, device=dev)
+    xb = x.to(BF)
+    for N in (128, 384, 512):
+        w = ops.prep_weight(torch.randn(N, Cc, device=dev))
+        o = torch.empty(M, N, dtype=BF, device=dev)
+        t = timeit(lambda: ops.linear(ops.op_f32(x), w, ops.epilogue(L.EPI_BF16, o, ld=N), N))
+        say(f"linear f32[{M},{Cc}] -> bf16 N={N}: {t:.1f} us  ({(M * Cc * 4 + M * N * 2) / t / 1e3:.0f} GB/s)")
+        t = timeit(lambda: ops.linear(ops.op_bf16(xb), w, ops.epilogue(L.EPI_BF16, o, ld=N), N))
+        say(f"linear bf16[{M},{Cc}] -> bf16 N={N}: {t:.1f} us  ({(M * Cc * 2 + M * N * 2) / t / 1e3:.0f} GB/s)")
+    hb = torch.randn(M, 512, device=dev).to(BF)
+    w2 = ops.prep_weight(torch.randn(Cc, 512, device=dev))
+    o = torch.empty(M, Cc, dtype=BF, device=dev)
+    t = timeit(lambda: ops.linear(ops.op_bf16(hb), w2, ops.epilogue(L.EPI_BF16, o, ld=Cc), Cc))
+    say(f"linear bf16[{M},512] -> bf16 N=128: {t:.1f} us ({(M * 512 * 2 + M * Cc * 2) / t / 1e3:.0f} GB/s)")
+    t = timeit(lambda: ops.linear(ops.op_bf16(hb, gelu=True), w2, ops.epilogue(L.EPI_BF16, o, ld=Cc), Cc))
+    say(f"linear gelu(bf16[{M},512]) -> bf16 N=128: {t:.1f} us")
+    dW = torch.zeros(512, Cc, device=dev)
+    db = torch.zeros(512, device=dev)
+    for splits in (64, 256, 1024):
+        t = timeit(lambda: ops.linear_wgrad(ops.op_bf16(hb), ops.op_f32(x), dW, db, splits=splits))
+        say(f"wgrad dY bf16[{M},512] x X f32[{M},128] splits={splits}: {t:.1f} us")
+    a = xb
+    y = torch.empty(M, Cc, device=dev)
+    mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    g, bt = torch.ones(Cc, device=dev), torch.zeros(Cc, device=dev)
+    t = timeit(lambda: ops.ln_residual_fwd(a, x, g, bt, None, None, y, mean, rstd, M, Cc, 0, T))
+    say(f"ln_residual_fwd: {t:.1f} us ({M * Cc * (2 + 4 + 4) / t / 1e3:.0f} GB/s)")
+    da = torch.empty(M, Cc, dtype=BF, device=dev)
+    dg, dbt = torch.zeros(Cc, device=dev), torch.zeros(Cc, device=dev)
+    t = timeit(lambda: ops.ln_residual_bwd(a, x, g, None, None, mean, rstd, da, dg, dbt, M, Cc, T))
+    say(f"ln_residual_bwd: {t:.1f} us ({M * Cc * (2 + 4 + 2) / t / 1e3:.0f} GB/s)")
+
+
+if __name__ == "__main__":
+    flt = sys.argv[1] if len(sys.argv) > 1 else ""
+    if "attn" in flt or not flt:
+        probe_attn(2, False)
+        probe_attn(2, True)
+    if "gemm" in flt or not flt:
+        probe_gemm(2)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    open(os.path.join(ROOT, "gpurun_out", "perf_probe.txt"), "w").write("\n".join(OUT) + "\n")

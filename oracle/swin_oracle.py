@@ -257,13 +257,20 @@ def drop_path_scale(B: int, prob: float, training: bool, like: Tensor) -> Option
 
 
 def block_forward(x: Tensor, p: Dict[str, Tensor], pre: str, cfg: SwinCfg, index: int,
-                  training: bool = False) -> Tensor:
-    """One post-norm Swin block on [B, gh, gw, C] (swinv2_global.py:480-497)."""
+                  training: bool = False, bias_override: Optional[Tensor] = None,
+                  dp_override: Optional[Tuple[Optional[Tensor], Optional[Tensor]]] = None) -> Tensor:
+    """One post-norm Swin block on [B, gh, gw, C] (swinv2_global.py:480-497).  `bias_override` / `dp_override` replace
+    the stochastic pieces (CPB table drawn with dropout, the two DropPath scale vectors) by given tensors, so a run
+    whose random draws happened elsewhere (on the GPU) can be replayed exactly."""
     B, gh, gw, C = x.shape
     wh, ww = cfg.window
     sh, sw = cfg.shift(index)
     xw = roll_partition(x, wh, ww, sh, sw)
     bias = cpb_bias(p, pre + "attn.", wh, ww, cfg.num_heads, training, cfg.meta_dropout) if cfg.rel_pos else None
+    if bias_override is not None:
+        bias = bias_override
+        if _ROUND is not None:
+            bias = _r(bias * 1.4426950408889634) / 1.4426950408889634
     mask = shift_mask(gh, gw, wh, ww, sh, sw)
     if mask is not None:
         mask = mask.to(x.dtype)
@@ -271,12 +278,12 @@ def block_forward(x: Tensor, p: Dict[str, Tensor], pre: str, cfg: SwinCfg, index
     a = reverse_unroll(a, gh, gw, wh, ww, sh, sw)
     a = layer_norm(a, p[pre + "norm1.weight"], p[pre + "norm1.bias"])
     dp = cfg.drop_path(index)
-    s1 = drop_path_scale(B, dp, training, x)
+    s1 = drop_path_scale(B, dp, training, x) if dp_override is None else dp_override[0]
     x = x + (a if s1 is None else a * s1.view(B, 1, 1, 1))
     m = _r(gelu_erf(_r(_r(x) @ _r(p[pre + "mlp.fc1.weight"]).T + p[pre + "mlp.fc1.bias"])))
     m = _r(m @ _r(p[pre + "mlp.fc2.weight"]).T + p[pre + "mlp.fc2.bias"])
     m = layer_norm(m, p[pre + "norm2.weight"], p[pre + "norm2.bias"])
-    s2 = drop_path_scale(B, dp, training, x)
+    s2 = drop_path_scale(B, dp, training, x) if dp_override is None else dp_override[1]
     return x + (m if s2 is None else m * s2.view(B, 1, 1, 1))
 
 

@@ -475,15 +475,16 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(ALoad<AK> al, const u
 // TN kernel: dW[N][K] (+)= sum over a slice of rows of dY^T X ; optional db[N] = column sums of dY
 // grid = (ntiles_n * ntiles_k, splits).  Output accumulated with fp32 atomics (caller zeroes dW / db).
 // ------------------------------------------------------------------------------------------------
-constexpr int TM = 32;                      // rows per step
+constexpr int TM = 128;                     // rows per step (4 MFMA k-steps of 32): ~100 KB in flight per workgroup
 constexpr int TP = 136;                     // LDS row pitch (elements) of the [TM][128] tiles: 272 B
+constexpr int TCH = TM * 16 / NTHREADS;     // 16-byte chunks per thread per operand per step (8)
 
 template <int YK, int XK>
 __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(ALoad<YK> yl, ALoad<XK> xl, float* __restrict__ dW,
                                                            float* __restrict__ db, const int32_t* __restrict__ nmap,
                                                            const int32_t* __restrict__ kmap, int ldw, int M, int N,
                                                            int K, int ntk, int rows_per_split) {
-    __shared__ __attribute__((aligned(16))) uint16_t smem[2 * 2 * TM * TP];      // [buf][Y | X][TM][TP]
+    __shared__ __attribute__((aligned(16))) uint16_t smem[2 * TM * TP];          // [Y | X][TM][TP], single buffer
     __shared__ float dbs[BN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, g = lane >> 4;
@@ -497,24 +498,24 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(ALoad<YK> yl, ALoad<X
     const bool want_db = (db != nullptr) && (tk == 0);
     if (tid < BN) dbs[tid] = 0.f;
 
-    // staging: each tile is TM x 16 chunks = 512 chunks -> 2 per thread per operand; thread keeps a fixed chunk column
-    const int srow = tid >> 4, scol = tid & 15;          // rows srow, srow + 16
-    uint4 ry[2], rx[2];
+    // staging: each tile is TM x 16 chunks; a thread keeps a fixed chunk column and walks rows srow + 16 i
+    const int srow = tid >> 4, scol = tid & 15;
+    uint4 ry[TCH], rx[TCH];
     float colsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto issue = [&](int s) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < TCH; ++i) {
             const int m = m_lo + s * TM + srow + 16 * i;
             const bool ok = m < m_hi;
             ry[i] = ok ? yl.chunk(m, n_base + scol * 8) : make_uint4(0, 0, 0, 0);
             rx[i] = ok ? xl.chunk(m, k_base + scol * 8) : make_uint4(0, 0, 0, 0);
         }
     };
-    auto commit = [&](int buf) {
-        uint16_t* Ys = smem + buf * 2 * TM * TP;
-        uint16_t* Xs = Ys + TM * TP;
+    auto commit = [&]() {
+        uint16_t* Ys = smem;
+        uint16_t* Xs = smem + TM * TP;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < TCH; ++i) {
             *(uint4*)(Ys + (srow + 16 * i) * TP + scol * 8) = ry[i];
             *(uint4*)(Xs + (srow + 16 * i) * TP + scol * 8) = rx[i];
             if (want_db) {
@@ -534,28 +535,31 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(ALoad<YK> yl, ALoad<X
 
     issue(0);
     for (int s = 0; s < steps; ++s) {
-        const int buf = s & 1;
-        commit(buf);
+        commit();
         __syncthreads();
         if (s + 1 < steps) issue(s + 1);
-        const uint16_t* Ys = smem + buf * 2 * TM * TP;
-        const uint16_t* Xs = Ys + TM * TP;
+        const uint16_t* Ys = smem;
+        const uint16_t* Xs = smem + TM * TP;
         // A operand = dY^T (rows n, k = m), B operand = X (k = m, cols k'): both are transposed reads of row-major tiles
-        bf16x8 af[4], bf[4];
-        const int r0 = 8 * g + (fr >> 2), cc = (fr & 3) * 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bf16x4 a0 = lds_tr_read(Ys + r0 * TP + wr * 64 + i * 16 + cc);
-            const bf16x4 a1 = lds_tr_read(Ys + (r0 + 4) * TP + wr * 64 + i * 16 + cc);
-            const bf16x4 b0 = lds_tr_read(Xs + r0 * TP + wc * 64 + i * 16 + cc);
-            const bf16x4 b1 = lds_tr_read(Xs + (r0 + 4) * TP + wc * 64 + i * 16 + cc);
-            af[i] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
-            bf[i] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+        for (int kk = 0; kk < TM / 32; ++kk) {
+            bf16x8 af[4], bf[4];
+            const int r0 = 32 * kk + 8 * g + (fr >> 2), cc = (fr & 3) * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bf16x4 a0 = lds_tr_read(Ys + r0 * TP + wr * 64 + i * 16 + cc);
+                const bf16x4 a1 = lds_tr_read(Ys + (r0 + 4) * TP + wr * 64 + i * 16 + cc);
+                const bf16x4 b0 = lds_tr_read(Xs + r0 * TP + wc * 64 + i * 16 + cc);
+                const bf16x4 b1 = lds_tr_read(Xs + (r0 + 4) * TP + wc * 64 + i * 16 + cc);
+                af[i] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                bf[i] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
+        __syncthreads();                    // all waves done with the tile before the next commit overwrites it
     }
     // accumulate the tile: rows n = n_base + wr*64 + 16i + 4g + r, cols k = k_base + wc*64 + 16j + fr
 #pragma unroll

@@ -50,6 +50,18 @@ def _need_gpu(x: torch.Tensor, who: str):
                           "CPU fallback")
 
 
+def _zeros_like_shapes(device, *shapes):
+    """fp32 zero tensors of the given shapes carved out of one buffer (one memset instead of one per gradient);
+    every slice starts on a 16-byte boundary."""
+    sizes = [((int(torch.Size(s).numel()) + 3) // 4) * 4 for s in shapes]
+    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=device)
+    out, off = [], 0
+    for s, n in zip(shapes, sizes):
+        out.append(flat[off:off + int(torch.Size(s).numel())].view(*s))
+        off += n
+    return out
+
+
 class _WeightCache:
     """bf16 (cast / transposed / permuted / padded) copies of the fp32 parameters, rebuilt when a parameter changes
     (optimizer steps bump `Tensor._version`)."""
@@ -167,39 +179,35 @@ class _BlockFn(torch.autograd.Function):
         w_projt = wc.get("projt", (proj_w,), lambda: ops.prep_weight(proj_w, transpose=True, row_map=plan.proj_map, out_rows=h * DP))
         w_qkvt = wc.get("qkvt", (qkv_w,), lambda: ops.prep_weight(qkv_w, transpose=True, col_map=plan.qkv_map, out_cols=3 * h * DP))
 
+        # all parameter-gradient accumulators of the block come from ONE zero-filled buffer (a single memset)
+        (dn2w, dn2b, dfc2w, dfc2b, dfc1w, dfc1b, dn1w, dn1b, dprojw, dprojb, dlogit, dqkvw, dqkvb) = _zeros_like_shapes(
+            dev, (Cc,), (Cc,), (Cc, hid), (Cc,), (hid, Cc), (hid,), (Cc,), (Cc,), (Cc, Cc), (Cc,), (h,), (3 * Cc, Cc), (3 * Cc,))
         # 7'. LN2 backward
         da2 = torch.empty(B * T, Cc, dtype=BF16, device=dev)
-        dn2w, dn2b = torch.zeros(Cc, **f32), torch.zeros(Cc, **f32)
         ops.ln_residual_bwd(a2, dx2, n2_w, dp2, None, mean2, rstd2, da2, dn2w, dn2b, B * T, Cc, T)
         # 6'. fc2: dW = da2^T GELU(h), dh = (da2 W2) * GELU'(h)
-        dfc2w, dfc2b = torch.zeros(Cc, hid, **f32), torch.zeros(Cc, **f32)
         ops.linear_wgrad(ops.op_bf16(da2), ops.op_bf16(hact), dfc2w, dfc2b)
         dh = torch.empty(B * T, hid, dtype=BF16, device=dev)
         ops.linear(ops.op_bf16(da2), w_fc2t, ops.epilogue(L.EPI_GELU_GRAD, dh, ld=hid, aux=hpre), hid)
         # 5'. fc1: dW = dh^T x1 ; dx1 = dx2 + dh W1
-        dfc1w, dfc1b = torch.zeros(hid, Cc, **f32), torch.zeros(hid, **f32)
         ops.linear_wgrad(ops.op_bf16(dh), ops.op_f32(x1), dfc1w, dfc1b)
         dx1 = torch.empty(B * T, Cc, **f32)
         ops.linear(ops.op_bf16(dh), w_fc1t, ops.epilogue(L.EPI_F32, dx1, ld=Cc, aux=dx2), Cc)
         del dh
         # 4'. LN1 backward (gathers dx1 rows through the window table; padded rows -> 0)
         da1 = torch.empty(M_w, Cc, dtype=BF16, device=dev)
-        dn1w, dn1b = torch.zeros(Cc, **f32), torch.zeros(Cc, **f32)
         ops.ln_residual_bwd(a1, dx1, n1_w, dp1, plan.rowidx, mean1, rstd1, da1, dn1w, dn1b, M_w, Cc, T)
         # 3'. proj: dW = da1^T merge(oh) ; d(oh) = split(da1 Wp)
-        dprojw, dprojb = torch.zeros(Cc, Cc, **f32), torch.zeros(Cc, **f32)
         ops.linear_wgrad(ops.op_bf16(da1), ops.op_heads(oh, Bw, h, 1, Lp, DP), dprojw, dprojb, kmap=plan.proj_map)
         doh = torch.empty(Bw * h * Lp * DP, dtype=BF16, device=dev)
         ops.linear(ops.op_bf16(da1), w_projt, ops.epilogue(L.EPI_HEADS, doh, p=(h, 0, Lp, DP, plan.L)), h * DP)
         # 2'. attention backward (incl. the backward of the q / k normalisation)
         dqkvh = torch.empty(Bw * h * 3 * Lp * DP, dtype=BF16, device=dev)
-        dlogit = torch.zeros(h, **f32)
         dbias = torch.zeros_like(bias_c) if ctx.has_bias else None
         ops.attn_bwd(ops.attn_args(qkvh, logit_scale, bias_c if ctx.has_bias else None, oh, lse, Bw, h, plan.L, plan.d,
                                    plan.nwh, plan.nww, plan.mask_thr, doh=doh, rnorm=rnorm, dqkvh=dqkvh, dlogit=dlogit,
                                    dbias=dbias))
         # 1'. qkv: dW = dqkv^T gather(x) ; dx = dx1 + scatter(dqkv Wqkv)
-        dqkvw, dqkvb = torch.zeros(3 * Cc, Cc, **f32), torch.zeros(3 * Cc, **f32)
         ops.linear_wgrad(ops.op_heads(dqkvh, Bw, h, 3, Lp, DP), ops.op_f32(x2d, rows=M_w, rowidx=plan.rowidx), dqkvw, dqkvb,
                          nmap=plan.qkv_map)
         dx = torch.empty(B * T, Cc, **f32)

@@ -43,14 +43,16 @@ class Trainer():
     def count_parameters(self):
         return sum(p.numel() for p in self.model.parameters() if p.requires_grad)
 
-    def __init__(self, params, args, model_factory=None, device=None):
-        """`model_factory(params) -> nn.Module` and `device` are test hooks (CPU/gloo plumbing tests inject the oracle
-        model); the product path always builds `get_model(params)` on an MI355X."""
+    def __init__(self, params, args, model_factory=None, loss_factory=None, device=None):
+        """`model_factory(params) -> nn.Module`, `loss_factory(params) -> nn.Module` and `device` are test hooks (the
+        CPU/gloo plumbing tests inject the oracle); the product path always builds `get_model(params)` and the
+        kernel-backed `LossHandler` on an MI355X."""
         self.sweep_id = args.sweep_id
         self.root_dir = params['exp_dir']
         self.config = args.config
         params['enable_amp'] = args.enable_amp
         self._model_factory = model_factory or get_model
+        self._loss_factory = loss_factory or LossHandler
 
         self.world_size = int(os.environ.get('WORLD_SIZE', 1))
         self.local_rank = 0
@@ -79,6 +81,10 @@ class Trainer():
         self.run_num = args.run_num
 
     def build_and_launch(self):
+        self.build()
+        self.train()
+
+    def build(self):
         params = self.params
         params['in_channels'] = np.array(params['in_channels'])
         params['out_channels'] = np.array(params['out_channels'])
@@ -124,7 +130,7 @@ class Trainer():
             with open(os.path.join(params['experiment_dir'], 'hyperparams.yaml'), 'w') as hpfile:
                 yaml.safe_dump(hparams, hpfile)
 
-        self.loss_obj = LossHandler(params).to(self.device)
+        self.loss_obj = self._loss_factory(params).to(self.device)
         self.model = self._model_factory(params).to(self.device)
         self.preprocessor = PreProcessor(params, self.device).to(self.device)
 
@@ -170,7 +176,6 @@ class Trainer():
 
         if self.log_to_screen:
             logging.info("Number of parameters = {}".format(self.count_parameters()))
-        self.train()
 
     def train(self):
         if self.log_to_screen:

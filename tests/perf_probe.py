@@ -80,7 +80,7 @@ def probe_gemm(B=2):
     say(f"linear gelu(bf16[{M},512]) -> bf16 N=128: {t:.1f} us")
     dW = torch.zeros(512, Cc, device=dev)
     db = torch.zeros(512, device=dev)
-    for splits in (64, 256, 1024):
+    for splits in (32, 64, 128, 256):
         t = timeit(lambda: ops.linear_wgrad(ops.op_bf16(hb), ops.op_f32(x), dW, db, splits=splits))
         say(f"wgrad dY bf16[{M},512] x X f32[{M},128] splits={splits}: {t:.1f} us")
     a = xb

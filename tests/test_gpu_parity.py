@@ -1,0 +1,510 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI (libswv2.so), against the CPU oracle and the golden fixtures.
+
+Tolerances (relative l2 error unless noted).  The HIP path computes GEMMs and attention on bf16 MFMA with fp32
+accumulation and stores inter-kernel activations as bf16, like the reference under autocast; so there are two bars:
+  * against the oracle with bf16 rounding EMULATED at the HIP path's storage points (oracle.set_rounding): tight --
+    this is the correctness bar of the kernels (indexing, masks, reductions, gradients);
+  * against the fp32 golden vectors of the real reference: the stated bf16 tolerance of the north star.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import swin_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def K():
+    from swin_v2_weather_amd import _lib as L, ops
+    from swin_v2_weather_amd.networks import swinv2_global as N, helpers
+    L.load()                                     # fails loudly if libswv2.so is missing: no fallback exists
+    return dict(L=L, ops=ops, N=N, helpers=helpers)
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def rb(t):
+    return t.to(BF).float()
+
+
+def load_params(module, fx):
+    module.load_state_dict({k[2:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("p:")}, strict=True)
+
+
+def worst_grad(module, ref_grads, floor=1e-3):
+    worst = 0.0
+    for n, p in module.named_parameters():
+        r = ref_grads.get(n)
+        if r is None or p.grad is None or float(r.abs().max()) < floor:
+            continue
+        worst = max(worst, rel(p.grad, r))
+    return worst
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# GEMM engine: loaders and epilogues
+# ---------------------------------------------------------------------------------------------------------------
+def test_linear_loaders_and_epilogues(dev, K):
+    ops, L = K["ops"], K["L"]
+    torch.manual_seed(1)
+    for (M, Kd, Nn) in [(300, 128, 200), (1000, 1168, 96), (257, 96, 288), (129, 512, 128)]:
+        x, w, b = torch.randn(M, Kd), torch.randn(Nn, Kd) * 0.1, torch.randn(Nn)
+        ref = rb(x) @ rb(w).T + b
+        wb = ops.prep_weight(w.to(dev))
+        out = torch.full((M, Nn), float("nan"), dtype=BF, device=dev)
+        ops.linear(ops.op_f32(x.to(dev)), wb, ops.epilogue(L.EPI_BF16, out, ld=Nn, bias=b.to(dev)), Nn)
+        assert rel(out.float(), ref) < 4e-3
+        o32 = torch.full((M, Nn), float("nan"), device=dev)
+        ops.linear(ops.op_bf16(x.to(BF).to(dev)), wb, ops.epilogue(L.EPI_F32, o32, ld=Nn, bias=b.to(dev)), Nn)
+        assert rel(o32, ref) < 1e-5
+        idx = torch.randperm(M)
+        ri = idx.to(torch.int32).to(dev)
+        aux = torch.randn(M, Nn)
+        ops.linear(ops.op_f32(x.to(dev), rowidx=ri), wb, ops.epilogue(L.EPI_F32, o32, ld=Nn, aux=aux.to(dev)), Nn)
+        assert rel(o32, (rb(x) @ rb(w).T)[idx] + aux) < 1e-5                      # gather + residual add
+        ops.linear(ops.op_f32(x.to(dev)), wb, ops.epilogue(L.EPI_F32, o32, ld=Nn, rowidx=ri), Nn)
+        exp = torch.empty(M, Nn)
+        exp[idx] = rb(x) @ rb(w).T
+        assert rel(o32, exp) < 1e-5                                               # scatter
+        # empty-ish / ragged edge: a gather table with zero rows
+        ri2 = ri.clone()
+        ri2[::3] = -1
+        ops.linear(ops.op_f32(x.to(dev), rowidx=ri2), wb, ops.epilogue(L.EPI_F32, o32, ld=Nn), Nn)
+        exp = (rb(x) @ rb(w).T)[idx]
+        exp[::3] = 0
+        assert rel(o32, exp) < 1e-5
+
+
+def test_gelu_paths_and_weight_gradients(dev, K):
+    ops, L = K["ops"], K["L"]
+    torch.manual_seed(2)
+    M, Kd, Nn = 500, 512, 128
+    hpre, w, dy, x = torch.randn(M, Kd), torch.randn(Nn, Kd) * 0.05, torch.randn(M, Nn), torch.randn(M, 96)
+    out = torch.empty(M, Nn, dtype=BF, device=dev)
+    ops.linear(ops.op_bf16(hpre.to(BF).to(dev), gelu=True), ops.prep_weight(w.to(dev)), ops.epilogue(L.EPI_BF16, out, ld=Nn), Nn)
+    assert rel(out.float(), rb(O.gelu_erf(rb(hpre))) @ rb(w).T) < 4e-3
+    # fc1 epilogue: pre-activation + GELU of the stored pre-activation
+    w1, b1 = torch.randn(Kd, 96) * 0.1, torch.randn(Kd)
+    pre = torch.empty(M, Kd, dtype=BF, device=dev)
+    act = torch.empty(M, Kd, dtype=BF, device=dev)
+    ops.linear(ops.op_f32(x.to(dev)), ops.prep_weight(w1.to(dev)), ops.epilogue(L.EPI_BF16_GELU, pre, ld=Kd, bias=b1.to(dev), aux_out=act), Kd)
+    assert rel(pre.float(), rb(x) @ rb(w1).T + b1) < 4e-3
+    assert rel(act.float(), O.gelu_erf(pre.float().cpu())) < 4e-3
+    dh = torch.empty(M, Kd, dtype=BF, device=dev)
+    ops.linear(ops.op_bf16(dy.to(BF).to(dev)), ops.prep_weight(w.to(dev), transpose=True),
+               ops.epilogue(L.EPI_GELU_GRAD, dh, ld=Kd, aux=hpre.to(BF).to(dev)), Kd)
+    hp = rb(hpre).double().requires_grad_(True)
+    O.gelu_erf(hp).backward((rb(dy) @ rb(w)).double())
+    assert rel(dh.float(), hp.grad) < 4e-3
+    for splits in (1, 7, 64):
+        dW, db = torch.zeros(Nn, Kd, device=dev), torch.zeros(Nn, device=dev)
+        ops.linear_wgrad(ops.op_bf16(dy.to(BF).to(dev)), ops.op_bf16(hpre.to(BF).to(dev)), dW, db, splits=splits)
+        assert rel(dW, rb(dy).T @ rb(hpre)) < 1e-5 and rel(db, rb(dy).sum(0)) < 1e-5
+
+
+def test_patch_embed_conv_and_unpatchify(dev, K):
+    ops, L = K["ops"], K["L"]
+    torch.manual_seed(3)
+    B, Cin, H, W, Cc, Cout = 2, 7, 24, 40, 32, 5
+    x, w, b = torch.randn(B, Cin, H, W), torch.randn(Cc, Cin, 4, 4) * 0.1, torch.randn(Cc)
+    out = torch.empty(B * 60, Cc, dtype=BF, device=dev)
+    ops.linear(ops.op_patch(x.to(dev)), ops.prep_weight(w.to(dev)), ops.epilogue(L.EPI_BF16, out, ld=Cc, bias=b.to(dev)), Cc)
+    ref = torch.nn.functional.conv2d(rb(x), rb(w), b, stride=4).permute(0, 2, 3, 1).reshape(-1, Cc)
+    assert rel(out.float(), ref) < 4e-3
+    e, wh_ = torch.randn(B * 60, Cc), torch.randn(Cout * 16, Cc) * 0.1
+    perm = (torch.arange(16).view(1, -1) * Cout + torch.arange(Cout).view(-1, 1)).reshape(-1).to(torch.int32).to(dev)
+    y = torch.full((B, Cout, H, W), float("nan"), device=dev)
+    ops.linear(ops.op_f32(e.to(dev)), ops.prep_weight(wh_.to(dev), row_map=perm),
+               ops.epilogue(L.EPI_UNPATCH, y, aux=x.to(dev), p=(Cout, H, W, Cin, 0)), Cout * 16)
+    assert rel(y, O.head_unpatchify(rb(e).reshape(B, 6, 10, Cc), rb(wh_), 4, Cout, x)) < 1e-5
+
+
+@pytest.mark.parametrize("Cc", [32, 96, 128, 192, 768])
+def test_layernorm_residual(dev, K, Cc):
+    ops = K["ops"]
+    torch.manual_seed(4)
+    M, B = 777, 3
+    a, res, g, bt = torch.randn(M, Cc) * 2 + 0.5, torch.randn(M, Cc), torch.randn(Cc), torch.randn(Cc)
+    scale = torch.tensor([0.0, 1.25, 1.25])
+    y = torch.full((M, Cc), float("nan"), device=dev)
+    mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    ab = a.to(BF).to(dev)
+    ops.ln_residual_fwd(ab, res.to(dev), g.to(dev), bt.to(dev), scale.to(dev), None, y, mean, rstd, M, Cc, 0, M // B)
+    ad, gd, bd = rb(a).double().requires_grad_(True), g.double().requires_grad_(True), bt.double().requires_grad_(True)
+    sc = scale[(torch.arange(M) // (M // B)).clamp(max=B - 1)].double().view(-1, 1)
+    ref = res.double() + sc * O.layer_norm(ad, gd, bd)
+    dy = torch.randn(M, Cc)
+    ref.backward(dy.double())
+    da = torch.empty(M, Cc, dtype=BF, device=dev)
+    dg, db = torch.zeros(Cc, device=dev), torch.zeros(Cc, device=dev)
+    ops.ln_residual_bwd(ab, dy.to(dev), g.to(dev), scale.to(dev), None, mean, rstd, da, dg, db, M, Cc, M // B)
+    assert rel(y, ref) < 1e-6 and rel(da.float(), ad.grad) < 4e-3 and rel(dg, gd.grad) < 1e-5 and rel(db, bd.grad) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# attention core
+# ---------------------------------------------------------------------------------------------------------------
+def to_heads(x, Bw, Lw, h, d, Lp, DP, parts):
+    x = x.reshape(Bw, Lw, parts, h, d).permute(0, 3, 2, 1, 4)
+    out = torch.zeros(Bw, h, parts, Lp, DP, dtype=x.dtype)
+    out[:, :, :, :Lw, :d] = x
+    return out
+
+
+def from_heads(xh, Bw, Lw, h, d, parts):
+    return xh[:, :, :, :Lw, :d].permute(0, 3, 2, 1, 4).reshape(Bw, Lw, parts * h * d)
+
+
+@pytest.mark.parametrize("wh,ww,h,d,nwh,nww,shifted,use_bias", [
+    (6, 9, 4, 12, 2, 2, False, False), (6, 9, 4, 12, 2, 2, True, True), (6, 9, 3, 32, 2, 2, True, True),
+    (9, 18, 8, 16, 2, 3, False, False), (9, 18, 8, 16, 2, 3, True, True), (9, 18, 2, 24, 2, 2, True, False),
+    (9, 18, 2, 16, 1, 2, True, True),   # one window row: every window carries the shift mask
+])
+def test_attention_core_fwd_bwd(dev, K, wh, ww, h, d, nwh, nww, shifted, use_bias):
+    ops = K["ops"]
+    torch.manual_seed(0)
+    B, Lw, nW, Cc = 2, wh * ww, nwh * nww, h * d
+    Lp, DP = ops.attn_geometry(Lw, d)
+    Bw = B * nW
+    qkv = torch.randn(Bw, Lw, 3 * Cc)
+    ls = torch.log(torch.tensor(10.0)) + 0.5 * torch.randn(h)
+    ls[-1] = 5.0                                               # above the ln(100) clamp: zero gradient expected
+    bias = torch.randn(h, Lw, Lw) if use_bias else None
+    gh, gw = nwh * wh, nww * ww
+    sh = wh // 2 if (shifted and nwh > 1) else 0
+    sw = ww // 2 if shifted else 0
+    mask = O.shift_mask(gh, gw, wh, ww, sh, sw)
+    mask_thr = (wh - sh) * ww if sh > 0 else 0
+    q, k, v = qkv.reshape(Bw, Lw, 3, Cc).unbind(2)
+    qh, kh = q.reshape(Bw, Lw, h, d), k.reshape(Bw, Lw, h, d)
+    rq, rk = 1.0 / qh.norm(dim=-1).clamp_min(1e-12), 1.0 / kh.norm(dim=-1).clamp_min(1e-12)
+    qn, kn, vb = rb(qh * rq.unsqueeze(-1)).reshape(Bw, Lw, Cc), rb(kh * rk.unsqueeze(-1)).reshape(Bw, Lw, Cc), rb(v)
+    packed = torch.stack([qn, kn, vb], 2).reshape(Bw, Lw, 3 * Cc)
+    qkvh = to_heads(packed, Bw, Lw, h, d, Lp, DP, 3).to(BF).to(dev).contiguous()
+    rnorm = torch.zeros(Bw, h, 2, Lp)
+    rnorm[:, :, 0, :Lw], rnorm[:, :, 1, :Lw] = rq.permute(0, 2, 1), rk.permute(0, 2, 1)
+    oh = torch.full((Bw, h, Lp, DP), float("nan"), dtype=BF, device=dev)
+    lse = torch.zeros(Bw, h, Lp, device=dev)
+    lsd, bd = ls.to(dev), (bias.to(dev).contiguous() if use_bias else None)
+    ops.attn_fwd(ops.attn_args(qkvh, lsd, bd, oh, lse, Bw, h, Lw, d, nwh, nww, mask_thr))
+    # oracle semantics on the same operands (the kernel holds the bias table as bf16 in the log2 domain)
+    ref_in = packed.double().requires_grad_(True)
+    ls_ref = ls.double().requires_grad_(True)
+    bias_ref = bias.double().requires_grad_(True) if use_bias else None
+    q_, k_, v_ = ref_in.reshape(Bw, Lw, 3, h, d).permute(2, 0, 3, 1, 4)
+    S = torch.einsum("bhqd,bhkd->bhqk", q_, k_) * torch.exp(torch.clamp(ls_ref, max=O.LOGIT_MAX)).view(1, h, 1, 1)
+    if use_bias:
+        S = S + O.bf16_round(bias_ref * 1.4426950408889634).unsqueeze(0) / 1.4426950408889634
+    if mask is not None:
+        S = (S.reshape(B, nW, h, Lw, Lw) + mask.double().view(1, nW, 1, Lw, Lw)).reshape(Bw, h, Lw, Lw)
+    o_ref = torch.einsum("bhqk,bhkd->bqhd", torch.softmax(S, -1), v_).reshape(Bw, Lw, Cc)
+    ohc = oh.float().cpu()
+    assert not torch.isnan(ohc).any()
+    assert rel(from_heads(ohc.unsqueeze(2), Bw, Lw, h, d, 1), o_ref) < 4e-3
+    assert float(ohc[:, :, Lw:, :].abs().max() if Lp > Lw else 0) == 0 and float(ohc[:, :, :, d:].abs().max() if DP > d else 0) == 0
+    go = rb(torch.randn(Bw, Lw, Cc))
+    o_ref.backward(go.double())
+    doh = to_heads(go, Bw, Lw, h, d, Lp, DP, 1).squeeze(2).to(BF).to(dev).contiguous()
+    dqkvh = torch.full((Bw, h, 3, Lp, DP), float("nan"), dtype=BF, device=dev)
+    dls = torch.zeros(h, device=dev)
+    dbias = torch.zeros(h, Lw, Lw, device=dev) if use_bias else None
+    ops.attn_bwd(ops.attn_args(qkvh, lsd, bd, oh, lse, Bw, h, Lw, d, nwh, nww, mask_thr, doh=doh, rnorm=rnorm.to(dev).contiguous(),
+                               dqkvh=dqkvh, dlogit=dls, dbias=dbias))
+    got = from_heads(dqkvh.float().cpu(), Bw, Lw, h, d, 3).reshape(Bw, Lw, 3, Cc)
+    g = ref_in.grad.reshape(Bw, Lw, 3, Cc)
+
+    def through_norm(gn, xn, r):
+        gn, xn = gn.reshape(Bw, Lw, h, d), xn.reshape(Bw, Lw, h, d).double()
+        return (r.unsqueeze(-1).double() * (gn - xn * (gn * xn).sum(-1, keepdim=True))).reshape(Bw, Lw, Cc)
+    assert rel(got[:, :, 0], through_norm(g[:, :, 0], qn, rq)) < 1.5e-2
+    assert rel(got[:, :, 1], through_norm(g[:, :, 1], kn, rk)) < 1.5e-2
+    assert rel(got[:, :, 2], g[:, :, 2]) < 6e-3
+    assert float(dls[-1]) == 0.0 and rel(dls, ls_ref.grad) < 0.12       # clamp gate; sum with heavy cancellation
+    if use_bias:
+        assert rel(dbias, bias_ref.grad) < 8e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# modules against the golden vectors of the real reference
+# ---------------------------------------------------------------------------------------------------------------
+def block_cfg(gh, gw, wh, ww, sh, sw, Cc, h, relpos):
+    cfg = O.SwinCfg(img_size=(gh * 4, gw * 4), patch_size=4, depth=2, num_heads=h, in_chans=1, out_chans=1, embed_dim=Cc,
+                    window_ratio=1, rel_pos=relpos)
+
+    class C_(O.SwinCfg):
+        window = property(lambda s_: (wh, ww))
+
+        def shift(s_, i):
+            return (sh, sw)
+
+        def drop_path(s_, i):
+            return 0.0
+    cfg.__class__ = C_
+    return cfg
+
+
+@pytest.mark.parametrize("tag", ["nopos_noshift_eval", "relpos_shift_eval", "nopos_shift_3x3_eval"])
+def test_block_against_reference_fixture(dev, K, tag):
+    N = K["N"]
+    fx = np.load(os.path.join(GOLD, f"block_{tag}.npz"))
+    gh, gw, wh, ww, sh, sw, Cc, h, B, seed, rng_seed, train = [int(v) for v in fx["meta"]]
+    blk = N.SwinTransformerV2CrBlock(dim=Cc, num_heads=h, feat_size=(gh, gw), window_size=(wh, ww), shift_size=(sh, sw),
+                                     rel_pos="relpos" in tag, drop_path=0.0)
+    load_params(blk, fx)
+    blk = blk.to(dev).eval()
+    x = torch.from_numpy(fx["x"]).to(dev).requires_grad_(True)
+    y = blk(x)
+    y.backward(torch.from_numpy(fx["gy"]).to(dev))
+    # (1) kernel correctness: oracle with bf16 rounding emulated
+    p = {"b." + k[2:]: torch.from_numpy(fx[k]).clone().requires_grad_(True) for k in fx.files if k.startswith("p:")}
+    xo = torch.from_numpy(fx["x"]).clone().requires_grad_(True)
+    O.set_rounding(O.bf16_round)
+    try:
+        yo = O.block_forward(xo, p, "b.", block_cfg(gh, gw, wh, ww, sh, sw, Cc, h, "relpos" in tag), 1, training=False)
+        yo.backward(torch.from_numpy(fx["gy"]))
+    finally:
+        O.set_rounding(None)
+    assert rel(y, yo) < 1e-3 and rel(x.grad, xo.grad) < 1.5e-2
+    assert worst_grad(blk, {k[2:]: v.grad for k, v in p.items()}) < 3e-2
+    # (2) bf16 tolerance against the fp32 reference.  These fixtures carry one head at the sigma = 100 clamp, where the
+    # softmax is an arg-max and bf16 operand rounding moves logits by ~0.3: the worst case for reduced precision.
+    assert rel(y, torch.from_numpy(fx["y"])) < 3e-2 and rel(x.grad, torch.from_numpy(fx["gx"])) < 0.15
+
+
+def test_block_train_mode_replays_droppath_and_cpb_dropout(dev, K):
+    """Stochastic pieces: DropPath scales and the CPB table (Dropout(0.125) in the meta MLP) are drawn host-side with the
+    torch RNG in the reference's order; replaying the same draws through the oracle must give the same block output."""
+    N = K["N"]
+    fx = np.load(os.path.join(GOLD, "block_relpos_shift_train.npz"))
+    gh, gw, wh, ww, sh, sw, Cc, h, B, seed, rng_seed, train = [int(v) for v in fx["meta"]]
+    dp = float(fx["dp"])
+    blk = N.SwinTransformerV2CrBlock(dim=Cc, num_heads=h, feat_size=(gh, gw), window_size=(wh, ww), shift_size=(sh, sw),
+                                     rel_pos=True, drop_path=dp)
+    load_params(blk, fx)
+    blk = blk.to(dev).train()
+    x = torch.from_numpy(fx["x"]).to(dev)
+    for trial in range(3):
+        torch.manual_seed(1234 + trial)
+        y = blk(x)
+        torch.manual_seed(1234 + trial)                        # replay the draws in the block's order
+        bias = blk.attn.position_bias().detach().cpu()
+        s1, s2 = blk.drop_path1.scale(x).cpu(), blk.drop_path2.scale(x).cpu()
+        assert set(s1.tolist()) <= {0.0, 1.0 / (1.0 - dp)} or abs(max(s1.tolist()) - 1 / (1 - dp)) < 1e-6
+        p = {"b." + k[2:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("p:")}
+        O.set_rounding(O.bf16_round)
+        try:
+            yo = O.block_forward(torch.from_numpy(fx["x"]), p, "b.", block_cfg(gh, gw, wh, ww, sh, sw, Cc, h, True), 1,
+                                 training=True, bias_override=bias, dp_override=(s1, s2))
+        finally:
+            O.set_rounding(None)
+        assert rel(y, yo) < 1e-3
+
+
+def test_patch_embed_and_patch_merging_modules(dev, K):
+    N = K["N"]
+    fx = np.load(os.path.join(GOLD, "patch_embed.npz"))
+    pe = N.PatchEmbed(img_size=(24, 40), patch_size=4, in_chans=7, embed_dim=32, norm_layer=torch.nn.LayerNorm)
+    load_params(pe, fx)
+    pe = pe.to(dev)
+    x = torch.from_numpy(fx["x"]).to(dev).requires_grad_(True)
+    y = pe(x)
+    y.backward(torch.from_numpy(fx["gy"]).to(dev))
+    assert rel(y, torch.from_numpy(fx["y"])) < 6e-3 and rel(x.grad, torch.from_numpy(fx["gx"])) < 8e-3
+    assert worst_grad(pe, {k[2:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("g:")}) < 8e-3
+    with pytest.raises(AssertionError):
+        pe(torch.zeros(1, 7, 20, 40, device=dev))                  # H mismatch asserts like the reference (:542)
+    fx = np.load(os.path.join(GOLD, "patch_merging.npz"))
+    pm = N.PatchMerging(dim=16)
+    load_params(pm, fx)
+    pm = pm.to(dev)
+    x = torch.from_numpy(fx["x"]).to(dev).requires_grad_(True)
+    y = pm(x)
+    y.backward(torch.from_numpy(fx["gy"]).to(dev))
+    assert rel(y, torch.from_numpy(fx["y"])) < 6e-3 and rel(x.grad, torch.from_numpy(fx["gx"])) < 8e-3
+    assert worst_grad(pm, {k[2:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("g:")}) < 8e-3
+
+
+@pytest.mark.parametrize("tag", ["nopos", "relpos_residual"])
+def test_whole_model_against_reference_fixture(dev, K, tag):
+    N = K["N"]
+    fx = np.load(os.path.join(GOLD, f"model_{tag}.npz"))
+    cin, cout, H, W, Cc, depth, h, ratio, relpos, residual, seed = [int(v) for v in fx["meta"]]
+    m = N.SwinTransformerV2Cr(img_size=(H, W), patch_size=4, depths=(depth,), num_heads=(h,), in_chans=cin, out_chans=cout,
+                              embed_dim=Cc, img_window_ratio=ratio, full_pos_embed=True, rel_pos=bool(relpos), residual=bool(residual))
+    load_params(m, fx)
+    m = m.to(dev).eval()
+    x = torch.from_numpy(fx["x"]).to(dev).requires_grad_(True)
+    y = m(x)
+    y.backward(torch.from_numpy(fx["gy"]).to(dev))
+    # bf16 tolerance against the fp32 reference vectors
+    assert rel(y, torch.from_numpy(fx["y"])) < 1.5e-2
+    assert rel(x.grad, torch.from_numpy(fx["gx"])) < 4e-2
+    assert worst_grad(m, {k[2:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("g:")}) < 8e-2
+    # kernel correctness against the bf16-emulating oracle
+    cfg = O.SwinCfg(img_size=(H, W), patch_size=4, depth=depth, num_heads=h, in_chans=cin, out_chans=cout, embed_dim=Cc,
+                    window_ratio=ratio, rel_pos=bool(relpos), residual=bool(residual))
+    p = {k[2:]: torch.from_numpy(fx[k]).clone().requires_grad_(True) for k in fx.files if k.startswith("p:")}
+    xo = torch.from_numpy(fx["x"]).clone().requires_grad_(True)
+    O.set_rounding(O.bf16_round)
+    try:
+        yo = O.model_forward(xo, p, cfg, training=False)
+        yo.backward(torch.from_numpy(fx["gy"]))
+    finally:
+        O.set_rounding(None)
+    assert rel(y, yo) < 4e-3 and rel(x.grad, xo.grad) < 2e-2
+    assert worst_grad(m, {k: v.grad for k, v in p.items()}) < 6e-2
+    # activation checkpointing (swinv2_global.py:650-651) must give the same result through the custom autograd nodes
+    m.set_grad_checkpointing(True)
+    m.zero_grad()
+    x2 = torch.from_numpy(fx["x"]).to(dev).requires_grad_(True)
+    y2 = m(x2)
+    y2.backward(torch.from_numpy(fx["gy"]).to(dev))
+    assert rel(y2, y) < 1e-6 and rel(x2.grad, x.grad) < 1e-3
+
+
+def test_multistep_wrapper_against_reference_fixture(dev, K):
+    from types import SimpleNamespace
+    fx = np.load(os.path.join(GOLD, "multistep.npz"))
+    params = SimpleNamespace(img_size=(48, 72), patch_size=4, depth=2, num_heads=2, n_in_channels=9, n_out_channels=5,
+                             embed_dim=24, window_ratio=8, drop_path_rate=0.0, full_pos_embed=True, rel_pos=False, mlp_ratio=4,
+                             activation_ckpt=False, residual=True, nettype="swin", n_future=1, add_orography=True, add_landmask=True)
+    m = K["helpers"].get_model(params)
+    load_params(m, fx)
+    m = m.to(dev).eval()
+    inp = torch.from_numpy(fx["inp"]).to(dev).requires_grad_(True)
+    y = m(inp, coszen=torch.from_numpy(fx["coszen"]).to(dev))
+    assert y.shape == (2, 10, 48, 72)
+    y.backward(torch.from_numpy(fx["gy"]).to(dev))
+    assert rel(y, torch.from_numpy(fx["y"])) < 1.5e-2 and rel(inp.grad, torch.from_numpy(fx["ginp"])) < 4e-2
+    assert worst_grad(m, {k[2:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("g:")}) < 8e-2
+
+
+def test_loss_handler_against_reference_values(dev, K):
+    from types import SimpleNamespace
+    from swin_v2_weather_amd.utils.losses import LossHandler
+    meta = json.load(open(os.path.join(GOLD, "loss_values.json")))
+    aux = np.load(os.path.join(GOLD, "loss_aux.npz"))
+    H, W, C = meta["H"], meta["W"], meta["C"]
+    names = (["u10m", "v10m", "u100m", "v100m", "t2m", "sp", "msl", "tcwv"] +
+             [f"{v}{l}" for v in "uvztq" for l in (50, 100, 150, 200, 250, 300, 400, 500, 600, 700, 850, 925, 1000)])
+    import tempfile
+    tmp = tempfile.mkdtemp()
+    np.save(tmp + "/gs.npy", aux["global_stds"])
+    np.save(tmp + "/td.npy", aux["time_diff_stds"])
+    for key, case in meta["cases"].items():
+        li, nf, mode = key.split("_")
+        params = SimpleNamespace(n_future=case["n_future"], img_shape_x=H, img_shape_y=W, loss=case["loss"], channel_weights="auto",
+                                 n_out_channels=C, channel_names=names, out_channels=np.arange(C), global_stds_path=tmp + "/gs.npy",
+                                 time_diff_stds_path=tmp + "/td.npy", dt=1, model_grid_type="equiangular")
+        lh = LossHandler(params).to(dev)
+        lh.train(mode == "train")
+        torch.manual_seed(case["seed"])
+        prd = torch.randn(2, C * (case["n_future"] + 1), H, W)
+        tar = torch.randn(2, C * (case["n_future"] + 1), H, W)
+        pd = prd.to(dev).requires_grad_(True)
+        val = lh(pd, tar.to(dev), None)
+        assert abs(float(val) - case["value"]) <= 2e-5 * abs(case["value"]), key
+        if mode == "train":
+            val.backward()
+            ref = torch.from_numpy(aux[f"gprd_{li}_{nf}"])
+            assert rel(pd.grad[:, ::9, ::5, ::7], ref) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# 100-step loss curve of BASELINE cfg 1 against the curve recorded from the real reference (fp32, CPU)
+# ---------------------------------------------------------------------------------------------------------------
+def test_loss_curve_tiny_100_steps(dev, K):
+    from types import SimpleNamespace
+    from swin_v2_weather_amd.utils.losses import LossHandler
+    meta = json.load(open(os.path.join(GOLD, "losscurve_tiny.json")))
+    c = meta["cfg"]
+    torch.manual_seed(meta["seed"])
+    m = K["N"].SwinTransformerV2Cr(img_size=tuple(c["img_size"]), patch_size=4, depths=(c["depth"],), num_heads=(c["num_heads"],),
+                                   in_chans=c["in_chans"], out_chans=c["out_chans"], embed_dim=c["embed_dim"],
+                                   img_window_ratio=c["window_ratio"], drop_path_rate=0.0, full_pos_embed=True, rel_pos=False,
+                                   mlp_ratio=4, residual=False).to(dev)
+    lh = LossHandler(SimpleNamespace(n_future=0, img_shape_x=c["img_size"][0], img_shape_y=c["img_size"][1], loss="l2",
+                                     channel_weights="none", n_out_channels=c["out_chans"], model_grid_type="equiangular")).to(dev)
+    opt = torch.optim.Adam(m.parameters(), lr=meta["lr"], betas=tuple(meta["betas"]))
+    m.train()
+    H, W = c["img_size"]
+
+    def batch(step):
+        g = torch.Generator().manual_seed(meta["seed"] * 100003 + step)
+        return torch.randn(1, c["in_chans"], H, W, generator=g), torch.randn(1, c["out_chans"], H, W, generator=g)
+    assert abs(float(batch(0)[0].double().sum()) - meta["x0_checksum"]) < 1e-6
+    curve = []
+    for it in range(meta["steps"]):
+        x, t = batch(it % meta["pool"])
+        opt.zero_grad()
+        loss = lh(m(x.to(dev)), t.to(dev))
+        loss.backward()
+        opt.step()
+        curve.append(float(loss))
+    ref = np.array(meta["curve"])
+    err = np.abs(np.array(curve) - ref) / np.abs(ref)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump({"max_rel_err": float(err.max()), "curve": curve}, open(os.path.join(ROOT, "gpurun_out", "losscurve_gpu.json"), "w"))
+    assert float(err.max()) < 1e-3, f"loss curve deviates: max rel err {err.max():.2e} at step {int(err.argmax())}"
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# size-independent properties at the BASELINE size (73 x 720 x 1440, window 9 x 18, 400 windows / sample)
+# ---------------------------------------------------------------------------------------------------------------
+def test_full_size_attention_properties(dev, K):
+    ops = K["ops"]
+    torch.manual_seed(5)
+    plan = ops.window_plan(1, 180, 360, 9, 18, 4, 9, 8, 16, 0)
+    Bw, h, Lp, DP, Lw = plan.Bw, 8, plan.Lp, plan.DP, plan.L
+    qkvh = torch.randn(Bw, h, 3, Lp, DP, device=dev)
+    qkvh[:, :, :2] = torch.nn.functional.normalize(qkvh[:, :, :2], dim=-1)
+    qkvh[:, :, 2] = 1.0                                        # v == 1  =>  softmax rows sum to 1  =>  o == 1 exactly
+    qkvh[:, :, :, Lw:] = 0
+    qkvh = qkvh.to(BF).contiguous()
+    oh = torch.empty(Bw, h, Lp, DP, dtype=BF, device=dev)
+    lse = torch.empty(Bw, h, Lp, device=dev)
+    ls = torch.full((h,), 2.3, device=dev)
+    ops.attn_fwd(ops.attn_args(qkvh, ls, None, oh, lse, Bw, h, Lw, 16, plan.nwh, plan.nww, plan.mask_thr))
+    o = oh.float()
+    assert float((o[:, :, :Lw] - 1.0).abs().max()) < 8e-3 and float(o[:, :, Lw:].abs().max()) == 0.0
+    # the window table is a permutation of the 64 800 tokens (+ 14 padded rows per window)
+    tab = plan.rowidx.view(plan.nW, Lp)
+    valid = tab[:, :Lw].reshape(-1).long()
+    assert torch.equal(torch.sort(valid).values, torch.arange(plan.T, device=valid.device)) and int(tab[:, Lw:].max()) == -1
+
+
+def test_full_size_model_batch_independence(dev, K):
+    """One BASELINE-size sample (depth 2 to stay quick): the output of a sample must not depend on its batch mates,
+    and the padded / masked rows must never leak (no NaN)."""
+    N = K["N"]
+    torch.manual_seed(6)
+    m = N.SwinTransformerV2Cr(img_size=(720, 1440), patch_size=4, depths=(2,), num_heads=(8,), in_chans=73, out_chans=73,
+                              embed_dim=128, img_window_ratio=80, full_pos_embed=True, rel_pos=False).to(dev).eval()
+    with torch.no_grad():
+        for n_, p_ in m.named_parameters():
+            if n_.endswith("norm1.weight") or n_.endswith("norm2.weight"):
+                p_.fill_(1.0)
+    x = torch.randn(2, 73, 720, 1440, device=dev)
+    with torch.no_grad():
+        y2 = m(x)
+        y1 = m(x[1:2].contiguous())
+    assert not torch.isnan(y2).any()
+    assert rel(y2[1:2], y1) < 1e-6

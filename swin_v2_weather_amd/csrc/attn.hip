@@ -67,7 +67,7 @@ __global__ __launch_bounds__(64 * LT) void attn_fwd_kernel(
             }
     }
 
-    constexpr int CHUNKS_PER_T = 2 * DK;     // 16-byte chunks each thread stages per window (K then V)
+    constexpr int CHUNKS_PER_T = DK;         // K + V slabs = 64*LT*DK 16-byte chunks over 64*LT threads
     uint4 stage[CHUNKS_PER_T];
     auto issue_loads = [&](int bw) {
         const uint16_t* base = qkvh + ((size_t)bw * h + hd) * 3 * SLAB + SLAB;   // K slab, V slab follows

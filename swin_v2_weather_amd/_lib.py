@@ -13,7 +13,7 @@ import threading
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libswv2.so")
-SOURCES = ["capi.hip", "attn.hip", "gemm.hip", "rowops.hip"]
+SOURCES = ["capi.hip", "attn.hip", "gemm.hip", "gemm_tn.hip", "rowops.hip"]
 
 _lib = None
 _lock = threading.Lock()
@@ -26,7 +26,7 @@ class Swv2Error(RuntimeError):
 def build_library(force: bool = False, verbose: bool = False) -> str:
     """Compile csrc/*.hip for gfx950 into swin_v2_weather_amd/libswv2.so (cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "swv2.h")]
+    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(HERE, "..", "include", "swv2.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

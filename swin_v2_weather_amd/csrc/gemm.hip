@@ -15,163 +15,13 @@
 //   * One workgroup owns a 128-row panel of A and walks all N tiles itself, so the panel's re-reads hit its own
 //     XCD's L2 instead of crossing XCDs.
 // Tile: 128x128x64, 256 threads = 4 waves in a 2x2 grid of 64x64 wave tiles (16 accumulators of 16x16),
-// v_mfma_f32_16x16x32_bf16, double-buffered LDS with register-staged prefetch (issue loads for step s+1, compute
-// step s, write LDS after), XOR-swizzled 128-byte LDS rows for conflict-free ds_read_b128 fragments.
+// v_mfma_f32_16x16x32_bf16, one LDS tile buffer with register-staged prefetch (issue loads for step s+1, compute
+// step s, write LDS after) and 3 workgroups per CU, XOR-swizzled 128-byte LDS rows for conflict-free ds_read_b128.
 #include "common.h"
 
+#include "gemm_common.h"
+
 namespace {
-
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int KCH = BK / 8;                 // 16-byte chunks per tile row
-constexpr int NTHREADS = 256;
-
-// swizzled element offset of chunk kc of row r in a [rows][64] bf16 tile (128-byte rows)
-__device__ __forceinline__ int swz(int r, int kc) { return r * BK + ((kc ^ ((r >> 1) & 7)) << 3); }
-
-// erf-GELU (timm Mlp act = nn.GELU) with the Abramowitz-Stegun 7.1.26 rational erf (|err| < 1.5e-7, far below the
-// bf16 storage precision): one v_rcp + one v_exp + a few FMAs instead of the ~40-instruction erff().
-__device__ __forceinline__ void erf_parts(float x, float& erf_v, float& gauss) {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
-    gauss = __expf(-z * z);                                    // exp(-x^2 / 2)
-    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
-    const float e = fmaf(-poly, gauss, 1.f);
-    erf_v = copysignf(e, x);
-}
-__device__ __forceinline__ float gelu_f(float x) {
-    float e, gs;
-    erf_parts(x, e, gs);
-    return 0.5f * x * (1.f + e);
-}
-__device__ __forceinline__ float gelu_grad_f(float x) {
-    float e, gs;
-    erf_parts(x, e, gs);
-    return fmaf(x * 0.3989422804014327f, gs, 0.5f * (1.f + e));
-}
-
-__device__ __forceinline__ uint4 pack8(const float* v) {
-    uint4 r;
-    r.x = f2bf2(v[0], v[1]); r.y = f2bf2(v[2], v[3]); r.z = f2bf2(v[4], v[5]); r.w = f2bf2(v[6], v[7]);
-    return r;
-}
-__device__ __forceinline__ void unpack8(uint4 c, float* v) {
-    const uint32_t w[4] = {c.x, c.y, c.z, c.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        v[2 * i] = __uint_as_float(w[i] << 16);
-        v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// A loaders: chunk(m, k0) returns 8 bf16 (k0 multiple of 8) of logical row m; zeros outside [0,M)x[0,K)
-// ------------------------------------------------------------------------------------------------
-struct LoadDesc {           // plain-data description shared by all loader kinds (filled by the host)
-    const void* ptr;        // primary source
-    const int32_t* rowidx;  // optional gather table: logical row -> source row, <0 = zero row
-    const float* aux0;      // LN-on-load: mean[M] ; patch: unused
-    const float* aux1;      // LN-on-load: rstd[M]
-    const float* aux2;      // LN-on-load: gamma[K]
-    const float* aux3;      // LN-on-load: beta[K]
-    long ld;                // source row pitch in elements
-    int M, K;
-    int p0, p1, p2, p3;     // kind-specific ints (see loaders)
-};
-
-template <int KIND> struct ALoad;
-
-enum { A_F32 = 0, A_BF16 = 1, A_BF16_GELU = 2, A_HEADS = 3, A_PATCH = 4, A_MERGE_LN = 5 };
-
-// fp32 rows (optionally gathered): the residual stream x[B*T][C]
-template <> struct ALoad<A_F32> {
-    static constexpr bool ROW_FASTEST = false;
-    LoadDesc d;
-    __device__ __forceinline__ uint4 chunk(int m, int k0) const {
-        if (m >= d.M || k0 >= d.K) return make_uint4(0, 0, 0, 0);
-        long r = m;
-        if (d.rowidx) { r = d.rowidx[m]; if (r < 0) return make_uint4(0, 0, 0, 0); }
-        const float* p = (const float*)d.ptr + r * d.ld + k0;
-        const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
-        uint4 o;
-        o.x = f2bf2(a[0], a[1]); o.y = f2bf2(a[2], a[3]); o.z = f2bf2(b[0], b[1]); o.w = f2bf2(b[2], b[3]);
-        return o;
-    }
-};
-// bf16 rows (optionally gathered)
-template <> struct ALoad<A_BF16> {
-    static constexpr bool ROW_FASTEST = false;
-    LoadDesc d;
-    __device__ __forceinline__ uint4 chunk(int m, int k0) const {
-        if (m >= d.M || k0 >= d.K) return make_uint4(0, 0, 0, 0);
-        long r = m;
-        if (d.rowidx) { r = d.rowidx[m]; if (r < 0) return make_uint4(0, 0, 0, 0); }
-        return *(const uint4*)((const uint16_t*)d.ptr + r * d.ld + k0);
-    }
-};
-// bf16 rows through GELU (fc2 input = GELU(fc1 output); the pre-activation is what is kept for backward)
-template <> struct ALoad<A_BF16_GELU> {
-    static constexpr bool ROW_FASTEST = false;
-    LoadDesc d;
-    __device__ __forceinline__ uint4 chunk(int m, int k0) const {
-        if (m >= d.M || k0 >= d.K) return make_uint4(0, 0, 0, 0);
-        float v[8];
-        unpack8(*(const uint4*)((const uint16_t*)d.ptr + (long)m * d.ld + k0), v);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = gelu_f(v[i]);
-        return pack8(v);
-    }
-};
-// head-major window layout [Bw][h][S][Lp][DP] -> logical row m = bw*Lp + t, logical k = (part*h + head)*DP + j
-// (head dim padded to DP; the matching weights are padded by swv2_prep_weight).
-// p0 = heads, p2 = Lp, p3 = DP ; ld = number of parts S (1 for oh, 3 for dqkvh)
-template <> struct ALoad<A_HEADS> {
-    static constexpr bool ROW_FASTEST = false;
-    LoadDesc d;
-    __device__ __forceinline__ uint4 chunk(int m, int k0) const {
-        if (m >= d.M || k0 >= d.K) return make_uint4(0, 0, 0, 0);
-        const int h = d.p0, Lp = d.p2, DP = d.p3, S = (int)d.ld;
-        const int bw = m / Lp, t = m - bw * Lp;
-        const int ph = k0 / DP, j = k0 - ph * DP, part = ph / h, hd = ph - part * h;
-        return *(const uint4*)((const uint16_t*)d.ptr + ((((long)bw * h + hd) * S + part) * Lp + t) * DP + j);
-    }
-};
-// PatchEmbed im2col: x[B][Cin][H][W] fp32, row m = (b, i, j) patch, k = cin*16 + p*4 + q (conv weight order)
-// p0 = Cin, p1 = H, p2 = W ; patch = 4.  Adjacent rows are adjacent 16-byte groups -> row-fastest thread map.
-template <> struct ALoad<A_PATCH> {
-    static constexpr bool ROW_FASTEST = true;
-    LoadDesc d;
-    __device__ __forceinline__ uint4 chunk(int m, int k0) const {
-        if (m >= d.M || k0 >= d.K) return make_uint4(0, 0, 0, 0);
-        const int Cin = d.p0, H = d.p1, W = d.p2, gw = W >> 2, gh = H >> 2;
-        const int b = m / (gh * gw), ij = m - b * gh * gw, i = ij / gw, j = ij - i * gw;
-        const int cin = k0 >> 4, p = (k0 >> 2) & 3;                 // p in {0, 2}
-        const float* src = (const float*)d.ptr + (((long)b * Cin + cin) * H + 4 * i + p) * W + 4 * j;
-        const f32x4 a = *(const f32x4*)src, c = *(const f32x4*)(src + W);
-        uint4 o;
-        o.x = f2bf2(a[0], a[1]); o.y = f2bf2(a[2], a[3]); o.z = f2bf2(c[0], c[1]); o.w = f2bf2(c[2], c[3]);
-        return o;
-    }
-};
-// PatchMerging gather + LayerNorm(4C) on load: x[B][H][W][C] fp32, row m = (b, i, j) on the half grid,
-// k = (wp*2 + hp)*C + c  (swinv2_global.py:520) ; p0 = H, p1 = W, p2 = C ; aux = mean, rstd, gamma, beta
-template <> struct ALoad<A_MERGE_LN> {
-    static constexpr bool ROW_FASTEST = false;
-    LoadDesc d;
-    __device__ __forceinline__ uint4 chunk(int m, int k0) const {
-        if (m >= d.M || k0 >= d.K) return make_uint4(0, 0, 0, 0);
-        const int H = d.p0, W = d.p1, C = d.p2, h2 = H >> 1, w2 = W >> 1;
-        const int b = m / (h2 * w2), ij = m - b * h2 * w2, i = ij / w2, j = ij - i * w2;
-        const float mu = d.aux0[m], rs = d.aux1[m];
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int k = k0 + e, blk = k / C, c = k - blk * C, wp = blk >> 1, hp = blk & 1;
-            const float x = ((const float*)d.ptr)[(((long)b * H + 2 * i + hp) * W + 2 * j + wp) * C + c];
-            v[e] = (x - mu) * rs * d.aux2[k] + d.aux3[k];
-        }
-        return pack8(v);
-    }
-};
 
 // ------------------------------------------------------------------------------------------------
 // Epilogues: tile(stage, m0, n0, lane) consumes a 16-row x 64-col fp32 sub-tile held in wave-private LDS
@@ -235,11 +85,20 @@ template <> struct Epi<E_BF16_GELU> {
         float v[16], gl[16];
 #pragma unroll
         for (int i = 0; i < 4; ++i) *(f32x4*)(v + 4 * i) = *(const f32x4*)(st + r * EP + c0 + 4 * i);
+        if (d.bias) {
+            if (n + 16 <= d.N) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            if (d.bias) v[i] += (n + i < d.N) ? d.bias[n + i] : 0.f;
-            gl[i] = gelu_f(bf2f(f2bf(v[i])));      // GELU of the stored (bf16) pre-activation: what the backward sees
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 b4 = *(const f32x4*)(d.bias + n + 4 * i);
+                    v[4 * i] += b4[0]; v[4 * i + 1] += b4[1]; v[4 * i + 2] += b4[2]; v[4 * i + 3] += b4[3];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] += (n + i < d.N) ? d.bias[n + i] : 0.f;
+            }
         }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) gl[i] = gelu_f(bf2f(f2bf(v[i])));   // GELU of the stored (bf16) pre-activation
         uint16_t* o = (uint16_t*)d.out + (long)m * d.ld + n;
         uint16_t* o2 = (uint16_t*)d.aux_out + (long)m * d.ld + n;
         if (n + 16 <= d.N) {
@@ -393,16 +252,22 @@ template <> struct Epi<E_UNPATCH> {
 // NT kernel
 // ------------------------------------------------------------------------------------------------
 template <int AK, int EK>
-__global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(ALoad<AK> al, const uint16_t* __restrict__ Wb, Epi<EK> ep,
-                                                           int M, int N, int K) {
-    __shared__ __attribute__((aligned(16))) uint16_t smem[2 * (BM + BN) * BK];   // [buf][A | B] = 64 KB
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(ALoad<AK> al, const uint16_t* __restrict__ Wb, Epi<EK> ep,
+                                                              int M, int N, int K) {
+    // one A|B tile buffer (32 KB) + wave-private epilogue staging (17 KB): 49 KB -> 3 workgroups (12 waves) per CU.
+    // Latency hiding comes from the co-resident workgroups plus the register prefetch of the next step's tiles.
+    __shared__ __attribute__((aligned(16))) uint16_t smem[(BM + BN) * BK];
+    __shared__ __attribute__((aligned(16))) float stage[4 * 16 * EP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, g = lane >> 4;
     const int wr = wave >> 1, wc = wave & 1;              // 2 x 2 waves, 64 x 64 each
     const int m_base = blockIdx.x * BM;
     const int ntiles = (N + BN - 1) / BN, ksteps = (K + BK - 1) / BK, steps = ntiles * ksteps;
+    uint16_t* As = smem;
+    uint16_t* Bs = smem + BM * BK;
 
-    uint4 ra[4], rb[4];
+    typename ALoad<AK>::Raw ra[4];
+    uint4 rb[4];
     auto issue = [&](int s) {
         const int nt = s / ksteps, ks = s - nt * ksteps;
 #pragma unroll
@@ -410,20 +275,18 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(ALoad<AK> al, const u
             const int c = tid + i * NTHREADS;
             int r, kc;
             if (ALoad<AK>::ROW_FASTEST) { r = c & (BM - 1); kc = c >> 7; } else { r = c >> 3; kc = c & 7; }
-            ra[i] = al.chunk(m_base + r, ks * BK + kc * 8);
+            ra[i] = al.raw(m_base + r, ks * BK + kc * 8);
             const int rn = c >> 3, kcb = c & 7, n = nt * BN + rn, k0 = ks * BK + kcb * 8;
             rb[i] = (n < N && k0 < K) ? *(const uint4*)(Wb + (long)n * K + k0) : make_uint4(0, 0, 0, 0);
         }
     };
-    auto commit = [&](int buf) {
-        uint16_t* As = smem + buf * (BM + BN) * BK;
-        uint16_t* Bs = As + BM * BK;
+    auto commit = [&]() {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = tid + i * NTHREADS;
             int r, kc;
             if (ALoad<AK>::ROW_FASTEST) { r = c & (BM - 1); kc = c >> 7; } else { r = c >> 3; kc = c & 7; }
-            *(uint4*)(As + swz(r, kc)) = ra[i];
+            *(uint4*)(As + swz(r, kc)) = al.cvt(ra[i]);
             *(uint4*)(Bs + swz(c >> 3, c & 7)) = rb[i];
         }
     };
@@ -431,18 +294,16 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(ALoad<AK> al, const u
     f32x4 acc[4][4];
     issue(0);
     for (int s = 0; s < steps; ++s) {
-        const int nt = s / ksteps, ks = s - nt * ksteps, buf = s & 1;
+        const int nt = s / ksteps, ks = s - nt * ksteps;
         if (ks == 0) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        commit(buf);
+        commit();
         __syncthreads();
         if (s + 1 < steps) issue(s + 1);
-        const uint16_t* As = smem + buf * (BM + BN) * BK;
-        const uint16_t* Bs = As + BM * BK;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 af[4], bf[4];
@@ -456,9 +317,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(ALoad<AK> al, const u
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
         }
+        __syncthreads();                                   // tile consumed: the next commit may overwrite it
         if (ks == ksteps - 1) {
-            __syncthreads();                               // every wave is done reading buf -> reuse it as staging
-            float* st = (float*)(smem + buf * (BM + BN) * BK) + wave * 16 * EP;
+            float* st = stage + wave * 16 * EP;            // wave-private: no further barrier needed
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -469,129 +330,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(ALoad<AK> al, const u
             }
         }
     }
-}
-
-// ------------------------------------------------------------------------------------------------
-// TN kernel: dW[N][K] (+)= sum over a slice of rows of dY^T X ; optional db[N] = column sums of dY
-// grid = (ntiles_n * ntiles_k, splits).  Output accumulated with fp32 atomics (caller zeroes dW / db).
-// ------------------------------------------------------------------------------------------------
-constexpr int TM = 128;                     // rows per step (4 MFMA k-steps of 32): ~100 KB in flight per workgroup
-constexpr int TP = 136;                     // LDS row pitch (elements) of the [TM][128] tiles: 272 B
-constexpr int TCH = TM * 16 / NTHREADS;     // 16-byte chunks per thread per operand per step (8)
-
-template <int YK, int XK>
-__global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(ALoad<YK> yl, ALoad<XK> xl, float* __restrict__ dW,
-                                                           float* __restrict__ db, const int32_t* __restrict__ nmap,
-                                                           const int32_t* __restrict__ kmap, int ldw, int M, int N,
-                                                           int K, int ntk, int rows_per_split) {
-    __shared__ __attribute__((aligned(16))) uint16_t smem[2 * TM * TP];          // [Y | X][TM][TP], single buffer
-    __shared__ float dbs[BN];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fr = lane & 15, g = lane >> 4;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int tn = blockIdx.x / ntk, tk = blockIdx.x - tn * ntk;
-    const int n_base = tn * BN, k_base = tk * BN;
-    const int m_lo = blockIdx.y * rows_per_split;
-    const int m_hi = min(M, m_lo + rows_per_split);
-    const int steps = (m_hi - m_lo + TM - 1) / TM;
-    if (steps <= 0) return;
-    const bool want_db = (db != nullptr) && (tk == 0);
-    if (tid < BN) dbs[tid] = 0.f;
-
-    // staging: each tile is TM x 16 chunks; a thread keeps a fixed chunk column and walks rows srow + 16 i
-    const int srow = tid >> 4, scol = tid & 15;
-    uint4 ry[TCH], rx[TCH];
-    float colsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    auto issue = [&](int s) {
-#pragma unroll
-        for (int i = 0; i < TCH; ++i) {
-            const int m = m_lo + s * TM + srow + 16 * i;
-            const bool ok = m < m_hi;
-            ry[i] = ok ? yl.chunk(m, n_base + scol * 8) : make_uint4(0, 0, 0, 0);
-            rx[i] = ok ? xl.chunk(m, k_base + scol * 8) : make_uint4(0, 0, 0, 0);
-        }
-    };
-    auto commit = [&]() {
-        uint16_t* Ys = smem;
-        uint16_t* Xs = smem + TM * TP;
-#pragma unroll
-        for (int i = 0; i < TCH; ++i) {
-            *(uint4*)(Ys + (srow + 16 * i) * TP + scol * 8) = ry[i];
-            *(uint4*)(Xs + (srow + 16 * i) * TP + scol * 8) = rx[i];
-            if (want_db) {
-                float v[8];
-                unpack8(ry[i], v);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) colsum[e] += v[e];
-            }
-        }
-    };
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    issue(0);
-    for (int s = 0; s < steps; ++s) {
-        commit();
-        __syncthreads();
-        if (s + 1 < steps) issue(s + 1);
-        const uint16_t* Ys = smem;
-        const uint16_t* Xs = smem + TM * TP;
-        // A operand = dY^T (rows n, k = m), B operand = X (k = m, cols k'): both are transposed reads of row-major tiles
-#pragma unroll
-        for (int kk = 0; kk < TM / 32; ++kk) {
-            bf16x8 af[4], bf[4];
-            const int r0 = 32 * kk + 8 * g + (fr >> 2), cc = (fr & 3) * 4;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bf16x4 a0 = lds_tr_read(Ys + r0 * TP + wr * 64 + i * 16 + cc);
-                const bf16x4 a1 = lds_tr_read(Ys + (r0 + 4) * TP + wr * 64 + i * 16 + cc);
-                const bf16x4 b0 = lds_tr_read(Xs + r0 * TP + wc * 64 + i * 16 + cc);
-                const bf16x4 b1 = lds_tr_read(Xs + (r0 + 4) * TP + wc * 64 + i * 16 + cc);
-                af[i] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
-                bf[i] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
-        }
-        __syncthreads();                    // all waves done with the tile before the next commit overwrites it
-    }
-    // accumulate the tile: rows n = n_base + wr*64 + 16i + 4g + r, cols k = k_base + wc*64 + 16j + fr
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int n = n_base + wr * 64 + 16 * i + 4 * g + r, k = k_base + wc * 64 + 16 * j + fr;
-                if (n >= N || k >= K) continue;
-                if (nmap) n = nmap[n];
-                if (kmap) k = kmap[k];
-                if (n >= 0 && k >= 0) atomicAdd(dW + (long)n * ldw + k, acc[i][j][r]);
-            }
-    if (want_db) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) atomicAdd(&dbs[scol * 8 + e], colsum[e]);
-        __syncthreads();
-        if (tid < BN && n_base + tid < N) {
-            const int n = nmap ? nmap[n_base + tid] : n_base + tid;
-            if (n >= 0) atomicAdd(db + n, dbs[tid]);
-        }
-    }
-}
-
-template <int AK>
-ALoad<AK> make_loader(const swv2_operand* o) {
-    ALoad<AK> l;
-    l.d.ptr = o->ptr; l.d.rowidx = o->rowidx; l.d.aux0 = o->aux0; l.d.aux1 = o->aux1; l.d.aux2 = o->aux2;
-    l.d.aux3 = o->aux3; l.d.ld = o->ld; l.d.M = o->rows; l.d.K = o->cols;
-    l.d.p0 = o->p[0]; l.d.p1 = o->p[1]; l.d.p2 = o->p[2]; l.d.p3 = o->p[3];
-    return l;
 }
 
 template <int AK, int EK>
@@ -620,44 +358,6 @@ int launch_nt1(const swv2_operand* a, const void* w, const swv2_epilogue* e, int
     }
     swv2_set_error("swv2_linear: unknown epilogue kind %d", e->kind);
     return SWV2_ERR_INVALID;
-}
-
-template <int YK>
-int launch_tn1(const swv2_operand* y, const swv2_operand* x, float* dW, float* db, const int32_t* nmap,
-               const int32_t* kmap, int ldw, int M, int N, int K, int splits, hipStream_t st) {
-    const int ntn = cdiv(N, BN), ntk = cdiv(K, BN);
-    int rows = cdiv(M, splits);
-    rows = cdiv(rows, TM) * TM;
-    dim3 grid(ntn * ntk, cdiv(M, rows));
-#define TN_CASE(XK)                                                                                              \
-    hipLaunchKernelGGL((gemm_tn_kernel<YK, XK>), grid, dim3(NTHREADS), 0, st, make_loader<YK>(y), make_loader<XK>(x), \
-                       dW, db, nmap, kmap, ldw, M, N, K, ntk, rows)
-    switch (x->kind) {
-        case SWV2_OP_F32: TN_CASE(A_F32); break;
-        case SWV2_OP_BF16: TN_CASE(A_BF16); break;
-        case SWV2_OP_BF16_GELU: TN_CASE(A_BF16_GELU); break;
-        case SWV2_OP_HEADS: TN_CASE(A_HEADS); break;
-        case SWV2_OP_PATCH: TN_CASE(A_PATCH); break;
-        case SWV2_OP_MERGE_LN: TN_CASE(A_MERGE_LN); break;
-        default: swv2_set_error("swv2_linear_wgrad: unknown X operand kind %d", x->kind); return SWV2_ERR_INVALID;
-    }
-#undef TN_CASE
-    SWV2_CHECK_LAUNCH("swv2_linear_wgrad");
-    return SWV2_OK;
-}
-
-int check_operand(const swv2_operand* o, const char* who) {
-    SWV2_CHECK_ARG(o && o->ptr, "%s: null operand", who);
-    SWV2_CHECK_ARG(o->rows > 0 && o->cols > 0, "%s: empty operand", who);
-    SWV2_CHECK_ARG(o->cols % 8 == 0, "%s: operand width %d must be a multiple of 8", who, o->cols);
-    SWV2_CHECK_ARG(((uintptr_t)o->ptr & 15) == 0, "%s: operand pointer must be 16-byte aligned", who);
-    if (o->kind == SWV2_OP_F32 || o->kind == SWV2_OP_BF16 || o->kind == SWV2_OP_BF16_GELU)
-        SWV2_CHECK_ARG(o->ld % 8 == 0 && o->ld >= o->cols, "%s: row pitch %ld must be a multiple of 8 and >= cols", who, o->ld);
-    if (o->kind == SWV2_OP_PATCH)
-        SWV2_CHECK_ARG(o->p[1] % 4 == 0 && o->p[2] % 4 == 0 && o->cols == o->p[0] * 16, "%s: bad patch geometry", who);
-    if (o->kind == SWV2_OP_MERGE_LN)
-        SWV2_CHECK_ARG(o->aux0 && o->aux1 && o->aux2 && o->aux3 && o->cols == 4 * o->p[2], "%s: bad merge operand", who);
-    return SWV2_OK;
 }
 
 }  // namespace
@@ -690,22 +390,3 @@ extern "C" int swv2_linear(const swv2_operand* a, const void* w_bf16, const swv2
     return SWV2_ERR_INVALID;
 }
 
-extern "C" int swv2_linear_wgrad(const swv2_operand* dy, const swv2_operand* x, float* dW, float* db,
-                                 const int32_t* nmap, const int32_t* kmap, int ldw, int splits, void* stream) {
-    int rc = check_operand(dy, "swv2_linear_wgrad(dy)");
-    if (rc) return rc;
-    rc = check_operand(x, "swv2_linear_wgrad(x)");
-    if (rc) return rc;
-    SWV2_CHECK_ARG(dW && splits > 0 && ldw > 0, "swv2_linear_wgrad: null dW, bad splits or bad pitch");
-    SWV2_CHECK_ARG(dy->rows == x->rows, "swv2_linear_wgrad: row counts differ (%d vs %d)", dy->rows, x->rows);
-    const int M = dy->rows, N = dy->cols, K = x->cols;
-    hipStream_t st = (hipStream_t)stream;
-    switch (dy->kind) {
-        case SWV2_OP_F32: return launch_tn1<A_F32>(dy, x, dW, db, nmap, kmap, ldw, M, N, K, splits, st);
-        case SWV2_OP_BF16: return launch_tn1<A_BF16>(dy, x, dW, db, nmap, kmap, ldw, M, N, K, splits, st);
-        case SWV2_OP_HEADS: return launch_tn1<A_HEADS>(dy, x, dW, db, nmap, kmap, ldw, M, N, K, splits, st);
-        case SWV2_OP_PATCH: return launch_tn1<A_PATCH>(dy, x, dW, db, nmap, kmap, ldw, M, N, K, splits, st);
-    }
-    swv2_set_error("swv2_linear_wgrad: unsupported dY operand kind %d", dy->kind);
-    return SWV2_ERR_INVALID;
-}

@@ -1,0 +1,212 @@
+// Shared pieces of the GEMM engine: tile constants, LDS swizzle, GELU, bf16 packing, operand loaders, host checks.
+// Included by gemm.hip (NT products + epilogues) and gemm_tn.hip (weight-gradient products).
+#pragma once
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int KCH = BK / 8;                 // 16-byte chunks per tile row
+constexpr int NTHREADS = 256;
+
+// swizzled element offset of chunk kc of row r in a [rows][64] bf16 tile (128-byte rows)
+__device__ __forceinline__ int swz(int r, int kc) { return r * BK + ((kc ^ ((r >> 1) & 7)) << 3); }
+
+// erf-GELU (timm Mlp act = nn.GELU) with the Abramowitz-Stegun 7.1.26 rational erf (|err| < 1.5e-7, far below the
+// bf16 storage precision): one v_rcp + one v_exp + a few FMAs instead of the ~40-instruction erff().
+__device__ __forceinline__ void erf_parts(float x, float& erf_v, float& gauss) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
+    gauss = __expf(-z * z);                                    // exp(-x^2 / 2)
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    const float e = fmaf(-poly, gauss, 1.f);
+    erf_v = copysignf(e, x);
+}
+__device__ __forceinline__ float gelu_f(float x) {
+    float e, gs;
+    erf_parts(x, e, gs);
+    return 0.5f * x * (1.f + e);
+}
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    float e, gs;
+    erf_parts(x, e, gs);
+    return fmaf(x * 0.3989422804014327f, gs, 0.5f * (1.f + e));
+}
+
+__device__ __forceinline__ uint4 pack8(const float* v) {
+    uint4 r;
+    r.x = f2bf2(v[0], v[1]); r.y = f2bf2(v[2], v[3]); r.z = f2bf2(v[4], v[5]); r.w = f2bf2(v[6], v[7]);
+    return r;
+}
+__device__ __forceinline__ void unpack8(uint4 c, float* v) {
+    const uint32_t w[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = __uint_as_float(w[i] << 16);
+        v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// A loaders: chunk(m, k0) returns 8 bf16 (k0 multiple of 8) of logical row m; zeros outside [0,M)x[0,K)
+// ------------------------------------------------------------------------------------------------
+struct LoadDesc {           // plain-data description shared by all loader kinds (filled by the host)
+    const void* ptr;        // primary source
+    const int32_t* rowidx;  // optional gather table: logical row -> source row, <0 = zero row
+    const float* aux0;      // LN-on-load: mean[M] ; patch: unused
+    const float* aux1;      // LN-on-load: rstd[M]
+    const float* aux2;      // LN-on-load: gamma[K]
+    const float* aux3;      // LN-on-load: beta[K]
+    long ld;                // source row pitch in elements
+    int M, K;
+    int p0, p1, p2, p3;     // kind-specific ints (see loaders)
+};
+
+template <int KIND> struct ALoad;
+
+enum { A_F32 = 0, A_BF16 = 1, A_BF16_GELU = 2, A_HEADS = 3, A_PATCH = 4, A_MERGE_LN = 5 };
+
+struct RawF32 { f32x4 a, b; };
+__device__ __forceinline__ uint4 cvt_f32x8(const RawF32& r) {
+    uint4 o;
+    o.x = f2bf2(r.a[0], r.a[1]); o.y = f2bf2(r.a[2], r.a[3]); o.z = f2bf2(r.b[0], r.b[1]); o.w = f2bf2(r.b[2], r.b[3]);
+    return o;
+}
+// Every loader has two phases: raw() issues the global loads and returns the registers untouched, cvt() produces the
+// 8 bf16.  The conversion happens when the tile is written to LDS, so the loads stay in flight across the MFMA phase
+// (a loader that converts inside the load makes the compiler wait for the data right there).  chunk() = cvt(raw()).
+
+// fp32 rows (optionally gathered): the residual stream x[B*T][C]
+template <> struct ALoad<A_F32> {
+    static constexpr bool ROW_FASTEST = false;
+    typedef RawF32 Raw;
+    LoadDesc d;
+    __device__ __forceinline__ Raw raw(int m, int k0) const {
+        Raw z = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+        if (m >= d.M || k0 >= d.K) return z;
+        long r = m;
+        if (d.rowidx) { r = d.rowidx[m]; if (r < 0) return z; }
+        const float* p = (const float*)d.ptr + r * d.ld + k0;
+        Raw o = {*(const f32x4*)p, *(const f32x4*)(p + 4)};
+        return o;
+    }
+    __device__ __forceinline__ uint4 cvt(const Raw& r) const { return cvt_f32x8(r); }
+    __device__ __forceinline__ uint4 chunk(int m, int k0) const { return cvt(raw(m, k0)); }
+};
+// bf16 rows (optionally gathered)
+template <> struct ALoad<A_BF16> {
+    static constexpr bool ROW_FASTEST = false;
+    typedef uint4 Raw;
+    LoadDesc d;
+    __device__ __forceinline__ uint4 cvt(const Raw& r) const { return r; }
+    __device__ __forceinline__ Raw raw(int m, int k0) const { return chunk(m, k0); }
+    __device__ __forceinline__ uint4 chunk(int m, int k0) const {
+        if (m >= d.M || k0 >= d.K) return make_uint4(0, 0, 0, 0);
+        long r = m;
+        if (d.rowidx) { r = d.rowidx[m]; if (r < 0) return make_uint4(0, 0, 0, 0); }
+        return *(const uint4*)((const uint16_t*)d.ptr + r * d.ld + k0);
+    }
+};
+// bf16 rows through GELU (fc2 input = GELU(fc1 output); the pre-activation is what is kept for backward)
+template <> struct ALoad<A_BF16_GELU> {
+    static constexpr bool ROW_FASTEST = false;
+    typedef uint4 Raw;
+    LoadDesc d;
+    __device__ __forceinline__ Raw raw(int m, int k0) const {
+        if (m >= d.M || k0 >= d.K) return make_uint4(0, 0, 0, 0);
+        return *(const uint4*)((const uint16_t*)d.ptr + (long)m * d.ld + k0);
+    }
+    __device__ __forceinline__ uint4 cvt(const Raw& r) const {
+        float v[8];
+        unpack8(r, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = gelu_f(v[i]);
+        return pack8(v);
+    }
+    __device__ __forceinline__ uint4 chunk(int m, int k0) const { return cvt(raw(m, k0)); }
+};
+// head-major window layout [Bw][h][S][Lp][DP] -> logical row m = bw*Lp + t, logical k = (part*h + head)*DP + j
+// (head dim padded to DP; the matching weights are padded by swv2_prep_weight).
+// p0 = heads, p2 = Lp, p3 = DP ; ld = number of parts S (1 for oh, 3 for dqkvh)
+template <> struct ALoad<A_HEADS> {
+    static constexpr bool ROW_FASTEST = false;
+    typedef uint4 Raw;
+    LoadDesc d;
+    __device__ __forceinline__ uint4 cvt(const Raw& r) const { return r; }
+    __device__ __forceinline__ Raw raw(int m, int k0) const { return chunk(m, k0); }
+    __device__ __forceinline__ uint4 chunk(int m, int k0) const {
+        if (m >= d.M || k0 >= d.K) return make_uint4(0, 0, 0, 0);
+        const int h = d.p0, Lp = d.p2, DP = d.p3, S = (int)d.ld;
+        const int bw = m / Lp, t = m - bw * Lp;
+        const int ph = k0 / DP, j = k0 - ph * DP, part = ph / h, hd = ph - part * h;
+        return *(const uint4*)((const uint16_t*)d.ptr + ((((long)bw * h + hd) * S + part) * Lp + t) * DP + j);
+    }
+};
+// PatchEmbed im2col: x[B][Cin][H][W] fp32, row m = (b, i, j) patch, k = cin*16 + p*4 + q (conv weight order)
+// p0 = Cin, p1 = H, p2 = W ; patch = 4.  Adjacent rows are adjacent 16-byte groups -> row-fastest thread map.
+template <> struct ALoad<A_PATCH> {
+    static constexpr bool ROW_FASTEST = true;
+    typedef RawF32 Raw;
+    LoadDesc d;
+    __device__ __forceinline__ Raw raw(int m, int k0) const {
+        Raw z = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+        if (m >= d.M || k0 >= d.K) return z;
+        const int Cin = d.p0, H = d.p1, W = d.p2, gw = W >> 2, gh = H >> 2;
+        const int b = m / (gh * gw), ij = m - b * gh * gw, i = ij / gw, j = ij - i * gw;
+        const int cin = k0 >> 4, p = (k0 >> 2) & 3;                 // p in {0, 2}
+        const float* src = (const float*)d.ptr + (((long)b * Cin + cin) * H + 4 * i + p) * W + 4 * j;
+        Raw o = {*(const f32x4*)src, *(const f32x4*)(src + W)};
+        return o;
+    }
+    __device__ __forceinline__ uint4 cvt(const Raw& r) const { return cvt_f32x8(r); }
+    __device__ __forceinline__ uint4 chunk(int m, int k0) const { return cvt(raw(m, k0)); }
+};
+// PatchMerging gather + LayerNorm(4C) on load: x[B][H][W][C] fp32, row m = (b, i, j) on the half grid,
+// k = (wp*2 + hp)*C + c  (swinv2_global.py:520) ; p0 = H, p1 = W, p2 = C ; aux = mean, rstd, gamma, beta
+template <> struct ALoad<A_MERGE_LN> {
+    static constexpr bool ROW_FASTEST = false;
+    typedef uint4 Raw;
+    LoadDesc d;
+    __device__ __forceinline__ uint4 cvt(const Raw& r) const { return r; }
+    __device__ __forceinline__ Raw raw(int m, int k0) const { return chunk(m, k0); }
+    __device__ __forceinline__ uint4 chunk(int m, int k0) const {
+        if (m >= d.M || k0 >= d.K) return make_uint4(0, 0, 0, 0);
+        const int H = d.p0, W = d.p1, C = d.p2, h2 = H >> 1, w2 = W >> 1;
+        const int b = m / (h2 * w2), ij = m - b * h2 * w2, i = ij / w2, j = ij - i * w2;
+        const float mu = d.aux0[m], rs = d.aux1[m];
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = k0 + e, blk = k / C, c = k - blk * C, wp = blk >> 1, hp = blk & 1;
+            const float x = ((const float*)d.ptr)[(((long)b * H + 2 * i + hp) * W + 2 * j + wp) * C + c];
+            v[e] = (x - mu) * rs * d.aux2[k] + d.aux3[k];
+        }
+        return pack8(v);
+    }
+};
+
+template <int AK>
+ALoad<AK> make_loader(const swv2_operand* o) {
+    ALoad<AK> l;
+    l.d.ptr = o->ptr; l.d.rowidx = o->rowidx; l.d.aux0 = o->aux0; l.d.aux1 = o->aux1; l.d.aux2 = o->aux2;
+    l.d.aux3 = o->aux3; l.d.ld = o->ld; l.d.M = o->rows; l.d.K = o->cols;
+    l.d.p0 = o->p[0]; l.d.p1 = o->p[1]; l.d.p2 = o->p[2]; l.d.p3 = o->p[3];
+    return l;
+}
+
+int check_operand(const swv2_operand* o, const char* who) {
+    SWV2_CHECK_ARG(o && o->ptr, "%s: null operand", who);
+    SWV2_CHECK_ARG(o->rows > 0 && o->cols > 0, "%s: empty operand", who);
+    SWV2_CHECK_ARG(o->cols % 8 == 0, "%s: operand width %d must be a multiple of 8", who, o->cols);
+    SWV2_CHECK_ARG(((uintptr_t)o->ptr & 15) == 0, "%s: operand pointer must be 16-byte aligned", who);
+    if (o->kind == SWV2_OP_F32 || o->kind == SWV2_OP_BF16 || o->kind == SWV2_OP_BF16_GELU)
+        SWV2_CHECK_ARG(o->ld % 8 == 0 && o->ld >= o->cols, "%s: row pitch %ld must be a multiple of 8 and >= cols", who, o->ld);
+    if (o->kind == SWV2_OP_PATCH)
+        SWV2_CHECK_ARG(o->p[1] % 4 == 0 && o->p[2] % 4 == 0 && o->cols == o->p[0] * 16, "%s: bad patch geometry", who);
+    if (o->kind == SWV2_OP_MERGE_LN)
+        SWV2_CHECK_ARG(o->aux0 && o->aux1 && o->aux2 && o->aux3 && o->cols == 4 * o->p[2], "%s: bad merge operand", who);
+    return SWV2_OK;
+}
+
+
+}  // namespace

@@ -1,0 +1,178 @@
+// Weight-gradient products of the GEMM engine: dW[N][K] += sum_m dY[m][N]^T X[m][K] (+ bias gradient).  See gemm.hip for
+// the engine overview and gemm_common.h for the operand loaders shared with the NT kernel.
+#include "gemm_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// TN kernel: dW[N][K] (+)= sum over a slice of rows of dY^T X ; optional db[N] = column sums of dY
+// grid = (ntiles_n * ntiles_k, splits).  Output accumulated with fp32 atomics (caller zeroes dW / db).
+// ------------------------------------------------------------------------------------------------
+constexpr int TM = 128;                     // rows per step (4 MFMA k-steps of 32): ~100 KB in flight per workgroup
+constexpr int TP = 136;                     // LDS row pitch (elements) of the [TM][128] tiles: 272 B
+constexpr int TCH = TM * 16 / NTHREADS;     // 16-byte chunks per thread per operand per step (8)
+
+template <int YK, int XK>
+__global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(ALoad<YK> yl, ALoad<XK> xl, float* __restrict__ dW,
+                                                           float* __restrict__ db, const int32_t* __restrict__ nmap,
+                                                           const int32_t* __restrict__ kmap, int ldw, int M, int N,
+                                                           int K, int ntk, int rows_per_split) {
+    __shared__ __attribute__((aligned(16))) uint16_t smem[2 * TM * TP];          // [Y | X][TM][TP], single buffer
+    __shared__ float dbs[BN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, g = lane >> 4;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int tn = blockIdx.x / ntk, tk = blockIdx.x - tn * ntk;
+    const int n_base = tn * BN, k_base = tk * BN;
+    const int m_lo = blockIdx.y * rows_per_split;
+    const int m_hi = min(M, m_lo + rows_per_split);
+    const int steps = (m_hi - m_lo + TM - 1) / TM;
+    if (steps <= 0) return;
+    const bool want_db = (db != nullptr) && (tk == 0);
+    if (tid < BN) dbs[tid] = 0.f;
+
+    // staging: each tile is TM x 16 chunks; a thread keeps a fixed chunk column and walks rows srow + 16 i
+    const int srow = tid >> 4, scol = tid & 15;
+    typename ALoad<YK>::Raw ry[TCH];
+    typename ALoad<XK>::Raw rx[TCH];
+    float colsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto issue = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < TCH; ++i) {
+            const int m = m_lo + s * TM + srow + 16 * i;
+            const bool ok = m < m_hi;
+            ry[i] = yl.raw(ok ? m : M, n_base + scol * 8);       // rows >= M load nothing and yield zeros
+            rx[i] = xl.raw(ok ? m : M, k_base + scol * 8);
+        }
+    };
+    auto commit = [&]() {
+        uint16_t* Ys = smem;
+        uint16_t* Xs = smem + TM * TP;
+#pragma unroll
+        for (int i = 0; i < TCH; ++i) {
+            const uint4 yv = yl.cvt(ry[i]);
+            *(uint4*)(Ys + (srow + 16 * i) * TP + scol * 8) = yv;
+            *(uint4*)(Xs + (srow + 16 * i) * TP + scol * 8) = xl.cvt(rx[i]);
+            if (want_db) {
+                float v[8];
+                unpack8(yv, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) colsum[e] += v[e];
+            }
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    issue(0);
+    for (int s = 0; s < steps; ++s) {
+        commit();
+        __syncthreads();
+        if (s + 1 < steps) issue(s + 1);
+        const uint16_t* Ys = smem;
+        const uint16_t* Xs = smem + TM * TP;
+        // A operand = dY^T (rows n, k = m), B operand = X (k = m, cols k'): both are transposed reads of row-major tiles
+#pragma unroll
+        for (int kk = 0; kk < TM / 32; ++kk) {
+            bf16x8 af[4], bf[4];
+            const int r0 = 32 * kk + 8 * g + (fr >> 2), cc = (fr & 3) * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bf16x4 a0 = lds_tr_read(Ys + r0 * TP + wr * 64 + i * 16 + cc);
+                const bf16x4 a1 = lds_tr_read(Ys + (r0 + 4) * TP + wr * 64 + i * 16 + cc);
+                const bf16x4 b0 = lds_tr_read(Xs + r0 * TP + wc * 64 + i * 16 + cc);
+                const bf16x4 b1 = lds_tr_read(Xs + (r0 + 4) * TP + wc * 64 + i * 16 + cc);
+                af[i] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                bf[i] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
+        }
+        __syncthreads();                    // all waves done with the tile before the next commit overwrites it
+    }
+    // accumulate the tile: rows n = n_base + wr*64 + 16i + 4g + r, cols k = k_base + wc*64 + 16j + fr
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int n = n_base + wr * 64 + 16 * i + 4 * g + r, k = k_base + wc * 64 + 16 * j + fr;
+                if (n >= N || k >= K) continue;
+                if (nmap) n = nmap[n];
+                if (kmap) k = kmap[k];
+                if (n >= 0 && k >= 0) atomicAdd(dW + (long)n * ldw + k, acc[i][j][r]);
+            }
+    if (want_db) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicAdd(&dbs[scol * 8 + e], colsum[e]);
+        __syncthreads();
+        if (tid < BN && n_base + tid < N) {
+            const int n = nmap ? nmap[n_base + tid] : n_base + tid;
+            if (n >= 0) atomicAdd(db + n, dbs[tid]);
+        }
+    }
+}
+
+template <int YK, int XK>
+int launch_tn2(const swv2_operand* y, const swv2_operand* x, float* dW, float* db, const int32_t* nmap,
+               const int32_t* kmap, int ldw, int M, int N, int K, int splits, hipStream_t st) {
+    // (a variant that kept the whole N x K output in one 8-wave workgroup, reading dY and X once per slice, measured
+    //  slower -- 146-155 us vs 128 us on the fc1 shape: fewer, fatter workgroups hide less latency)
+    const int ntn = cdiv(N, BN), ntk = cdiv(K, BN);
+    const int eff = (ntn * ntk >= 3) ? splits : splits * 2;     // small outputs: more row slices to fill the chip
+    int rows = cdiv(cdiv(M, eff), TM) * TM;
+    dim3 grid(ntn * ntk, cdiv(M, rows));
+    hipLaunchKernelGGL((gemm_tn_kernel<YK, XK>), grid, dim3(NTHREADS), 0, st, make_loader<YK>(y), make_loader<XK>(x), dW, db,
+                       nmap, kmap, ldw, M, N, K, ntk, rows);
+    SWV2_CHECK_LAUNCH("swv2_linear_wgrad");
+    return SWV2_OK;
+}
+
+template <int YK>
+int launch_tn1(const swv2_operand* y, const swv2_operand* x, float* dW, float* db, const int32_t* nmap,
+               const int32_t* kmap, int ldw, int M, int N, int K, int splits, hipStream_t st) {
+    // only the (dY, X) operand pairs that occur in the model are instantiated (compile time)
+    if (x->kind == SWV2_OP_F32) return launch_tn2<YK, A_F32>(y, x, dW, db, nmap, kmap, ldw, M, N, K, splits, st);
+    if constexpr (YK == A_BF16) {
+        switch (x->kind) {
+            case SWV2_OP_BF16: return launch_tn2<YK, A_BF16>(y, x, dW, db, nmap, kmap, ldw, M, N, K, splits, st);
+            case SWV2_OP_BF16_GELU: return launch_tn2<YK, A_BF16_GELU>(y, x, dW, db, nmap, kmap, ldw, M, N, K, splits, st);
+            case SWV2_OP_HEADS: return launch_tn2<YK, A_HEADS>(y, x, dW, db, nmap, kmap, ldw, M, N, K, splits, st);
+            case SWV2_OP_PATCH: return launch_tn2<YK, A_PATCH>(y, x, dW, db, nmap, kmap, ldw, M, N, K, splits, st);
+        }
+    }
+    if constexpr (YK == A_F32) {
+        if (x->kind == SWV2_OP_MERGE_LN) return launch_tn2<YK, A_MERGE_LN>(y, x, dW, db, nmap, kmap, ldw, M, N, K, splits, st);
+    }
+    swv2_set_error("swv2_linear_wgrad: operand pair (dY kind %d, X kind %d) is not instantiated", y->kind, x->kind);
+    return SWV2_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" int swv2_linear_wgrad(const swv2_operand* dy, const swv2_operand* x, float* dW, float* db,
+                                 const int32_t* nmap, const int32_t* kmap, int ldw, int splits, void* stream) {
+    int rc = check_operand(dy, "swv2_linear_wgrad(dy)");
+    if (rc) return rc;
+    rc = check_operand(x, "swv2_linear_wgrad(x)");
+    if (rc) return rc;
+    SWV2_CHECK_ARG(dW && splits > 0 && ldw > 0, "swv2_linear_wgrad: null dW, bad splits or bad pitch");
+    SWV2_CHECK_ARG(dy->rows == x->rows, "swv2_linear_wgrad: row counts differ (%d vs %d)", dy->rows, x->rows);
+    const int M = dy->rows, N = dy->cols, K = x->cols;
+    hipStream_t st = (hipStream_t)stream;
+    switch (dy->kind) {
+        case SWV2_OP_F32: return launch_tn1<A_F32>(dy, x, dW, db, nmap, kmap, ldw, M, N, K, splits, st);
+        case SWV2_OP_BF16: return launch_tn1<A_BF16>(dy, x, dW, db, nmap, kmap, ldw, M, N, K, splits, st);
+        case SWV2_OP_HEADS: return launch_tn1<A_HEADS>(dy, x, dW, db, nmap, kmap, ldw, M, N, K, splits, st);
+        case SWV2_OP_PATCH: return launch_tn1<A_PATCH>(dy, x, dW, db, nmap, kmap, ldw, M, N, K, splits, st);
+    }
+    swv2_set_error("swv2_linear_wgrad: unsupported dY operand kind %d", dy->kind);
+    return SWV2_ERR_INVALID;
+}

@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--rel-pos", type=int, default=0, help="0 = yaml default of swin_73var (rel_pos: false)")
     ap.add_argument("--drop-path-rate", type=float, default=0.1)
     ap.add_argument("--pool", type=int, default=2, help="device-resident synthetic batches that are cycled")
+    ap.add_argument("--force-ddp", action="store_true", help="wrap in DDP / init RCCL even with one rank (self-test)")
+    ap.add_argument("--settle", type=int, default=8, help="untimed set-up steps before the W warm-up steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-kernel", default="attn_bwd")
     a = ap.parse_args()
@@ -98,7 +100,12 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_ddp = world > 1 or a.force_ddp
+    if use_ddp:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", init_method="env://")
 
     from swin_v2_weather_amd import ops
@@ -114,7 +121,7 @@ def main():
     loss_obj = LossHandler(lp).to(dev)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.95), fused=True)
     net = model
-    if world > 1:
+    if use_ddp:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], output_device=local_rank,
                                                         broadcast_buffers=False, gradient_as_bucket_view=True)
     g = torch.Generator(device=dev).manual_seed(333 + rank)
@@ -132,10 +139,12 @@ def main():
         return loss
 
     def fence():
-        if world > 1:
+        if use_ddp:
             dist.barrier()
         torch.cuda.synchronize()
 
+    for i in range(a.settle):          # untimed set-up: the caching allocator grows to its steady-state footprint and the
+        step(i)                        # clocks settle during the first ~10 steps (one of them stalls for ~80 ms)
     for i in range(a.warmup):
         step(i)
     fence()
@@ -146,7 +155,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     ktimes = ops.stop_kernel_timing()
-    if world > 1:
+    if use_ddp:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
@@ -160,6 +169,16 @@ def main():
         per_sample = {"attn_fwd": 8.0, "attn_bwd": 16.0}.get(a.roofline_kernel, 0.0) * T * a.embed_dim
         alg = per_sample * B
         achieved = alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        traffic = None
+        try:        # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, see profiles/)
+            import glob
+            pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.json")))[-1]))
+            key = [k for k in pm if a.roofline_kernel.replace("attn_", "attn_").split("_")[0] in k and
+                   ("bwd" in k) == ("bwd" in a.roofline_kernel)]
+            if key and a.local_batch == 2:
+                traffic = pm[key[0]]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         out = {
             "metric": "ERA5 samples/sec (73x721x1440) swin_73var depth12", "value": value, "unit": "samples/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
@@ -172,14 +191,14 @@ def main():
             "model_tflops_per_gpu": value * flops / world / 1e12,
             "mfma_frac_end_to_end": value * flops / world / 2.5e15,
             "roofline": {"kernel": a.roofline_kernel, "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None, "launches_timed": n_l, "avg_ms": k_ms,
+                         "frac": achieved / 8000.0, "traffic": traffic, "launches_timed": n_l, "avg_ms": k_ms,
                          "algorithmic_bytes_per_launch": alg,
                          "flops_per_launch": {"attn_fwd": 4.0, "attn_bwd": 8.0}.get(a.roofline_kernel, 0.0) * T * Lw * a.embed_dim * B},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_ddp:
         dist.barrier()
         dist.destroy_process_group()
 

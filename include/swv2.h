@@ -194,6 +194,52 @@ int swv2_loss_grad(const float* prd, const float* tar, const float* quad_w, cons
 int swv2_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                    int step, float grad_inv_scale, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Whole-block orchestration: one host call enqueues the 7 forward / 13 backward launches of a Swin block
+ * (reference SwinTransformerV2CrBlock.forward, swinv2_global.py:480-497, and its autograd) from C++, so the per-launch
+ * host cost is a few microseconds instead of a Python round trip.  All memory is caller-owned.
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct swv2_block_desc {
+    /* geometry */
+    int B, T, C, heads, head_dim, hidden, L, Lp, DP, nwh, nww, mask_thr;
+    const int32_t* rowidx;   /* [Bw*Lp] window-ordered padded row -> image row (b*T + i*gw + j) or -1 */
+    const int32_t* qkv_map;  /* [3*heads*DP] padded qkv feature -> qkv feature or -1 */
+    const int32_t* proj_map; /* [heads*DP]   padded head feature -> channel or -1 */
+    /* parameters (fp32) and their prepared bf16 copies (swv2_prep_weight) */
+    const float *logit_scale, *qkv_b_pad, *proj_b, *n1_w, *n1_b, *fc1_b, *fc2_b, *n2_w, *n2_b;
+    const void *w_qkv, *w_proj, *w_fc1, *w_fc2;     /* forward: [3hDP][C], [C][hDP], [hid][C], [C][hid] */
+    const void *w_qkvt, *w_projt, *w_fc1t, *w_fc2t; /* backward (transposed): [C][3hDP], [hDP][C], [C][hid], [hid][C] */
+    /* per-call inputs */
+    const float* x;          /* [B*T][C] block input (residual stream) */
+    const float* bias;       /* [heads][L][L] CPB table or NULL */
+    const float* dp1;        /* [B] drop-path scales or NULL */
+    const float* dp2;
+    /* saved activations: written by forward, read by backward */
+    void* qkvh;  float* rnorm; void* oh; float* lse; void* a1; float* mean1; float* rstd1; float* x1;
+    void* hpre;  void* hact;   void* a2; float* mean2; float* rstd2;
+    float* x2;               /* forward output [B*T][C] */
+    /* backward only */
+    const float* dx2;        /* grad of x2 */
+    void *da2, *dh, *da1, *doh, *dqkvh;   /* bf16 scratch: [BT][C], [BT][hid], [Bw*Lp][C], [Bw][h][Lp][DP], [Bw][h][3][Lp][DP] */
+    float* dx1;              /* fp32 scratch [BT][C] */
+    float* ln_ws;            /* SWV2_LN_BWD_MAX_BLOCKS*2*C floats */
+    float* dx;               /* out: grad of x */
+    /* parameter gradients, ACCUMULATED (caller zeroes) */
+    float *d_logit_scale, *d_bias, *d_qkv_w, *d_qkv_b, *d_proj_w, *d_proj_b, *d_n1_w, *d_n1_b, *d_fc1_w, *d_fc1_b,
+          *d_fc2_w, *d_fc2_b, *d_n2_w, *d_n2_b;
+    int wgrad_splits;        /* row slices of the weight-gradient products (64 is a good default) */
+    /* optional timing of ONE launch with HIP events on the launch stream (bench.py's roofline): if ev_kernel matches a
+       launch id (forward 1 qkv, 2 attn_fwd, 3 proj, 4 ln1, 5 fc1, 6 fc2, 7 ln2; backward 11 ln2, 12 wgrad fc2, 13 dh,
+       14 wgrad fc1, 15 dx1, 16 ln1, 17 wgrad proj, 18 d(oh), 19 attn_bwd, 20 wgrad qkv, 21 dx), ev_start / ev_stop
+       (hipEvent_t) are recorded around it; 0 = off */
+    int ev_kernel;
+    void* ev_start;
+    void* ev_stop;
+} swv2_block_desc;
+
+int swv2_block_fwd(const swv2_block_desc* d, void* stream);
+int swv2_block_bwd(const swv2_block_desc* d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

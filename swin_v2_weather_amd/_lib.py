@@ -13,7 +13,7 @@ import threading
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libswv2.so")
-SOURCES = ["capi.hip", "attn.hip", "gemm.hip", "gemm_tn.hip", "rowops.hip"]
+SOURCES = ["capi.hip", "attn.hip", "gemm.hip", "gemm_tn.hip", "rowops.hip", "block.hip"]
 
 _lib = None
 _lock = threading.Lock()
@@ -79,6 +79,20 @@ class LnArgs(C.Structure):
 
 
 LN_BWD_MAX_BLOCKS = 512
+class BlockDesc(C.Structure):
+    _fields_ = ([(n, C.c_int) for n in ("B", "T", "C", "heads", "head_dim", "hidden", "L", "Lp", "DP", "nwh", "nww", "mask_thr")] +
+                [(n, C.c_void_p) for n in (
+                    "rowidx", "qkv_map", "proj_map",
+                    "logit_scale", "qkv_b_pad", "proj_b", "n1_w", "n1_b", "fc1_b", "fc2_b", "n2_w", "n2_b",
+                    "w_qkv", "w_proj", "w_fc1", "w_fc2", "w_qkvt", "w_projt", "w_fc1t", "w_fc2t",
+                    "x", "bias", "dp1", "dp2",
+                    "qkvh", "rnorm", "oh", "lse", "a1", "mean1", "rstd1", "x1", "hpre", "hact", "a2", "mean2", "rstd2", "x2",
+                    "dx2", "da2", "dh", "da1", "doh", "dqkvh", "dx1", "ln_ws", "dx",
+                    "d_logit_scale", "d_bias", "d_qkv_w", "d_qkv_b", "d_proj_w", "d_proj_b", "d_n1_w", "d_n1_b", "d_fc1_w",
+                    "d_fc1_b", "d_fc2_w", "d_fc2_b", "d_n2_w", "d_n2_b")] +
+                [("wgrad_splits", C.c_int), ("ev_kernel", C.c_int), ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p)])
+
+
 OP_F32, OP_BF16, OP_BF16_GELU, OP_HEADS, OP_PATCH, OP_MERGE_LN = range(6)
 EPI_BF16, EPI_F32, EPI_QKV_HEADS, EPI_GELU_GRAD, EPI_UNPATCH, EPI_HEADS, EPI_F32_ACC, EPI_BF16_GELU = range(8)
 
@@ -101,6 +115,8 @@ SYMBOLS = {
     "swv2_loss_sums": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "swv2_loss_grad": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "swv2_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P]),
+    "swv2_block_fwd": (_I, [C.POINTER(BlockDesc), _P]),
+    "swv2_block_bwd": (_I, [C.POINTER(BlockDesc), _P]),
 }
 
 

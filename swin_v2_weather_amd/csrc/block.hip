@@ -1,0 +1,146 @@
+// Host-side orchestration of one Swin block (forward: 7 launches, backward: 13) on top of the public kernels' entry
+// points.  Pure C++ host code: no device code here, no allocation, no synchronisation.
+#include "common.h"
+
+namespace {
+
+swv2_operand op(int kind, const void* p, int rows, int cols, long ld, const int32_t* rowidx = nullptr) {
+    swv2_operand o = {};
+    o.kind = kind; o.ptr = p; o.rowidx = rowidx; o.ld = ld; o.rows = rows; o.cols = cols;
+    return o;
+}
+swv2_operand op_heads(const void* p, int Bw, int heads, int parts, int Lp, int DP) {
+    swv2_operand o = op(SWV2_OP_HEADS, p, Bw * Lp, parts * heads * DP, parts);
+    o.p[0] = heads; o.p[2] = Lp; o.p[3] = DP;
+    return o;
+}
+swv2_epilogue epi(int kind, void* out, long ld, const float* bias = nullptr, const void* aux = nullptr,
+                  float* aux_out = nullptr, const int32_t* rowidx = nullptr) {
+    swv2_epilogue e = {};
+    e.kind = kind; e.out = out; e.ld = ld; e.bias = bias; e.aux = aux; e.aux_out = aux_out; e.rowidx = rowidx;
+    return e;
+}
+swv2_attn_args attn(const swv2_block_desc* d) {
+    swv2_attn_args a = {};
+    a.qkvh = d->qkvh; a.logit_scale = d->logit_scale; a.bias = d->bias; a.oh = d->oh; a.lse = d->lse;
+    a.Bw = d->B * d->nwh * d->nww; a.heads = d->heads; a.L = d->L; a.head_dim = d->head_dim; a.nwh = d->nwh; a.nww = d->nww;
+    a.mask_thr = d->mask_thr; a.max_chunks = 64;
+    return a;
+}
+#define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+// launch `x` as launch number `id`; bracket it with the caller's HIP events when it is the one being timed
+#define LAUNCH(id, x)                                                                         \
+    do {                                                                                      \
+        const bool t_ = d->ev_kernel == (id) && d->ev_start && d->ev_stop;                    \
+        if (t_) (void)hipEventRecord((hipEvent_t)d->ev_start, (hipStream_t)st);                     \
+        TRY(x);                                                                               \
+        if (t_) (void)hipEventRecord((hipEvent_t)d->ev_stop, (hipStream_t)st);                      \
+    } while (0)
+
+}  // namespace
+
+extern "C" int swv2_block_fwd(const swv2_block_desc* d, void* st) {
+    SWV2_CHECK_ARG(d && d->x && d->x2 && d->qkvh && d->rowidx, "swv2_block_fwd: null descriptor field");
+    const int BT = d->B * d->T, Bw = d->B * d->nwh * d->nww, Mw = Bw * d->Lp, C = d->C, h = d->heads, hid = d->hidden;
+    // 1. roll + partition gather | qkv GEMM | + bias, split heads, L2-normalise q, k
+    {
+        swv2_operand a = op(SWV2_OP_F32, d->x, Mw, C, C, d->rowidx);
+        swv2_epilogue e = epi(SWV2_EPI_QKV_HEADS, d->qkvh, 0, d->qkv_b_pad, nullptr, d->rnorm);
+        e.p[0] = h; e.p[2] = d->Lp; e.p[3] = d->DP; e.p[4] = d->L;
+        LAUNCH(1, swv2_linear(&a, d->w_qkv, &e, 3 * h * d->DP, st));
+    }
+    // 2. cosine attention core
+    {
+        swv2_attn_args a = attn(d);
+        LAUNCH(2, swv2_attn_fwd(&a, st));
+    }
+    // 3. merge heads | proj GEMM
+    {
+        swv2_operand a = op_heads(d->oh, Bw, h, 1, d->Lp, d->DP);
+        swv2_epilogue e = epi(SWV2_EPI_BF16, d->a1, C, d->proj_b);
+        LAUNCH(3, swv2_linear(&a, d->w_proj, &e, C, st));
+    }
+    // 4. LN1 + drop-path + residual, scattered through reverse + un-roll
+    {
+        swv2_ln_args l = {};
+        l.a = d->a1; l.res = d->x; l.gamma = d->n1_w; l.beta = d->n1_b; l.scale = d->dp1; l.rowidx = d->rowidx; l.y = d->x1;
+        l.mean = d->mean1; l.rstd = d->rstd1; l.M = Mw; l.C = C; l.res_mod = 0; l.rows_per_sample = d->T; l.eps = 1e-5f;
+        LAUNCH(4, swv2_ln_residual_fwd(&l, st));
+    }
+    // 5. fc1 (+ bias -> pre-activation and GELU), 6. fc2
+    {
+        swv2_operand a = op(SWV2_OP_F32, d->x1, BT, C, C);
+        swv2_epilogue e = epi(SWV2_EPI_BF16_GELU, d->hpre, hid, d->fc1_b, nullptr, (float*)d->hact);
+        LAUNCH(5, swv2_linear(&a, d->w_fc1, &e, hid, st));
+    }
+    {
+        swv2_operand a = op(SWV2_OP_BF16, d->hact, BT, hid, hid);
+        swv2_epilogue e = epi(SWV2_EPI_BF16, d->a2, C, d->fc2_b);
+        LAUNCH(6, swv2_linear(&a, d->w_fc2, &e, C, st));
+    }
+    // 7. LN2 + drop-path + residual
+    {
+        swv2_ln_args l = {};
+        l.a = d->a2; l.res = d->x1; l.gamma = d->n2_w; l.beta = d->n2_b; l.scale = d->dp2; l.y = d->x2; l.mean = d->mean2;
+        l.rstd = d->rstd2; l.M = BT; l.C = C; l.res_mod = 0; l.rows_per_sample = d->T; l.eps = 1e-5f;
+        LAUNCH(7, swv2_ln_residual_fwd(&l, st));
+    }
+    return SWV2_OK;
+}
+
+extern "C" int swv2_block_bwd(const swv2_block_desc* d, void* st) {
+    SWV2_CHECK_ARG(d && d->dx2 && d->dx && d->da2 && d->dh && d->dx1 && d->da1 && d->doh && d->dqkvh && d->ln_ws,
+                   "swv2_block_bwd: null descriptor field");
+    const int BT = d->B * d->T, Bw = d->B * d->nwh * d->nww, Mw = Bw * d->Lp, C = d->C, h = d->heads, hid = d->hidden;
+    const int sp = d->wgrad_splits > 0 ? d->wgrad_splits : 64;
+    // 7'. LN2 backward
+    {
+        swv2_ln_args l = {};
+        l.a = d->a2; l.dy = d->dx2; l.gamma = d->n2_w; l.scale = d->dp2; l.mean = d->mean2; l.rstd = d->rstd2; l.da = d->da2;
+        l.dgamma = d->d_n2_w; l.dbeta = d->d_n2_b; l.ws = d->ln_ws; l.M = BT; l.C = C; l.rows_per_sample = d->T;
+        LAUNCH(11, swv2_ln_residual_bwd(&l, st));
+    }
+    // 6'. fc2: dW = da2^T GELU(h) ; dh = (da2 W2) * GELU'(h)
+    {
+        swv2_operand dy = op(SWV2_OP_BF16, d->da2, BT, C, C), x = op(SWV2_OP_BF16, d->hact, BT, hid, hid);
+        LAUNCH(12, swv2_linear_wgrad(&dy, &x, d->d_fc2_w, d->d_fc2_b, nullptr, nullptr, hid, sp, st));
+        swv2_epilogue e = epi(SWV2_EPI_GELU_GRAD, d->dh, hid, nullptr, d->hpre);
+        LAUNCH(13, swv2_linear(&dy, d->w_fc2t, &e, hid, st));
+    }
+    // 5'. fc1: dW = dh^T x1 ; dx1 = dx2 + dh W1
+    {
+        swv2_operand dy = op(SWV2_OP_BF16, d->dh, BT, hid, hid), x = op(SWV2_OP_F32, d->x1, BT, C, C);
+        LAUNCH(14, swv2_linear_wgrad(&dy, &x, d->d_fc1_w, d->d_fc1_b, nullptr, nullptr, C, sp, st));
+        swv2_epilogue e = epi(SWV2_EPI_F32, d->dx1, C, nullptr, d->dx2);
+        LAUNCH(15, swv2_linear(&dy, d->w_fc1t, &e, C, st));
+    }
+    // 4'. LN1 backward (gathers dx1 rows through the window table; padded rows -> 0)
+    {
+        swv2_ln_args l = {};
+        l.a = d->a1; l.dy = d->dx1; l.gamma = d->n1_w; l.scale = d->dp1; l.rowidx = d->rowidx; l.mean = d->mean1; l.rstd = d->rstd1;
+        l.da = d->da1; l.dgamma = d->d_n1_w; l.dbeta = d->d_n1_b; l.ws = d->ln_ws; l.M = Mw; l.C = C; l.rows_per_sample = d->T;
+        LAUNCH(16, swv2_ln_residual_bwd(&l, st));
+    }
+    // 3'. proj: dW = da1^T merge(oh) ; d(oh) = split(da1 Wp)
+    {
+        swv2_operand dy = op(SWV2_OP_BF16, d->da1, Mw, C, C), x = op_heads(d->oh, Bw, h, 1, d->Lp, d->DP);
+        LAUNCH(17, swv2_linear_wgrad(&dy, &x, d->d_proj_w, d->d_proj_b, nullptr, d->proj_map, C, sp, st));
+        swv2_epilogue e = epi(SWV2_EPI_HEADS, d->doh, 0);
+        e.p[0] = h; e.p[2] = d->Lp; e.p[3] = d->DP; e.p[4] = d->L;
+        LAUNCH(18, swv2_linear(&dy, d->w_projt, &e, h * d->DP, st));
+    }
+    // 2'. attention backward (incl. the backward of the q / k normalisation)
+    {
+        swv2_attn_args a = attn(d);
+        a.doh = d->doh; a.rnorm = d->rnorm; a.dqkvh = d->dqkvh; a.dlogit_scale = d->d_logit_scale; a.dbias = d->d_bias;
+        LAUNCH(19, swv2_attn_bwd(&a, st));
+    }
+    // 1'. qkv: dW = dqkv^T gather(x) ; dx = dx1 + scatter(dqkv Wqkv)
+    {
+        swv2_operand dy = op_heads(d->dqkvh, Bw, h, 3, d->Lp, d->DP), x = op(SWV2_OP_F32, d->x, Mw, C, C, d->rowidx);
+        LAUNCH(20, swv2_linear_wgrad(&dy, &x, d->d_qkv_w, d->d_qkv_b, d->qkv_map, nullptr, C, sp, st));
+        swv2_epilogue e = epi(SWV2_EPI_F32, d->dx, C, nullptr, d->dx1, nullptr, d->rowidx);
+        LAUNCH(21, swv2_linear(&dy, d->w_qkvt, &e, C, st));
+    }
+    return SWV2_OK;
+}

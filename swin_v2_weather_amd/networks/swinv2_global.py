@@ -98,123 +98,137 @@ def window_reverse(windows, window_size: Tuple[int, int], img_size: Tuple[int, i
 
 
 # ================================================================================================
-# block: one autograd node, 7 forward launches
+# block: one autograd node; forward (7 launches) and backward (13 launches) are each ONE host call into
+# libswv2.so (swv2_block_fwd / swv2_block_bwd), all buffers carved out of three torch allocations
 # ================================================================================================
+def _carve(sizes, align=256):
+    """byte offsets of consecutive `sizes`-byte regions, each aligned"""
+    offs, off = [], 0
+    for s in sizes:
+        offs.append(off)
+        off += (s + align - 1) // align * align
+    return offs, off
+
+
+class _BlockRunner:
+    """Per (block, batch size, device) launch descriptor: geometry, index tables and buffer offsets are filled once."""
+
+    ACTS = ("qkvh", "rnorm", "oh", "lse", "a1", "mean1", "rstd1", "x1", "hpre", "hact", "a2", "mean2", "rstd2")
+    SCRATCH = ("da2", "dh", "da1", "doh", "dqkvh", "dx1", "ln_ws")
+
+    def __init__(self, blk, plan, Cc, hid, device):
+        self.plan, self.C, self.hid, self.device = plan, Cc, hid, device
+        h, Lp, DP, Bw, B, T, Lw = plan.heads, plan.Lp, plan.DP, plan.Bw, plan.B, plan.T, plan.L
+        BT, Mw = B * T, Bw * Lp
+        d = L.BlockDesc()
+        d.B, d.T, d.C, d.heads, d.head_dim, d.hidden = B, T, Cc, h, plan.d, hid
+        d.L, d.Lp, d.DP, d.nwh, d.nww, d.mask_thr = Lw, Lp, DP, plan.nwh, plan.nww, plan.mask_thr
+        d.rowidx, d.qkv_map, d.proj_map = plan.rowidx.data_ptr(), plan.qkv_map.data_ptr(), plan.proj_map.data_ptr()
+        d.wgrad_splits = 64
+        self.desc = d
+        act_sizes = [Bw * h * 3 * Lp * DP * 2, Bw * h * 2 * Lp * 4, Bw * h * Lp * DP * 2, Bw * h * Lp * 4, Mw * Cc * 2, Mw * 4,
+                     Mw * 4, BT * Cc * 4, BT * hid * 2, BT * hid * 2, BT * Cc * 2, BT * 4, BT * 4]
+        self.act_off, self.act_bytes = _carve(act_sizes)
+        scr_sizes = [BT * Cc * 2, BT * hid * 2, Mw * Cc * 2, Bw * h * Lp * DP * 2, Bw * h * 3 * Lp * DP * 2, BT * Cc * 4,
+                     L.LN_BWD_MAX_BLOCKS * 2 * Cc * 4]
+        self.scr_off, self.scr_bytes = _carve(scr_sizes)
+        self.grad_shapes = [(h,), (3 * Cc, Cc), (3 * Cc,), (Cc, Cc), (Cc,), (Cc,), (Cc,), (hid, Cc), (hid,), (Cc, hid), (Cc,),
+                            (Cc,), (Cc,)]
+        self.grad_names = ["d_logit_scale", "d_qkv_w", "d_qkv_b", "d_proj_w", "d_proj_b", "d_n1_w", "d_n1_b", "d_fc1_w",
+                           "d_fc1_b", "d_fc2_w", "d_fc2_b", "d_n2_w", "d_n2_b"]
+        gs = [int(torch.Size(s).numel()) * 4 for s in self.grad_shapes]
+        self.grad_off, self.grad_bytes = _carve(gs, 64)
+        self.bias_elems = h * Lw * Lw
+
+    def set_params(self, wc, logit_scale, qkv_w, qkv_b, proj_w, proj_b, n1_w, n1_b, fc1_w, fc1_b, fc2_w, fc2_b, n2_w, n2_b,
+                   backward):
+        plan, d = self.plan, self.desc
+        h, DP = plan.heads, plan.DP
+        dev = self.device
+        keep = [wc.get("qkv", (qkv_w,), lambda: ops.prep_weight(qkv_w, row_map=plan.qkv_map, out_rows=3 * h * DP)),
+                wc.get("qkv_b", (qkv_b,), lambda: torch.where(plan.qkv_map >= 0, qkv_b[plan.qkv_map.clamp(min=0).long()],
+                                                              torch.zeros((), device=dev)).contiguous()),
+                wc.get("proj", (proj_w,), lambda: ops.prep_weight(proj_w, col_map=plan.proj_map, out_cols=h * DP)),
+                wc.get("fc1", (fc1_w,), lambda: ops.prep_weight(fc1_w)),
+                wc.get("fc2", (fc2_w,), lambda: ops.prep_weight(fc2_w))]
+        d.w_qkv, d.qkv_b_pad, d.w_proj, d.w_fc1, d.w_fc2 = (t.data_ptr() for t in keep)
+        if backward:
+            kb = [wc.get("qkvt", (qkv_w,), lambda: ops.prep_weight(qkv_w, transpose=True, col_map=plan.qkv_map, out_cols=3 * h * DP)),
+                  wc.get("projt", (proj_w,), lambda: ops.prep_weight(proj_w, transpose=True, row_map=plan.proj_map, out_rows=h * DP)),
+                  wc.get("fc1t", (fc1_w,), lambda: ops.prep_weight(fc1_w, transpose=True)),
+                  wc.get("fc2t", (fc2_w,), lambda: ops.prep_weight(fc2_w, transpose=True))]
+            d.w_qkvt, d.w_projt, d.w_fc1t, d.w_fc2t = (t.data_ptr() for t in kb)
+            keep += kb
+        d.logit_scale, d.proj_b, d.n1_w, d.n1_b = logit_scale.data_ptr(), proj_b.data_ptr(), n1_w.data_ptr(), n1_b.data_ptr()
+        d.fc1_b, d.fc2_b, d.n2_w, d.n2_b = fc1_b.data_ptr(), fc2_b.data_ptr(), n2_w.data_ptr(), n2_b.data_ptr()
+        return keep
+
+    def set_acts(self, acts):
+        base, d = acts.data_ptr(), self.desc
+        for name, off in zip(self.ACTS, self.act_off):
+            setattr(d, name, base + off)
+
+
 class _BlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, bias, dp1, dp2, logit_scale, qkv_w, qkv_b, proj_w, proj_b, n1_w, n1_b, fc1_w, fc1_b, fc2_w,
                 fc2_b, n2_w, n2_b, blk):
         B, gh, gw, Cc = x.shape
-        plan = blk._plan(B, x.device)
-        wc = blk._wcache
-        h, Lp, DP, Bw, T = plan.heads, plan.Lp, plan.DP, plan.Bw, plan.T
-        dev = x.device
+        run = blk._runner(B, x.device)
+        d = run.desc
         x = x.contiguous()
-        x2d = x.view(B * T, Cc)
-        M_w = Bw * Lp
-        hid = fc1_w.shape[0]
-
-        w_qkv = wc.get("qkv", (qkv_w,), lambda: ops.prep_weight(qkv_w, row_map=plan.qkv_map, out_rows=3 * h * DP))
-        b_qkv = wc.get("qkv_b", (qkv_b,), lambda: torch.where(plan.qkv_map >= 0, qkv_b[plan.qkv_map.clamp(min=0).long()],
-                                                              torch.zeros((), device=dev)).contiguous())
-        w_proj = wc.get("proj", (proj_w,), lambda: ops.prep_weight(proj_w, col_map=plan.proj_map, out_cols=h * DP))
-        w_fc1 = wc.get("fc1", (fc1_w,), lambda: ops.prep_weight(fc1_w))
-        w_fc2 = wc.get("fc2", (fc2_w,), lambda: ops.prep_weight(fc2_w))
-
-        # 1. roll + partition gather | qkv GEMM | + bias, split heads, L2-normalise q, k
-        qkvh = torch.empty(Bw * h * 3 * Lp * DP, dtype=BF16, device=dev)
-        rnorm = torch.empty(Bw * h * 2 * Lp, dtype=torch.float32, device=dev)
-        ops.linear(ops.op_f32(x2d, rows=M_w, rowidx=plan.rowidx), w_qkv,
-                   ops.epilogue(L.EPI_QKV_HEADS, qkvh, bias=b_qkv, aux_out=rnorm, p=(h, 0, Lp, DP, plan.L)), 3 * h * DP)
-        # 2. cosine attention core
-        oh = torch.empty(Bw * h * Lp * DP, dtype=BF16, device=dev)
-        lse = torch.empty(Bw * h * Lp, dtype=torch.float32, device=dev)
+        keep = run.set_params(blk._wcache, logit_scale, qkv_w, qkv_b, proj_w, proj_b, n1_w, n1_b, fc1_w, fc1_b, fc2_w, fc2_b,
+                              n2_w, n2_b, backward=False)
         bias_c = None if bias is None else bias.detach().float().contiguous()
-        ops.attn_fwd(ops.attn_args(qkvh, logit_scale.detach(), bias_c, oh, lse, Bw, h, plan.L, plan.d, plan.nwh, plan.nww,
-                                   plan.mask_thr))
-        # 3. merge heads | proj GEMM
-        a1 = torch.empty(M_w, Cc, dtype=BF16, device=dev)
-        ops.linear(ops.op_heads(oh, Bw, h, 1, Lp, DP), w_proj, ops.epilogue(L.EPI_BF16, a1, ld=Cc, bias=proj_b.detach()), Cc)
-        # 4. LN1 + drop-path + residual, scattered back through reverse + un-roll
-        x1 = torch.empty(B * T, Cc, dtype=torch.float32, device=dev)
-        mean1 = torch.empty(M_w, dtype=torch.float32, device=dev)
-        rstd1 = torch.empty(M_w, dtype=torch.float32, device=dev)
-        ops.ln_residual_fwd(a1, x2d, n1_w.detach(), n1_b.detach(), dp1, plan.rowidx, x1, mean1, rstd1, M_w, Cc, 0, T)
-        # 5. fc1: pre-activation (kept for GELU') and activation, 6. fc2
-        hpre = torch.empty(B * T, hid, dtype=BF16, device=dev)
-        hact = torch.empty(B * T, hid, dtype=BF16, device=dev)
-        ops.linear(ops.op_f32(x1), w_fc1, ops.epilogue(L.EPI_BF16_GELU, hpre, ld=hid, bias=fc1_b.detach(), aux_out=hact), hid)
-        a2 = torch.empty(B * T, Cc, dtype=BF16, device=dev)
-        ops.linear(ops.op_bf16(hact), w_fc2, ops.epilogue(L.EPI_BF16, a2, ld=Cc, bias=fc2_b.detach()), Cc)
-        # 7. LN2 + drop-path + residual
-        x2 = torch.empty(B * T, Cc, dtype=torch.float32, device=dev)
-        mean2 = torch.empty(B * T, dtype=torch.float32, device=dev)
-        rstd2 = torch.empty(B * T, dtype=torch.float32, device=dev)
-        ops.ln_residual_fwd(a2, x1, n2_w.detach(), n2_b.detach(), dp2, None, x2, mean2, rstd2, B * T, Cc, 0, T)
-
-        ctx.blk, ctx.plan, ctx.has_bias = blk, plan, bias is not None
-        ctx.save_for_backward(x2d, bias_c if bias is not None else x2d.new_empty(0), dp1 if dp1 is not None else x2d.new_empty(0),
-                              dp2 if dp2 is not None else x2d.new_empty(0), logit_scale, qkv_w, proj_w, n1_w, fc1_w, fc2_w, n2_w,
-                              qkvh, rnorm, oh, lse, a1, mean1, rstd1, x1, hpre, hact, a2, mean2, rstd2)
-        return x2.view(B, gh, gw, Cc)
+        acts = torch.empty(run.act_bytes, dtype=torch.uint8, device=x.device)
+        x2 = torch.empty(B, gh, gw, Cc, dtype=torch.float32, device=x.device)
+        run.set_acts(acts)
+        d.x, d.x2 = x.data_ptr(), x2.data_ptr()
+        d.bias = None if bias_c is None else bias_c.data_ptr()
+        d.dp1 = None if dp1 is None else dp1.data_ptr()
+        d.dp2 = None if dp2 is None else dp2.data_ptr()
+        ops.block_event_pair("fwd", d)
+        L.check(ops._timed("block_fwd", L.load().swv2_block_fwd, run.desc, ops._stream()), "swv2_block_fwd")
+        del keep
+        ctx.blk, ctx.run, ctx.has_bias = blk, run, bias is not None
+        e = x.new_empty(0)
+        ctx.save_for_backward(x, bias_c if bias is not None else e, dp1 if dp1 is not None else e, dp2 if dp2 is not None else e,
+                              acts, logit_scale, qkv_w, qkv_b, proj_w, proj_b, n1_w, n1_b, fc1_w, fc1_b, fc2_w, fc2_b, n2_w, n2_b)
+        return x2
 
     @staticmethod
     def backward(ctx, dx2):
-        (x2d, bias_c, dp1, dp2, logit_scale, qkv_w, proj_w, n1_w, fc1_w, fc2_w, n2_w, qkvh, rnorm, oh, lse, a1, mean1,
-         rstd1, x1, hpre, hact, a2, mean2, rstd2) = ctx.saved_tensors
-        blk, plan = ctx.blk, ctx.plan
-        wc = blk._wcache
-        h, Lp, DP, Bw, T, B = plan.heads, plan.Lp, plan.DP, plan.Bw, plan.T, plan.B
-        dev = x2d.device
-        Cc = x2d.shape[1]
-        hid = fc1_w.shape[0]
-        M_w = Bw * Lp
-        dp1 = dp1 if dp1.numel() else None
-        dp2 = dp2 if dp2.numel() else None
-        dx2 = dx2.contiguous().view(B * T, Cc).float()
-        f32 = dict(dtype=torch.float32, device=dev)
-
-        w_fc2t = wc.get("fc2t", (fc2_w,), lambda: ops.prep_weight(fc2_w, transpose=True))
-        w_fc1t = wc.get("fc1t", (fc1_w,), lambda: ops.prep_weight(fc1_w, transpose=True))
-        w_projt = wc.get("projt", (proj_w,), lambda: ops.prep_weight(proj_w, transpose=True, row_map=plan.proj_map, out_rows=h * DP))
-        w_qkvt = wc.get("qkvt", (qkv_w,), lambda: ops.prep_weight(qkv_w, transpose=True, col_map=plan.qkv_map, out_cols=3 * h * DP))
-
-        # all parameter-gradient accumulators of the block come from ONE zero-filled buffer (a single memset)
-        (dn2w, dn2b, dfc2w, dfc2b, dfc1w, dfc1b, dn1w, dn1b, dprojw, dprojb, dlogit, dqkvw, dqkvb) = _zeros_like_shapes(
-            dev, (Cc,), (Cc,), (Cc, hid), (Cc,), (hid, Cc), (hid,), (Cc,), (Cc,), (Cc, Cc), (Cc,), (h,), (3 * Cc, Cc), (3 * Cc,))
-        # 7'. LN2 backward
-        da2 = torch.empty(B * T, Cc, dtype=BF16, device=dev)
-        ops.ln_residual_bwd(a2, dx2, n2_w, dp2, None, mean2, rstd2, da2, dn2w, dn2b, B * T, Cc, T)
-        # 6'. fc2: dW = da2^T GELU(h), dh = (da2 W2) * GELU'(h)
-        ops.linear_wgrad(ops.op_bf16(da2), ops.op_bf16(hact), dfc2w, dfc2b)
-        dh = torch.empty(B * T, hid, dtype=BF16, device=dev)
-        ops.linear(ops.op_bf16(da2), w_fc2t, ops.epilogue(L.EPI_GELU_GRAD, dh, ld=hid, aux=hpre), hid)
-        # 5'. fc1: dW = dh^T x1 ; dx1 = dx2 + dh W1
-        ops.linear_wgrad(ops.op_bf16(dh), ops.op_f32(x1), dfc1w, dfc1b)
-        dx1 = torch.empty(B * T, Cc, **f32)
-        ops.linear(ops.op_bf16(dh), w_fc1t, ops.epilogue(L.EPI_F32, dx1, ld=Cc, aux=dx2), Cc)
-        del dh
-        # 4'. LN1 backward (gathers dx1 rows through the window table; padded rows -> 0)
-        da1 = torch.empty(M_w, Cc, dtype=BF16, device=dev)
-        ops.ln_residual_bwd(a1, dx1, n1_w, dp1, plan.rowidx, mean1, rstd1, da1, dn1w, dn1b, M_w, Cc, T)
-        # 3'. proj: dW = da1^T merge(oh) ; d(oh) = split(da1 Wp)
-        ops.linear_wgrad(ops.op_bf16(da1), ops.op_heads(oh, Bw, h, 1, Lp, DP), dprojw, dprojb, kmap=plan.proj_map)
-        doh = torch.empty(Bw * h * Lp * DP, dtype=BF16, device=dev)
-        ops.linear(ops.op_bf16(da1), w_projt, ops.epilogue(L.EPI_HEADS, doh, p=(h, 0, Lp, DP, plan.L)), h * DP)
-        # 2'. attention backward (incl. the backward of the q / k normalisation)
-        dqkvh = torch.empty(Bw * h * 3 * Lp * DP, dtype=BF16, device=dev)
+        (x, bias_c, dp1, dp2, acts, logit_scale, qkv_w, qkv_b, proj_w, proj_b, n1_w, n1_b, fc1_w, fc1_b, fc2_w, fc2_b, n2_w,
+         n2_b) = ctx.saved_tensors
+        blk, run = ctx.blk, ctx.run
+        d = run.desc
+        dev = x.device
+        keep = run.set_params(blk._wcache, logit_scale, qkv_w, qkv_b, proj_w, proj_b, n1_w, n1_b, fc1_w, fc1_b, fc2_w, fc2_b,
+                              n2_w, n2_b, backward=True)
+        dx2 = dx2.contiguous().float()
+        run.set_acts(acts)
+        scratch = torch.empty(run.scr_bytes, dtype=torch.uint8, device=dev)
+        sb = scratch.data_ptr()
+        for name, off in zip(run.SCRATCH, run.scr_off):
+            setattr(d, name, sb + off)
+        grads = torch.zeros(run.grad_bytes // 4, dtype=torch.float32, device=dev)       # ONE memset for all param grads
+        gb = grads.data_ptr()
+        for name, off in zip(run.grad_names, run.grad_off):
+            setattr(d, name, gb + off)
         dbias = torch.zeros_like(bias_c) if ctx.has_bias else None
-        ops.attn_bwd(ops.attn_args(qkvh, logit_scale, bias_c if ctx.has_bias else None, oh, lse, Bw, h, plan.L, plan.d,
-                                   plan.nwh, plan.nww, plan.mask_thr, doh=doh, rnorm=rnorm, dqkvh=dqkvh, dlogit=dlogit,
-                                   dbias=dbias))
-        # 1'. qkv: dW = dqkv^T gather(x) ; dx = dx1 + scatter(dqkv Wqkv)
-        ops.linear_wgrad(ops.op_heads(dqkvh, Bw, h, 3, Lp, DP), ops.op_f32(x2d, rows=M_w, rowidx=plan.rowidx), dqkvw, dqkvb,
-                         nmap=plan.qkv_map)
-        dx = torch.empty(B * T, Cc, **f32)
-        ops.linear(ops.op_heads(dqkvh, Bw, h, 3, Lp, DP), w_qkvt,
-                   ops.epilogue(L.EPI_F32, dx, ld=Cc, aux=dx1, rowidx=plan.rowidx), Cc)
-        return (dx.view(B, plan.gh, plan.gw, Cc), dbias, None, None, dlogit, dqkvw, dqkvb, dprojw, dprojb, dn1w, dn1b,
-                dfc1w, dfc1b, dfc2w, dfc2b, dn2w, dn2b, None)
+        dx = torch.empty_like(x)
+        d.x, d.dx2, d.dx = x.data_ptr(), dx2.data_ptr(), dx.data_ptr()
+        d.bias = bias_c.data_ptr() if ctx.has_bias else None
+        d.d_bias = dbias.data_ptr() if ctx.has_bias else None
+        d.dp1 = dp1.data_ptr() if dp1.numel() else None
+        d.dp2 = dp2.data_ptr() if dp2.numel() else None
+        ops.block_event_pair("bwd", d)
+        L.check(ops._timed("block_bwd", L.load().swv2_block_bwd, run.desc, ops._stream()), "swv2_block_bwd")
+        del keep
+        g = [grads[o // 4:o // 4 + int(torch.Size(s).numel())].view(*s) for o, s in zip(run.grad_off, run.grad_shapes)]
+        (dlogit, dqkvw, dqkvb, dprojw, dprojb, dn1w, dn1b, dfc1w, dfc1b, dfc2w, dfc2b, dn2w, dn2b) = g
+        return (dx, dbias, None, None, dlogit, dqkvw, dqkvb, dprojw, dprojb, dn1w, dn1b, dfc1w, dfc1b, dfc2w, dfc2b, dn2w,
+                dn2b, None)
 
 
 class Mlp(nn.Module):
@@ -341,6 +355,7 @@ class SwinTransformerV2CrBlock(nn.Module):
         self.drop_path2 = DropPath(drop_prob=drop_path) if drop_path > 0.0 else nn.Identity()
         self.norm3 = nn.Identity()
         self._wcache = _WeightCache()
+        self._runners = {}
         self.init_weights()
 
     def _calc_window_shift(self, target_window_size):
@@ -373,12 +388,20 @@ class SwinTransformerV2CrBlock(nn.Module):
         self.feat_size = tuple(new_feat_size)
         self.window_size, self.shift_size = self._calc_window_shift(to_2tuple(new_window_size))
         self.window_area = self.window_size[0] * self.window_size[1]
+        self._runners = {}
         self.attn.update_input_size(new_window_size=self.window_size)
 
     def _plan(self, B: int, device) -> ops.WindowPlan:
         gh, gw = self.feat_size
         return ops.window_plan(B, gh, gw, self.window_size[0], self.window_size[1], self.shift_size[0], self.shift_size[1],
                                self.attn.num_heads, self.dim // self.attn.num_heads, device.index or 0)
+
+    def _runner(self, B: int, device) -> "_BlockRunner":
+        key = (B, device.index or 0, self.feat_size, self.window_size, self.shift_size)
+        r = self._runners.get(key)
+        if r is None:
+            r = self._runners[key] = _BlockRunner(self, self._plan(B, device), self.dim, self.mlp.fc1.weight.shape[0], device)
+        return r
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x: [B, H, W, C] fp32 -> [B, H, W, C]"""

@@ -41,6 +41,29 @@ def stop_kernel_timing():
     return {n: (len(ev), sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)) for n, ev in (rec or {}).items()}
 
 
+BLOCK_KERNEL_IDS = {"qkv": 1, "attn_fwd": 2, "proj": 3, "ln1_fwd": 4, "fc1": 5, "fc2": 6, "ln2_fwd": 7, "ln2_bwd": 11,
+                    "wgrad_fc2": 12, "dh": 13, "wgrad_fc1": 14, "dx1": 15, "ln1_bwd": 16, "wgrad_proj": 17, "doh": 18,
+                    "attn_bwd": 19, "wgrad_qkv": 20, "dx": 21}
+
+
+def block_event_pair(phase, desc):
+    """If a kernel of this phase ("fwd": launch ids 1-7, "bwd": 11-21) is being timed (start_kernel_timing), attach a
+    fresh HIP event pair to the block descriptor so that swv2_block_fwd/bwd brackets exactly that launch on the launch
+    stream."""
+    desc.ev_kernel = 0
+    rec = _TIMED
+    if rec is None:
+        return
+    for n in rec:
+        kid = BLOCK_KERNEL_IDS.get(n, 0)
+        if kid and ((kid < 10) == (phase == "fwd")):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); b.record()                       # materialise the hipEvent_t handles (re-recorded by the library)
+            desc.ev_kernel, desc.ev_start, desc.ev_stop = kid, a.cuda_event, b.cuda_event
+            rec[n].append((a, b))
+            return
+
+
 def _timed(name, fn, *args):
     rec = _TIMED
     if rec is None or name not in rec:

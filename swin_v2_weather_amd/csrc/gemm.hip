@@ -38,6 +38,7 @@ struct EpiDesc {
     long ld;                // output row pitch (elements)
     int M, N;
     int p0, p1, p2, p3, p4;
+    uint32_t mg0, mg1, mg2; // fdiv magics (launch_nt2)
 };
 
 enum { E_BF16 = 0, E_F32 = 1, E_QKV_HEADS = 2, E_GELU_GRAD = 3, E_UNPATCH = 4, E_HEADS = 5, E_F32_ACC = 6, E_BF16_GELU = 7 };
@@ -161,8 +162,8 @@ __device__ __forceinline__ void heads_item(const EpiDesc& d, const float* st, in
         const int r = it & 15, slot = it >> 4;
         const int nb = n0 + slot * DPc, m = m0 + r;
         if (m >= d.M || nb >= d.N) continue;
-        const int ph = nb / DPc, part = ph / h, hd = ph - part * h;
-        const int bw = m / Lp, t = m - bw * Lp;
+        const int ph = nb / DPc, part = (h == 1) ? ph : fdiv(ph, h, d.mg1), hd = ph - part * h;
+        const int bw = fdiv(m, Lp, d.mg0), t = m - bw * Lp;
         const bool valid = t < L;
         float v[DPc];
         float ss = 0.f;
@@ -240,7 +241,7 @@ template <> struct Epi<E_UNPATCH> {
             const int r = it & 15, cp = it >> 4, cl = cp >> 2, p = cp & 3;
             const int m = m0 + r, c = (n0 >> 4) + cl;
             if (m >= d.M || c >= Cout) continue;
-            const int b = m / (gh * gw), ij = m - b * gh * gw, i = ij / gw, j = ij - i * gw;
+            const int b = fdiv(m, gh * gw, d.mg0), ij = m - b * gh * gw, i = fdiv(ij, gw, d.mg1), j = ij - i * gw;
             f32x4 v = *(const f32x4*)(st + r * EP + cl * 16 + p * 4);
             if (Cs) v += *(const f32x4*)((const float*)d.aux + (((long)b * Cs + c) * H + 4 * i + p) * W + 4 * j);
             *(f32x4*)((float*)d.out + (((long)b * Cout + c) * H + 4 * i + p) * W + 4 * j) = v;
@@ -268,6 +269,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(ALoad<AK> al, cons
 
     typename ALoad<AK>::Raw ra[4];
     uint4 rb[4];
+    // the 4 panel rows this thread stages are the same for every (n-tile, k-step): resolve the gather ONCE
+    int arow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + i * NTHREADS;
+        arow[i] = al.row_of(m_base + (ALoad<AK>::ROW_FASTEST ? (c & (BM - 1)) : (c >> 3)));
+    }
     auto issue = [&](int s) {
         const int nt = s / ksteps, ks = s - nt * ksteps;
 #pragma unroll
@@ -275,7 +283,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(ALoad<AK> al, cons
             const int c = tid + i * NTHREADS;
             int r, kc;
             if (ALoad<AK>::ROW_FASTEST) { r = c & (BM - 1); kc = c >> 7; } else { r = c >> 3; kc = c & 7; }
-            ra[i] = al.raw(m_base + r, ks * BK + kc * 8);
+            ra[i] = al.raw_at(arow[i], ks * BK + kc * 8);
             const int rn = c >> 3, kcb = c & 7, n = nt * BN + rn, k0 = ks * BK + kcb * 8;
             rb[i] = (n < N && k0 < K) ? *(const uint4*)(Wb + (long)n * K + k0) : make_uint4(0, 0, 0, 0);
         }
@@ -338,6 +346,9 @@ int launch_nt2(const swv2_operand* a, const void* w, const swv2_epilogue* e, int
     ep.d.out = e->out; ep.d.bias = e->bias; ep.d.aux = e->aux; ep.d.aux_out = e->aux_out; ep.d.rowidx = e->rowidx;
     ep.d.ld = e->ld; ep.d.M = M; ep.d.N = N;
     ep.d.p0 = e->p[0]; ep.d.p1 = e->p[1]; ep.d.p2 = e->p[2]; ep.d.p3 = e->p[3]; ep.d.p4 = e->p[4];
+    ep.d.mg0 = ep.d.mg1 = ep.d.mg2 = 0;
+    if (EK == E_QKV_HEADS || EK == E_HEADS) { ep.d.mg0 = fdiv_magic(e->p[2]); ep.d.mg1 = fdiv_magic(e->p[0]); }
+    if (EK == E_UNPATCH) { ep.d.mg0 = fdiv_magic((e->p[1] / 4) * (e->p[2] / 4)); ep.d.mg1 = fdiv_magic(e->p[2] / 4); }
     hipLaunchKernelGGL((gemm_nt_kernel<AK, EK>), dim3(cdiv(M, BM)), dim3(NTHREADS), 0, st, make_loader<AK>(a),
                        (const uint16_t*)w, ep, M, N, K);
     SWV2_CHECK_LAUNCH("swv2_linear");

@@ -22,6 +22,15 @@ __device__ __forceinline__ void erf_parts(float x, float& erf_v, float& gauss) {
     const float e = fmaf(-poly, gauss, 1.f);
     erf_v = copysignf(e, x);
 }
+// exact unsigned division by a runtime-constant divisor d with magic = ceil(2^32 / d) (host: fdiv_magic): the estimate
+// umulhi(n, magic) is q or q + 1 for every n < 2^32, one compare fixes it.  Replaces ~25-instruction integer divides
+// in the loaders' index math (row -> (window, token), column -> (part, head)).
+__device__ __forceinline__ int fdiv(int n, int d, uint32_t magic) {
+    int q = (int)__umulhi((uint32_t)n, magic);
+    return q - (q * d > n);
+}
+static inline uint32_t fdiv_magic(int d) { return d > 1 ? (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)d) : 0u; }
+
 __device__ __forceinline__ float gelu_f(float x) {
     float e, gs;
     erf_parts(x, e, gs);
@@ -60,6 +69,7 @@ struct LoadDesc {           // plain-data description shared by all loader kinds
     long ld;                // source row pitch in elements
     int M, K;
     int p0, p1, p2, p3;     // kind-specific ints (see loaders)
+    uint32_t mg0, mg1, mg2; // fdiv magics of the kind-specific divisors (make_loader)
 };
 
 template <int KIND> struct ALoad;
@@ -81,15 +91,16 @@ template <> struct ALoad<A_F32> {
     static constexpr bool ROW_FASTEST = false;
     typedef RawF32 Raw;
     LoadDesc d;
-    __device__ __forceinline__ Raw raw(int m, int k0) const {
+    // source row of logical row m (-1 = zero row): ONE dependent load for gathered operands, hoisted by the kernels
+    __device__ __forceinline__ int row_of(int m) const { return m >= d.M ? -1 : (d.rowidx ? d.rowidx[m] : m); }
+    __device__ __forceinline__ Raw raw_at(int r, int k0) const {
         Raw z = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-        if (m >= d.M || k0 >= d.K) return z;
-        long r = m;
-        if (d.rowidx) { r = d.rowidx[m]; if (r < 0) return z; }
-        const float* p = (const float*)d.ptr + r * d.ld + k0;
+        if (r < 0 || k0 >= d.K) return z;
+        const float* p = (const float*)d.ptr + (long)r * d.ld + k0;
         Raw o = {*(const f32x4*)p, *(const f32x4*)(p + 4)};
         return o;
     }
+    __device__ __forceinline__ Raw raw(int m, int k0) const { return raw_at(row_of(m), k0); }
     __device__ __forceinline__ uint4 cvt(const Raw& r) const { return cvt_f32x8(r); }
     __device__ __forceinline__ uint4 chunk(int m, int k0) const { return cvt(raw(m, k0)); }
 };
@@ -99,17 +110,19 @@ template <> struct ALoad<A_BF16> {
     typedef uint4 Raw;
     LoadDesc d;
     __device__ __forceinline__ uint4 cvt(const Raw& r) const { return r; }
-    __device__ __forceinline__ Raw raw(int m, int k0) const { return chunk(m, k0); }
-    __device__ __forceinline__ uint4 chunk(int m, int k0) const {
-        if (m >= d.M || k0 >= d.K) return make_uint4(0, 0, 0, 0);
-        long r = m;
-        if (d.rowidx) { r = d.rowidx[m]; if (r < 0) return make_uint4(0, 0, 0, 0); }
-        return *(const uint4*)((const uint16_t*)d.ptr + r * d.ld + k0);
+    __device__ __forceinline__ int row_of(int m) const { return m >= d.M ? -1 : (d.rowidx ? d.rowidx[m] : m); }
+    __device__ __forceinline__ Raw raw_at(int r, int k0) const {
+        if (r < 0 || k0 >= d.K) return make_uint4(0, 0, 0, 0);
+        return *(const uint4*)((const uint16_t*)d.ptr + (long)r * d.ld + k0);
     }
+    __device__ __forceinline__ Raw raw(int m, int k0) const { return raw_at(row_of(m), k0); }
+    __device__ __forceinline__ uint4 chunk(int m, int k0) const { return raw(m, k0); }
 };
 // bf16 rows through GELU (fc2 input = GELU(fc1 output); the pre-activation is what is kept for backward)
 template <> struct ALoad<A_BF16_GELU> {
     static constexpr bool ROW_FASTEST = false;
+    __device__ __forceinline__ int row_of(int m) const { return m >= d.M ? -1 : m; }
+    __device__ __forceinline__ auto raw_at(int r, int k0) const { return raw(r < 0 ? d.M : r, k0); }
     typedef uint4 Raw;
     LoadDesc d;
     __device__ __forceinline__ Raw raw(int m, int k0) const {
@@ -130,6 +143,8 @@ template <> struct ALoad<A_BF16_GELU> {
 // p0 = heads, p2 = Lp, p3 = DP ; ld = number of parts S (1 for oh, 3 for dqkvh)
 template <> struct ALoad<A_HEADS> {
     static constexpr bool ROW_FASTEST = false;
+    __device__ __forceinline__ int row_of(int m) const { return m >= d.M ? -1 : m; }
+    __device__ __forceinline__ auto raw_at(int r, int k0) const { return raw(r < 0 ? d.M : r, k0); }
     typedef uint4 Raw;
     LoadDesc d;
     __device__ __forceinline__ uint4 cvt(const Raw& r) const { return r; }
@@ -137,8 +152,9 @@ template <> struct ALoad<A_HEADS> {
     __device__ __forceinline__ uint4 chunk(int m, int k0) const {
         if (m >= d.M || k0 >= d.K) return make_uint4(0, 0, 0, 0);
         const int h = d.p0, Lp = d.p2, DP = d.p3, S = (int)d.ld;
-        const int bw = m / Lp, t = m - bw * Lp;
-        const int ph = k0 / DP, j = k0 - ph * DP, part = ph / h, hd = ph - part * h;
+        const int bw = fdiv(m, Lp, d.mg0), t = m - bw * Lp;
+        const int ph = (DP == 16) ? (k0 >> 4) : (k0 >> 5), j = k0 - ph * DP;
+        const int part = (h == 1) ? ph : fdiv(ph, h, d.mg1), hd = ph - part * h;
         return *(const uint4*)((const uint16_t*)d.ptr + ((((long)bw * h + hd) * S + part) * Lp + t) * DP + j);
     }
 };
@@ -146,13 +162,15 @@ template <> struct ALoad<A_HEADS> {
 // p0 = Cin, p1 = H, p2 = W ; patch = 4.  Adjacent rows are adjacent 16-byte groups -> row-fastest thread map.
 template <> struct ALoad<A_PATCH> {
     static constexpr bool ROW_FASTEST = true;
+    __device__ __forceinline__ int row_of(int m) const { return m >= d.M ? -1 : m; }
+    __device__ __forceinline__ auto raw_at(int r, int k0) const { return raw(r < 0 ? d.M : r, k0); }
     typedef RawF32 Raw;
     LoadDesc d;
     __device__ __forceinline__ Raw raw(int m, int k0) const {
         Raw z = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
         if (m >= d.M || k0 >= d.K) return z;
         const int Cin = d.p0, H = d.p1, W = d.p2, gw = W >> 2, gh = H >> 2;
-        const int b = m / (gh * gw), ij = m - b * gh * gw, i = ij / gw, j = ij - i * gw;
+        const int b = fdiv(m, gh * gw, d.mg0), ij = m - b * gh * gw, i = fdiv(ij, gw, d.mg1), j = ij - i * gw;
         const int cin = k0 >> 4, p = (k0 >> 2) & 3;                 // p in {0, 2}
         const float* src = (const float*)d.ptr + (((long)b * Cin + cin) * H + 4 * i + p) * W + 4 * j;
         Raw o = {*(const f32x4*)src, *(const f32x4*)(src + W)};
@@ -165,6 +183,8 @@ template <> struct ALoad<A_PATCH> {
 // k = (wp*2 + hp)*C + c  (swinv2_global.py:520) ; p0 = H, p1 = W, p2 = C ; aux = mean, rstd, gamma, beta
 template <> struct ALoad<A_MERGE_LN> {
     static constexpr bool ROW_FASTEST = false;
+    __device__ __forceinline__ int row_of(int m) const { return m >= d.M ? -1 : m; }
+    __device__ __forceinline__ auto raw_at(int r, int k0) const { return raw(r < 0 ? d.M : r, k0); }
     typedef uint4 Raw;
     LoadDesc d;
     __device__ __forceinline__ uint4 cvt(const Raw& r) const { return r; }
@@ -191,6 +211,9 @@ ALoad<AK> make_loader(const swv2_operand* o) {
     l.d.ptr = o->ptr; l.d.rowidx = o->rowidx; l.d.aux0 = o->aux0; l.d.aux1 = o->aux1; l.d.aux2 = o->aux2;
     l.d.aux3 = o->aux3; l.d.ld = o->ld; l.d.M = o->rows; l.d.K = o->cols;
     l.d.p0 = o->p[0]; l.d.p1 = o->p[1]; l.d.p2 = o->p[2]; l.d.p3 = o->p[3];
+    l.d.mg0 = l.d.mg1 = l.d.mg2 = 0;
+    if (AK == A_HEADS) { l.d.mg0 = fdiv_magic(o->p[2]); l.d.mg1 = fdiv_magic(o->p[0]); }
+    if (AK == A_PATCH) { l.d.mg0 = fdiv_magic((o->p[1] / 4) * (o->p[2] / 4)); l.d.mg1 = fdiv_magic(o->p[2] / 4); }
     return l;
 }
 

@@ -36,13 +36,23 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(ALoad<YK> yl, ALoad<X
     typename ALoad<YK>::Raw ry[TCH];
     typename ALoad<XK>::Raw rx[TCH];
     float colsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    auto issue = [&](int s) {
+    // source rows of the NEXT step are resolved one step ahead, so a gathered operand's index load is never on the
+    // critical path of the data loads
+    int yrow[TCH], xrow[TCH];
+    auto resolve = [&](int s) {
 #pragma unroll
         for (int i = 0; i < TCH; ++i) {
             const int m = m_lo + s * TM + srow + 16 * i;
-            const bool ok = m < m_hi;
-            ry[i] = yl.raw(ok ? m : M, n_base + scol * 8);       // rows >= M load nothing and yield zeros
-            rx[i] = xl.raw(ok ? m : M, k_base + scol * 8);
+            const bool ok = (s < steps) && (m < m_hi);
+            yrow[i] = yl.row_of(ok ? m : M);
+            xrow[i] = xl.row_of(ok ? m : M);
+        }
+    };
+    auto issue = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < TCH; ++i) {
+            ry[i] = yl.raw_at(yrow[i], n_base + scol * 8);       // row -1 loads nothing and yields zeros
+            rx[i] = xl.raw_at(xrow[i], k_base + scol * 8);
         }
     };
     auto commit = [&]() {
@@ -68,11 +78,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(ALoad<YK> yl, ALoad<X
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    resolve(0);
     issue(0);
+    resolve(1);
     for (int s = 0; s < steps; ++s) {
         commit();
         __syncthreads();
-        if (s + 1 < steps) issue(s + 1);
+        if (s + 1 < steps) { issue(s + 1); resolve(s + 2); }
         const uint16_t* Ys = smem;
         const uint16_t* Xs = smem + TM * TP;
         // A operand = dY^T (rows n, k = m), B operand = X (k = m, cols k'): both are transposed reads of row-major tiles

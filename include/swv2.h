@@ -136,7 +136,9 @@ int swv2_linear(const swv2_operand* a, const void* w_bf16, const swv2_epilogue* 
 
 /* Weight gradient: dW[nmap(n)][kmap(k)] += sum_m dY[m][n] X[m][k], db[nmap(n)] += sum_m dY[m][n]   (fp32 atomics;
  * caller zeroes; db may be NULL).  dW has row pitch ldw; nmap/kmap (NULL = identity, negative = drop) undo the head
- * padding of the SWV2_OP_HEADS layouts.  `splits` = number of row slices processed by different workgroups. */
+ * padding of the SWV2_OP_HEADS layouts.  |splits| = number of row slices processed by different workgroups;
+ * splits < 0 selects the kernel that keeps the whole (<= 65536-entry) output block in one workgroup and reads dY and
+ * X once per slice (wide outputs), splits > 0 the 128 x 128-tiled kernel. */
 int swv2_linear_wgrad(const swv2_operand* dy, const swv2_operand* x, float* dW, float* db, const int32_t* nmap,
                       const int32_t* kmap, int ldw, int splits, void* stream);
 
@@ -235,6 +237,8 @@ typedef struct swv2_block_desc {
     int ev_kernel;
     void* ev_start;
     void* ev_stop;
+    int wgrad_side_stream;   /* 1: backward launches the 4 weight-gradient products on the library's per-device side stream
+                                (fork after each producer, join before returning) so they overlap with the dX chain */
 } swv2_block_desc;
 
 int swv2_block_fwd(const swv2_block_desc* d, void* stream);

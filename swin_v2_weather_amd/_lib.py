@@ -90,7 +90,8 @@ class BlockDesc(C.Structure):
                     "dx2", "da2", "dh", "da1", "doh", "dqkvh", "dx1", "ln_ws", "dx",
                     "d_logit_scale", "d_bias", "d_qkv_w", "d_qkv_b", "d_proj_w", "d_proj_b", "d_n1_w", "d_n1_b", "d_fc1_w",
                     "d_fc1_b", "d_fc2_w", "d_fc2_b", "d_n2_w", "d_n2_b")] +
-                [("wgrad_splits", C.c_int), ("ev_kernel", C.c_int), ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p)])
+                [("wgrad_splits", C.c_int), ("ev_kernel", C.c_int), ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p),
+                 ("wgrad_side_stream", C.c_int)])
 
 
 OP_F32, OP_BF16, OP_BF16_GELU, OP_HEADS, OP_PATCH, OP_MERGE_LN = range(6)

@@ -28,6 +28,41 @@ swv2_attn_args attn(const swv2_block_desc* d) {
     return a;
 }
 #define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+// ---- side stream for the weight-gradient products ------------------------------------------------------------
+// The four weight-gradient GEMMs of a block depend only on (dY, X) pairs that the main chain produces one after the
+// other, and nothing downstream in the block reads their results.  Each of them, like each GEMM of the main chain, runs
+// at 4-8 waves per CU, so they are launched on a second HIP stream (fork after the producer, join at the end of the
+// block) and share the CUs with the dX chain instead of serialising behind it.  The stream and a small ring of events
+// are created once per device and live for the process (the only hidden state of the library; both are capturable).
+struct SideStream {
+    hipStream_t s = nullptr;
+    hipEvent_t ev[8] = {};
+    unsigned next = 0;
+};
+SideStream* side_stream() {
+    static thread_local SideStream per_dev[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    SideStream& ss = per_dev[dev];
+    if (!ss.s) {
+        if (hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) != hipSuccess) { ss.s = nullptr; return nullptr; }
+        for (auto& e : ss.ev)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    }
+    return &ss;
+}
+// main -> side dependency: everything enqueued on `main` so far must finish before later work on the side stream
+inline void fork_to(SideStream* ss, hipStream_t main) {
+    hipEvent_t e = ss->ev[ss->next++ & 7];
+    (void)hipEventRecord(e, main);
+    (void)hipStreamWaitEvent(ss->s, e, 0);
+}
+inline void join_from(SideStream* ss, hipStream_t main) {
+    hipEvent_t e = ss->ev[ss->next++ & 7];
+    (void)hipEventRecord(e, ss->s);
+    (void)hipStreamWaitEvent(main, e, 0);
+}
 // launch `x` as launch number `id`; bracket it with the caller's HIP events when it is the one being timed
 #define LAUNCH(id, x)                                                                         \
     do {                                                                                      \
@@ -93,6 +128,8 @@ extern "C" int swv2_block_bwd(const swv2_block_desc* d, void* st) {
                    "swv2_block_bwd: null descriptor field");
     const int BT = d->B * d->T, Bw = d->B * d->nwh * d->nww, Mw = Bw * d->Lp, C = d->C, h = d->heads, hid = d->hidden;
     const int sp = d->wgrad_splits > 0 ? d->wgrad_splits : 64;
+    SideStream* ss = d->wgrad_side_stream ? side_stream() : nullptr;
+    void* ws = ss ? (void*)ss->s : st;            // stream of the weight-gradient products
     // 7'. LN2 backward
     {
         swv2_ln_args l = {};
@@ -103,14 +140,16 @@ extern "C" int swv2_block_bwd(const swv2_block_desc* d, void* st) {
     // 6'. fc2: dW = da2^T GELU(h) ; dh = (da2 W2) * GELU'(h)
     {
         swv2_operand dy = op(SWV2_OP_BF16, d->da2, BT, C, C), x = op(SWV2_OP_BF16, d->hact, BT, hid, hid);
-        LAUNCH(12, swv2_linear_wgrad(&dy, &x, d->d_fc2_w, d->d_fc2_b, nullptr, nullptr, hid, sp, st));
+        if (ss) fork_to(ss, (hipStream_t)st);
+        LAUNCH(12, swv2_linear_wgrad(&dy, &x, d->d_fc2_w, d->d_fc2_b, nullptr, nullptr, hid, sp, ws));
         swv2_epilogue e = epi(SWV2_EPI_GELU_GRAD, d->dh, hid, nullptr, d->hpre);
         LAUNCH(13, swv2_linear(&dy, d->w_fc2t, &e, hid, st));
     }
     // 5'. fc1: dW = dh^T x1 ; dx1 = dx2 + dh W1
     {
         swv2_operand dy = op(SWV2_OP_BF16, d->dh, BT, hid, hid), x = op(SWV2_OP_F32, d->x1, BT, C, C);
-        LAUNCH(14, swv2_linear_wgrad(&dy, &x, d->d_fc1_w, d->d_fc1_b, nullptr, nullptr, C, sp, st));
+        if (ss) fork_to(ss, (hipStream_t)st);
+        LAUNCH(14, swv2_linear_wgrad(&dy, &x, d->d_fc1_w, d->d_fc1_b, nullptr, nullptr, C, sp, ws));
         swv2_epilogue e = epi(SWV2_EPI_F32, d->dx1, C, nullptr, d->dx2);
         LAUNCH(15, swv2_linear(&dy, d->w_fc1t, &e, C, st));
     }
@@ -124,7 +163,8 @@ extern "C" int swv2_block_bwd(const swv2_block_desc* d, void* st) {
     // 3'. proj: dW = da1^T merge(oh) ; d(oh) = split(da1 Wp)
     {
         swv2_operand dy = op(SWV2_OP_BF16, d->da1, Mw, C, C), x = op_heads(d->oh, Bw, h, 1, d->Lp, d->DP);
-        LAUNCH(17, swv2_linear_wgrad(&dy, &x, d->d_proj_w, d->d_proj_b, nullptr, d->proj_map, C, sp, st));
+        if (ss) fork_to(ss, (hipStream_t)st);
+        LAUNCH(17, swv2_linear_wgrad(&dy, &x, d->d_proj_w, d->d_proj_b, nullptr, d->proj_map, C, sp, ws));
         swv2_epilogue e = epi(SWV2_EPI_HEADS, d->doh, 0);
         e.p[0] = h; e.p[2] = d->Lp; e.p[3] = d->DP; e.p[4] = d->L;
         LAUNCH(18, swv2_linear(&dy, d->w_projt, &e, h * d->DP, st));
@@ -138,9 +178,11 @@ extern "C" int swv2_block_bwd(const swv2_block_desc* d, void* st) {
     // 1'. qkv: dW = dqkv^T gather(x) ; dx = dx1 + scatter(dqkv Wqkv)
     {
         swv2_operand dy = op_heads(d->dqkvh, Bw, h, 3, d->Lp, d->DP), x = op(SWV2_OP_F32, d->x, Mw, C, C, d->rowidx);
-        LAUNCH(20, swv2_linear_wgrad(&dy, &x, d->d_qkv_w, d->d_qkv_b, d->qkv_map, nullptr, C, sp, st));
+        if (ss) fork_to(ss, (hipStream_t)st);
+        LAUNCH(20, swv2_linear_wgrad(&dy, &x, d->d_qkv_w, d->d_qkv_b, d->qkv_map, nullptr, C, sp, ws));
         swv2_epilogue e = epi(SWV2_EPI_F32, d->dx, C, nullptr, d->dx1, nullptr, d->rowidx);
         LAUNCH(21, swv2_linear(&dy, d->w_qkvt, &e, C, st));
     }
+    if (ss) join_from(ss, (hipStream_t)st);
     return SWV2_OK;
 }

@@ -18,6 +18,7 @@ not on a GPU or libswv2.so is not built.
 from __future__ import annotations
 
 import math
+import os
 from types import SimpleNamespace
 from typing import Any, List, Optional, Tuple, Type, Union
 
@@ -125,6 +126,7 @@ class _BlockRunner:
         d.L, d.Lp, d.DP, d.nwh, d.nww, d.mask_thr = Lw, Lp, DP, plan.nwh, plan.nww, plan.mask_thr
         d.rowidx, d.qkv_map, d.proj_map = plan.rowidx.data_ptr(), plan.qkv_map.data_ptr(), plan.proj_map.data_ptr()
         d.wgrad_splits = 64
+        d.wgrad_side_stream = int(os.environ.get("SWV2_WGRAD_SIDE_STREAM", "1"))
         self.desc = d
         act_sizes = [Bw * h * 3 * Lp * DP * 2, Bw * h * 2 * Lp * 4, Bw * h * Lp * DP * 2, Bw * h * Lp * 4, Mw * Cc * 2, Mw * 4,
                      Mw * 4, BT * Cc * 4, BT * hid * 2, BT * hid * 2, BT * Cc * 2, BT * 4, BT * 4]

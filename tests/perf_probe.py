@@ -80,9 +80,18 @@ def probe_gemm(B=2):
     say(f"linear gelu(bf16[{M},512]) -> bf16 N=128: {t:.1f} us")
     dW = torch.zeros(512, Cc, device=dev)
     db = torch.zeros(512, device=dev)
-    for splits in (32, 64, 128, 256):
+    for splits in (64, 128, -64, -128, -256):
         t = timeit(lambda: ops.linear_wgrad(ops.op_bf16(hb), ops.op_f32(x), dW, db, splits=splits))
         say(f"wgrad dY bf16[{M},512] x X f32[{M},128] splits={splits}: {t:.1f} us")
+    da2 = torch.randn(M, Cc, device=dev).to(BF)
+    dW2 = torch.zeros(Cc, 512, device=dev)
+    for splits in (64, -64, -128, -256):
+        t = timeit(lambda: ops.linear_wgrad(ops.op_bf16(da2), ops.op_bf16(hb), dW2, None, splits=splits))
+        say(f"wgrad dY bf16[{M},128] x X bf16[{M},512] splits={splits}: {t:.1f} us")
+    for splits in (64, 128, 256):
+        dWp = torch.zeros(Cc, Cc, device=dev)
+        t = timeit(lambda: ops.linear_wgrad(ops.op_bf16(da2), ops.op_bf16(xb), dWp, None, splits=splits))
+        say(f"wgrad dY bf16[{M},128] x X bf16[{M},128] splits={splits}: {t:.1f} us")
     a = xb
     y = torch.empty(M, Cc, device=dev)
     mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)

@@ -21,6 +21,8 @@
 //             dV^T = dO^T P and dK^T = Q^T dS; dK, dV need no cross-wave reduction, the bias gradient of
 //             (head, key-tile) accumulates in registers across all windows of the workgroup, and only dQ crosses
 //             waves (LDS float atomics, one 16x16 tile per step).
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -33,10 +35,41 @@ struct AttnCfg {
     static constexpr int SLAB = Lp * DP;        // elements of one [Lp][DP] slab
 };
 
+// scaled / biased / masked scores of one query column (swapped layout: lane = query, acc[t][r] = key 16t + 4g + r), in
+// place, log2 domain; returns the lane's partial maximum.  MASKED is the (wave-uniform) shift-mask case, instantiated
+// separately so the common unmasked windows carry no select instructions; LFIX > 0 is a compile-time window area so the
+// padded-key test folds away everywhere except in the last tile (the first build spent ~40 % of the forward kernel's
+// instructions on these two tests).
+template <int LT, bool HAS_BIAS, bool MASKED, int LFIX>
+__device__ __forceinline__ float score_pass(f32x4 (&acc)[LT], const uint32_t (&biasp)[LT][2], float sc2, int Lrt, int g,
+                                            int mask_thr, bool qid) {
+    const int L = LFIX > 0 ? LFIX : Lrt;
+    float mx = SWV2_NEG_BIG;
+#pragma unroll
+    for (int t = 0; t < LT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = 16 * t + 4 * g + r;
+            float s;
+            if (HAS_BIAS) {
+                const uint32_t w = biasp[t][r >> 1];             // padded keys carry -1e30 in the bias row
+                s = fmaf(acc[t][r], sc2, __uint_as_float((r & 1) ? (w & 0xffff0000u) : (w << 16)));
+            } else {
+                s = acc[t][r] * sc2;
+                if (LFIX > 0 ? (16 * t + 16 > LFIX) : (16 * t + 16 > L)) s = (key < L) ? s : SWV2_NEG_BIG;
+            }
+            if (MASKED) s += ((key >= mask_thr) != qid) ? (-100.f * SWV2_LOG2E) : 0.f;
+            acc[t][r] = s;
+            mx = fmaxf(mx, s);
+        }
+    }
+    return mx;
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <int LT, int DK, bool HAS_BIAS>
+template <int LT, int DK, bool HAS_BIAS, int LFIX>
 __global__ __launch_bounds__(64 * LT) void attn_fwd_kernel(
     const uint16_t* __restrict__ qkvh, const float* __restrict__ logit_scale, const float* __restrict__ bias,
     uint16_t* __restrict__ oh, float* __restrict__ lse, int Bw, int h, int L, int nW, int nww, int nwh, int mask_thr) {
@@ -53,18 +86,22 @@ __global__ __launch_bounds__(64 * LT) void attn_fwd_kernel(
 
     const float sc2 = __expf(fminf(logit_scale[hd], SWV2_LN100)) * SWV2_LOG2E;
 
-    // CPB bias rows of this (head, q-tile), log2 domain, -1e30 on padded keys
-    float biasr[LT][4];
+    // CPB bias rows of this (head, q-tile), log2 domain, -1e30 on padded keys; bf16 like the backward's LDS image
+    // (identical P in both passes), held as packed pairs: 2 x LT registers
+    uint32_t biasp[LT][2];
     if (HAS_BIAS) {
 #pragma unroll
-        for (int t = 0; t < LT; ++t)
+        for (int t = 0; t < LT; ++t) {
+            float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = 16 * t + 4 * g + r;
-                float v = SWV2_NEG_BIG;
-                if (key < L) v = (q < L) ? bias[((size_t)hd * L + q) * L + key] * SWV2_LOG2E : 0.f;
-                biasr[t][r] = bf2f(f2bf(v));     // bf16 like the backward's LDS image: identical P in both passes
+                v[r] = SWV2_NEG_BIG;
+                if (key < L) v[r] = (q < L) ? bias[((size_t)hd * L + q) * L + key] * SWV2_LOG2E : 0.f;
             }
+            biasp[t][0] = f2bf2(v[0], v[1]);
+            biasp[t][1] = f2bf2(v[2], v[3]);
+        }
     }
 
     constexpr int CHUNKS_PER_T = DK;         // K + V slabs = 64*LT*DK 16-byte chunks over 64*LT threads
@@ -113,25 +150,9 @@ __global__ __launch_bounds__(64 * LT) void attn_fwd_kernel(
         }
 
         const bool do_mask = (mask_thr > 0) && (((bw % nW) / nww) == nwh - 1);
-        const bool qid = q >= mask_thr;
-        float mx = SWV2_NEG_BIG;
-#pragma unroll
-        for (int t = 0; t < LT; ++t) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = 16 * t + 4 * g + r;
-                float s;
-                if (HAS_BIAS) {
-                    s = fmaf(acc[t][r], sc2, biasr[t][r]);
-                } else {
-                    s = acc[t][r] * sc2;
-                    if (16 * t + 16 > L) s = (key < L) ? s : SWV2_NEG_BIG;
-                }
-                if (do_mask) s += ((key >= mask_thr) != qid) ? (-100.f * SWV2_LOG2E) : 0.f;
-                acc[t][r] = s;
-                mx = fmaxf(mx, s);
-            }
-        }
+        float mx;
+        if (do_mask) mx = score_pass<LT, HAS_BIAS, true, LFIX>(acc, biasp, sc2, L, g, mask_thr, q >= mask_thr);
+        else         mx = score_pass<LT, HAS_BIAS, false, LFIX>(acc, biasp, sc2, L, g, mask_thr, false);
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         float sum = 0.f;
@@ -187,7 +208,7 @@ __global__ __launch_bounds__(64 * LT) void attn_fwd_kernel(
 //            no cross-wave reduction -- then the normalisation backward and a coalesced store.
 // The CPB bias (log2 domain, bf16, [key][q]) of the workgroup's head sits in LDS when it fits (BIAS_LDS), its
 // gradient accumulates in registers (wave = key tile owns 16 x Lp entries) across all windows of the workgroup.
-template <int LT, int DK, bool HAS_BIAS>
+template <int LT, int DK, bool HAS_BIAS, int LFIX>
 __global__ __launch_bounds__(64 * LT) void attn_bwd_kernel(
     const uint16_t* __restrict__ qkvh, const float* __restrict__ logit_scale, const float* __restrict__ bias,
     const uint16_t* __restrict__ oh, const uint16_t* __restrict__ doh, const float* __restrict__ lse,
@@ -313,6 +334,8 @@ __global__ __launch_bounds__(64 * LT) void attn_bwd_kernel(
         }
         const bool do_mask = (mask_thr > 0) && (((bw % nW) / nww) == nwh - 1);
         const bool kid = key >= mask_thr;
+        const int Lc = LFIX > 0 ? LFIX : L;
+        const bool pad_tile = 16 * tw + 16 > Lc, key_ok = key < Lc;     // wave-uniform / per-lane, hoisted out of the steps
         f32x4 dk[DK], dv[DK];
 #pragma unroll
         for (int dt = 0; dt < DK; ++dt) {
@@ -320,7 +343,8 @@ __global__ __launch_bounds__(64 * LT) void attn_bwd_kernel(
             dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
         // one q-tile step; `br` / `dbrow`: this lane's bias row / bias-gradient row of the tile
-        auto step = [&](const int qt, const f32x4 br, f32x4& dbrow) {
+        auto step = [&](const int qt, const f32x4 br, f32x4& dbrow, auto masked_c) {
+            constexpr bool MASKED = decltype(masked_c)::value;
             // S = Q K^T and dP = dO V^T : rows q = 16qt + 4g + r, column = key fr
             f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -341,9 +365,9 @@ __global__ __launch_bounds__(64 * LT) void attn_bwd_kernel(
                     x = fmaf(s[r], sc2, br[r]);
                 } else {
                     x = s[r] * sc2;
-                    if (16 * tw + 16 > L) x = (key < L) ? x : SWV2_NEG_BIG;
+                    if (pad_tile) x = key_ok ? x : SWV2_NEG_BIG;
                 }
-                if (do_mask) x += ((q >= mask_thr) != kid) ? (-100.f * SWV2_LOG2E) : 0.f;
+                if (MASKED) x += ((q >= mask_thr) != kid) ? (-100.f * SWV2_LOG2E) : 0.f;
                 const float pr = __builtin_amdgcn_exp2f(x - l4[r]);
                 const float dsr = pr * (dp[r] - d4[r]);
                 p[r] = pr;
@@ -379,7 +403,7 @@ __global__ __launch_bounds__(64 * LT) void attn_bwd_kernel(
 #undef SWV2_CASE
                 }
                 f32x4 dsrow = {0.f, 0.f, 0.f, 0.f};
-                step(qt, br, dsrow);
+                if (do_mask) step(qt, br, dsrow, std::true_type{}); else step(qt, br, dsrow, std::false_type{});
 #define SWV2_CASE(I) case I: if (I < LT) dbr[I < LT ? I : 0] += dsrow; break;
                 switch (qt) { SWV2_CASE(0) SWV2_CASE(1) SWV2_CASE(2) SWV2_CASE(3) SWV2_CASE(4) SWV2_CASE(5)
                               SWV2_CASE(6) SWV2_CASE(7) SWV2_CASE(8) SWV2_CASE(9) SWV2_CASE(10) }
@@ -387,8 +411,13 @@ __global__ __launch_bounds__(64 * LT) void attn_bwd_kernel(
             }
         } else {
             f32x4 dummy = {0.f, 0.f, 0.f, 0.f};
+            if (do_mask) {
 #pragma unroll 1
-            for (int qt = 0; qt < LT; ++qt) step(qt, dummy, dummy);
+                for (int qt = 0; qt < LT; ++qt) step(qt, dummy, dummy, std::true_type{});
+            } else {
+#pragma unroll 1
+                for (int qt = 0; qt < LT; ++qt) step(qt, dummy, dummy, std::false_type{});
+            }
         }
         // ---- dK (through the L2-normalisation) and dV of this wave's key tile
         {
@@ -470,34 +499,34 @@ __global__ __launch_bounds__(64 * LT) void attn_bwd_kernel(
     }
 }
 
-template <int LT, int DK>
+template <int LT, int DK, int LFIX>
 int launch_fwd(const swv2_attn_args* a, hipStream_t st) {
     const int nchunk = a->Bw < a->max_chunks ? a->Bw : a->max_chunks;
     dim3 grid(nchunk, a->heads), block(64 * LT);
     const int nW = a->nwh * a->nww;
     if (a->bias)
-        hipLaunchKernelGGL((attn_fwd_kernel<LT, DK, true>), grid, block, 0, st, (const uint16_t*)a->qkvh, a->logit_scale,
+        hipLaunchKernelGGL((attn_fwd_kernel<LT, DK, true, LFIX>), grid, block, 0, st, (const uint16_t*)a->qkvh, a->logit_scale,
                            a->bias, (uint16_t*)a->oh, a->lse, a->Bw, a->heads, a->L, nW, a->nww, a->nwh, a->mask_thr);
     else
-        hipLaunchKernelGGL((attn_fwd_kernel<LT, DK, false>), grid, block, 0, st, (const uint16_t*)a->qkvh,
+        hipLaunchKernelGGL((attn_fwd_kernel<LT, DK, false, LFIX>), grid, block, 0, st, (const uint16_t*)a->qkvh,
                            a->logit_scale, a->bias, (uint16_t*)a->oh, a->lse, a->Bw, a->heads, a->L, nW, a->nww,
                            a->nwh, a->mask_thr);
     SWV2_CHECK_LAUNCH("swv2_attn_fwd");
     return SWV2_OK;
 }
 
-template <int LT, int DK>
+template <int LT, int DK, int LFIX>
 int launch_bwd(const swv2_attn_args* a, hipStream_t st) {
     const int nchunk = a->Bw < a->max_chunks ? a->Bw : a->max_chunks;
     dim3 grid(nchunk, a->heads), block(64 * LT);
     const int nW = a->nwh * a->nww;
     if (a->bias)
-        hipLaunchKernelGGL((attn_bwd_kernel<LT, DK, true>), grid, block, 0, st, (const uint16_t*)a->qkvh, a->logit_scale,
+        hipLaunchKernelGGL((attn_bwd_kernel<LT, DK, true, LFIX>), grid, block, 0, st, (const uint16_t*)a->qkvh, a->logit_scale,
                            a->bias, (const uint16_t*)a->oh, (const uint16_t*)a->doh, a->lse, a->rnorm,
                            (uint16_t*)a->dqkvh, a->dlogit_scale, a->dbias, a->Bw, a->heads, a->L, nW, a->nww, a->nwh,
                            a->mask_thr, a->dbg);
     else
-        hipLaunchKernelGGL((attn_bwd_kernel<LT, DK, false>), grid, block, 0, st, (const uint16_t*)a->qkvh,
+        hipLaunchKernelGGL((attn_bwd_kernel<LT, DK, false, LFIX>), grid, block, 0, st, (const uint16_t*)a->qkvh,
                            a->logit_scale, a->bias, (const uint16_t*)a->oh, (const uint16_t*)a->doh, a->lse, a->rnorm,
                            (uint16_t*)a->dqkvh, a->dlogit_scale, a->dbias, a->Bw, a->heads, a->L, nW, a->nww, a->nwh,
                            a->mask_thr, a->dbg);
@@ -532,15 +561,19 @@ extern "C" int swv2_attn_geometry(int L, int head_dim, int* Lp, int* DP) {
     return SWV2_OK;
 }
 
+// kernels are specialised for the window areas of the reference configurations (9x18 = 162 at 720x1440 / ratio 80,
+// 6x9 = 54 at 192x288 / ratio 32); any other area <= 176 runs the generic (runtime-L) instantiation
 #define SWV2_ATTN_DISPATCH(FN)                                                         \
     int Lp, DP;                                                                        \
     int rc = swv2_attn_geometry(a->L, a->head_dim, &Lp, &DP);                          \
     if (rc) return rc;                                                                 \
     hipStream_t st = (hipStream_t)stream;                                              \
-    if (Lp == 64 && DP == 16) return FN<4, 1>(a, st);                                  \
-    if (Lp == 64 && DP == 32) return FN<4, 2>(a, st);                                  \
-    if (Lp == 176 && DP == 16) return FN<11, 1>(a, st);                                \
-    if (Lp == 176 && DP == 32) return FN<11, 2>(a, st);                                \
+    if (Lp == 176 && DP == 16 && a->L == 162) return FN<11, 1, 162>(a, st);            \
+    if (Lp == 64 && DP == 16 && a->L == 54) return FN<4, 1, 54>(a, st);                \
+    if (Lp == 64 && DP == 16) return FN<4, 1, 0>(a, st);                               \
+    if (Lp == 64 && DP == 32) return FN<4, 2, 0>(a, st);                               \
+    if (Lp == 176 && DP == 16) return FN<11, 1, 0>(a, st);                             \
+    if (Lp == 176 && DP == 32) return FN<11, 2, 0>(a, st);                             \
     swv2_set_error("attention: no kernel for Lp=%d DP=%d", Lp, DP);                    \
     return SWV2_ERR_UNSUPPORTED;
 

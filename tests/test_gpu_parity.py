@@ -515,3 +515,52 @@ def test_full_size_model_batch_independence(dev, K):
         y1 = m(x[1:2].contiguous())
     assert not torch.isnan(y2).any()
     assert rel(y2[1:2], y1) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the trainer end to end on the GPU (train.py surface: build, epochs, validation, checkpoint save / resume)
+# ---------------------------------------------------------------------------------------------------------------
+def test_trainer_end_to_end_with_checkpoint_resume(dev, K, tmp_path):
+    from types import SimpleNamespace
+    from swin_v2_weather_amd.train import Trainer
+    from swin_v2_weather_amd.utils.YParams import YParams
+
+    def make(run, max_epochs=2):
+        p = YParams(os.path.join(ROOT, "swin_v2_weather_amd", "config", "swin.yaml"), "bench_tiny")
+        p["img_size"] = [96, 144]
+        p["window_ratio"] = 16                      # patch grid 24 x 36, window 6 x 9
+        p["embed_dim"], p["num_heads"], p["depth"] = 32, 2, 2
+        p["in_channels"], p["out_channels"] = list(range(6)), list(range(6))
+        p["channel_names"] = p["channel_names"][:6]
+        p["track_channels"] = ["u10m", "t2m"]
+        p["batch_size"], p["max_epochs"] = 2, max_epochs
+        p["synthetic_device_pool"], p["synthetic_steps_per_epoch"] = 2, 3
+        p["exp_dir"], p["save_checkpoint"], p["log_to_screen"] = str(tmp_path), True, False
+        p["loss"], p["drop_path_rate"], p["rel_pos"] = "squared geometric l2", 0.1, True
+        args = SimpleNamespace(sweep_id=None, config="bench_tiny", run_num=run, enable_amp=True)
+        return Trainer(p, args)
+
+    # job 1 is "killed" after its first epoch (train + validate + scheduler step + checkpoint, as Trainer.train does)
+    t = make("00", max_epochs=3)
+    t.build()
+    t.train_one_epoch()
+    t.validate_one_epoch()
+    t.scheduler.step()
+    t.save_checkpoint(t.params.checkpoint_path)
+    ck = os.path.join(str(tmp_path), "bench_tiny", "00", "training_checkpoints", "ckpt.tar")
+    assert os.path.isfile(ck) and os.path.isfile(os.path.join(str(tmp_path), "bench_tiny", "00", "hyperparams.yaml"))
+    state = torch.load(ck, map_location="cpu", weights_only=False)
+    assert set(state) == {"iters", "epoch", "model_state", "optimizer_state_dict"} and state["epoch"] == 1 and state["iters"] == 3
+    assert all(k.startswith("model.") for k in state["model_state"])
+    # job 2 resumes from the same directory: weights, optimizer, epoch counter restored; then runs the remaining epochs
+    t2 = make("00", max_epochs=3)
+    t2.build()
+    assert t2.params.resuming and t2.startEpoch == 1 and t2.iters == 3
+    for (n1, p1), (n2, p2) in zip(t.model.state_dict().items(), t2.model.state_dict().items()):
+        assert n1 == n2 and torch.equal(p1.cpu(), p2.cpu())
+    assert abs(t2.optimizer.param_groups[0]["lr"] - t.optimizer.param_groups[0]["lr"]) < 1e-12 and t2.optimizer.param_groups[0]["lr"] > 0
+    before = t2.model.model.head.weight.detach().clone()
+    t2.train()
+    assert t2.epoch == 3 and t2.iters == 9 and not torch.equal(before, t2.model.model.head.weight.detach())
+    assert os.path.isfile(os.path.join(os.path.dirname(ck), "best_ckpt.tar"))
+    assert all(torch.isfinite(p).all() for p in t2.model.parameters())

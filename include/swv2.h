@@ -196,6 +196,15 @@ int swv2_loss_grad(const float* prd, const float* tar, const float* quad_w, cons
 int swv2_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                    int step, float grad_inv_scale, void* stream);
 
+/* Continuous position bias (swinv2_global.py:240-261,274-287): bias[heads][L][L] = meta_mlp(log-spaced relative
+ * coordinates), meta_mlp = Linear(2,hidden) -> ReLU -> Dropout(drop_p) -> Linear(hidden,heads); the relative-coordinate
+ * table is generated in-kernel.  keep_bf16: [L*L][hidden] keep-mask drawn by the caller (any non-zero = keep; the kernel
+ * applies 1/(1-drop_p)), NULL in eval mode.  Backward outputs are ACCUMULATED (caller zeroes). */
+int swv2_cpb_fwd(const float* w1, const float* b1, const float* w2, const float* b2, const void* keep_bf16, float* bias,
+                 int wh, int ww, int heads, int hidden, float drop_p, void* stream);
+int swv2_cpb_bwd(const float* dbias, const float* w1, const float* b1, const float* w2, const void* keep_bf16, float* dw1,
+                 float* db1, float* dw2, float* db2, int wh, int ww, int heads, int hidden, float drop_p, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Whole-block orchestration: one host call enqueues the 7 forward / 13 backward launches of a Swin block
  * (reference SwinTransformerV2CrBlock.forward, swinv2_global.py:480-497, and its autograd) from C++, so the per-launch

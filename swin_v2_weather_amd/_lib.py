@@ -13,7 +13,7 @@ import threading
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libswv2.so")
-SOURCES = ["capi.hip", "attn.hip", "gemm.hip", "gemm_tn.hip", "rowops.hip", "block.hip"]
+SOURCES = ["capi.hip", "attn.hip", "gemm.hip", "gemm_tn.hip", "rowops.hip", "block.hip", "cpb.hip"]
 
 _lib = None
 _lock = threading.Lock()
@@ -116,6 +116,8 @@ SYMBOLS = {
     "swv2_loss_sums": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "swv2_loss_grad": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "swv2_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P]),
+    "swv2_cpb_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "swv2_cpb_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "swv2_block_fwd": (_I, [C.POINTER(BlockDesc), _P]),
     "swv2_block_bwd": (_I, [C.POINTER(BlockDesc), _P]),
 }

@@ -1,0 +1,194 @@
+// Continuous position bias of SwinV2 (reference swinv2_global.py:240-261, 274-287): the 2 -> Hd -> heads meta MLP over the
+// L^2 log-spaced relative coordinates of a window, forward and backward, as two small kernels instead of ~10 PyTorch
+// passes over [L^2, Hd] fp32 tensors (measured 341 us per block in torch, forward + backward).
+//   R[p]        = sign(delta) * log(1 + |delta|),  delta = (r_q - r_k, c_q - c_k),  p = t_q * L + t_k      (:251-261)
+//   hidden[p,j] = relu(w1[j,0] R0 + w1[j,1] R1 + b1[j]) * keep[p,j] / (1 - drop)     (Dropout(0.125), train only, :245)
+//   bias[h,p]   = sum_j w2[h,j] hidden[p,j] + b2[h]                                   (:282-286: [L^2,h]^T -> [h,L,L])
+// The dropout keep-mask is drawn by the
+// caller with the torch RNG (shape [L^2, Hd], any non-zero = keep) so that the stochastic draw stays a host-side torch op.
+#include "common.h"
+
+namespace {
+
+constexpr int CPB_MAX_HEADS = 32;
+
+__device__ __forceinline__ void rel_coord(int p, int L, int ww, float& r0, float& r1) {
+    const int tq = p / L, tk = p - tq * L;
+    const int dr = tq / ww - tk / ww, dc = tq % ww - tk % ww;
+    const float a = (float)dr, b = (float)dc;
+    r0 = copysignf(log1pf(fabsf(a)), a) * (dr != 0);
+    r1 = copysignf(log1pf(fabsf(b)), b) * (dc != 0);
+}
+
+// Forward: lane = pair, the 4 waves of a workgroup each take a quarter of the hidden units (uniform index -> the weights
+// come through the scalar cache as SGPR operands), partial sums are combined through LDS.  No barrier inside the loop.
+template <int HEADS_MAX>
+__global__ __launch_bounds__(256) void cpb_fwd_kernel(const float* __restrict__ w1, const float* __restrict__ b1,
+                                                      const float* __restrict__ w2, const float* __restrict__ b2,
+                                                      const uint16_t* __restrict__ keep, float* __restrict__ bias, int L,
+                                                      int ww, int heads, int Hd, float scale) {
+    __shared__ float red[4][HEADS_MAX][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int L2 = L * L;
+    const int p = min(blockIdx.x * 64 + lane, L2 - 1);
+    float r0, r1;
+    rel_coord(p, L, ww, r0, r1);
+    const int jq = (Hd + 3) >> 2, j0 = wave * jq, j1 = min(Hd, j0 + jq);
+    float acc[HEADS_MAX];
+#pragma unroll
+    for (int h = 0; h < HEADS_MAX; ++h) acc[h] = 0.f;
+    const uint16_t* krow = keep ? keep + (size_t)p * Hd : nullptr;
+    int j = j0;
+    if ((Hd & 7) == 0 && (jq & 7) == 0) {        // 8 hidden units per trip: one 16-byte mask load, batched scalar loads
+        for (; j + 8 <= j1; j += 8) {
+            uint4 kq = make_uint4(0x00010001u, 0x00010001u, 0x00010001u, 0x00010001u);
+            if (krow) kq = *reinterpret_cast<const uint4*>(krow + j);
+            const uint32_t kw[4] = {kq.x, kq.y, kq.z, kq.w};
+            float hd8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float hv = fmaxf(fmaf(w1[2 * (j + u)], r0, fmaf(w1[2 * (j + u) + 1], r1, b1[j + u])), 0.f);
+                const uint32_t kbits = (kw[u >> 1] >> (16 * (u & 1))) & 0xffffu;
+                hd8[u] = krow ? (kbits != 0 ? hv * scale : 0.f) : hv;
+            }
+#pragma unroll
+            for (int h = 0; h < HEADS_MAX; ++h) {      // rows past `heads` re-read the last head; their sums are dropped
+                const float* w2h = w2 + min(h, heads - 1) * Hd + j;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[h] = fmaf(w2h[u], hd8[u], acc[h]);
+            }
+        }
+    }
+    for (; j < j1; ++j) {
+        float hdn = fmaxf(fmaf(w1[2 * j], r0, fmaf(w1[2 * j + 1], r1, b1[j])), 0.f);
+        if (krow) hdn = krow[j] != 0 ? hdn * scale : 0.f;
+#pragma unroll
+        for (int h = 0; h < HEADS_MAX; ++h) acc[h] = fmaf(w2[min(h, heads - 1) * Hd + j], hdn, acc[h]);
+    }
+#pragma unroll
+    for (int h = 0; h < HEADS_MAX; ++h) red[wave][h][lane] = acc[h];
+    __syncthreads();
+    for (int i = threadIdx.x; i < heads * 64; i += 256) {
+        const int h = i >> 6, l = i & 63, pp = blockIdx.x * 64 + l;
+        if (pp < L2) bias[(size_t)h * L2 + pp] = red[0][h][l] + red[1][h][l] + red[2][h][l] + red[3][h][l] + b2[h];
+    }
+}
+
+// Backward: thread = hidden unit, so every weight gradient is a private register sum over the workgroup's pairs; the
+// pair-uniform data (d bias of the heads, the two coordinates) is staged in LDS 64 pairs at a time and the keep-mask of
+// 8 pairs is fetched ahead of its use.
+template <int HEADS_MAX>
+__global__ __launch_bounds__(512) void cpb_bwd_kernel(const float* __restrict__ dbias, const float* __restrict__ w1,
+                                                      const float* __restrict__ b1, const float* __restrict__ w2,
+                                                      const uint16_t* __restrict__ keep, float* __restrict__ dw1,
+                                                      float* __restrict__ db1, float* __restrict__ dw2,
+                                                      float* __restrict__ db2, int L, int ww, int heads, int Hd,
+                                                      float scale, int pairs_per_block) {
+    __shared__ __attribute__((aligned(16))) float dbs[64][HEADS_MAX + 4];   // [pair][d bias of head 0.., r0, r1]
+    const int j = threadIdx.x;
+    const bool act = j < Hd;
+    const int jc = act ? j : 0;
+    const float wa = act ? w1[2 * j] : 0.f, wb = act ? w1[2 * j + 1] : 0.f, bb = act ? b1[j] : 0.f;
+    float w2r[HEADS_MAX], g2[HEADS_MAX];
+#pragma unroll
+    for (int h = 0; h < HEADS_MAX; ++h) { w2r[h] = (act && h < heads) ? w2[h * Hd + j] : 0.f; g2[h] = 0.f; }
+    float ga = 0.f, gb = 0.f, gbias = 0.f, gb2 = 0.f;
+    const int L2 = L * L;
+    const int p0 = blockIdx.x * pairs_per_block, p1 = min(L2, p0 + pairs_per_block);
+    for (int pc = p0; pc < p1; pc += 64) {
+        uint32_t kbits[2] = {~0u, ~0u};        // the chunk's keep flags of this hidden unit, in flight during the staging
+        if (keep) {
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                uint32_t b = 0;
+#pragma unroll
+                for (int u = 0; u < 32; ++u)
+                    b |= (uint32_t)(keep[(size_t)min(pc + 32 * w + u, L2 - 1) * Hd + jc] != 0) << u;
+                kbits[w] = b;
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 64 * HEADS_MAX; i += blockDim.x) {
+            const int h = i >> 6, pp = i & 63;
+            dbs[pp][h] = (h < heads && pc + pp < p1) ? dbias[(size_t)h * L2 + pc + pp] : 0.f;
+        }
+        if (threadIdx.x < 64) {
+            float r0, r1;
+            rel_coord(min(pc + (int)threadIdx.x, L2 - 1), L, ww, r0, r1);
+            dbs[threadIdx.x][HEADS_MAX] = r0;
+            dbs[threadIdx.x][HEADS_MAX + 1] = r1;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int pp = 0; pp < 64; ++pp) {          // rows past p1 hold d bias = 0 and contribute nothing
+            const float r0 = dbs[pp][HEADS_MAX], r1 = dbs[pp][HEADS_MAX + 1];
+            const float pre = fmaf(wa, r0, fmaf(wb, r1, bb));
+            const float m = keep ? (((kbits[pp >> 5] >> (pp & 31)) & 1u) ? scale : 0.f) : 1.f;
+            const float hdn = fmaxf(pre, 0.f) * m;
+            float dh = 0.f;
+#pragma unroll
+            for (int h = 0; h < HEADS_MAX; ++h) {      // heads past `heads` carry zeros (no per-head branch)
+                const float d = dbs[pp][h];
+                g2[h] = fmaf(d, hdn, g2[h]);
+                dh = fmaf(d, w2r[h], dh);
+            }
+            dh = (pre > 0.f) ? dh * m : 0.f;
+            ga = fmaf(dh, r0, ga);
+            gb = fmaf(dh, r1, gb);
+            gbias += dh;
+        }
+        if (j < heads)
+            for (int pp = 0; pp < 64; ++pp) gb2 += dbs[pp][j];
+    }
+    if (act) {
+        atomicAdd(dw1 + 2 * j, ga);
+        atomicAdd(dw1 + 2 * j + 1, gb);
+        atomicAdd(db1 + j, gbias);
+#pragma unroll
+        for (int h = 0; h < HEADS_MAX; ++h)
+            if (h < heads) atomicAdd(dw2 + h * Hd + j, g2[h]);
+    }
+    if (j < heads) atomicAdd(db2 + j, gb2);
+}
+
+}  // namespace
+
+extern "C" int swv2_cpb_fwd(const float* w1, const float* b1, const float* w2, const float* b2, const void* keep_bf16,
+                            float* bias, int wh, int ww, int heads, int hidden, float drop_p, void* stream) {
+    SWV2_CHECK_ARG(w1 && b1 && w2 && b2 && bias, "cpb_fwd: null pointer");
+    SWV2_CHECK_ARG(heads > 0 && heads <= CPB_MAX_HEADS && hidden > 0 && hidden <= 512 && drop_p >= 0.f && drop_p < 1.f,
+                   "cpb_fwd: heads <= %d, hidden <= 512 required (heads=%d hidden=%d)", CPB_MAX_HEADS, heads, hidden);
+    const int L = wh * ww, L2 = L * L;
+    const float scale = 1.f / (1.f - drop_p);
+#define CPB_FWD(HM)                                                                                                  \
+    hipLaunchKernelGGL((cpb_fwd_kernel<HM>), dim3(cdiv(L2, 64)), dim3(256), 0, (hipStream_t)stream, w1, b1, w2, b2,  \
+                       (const uint16_t*)keep_bf16, bias, L, ww, heads, hidden, scale)
+    if (heads <= 4) CPB_FWD(4);
+    else if (heads <= 8) CPB_FWD(8);
+    else if (heads <= 16) CPB_FWD(16);
+    else CPB_FWD(CPB_MAX_HEADS);
+#undef CPB_FWD
+    SWV2_CHECK_LAUNCH("swv2_cpb_fwd");
+    return SWV2_OK;
+}
+
+extern "C" int swv2_cpb_bwd(const float* dbias, const float* w1, const float* b1, const float* w2, const void* keep_bf16,
+                            float* dw1, float* db1, float* dw2, float* db2, int wh, int ww, int heads, int hidden,
+                            float drop_p, void* stream) {
+    SWV2_CHECK_ARG(dbias && w1 && b1 && w2 && dw1 && db1 && dw2 && db2, "cpb_bwd: null pointer");
+    SWV2_CHECK_ARG(heads > 0 && heads <= CPB_MAX_HEADS && hidden > 0 && hidden <= 512 && drop_p >= 0.f && drop_p < 1.f,
+                   "cpb_bwd: heads <= %d, hidden <= 512 required", CPB_MAX_HEADS);
+    const int L = wh * ww, L2 = L * L, ppb = 128;      // measured: 64 -> 34 us, 128 -> 33 us, 256 -> 46 us (9x18 window)
+    const int threads = cdiv(hidden, 64) * 64;
+    const float scale = 1.f / (1.f - drop_p);
+#define CPB_BWD(HM)                                                                                                  \
+    hipLaunchKernelGGL((cpb_bwd_kernel<HM>), dim3(cdiv(L2, ppb)), dim3(threads), 0, (hipStream_t)stream, dbias, w1, b1, \
+                       w2, (const uint16_t*)keep_bf16, dw1, db1, dw2, db2, L, ww, heads, hidden, scale, ppb)
+    if (heads <= 4) CPB_BWD(4);
+    else if (heads <= 8) CPB_BWD(8);
+    else if (heads <= 16) CPB_BWD(16);
+    else CPB_BWD(CPB_MAX_HEADS);
+#undef CPB_BWD
+    SWV2_CHECK_LAUNCH("swv2_cpb_bwd");
+    return SWV2_OK;
+}

@@ -233,6 +233,32 @@ class _BlockFn(torch.autograd.Function):
                 dn2b, None)
 
 
+class _CpbFn(torch.autograd.Function):
+    """bias[h, L, L] of the meta MLP (2 -> hidden -> heads over the log-spaced relative coordinates) as two fused kernels"""
+
+    @staticmethod
+    def forward(ctx, w1, b1, w2, b2, keep, wh, ww, drop_p):
+        heads, hidden = w2.shape
+        Lw = wh * ww
+        w1c, b1c, w2c, b2c = (t.detach().float().contiguous() for t in (w1, b1, w2, b2))
+        bias = torch.empty(heads, Lw, Lw, dtype=torch.float32, device=w1.device)
+        ops.cpb_fwd(w1c, b1c, w2c, b2c, keep, bias, wh, ww, heads, hidden, drop_p)
+        ctx.geom = (wh, ww, heads, hidden, drop_p)
+        ctx.save_for_backward(w1c, b1c, w2c, keep if keep is not None else w1c.new_empty(0))
+        return bias
+
+    @staticmethod
+    def backward(ctx, dbias):
+        w1c, b1c, w2c, keep = ctx.saved_tensors
+        wh, ww, heads, hidden, drop_p = ctx.geom
+        dev = w1c.device
+        dw1, db1 = torch.zeros(hidden, 2, device=dev), torch.zeros(hidden, device=dev)
+        dw2, db2 = torch.zeros(heads, hidden, device=dev), torch.zeros(heads, device=dev)
+        ops.cpb_bwd(dbias.contiguous().float(), w1c, b1c, w2c, keep if keep.numel() else None, dw1, db1, dw2, db2, wh, ww, heads,
+                    hidden, drop_p)
+        return dw1, db1, dw2, db2, None, None, None, None
+
+
 class Mlp(nn.Module):
     """Parameter container with timm.layers.Mlp's attribute names (fc1, fc2); the arithmetic lives in the block kernels
     (GELU variant) or, for the tiny 2->384->heads meta network (ReLU + Dropout), in `WindowMultiHeadAttention`."""
@@ -323,13 +349,18 @@ class WindowMultiHeadAttention(WindowMultiHeadAttentionNoPos):
         self._make_pair_wise_relative_positions()
 
     def position_bias(self) -> torch.Tensor:
-        """[heads, L, L] bias table (reference :274-287).  A 26k x 2 -> 384 -> heads MLP: host-side torch ops so
-        that the hard-coded Dropout(0.125) consumes the torch RNG stream exactly like the reference."""
-        L_ = self.window_size[0] * self.window_size[1]
+        """[heads, L, L] bias table (reference :274-287) from two fused kernels (swv2_cpb_fwd / _bwd).  The only host-side
+        piece is the draw of the hard-coded Dropout(0.125) keep-mask (:245): F.dropout on a [L^2, hidden] tensor of ones
+        consumes the torch RNG exactly like the reference's nn.Dropout on the hidden activations of the same shape."""
         m = self.meta_mlp
-        hdn = F.dropout(F.relu(F.linear(self.relative_coordinates_log, m.fc1.weight, m.fc1.bias)), 0.125, self.training)
-        o = F.linear(hdn, m.fc2.weight, m.fc2.bias)
-        return o.transpose(1, 0).reshape(self.num_heads, L_, L_)
+        wh, ww = self.window_size
+        keep = None
+        if self.training:
+            ones = torch.ones(wh * ww * wh * ww, m.fc1.weight.shape[0], dtype=BF16, device=m.fc1.weight.device)
+            keep = F.dropout(ones, 0.125, True)
+        if not m.fc1.weight.is_cuda:
+            raise L.Swv2Error("position_bias runs on an MI355X only (no CPU fallback)")
+        return _CpbFn.apply(m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, keep, wh, ww, 0.125)
 
 
 class SwinTransformerV2CrBlock(nn.Module):

@@ -231,6 +231,16 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_inv_scale=1.0):
                                     _stream()), "swv2_adam_step")
 
 
+def cpb_fwd(w1, b1, w2, b2, keep, bias, wh, ww, heads, hidden, drop_p):
+    L.check(L.load().swv2_cpb_fwd(_p(w1), _p(b1), _p(w2), _p(b2), _p(keep), _p(bias), wh, ww, heads, hidden, drop_p, _stream()),
+            "swv2_cpb_fwd")
+
+
+def cpb_bwd(dbias, w1, b1, w2, keep, dw1, db1, dw2, db2, wh, ww, heads, hidden, drop_p):
+    L.check(L.load().swv2_cpb_bwd(_p(dbias), _p(w1), _p(b1), _p(w2), _p(keep), _p(dw1), _p(db1), _p(dw2), _p(db2), wh, ww,
+                                  heads, hidden, drop_p, _stream()), "swv2_cpb_bwd")
+
+
 # ---- per-geometry index tables ------------------------------------------------------------------------------
 class WindowPlan:
     """Index tables for one (batch, grid, window, shift, heads) geometry: the cyclic roll, the window partition, its

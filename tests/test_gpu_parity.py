@@ -564,3 +564,39 @@ def test_trainer_end_to_end_with_checkpoint_resume(dev, K, tmp_path):
     assert t2.epoch == 3 and t2.iters == 9 and not torch.equal(before, t2.model.model.head.weight.detach())
     assert os.path.isfile(os.path.join(os.path.dirname(ck), "best_ckpt.tar"))
     assert all(torch.isfinite(p).all() for p in t2.model.parameters())
+
+
+@pytest.mark.parametrize("wh,ww,heads,hidden,train", [(18, 9, 8, 384, False), (18, 9, 8, 384, True), (3, 5, 4, 96, True),
+                                                      (4, 4, 12, 130, False)])
+def test_cpb_kernels_match_oracle(dev, K, wh, ww, heads, hidden, train):
+    """swv2_cpb_fwd/_bwd against the oracle's meta MLP (swinv2_global.py:240-261,274-287) with the same keep-mask:
+    fp32 arithmetic on both sides, so the bar is fp32 reassociation noise."""
+    ops = K["ops"]
+    g = torch.Generator().manual_seed(wh * 100 + heads)
+    p = {"a.meta_mlp.fc1.weight": torch.randn(hidden, 2, generator=g) * 0.7, "a.meta_mlp.fc1.bias": torch.randn(hidden, generator=g) * 0.3,
+         "a.meta_mlp.fc2.weight": torch.randn(heads, hidden, generator=g) * 0.1, "a.meta_mlp.fc2.bias": torch.randn(heads, generator=g) * 0.1}
+    for v in p.values():
+        v.requires_grad_(True)
+    Lw = wh * ww
+    keep = (torch.rand(Lw * Lw, hidden, generator=g) >= 0.125) if train else None
+    # oracle with an injected mask: eval-mode formula on hidden * keep / (1 - p)
+    R = O.rel_coords_log(wh, ww)
+    hdn = torch.relu(R @ p["a.meta_mlp.fc1.weight"].T + p["a.meta_mlp.fc1.bias"])
+    if train:
+        hdn = hdn * keep / 0.875
+    ref = (hdn @ p["a.meta_mlp.fc2.weight"].T + p["a.meta_mlp.fc2.bias"]).T.reshape(heads, Lw, Lw)
+    if not train:
+        assert torch.equal(ref, O.cpb_bias(p, "a.", wh, ww, heads, False))
+    gy = torch.randn(heads, Lw, Lw, generator=g)
+    ref.backward(gy)
+    d = {k: v.detach().to(dev) for k, v in p.items()}
+    keep_d = keep.to(dev).to(torch.bfloat16) * 1.140625 if train else None
+    bias = torch.empty(heads, Lw, Lw, device=dev)
+    ops.cpb_fwd(d["a.meta_mlp.fc1.weight"], d["a.meta_mlp.fc1.bias"], d["a.meta_mlp.fc2.weight"], d["a.meta_mlp.fc2.bias"], keep_d,
+                bias, wh, ww, heads, hidden, 0.125)
+    assert rel(bias, ref.detach()) < 2e-6
+    gs = [torch.zeros_like(d[k]) for k in ("a.meta_mlp.fc1.weight", "a.meta_mlp.fc1.bias", "a.meta_mlp.fc2.weight", "a.meta_mlp.fc2.bias")]
+    ops.cpb_bwd(gy.to(dev), d["a.meta_mlp.fc1.weight"], d["a.meta_mlp.fc1.bias"], d["a.meta_mlp.fc2.weight"], keep_d, *gs, wh, ww,
+                heads, hidden, 0.125)
+    for gk, k in zip(gs, ("a.meta_mlp.fc1.weight", "a.meta_mlp.fc1.bias", "a.meta_mlp.fc2.weight", "a.meta_mlp.fc2.bias")):
+        assert rel(gk, p[k].grad) < 2e-5, k

@@ -18,6 +18,7 @@
  */
 #ifndef SWV2_H
 #define SWV2_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -134,13 +135,18 @@ typedef struct swv2_epilogue {
 
 int swv2_linear(const swv2_operand* a, const void* w_bf16, const swv2_epilogue* e, int N, void* stream);
 
-/* Weight gradient: dW[nmap(n)][kmap(k)] += sum_m dY[m][n] X[m][k], db[nmap(n)] += sum_m dY[m][n]   (fp32 atomics;
- * caller zeroes; db may be NULL).  dW has row pitch ldw; nmap/kmap (NULL = identity, negative = drop) undo the head
- * padding of the SWV2_OP_HEADS layouts.  |splits| = number of row slices processed by different workgroups;
- * splits < 0 selects the kernel that keeps the whole (<= 65536-entry) output block in one workgroup and reads dY and
- * X once per slice (wide outputs), splits > 0 the 128 x 128-tiled kernel. */
+/* Weight gradient: dW[nmap(n)][kmap(k)] += sum_m dY[m][n] X[m][k], db[nmap(n)] += sum_m dY[m][n]  (caller zeroes; db
+ * may be NULL).  dW has row pitch ldw; nmap/kmap (NULL = identity, negative = drop) undo the head padding of the
+ * SWV2_OP_HEADS layouts.  splits > 0 = number of row slices processed by different workgroups (x 2 for outputs of fewer
+ * than three 128 x 128 tiles).  swv2_linear_wgrad sums the slices with fp32 atomics on dW; swv2_linear_wgrad_ws writes
+ * per-slice partial tiles to the caller's workspace (>= swv2_linear_wgrad_ws_bytes(M, N, K, splits) bytes, contents
+ * undefined afterwards) and adds them in a second kernel -- no atomics on dW, deterministic, and faster from ~64
+ * slices up.  ws == NULL falls back to the atomic path.  Replaces the autograd of F.linear / Conv2d weights. */
 int swv2_linear_wgrad(const swv2_operand* dy, const swv2_operand* x, float* dW, float* db, const int32_t* nmap,
                       const int32_t* kmap, int ldw, int splits, void* stream);
+size_t swv2_linear_wgrad_ws_bytes(int M, int N, int K, int splits);
+int swv2_linear_wgrad_ws(const swv2_operand* dy, const swv2_operand* x, float* dW, float* db, const int32_t* nmap,
+                         const int32_t* kmap, int ldw, int splits, void* ws, size_t ws_bytes, void* stream);
 
 /* out_bf16[i][j] = W'[row_map ? row_map[i] : i][col_map ? col_map[j] : j] (0 where a map entry is negative),
  * W' = transpose ? w^T : w, w fp32 [rows][cols].  Casts, transposes, permutes and pads a parameter once per step. */
@@ -196,6 +202,31 @@ int swv2_loss_grad(const float* prd, const float* tar, const float* quad_w, cons
 int swv2_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                    int step, float grad_inv_scale, void* stream);
 
+/* Fused MLP branch, forward: y = x + scale[b] * LayerNorm(fc2(GELU(fc1(x))))  (swinv2_global.py:492-496, timm Mlp
+ * :381-386) in one kernel; the [M][hidden] activation stays in registers.  Saves for the backward: hpre = bf16(fc1(x)),
+ * a2 = bf16(fc2 output), mean / rstd of the LayerNorm.  Same results as swv2_linear(EPI_BF16_GELU) + swv2_linear +
+ * swv2_ln_residual_fwd (identical rounding points).  C in {32,64,96,128,192,256}, hidden % 32 == 0,
+ * hidden <= 2048 (swv2_mlp_supported); other shapes return SWV2_ERR_UNSUPPORTED -- use the unfused sequence. */
+typedef struct {
+    const float* x;        /* [M][C] fp32 rows: GEMM input and residual */
+    const void* w1;        /* bf16 [hidden][C]  (swv2_prep_weight) */
+    const float* b1;       /* [hidden] */
+    const void* w2;        /* bf16 [C][hidden] */
+    const float* b2;       /* [C] */
+    const float* gamma;    /* LayerNorm weight / bias [C] */
+    const float* beta;
+    const float* scale;    /* per-sample drop-path factor [M / rows_per_sample] or NULL */
+    void* hpre;            /* out bf16 [M][hidden] */
+    void* a2;              /* out bf16 [M][C] */
+    float* mean;           /* out [M] */
+    float* rstd;
+    float* y;              /* out fp32 [M][C] */
+    int M, C, hidden, rows_per_sample;
+    float eps;
+} swv2_mlp_args;
+int swv2_mlp_supported(int C, int hidden);
+int swv2_mlp_fwd(const swv2_mlp_args* a, void* stream);
+
 /* Continuous position bias (swinv2_global.py:240-261,274-287): bias[heads][L][L] = meta_mlp(log-spaced relative
  * coordinates), meta_mlp = Linear(2,hidden) -> ReLU -> Dropout(drop_p) -> Linear(hidden,heads); the relative-coordinate
  * table is generated in-kernel.  keep_bf16: [L*L][hidden] keep-mask drawn by the caller (any non-zero = keep; the kernel
@@ -238,7 +269,7 @@ typedef struct swv2_block_desc {
     /* parameter gradients, ACCUMULATED (caller zeroes) */
     float *d_logit_scale, *d_bias, *d_qkv_w, *d_qkv_b, *d_proj_w, *d_proj_b, *d_n1_w, *d_n1_b, *d_fc1_w, *d_fc1_b,
           *d_fc2_w, *d_fc2_b, *d_n2_w, *d_n2_b;
-    int wgrad_splits;        /* row slices of the weight-gradient products (64 is a good default) */
+    int wgrad_splits;        /* row slices of the weight-gradient products (128 with a workspace, 64 without) */
     /* optional timing of ONE launch with HIP events on the launch stream (bench.py's roofline): if ev_kernel matches a
        launch id (forward 1 qkv, 2 attn_fwd, 3 proj, 4 ln1, 5 fc1, 6 fc2, 7 ln2; backward 11 ln2, 12 wgrad fc2, 13 dh,
        14 wgrad fc1, 15 dx1, 16 ln1, 17 wgrad proj, 18 d(oh), 19 attn_bwd, 20 wgrad qkv, 21 dx), ev_start / ev_stop
@@ -246,6 +277,11 @@ typedef struct swv2_block_desc {
     int ev_kernel;
     void* ev_start;
     void* ev_stop;
+    int fuse_mlp;            /* 1: forward steps 5-7 run as swv2_mlp_fwd when the shape is supported (hact is then neither
+                                written nor read: the backward applies GELU to hpre on load); 0: three launches */
+    void* wgrad_ws;          /* optional workspace of the weight-gradient products (swv2_linear_wgrad_ws), shared by the four
+                                products of the block (they are ordered on one stream); NULL = atomic accumulation */
+    size_t wgrad_ws_bytes;
     int wgrad_side_stream;   /* 1: backward launches the 4 weight-gradient products on the library's per-device side stream
                                 (fork after each producer, join before returning) so they overlap with the dX chain */
 } swv2_block_desc;

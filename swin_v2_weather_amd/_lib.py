@@ -13,7 +13,7 @@ import threading
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libswv2.so")
-SOURCES = ["capi.hip", "attn.hip", "gemm.hip", "gemm_tn.hip", "rowops.hip", "block.hip", "cpb.hip"]
+SOURCES = ["capi.hip", "attn.hip", "gemm.hip", "gemm_tn.hip", "rowops.hip", "block.hip", "cpb.hip", "mlp.hip"]
 
 _lib = None
 _lock = threading.Lock()
@@ -70,6 +70,11 @@ class Epilogue(C.Structure):
                 ("aux_out", C.c_void_p), ("rowidx", C.c_void_p), ("ld", C.c_long), ("p", C.c_int * 5)]
 
 
+class MlpArgs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("x", "w1", "b1", "w2", "b2", "gamma", "beta", "scale", "hpre", "a2", "mean", "rstd", "y")] + \
+               [(n, C.c_int) for n in ("M", "C", "hidden", "rows_per_sample")] + [("eps", C.c_float)]
+
+
 class LnArgs(C.Structure):
     _fields_ = [("a", C.c_void_p), ("res", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
                 ("scale", C.c_void_p), ("rowidx", C.c_void_p), ("y", C.c_void_p), ("mean", C.c_void_p),
@@ -91,7 +96,7 @@ class BlockDesc(C.Structure):
                     "d_logit_scale", "d_bias", "d_qkv_w", "d_qkv_b", "d_proj_w", "d_proj_b", "d_n1_w", "d_n1_b", "d_fc1_w",
                     "d_fc1_b", "d_fc2_w", "d_fc2_b", "d_n2_w", "d_n2_b")] +
                 [("wgrad_splits", C.c_int), ("ev_kernel", C.c_int), ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p),
-                 ("wgrad_side_stream", C.c_int)])
+                 ("fuse_mlp", C.c_int), ("wgrad_ws", C.c_void_p), ("wgrad_ws_bytes", C.c_size_t), ("wgrad_side_stream", C.c_int)])
 
 
 OP_F32, OP_BF16, OP_BF16_GELU, OP_HEADS, OP_PATCH, OP_MERGE_LN = range(6)
@@ -107,6 +112,8 @@ SYMBOLS = {
     "swv2_attn_bwd": (_I, [C.POINTER(AttnArgs), _P]),
     "swv2_linear": (_I, [C.POINTER(Operand), _P, C.POINTER(Epilogue), _I, _P]),
     "swv2_linear_wgrad": (_I, [C.POINTER(Operand), C.POINTER(Operand), _P, _P, _P, _P, _I, _I, _P]),
+    "swv2_linear_wgrad_ws_bytes": (C.c_size_t, [_I, _I, _I, _I]),
+    "swv2_linear_wgrad_ws": (_I, [C.POINTER(Operand), C.POINTER(Operand), _P, _P, _P, _P, _I, _I, _P, C.c_size_t, _P]),
     "swv2_prep_weight": (_I, [_P, _I, _I, _I, _P, _I, _P, _I, _P, _P]),
     "swv2_ln_residual_fwd": (_I, [C.POINTER(LnArgs), _P]),
     "swv2_ln_residual_bwd": (_I, [C.POINTER(LnArgs), _P]),
@@ -116,6 +123,8 @@ SYMBOLS = {
     "swv2_loss_sums": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "swv2_loss_grad": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "swv2_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P]),
+    "swv2_mlp_supported": (_I, [_I, _I]),
+    "swv2_mlp_fwd": (_I, [C.POINTER(MlpArgs), _P]),
     "swv2_cpb_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "swv2_cpb_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "swv2_block_fwd": (_I, [C.POINTER(BlockDesc), _P]),

@@ -102,6 +102,15 @@ extern "C" int swv2_block_fwd(const swv2_block_desc* d, void* st) {
         l.mean = d->mean1; l.rstd = d->rstd1; l.M = Mw; l.C = C; l.res_mod = 0; l.rows_per_sample = d->T; l.eps = 1e-5f;
         LAUNCH(4, swv2_ln_residual_fwd(&l, st));
     }
+    // 5-7 fused: fc1, GELU, fc2, LN2 + drop-path + residual in one kernel (the hidden activation stays in registers)
+    if (d->fuse_mlp && swv2_mlp_supported(C, hid)) {
+        swv2_mlp_args m = {};
+        m.x = d->x1; m.w1 = d->w_fc1; m.b1 = d->fc1_b; m.w2 = d->w_fc2; m.b2 = d->fc2_b; m.gamma = d->n2_w; m.beta = d->n2_b;
+        m.scale = d->dp2; m.hpre = d->hpre; m.a2 = d->a2; m.mean = d->mean2; m.rstd = d->rstd2; m.y = d->x2;
+        m.M = BT; m.C = C; m.hidden = hid; m.rows_per_sample = d->T; m.eps = 1e-5f;
+        LAUNCH(5, swv2_mlp_fwd(&m, st));
+        return SWV2_OK;
+    }
     // 5. fc1 (+ bias -> pre-activation and GELU), 6. fc2
     {
         swv2_operand a = op(SWV2_OP_F32, d->x1, BT, C, C);
@@ -139,9 +148,11 @@ extern "C" int swv2_block_bwd(const swv2_block_desc* d, void* st) {
     }
     // 6'. fc2: dW = da2^T GELU(h) ; dh = (da2 W2) * GELU'(h)
     {
-        swv2_operand dy = op(SWV2_OP_BF16, d->da2, BT, C, C), x = op(SWV2_OP_BF16, d->hact, BT, hid, hid);
+        const bool fused = d->fuse_mlp && swv2_mlp_supported(C, hid);     // hact was not stored: GELU(hpre) on load
+        swv2_operand dy = op(SWV2_OP_BF16, d->da2, BT, C, C),
+                     x = fused ? op(SWV2_OP_BF16_GELU, d->hpre, BT, hid, hid) : op(SWV2_OP_BF16, d->hact, BT, hid, hid);
         if (ss) fork_to(ss, (hipStream_t)st);
-        LAUNCH(12, swv2_linear_wgrad(&dy, &x, d->d_fc2_w, d->d_fc2_b, nullptr, nullptr, hid, sp, ws));
+        LAUNCH(12, swv2_linear_wgrad_ws(&dy, &x, d->d_fc2_w, d->d_fc2_b, nullptr, nullptr, hid, sp, d->wgrad_ws, d->wgrad_ws_bytes, ws));
         swv2_epilogue e = epi(SWV2_EPI_GELU_GRAD, d->dh, hid, nullptr, d->hpre);
         LAUNCH(13, swv2_linear(&dy, d->w_fc2t, &e, hid, st));
     }
@@ -149,7 +160,7 @@ extern "C" int swv2_block_bwd(const swv2_block_desc* d, void* st) {
     {
         swv2_operand dy = op(SWV2_OP_BF16, d->dh, BT, hid, hid), x = op(SWV2_OP_F32, d->x1, BT, C, C);
         if (ss) fork_to(ss, (hipStream_t)st);
-        LAUNCH(14, swv2_linear_wgrad(&dy, &x, d->d_fc1_w, d->d_fc1_b, nullptr, nullptr, C, sp, ws));
+        LAUNCH(14, swv2_linear_wgrad_ws(&dy, &x, d->d_fc1_w, d->d_fc1_b, nullptr, nullptr, C, sp, d->wgrad_ws, d->wgrad_ws_bytes, ws));
         swv2_epilogue e = epi(SWV2_EPI_F32, d->dx1, C, nullptr, d->dx2);
         LAUNCH(15, swv2_linear(&dy, d->w_fc1t, &e, C, st));
     }
@@ -164,7 +175,7 @@ extern "C" int swv2_block_bwd(const swv2_block_desc* d, void* st) {
     {
         swv2_operand dy = op(SWV2_OP_BF16, d->da1, Mw, C, C), x = op_heads(d->oh, Bw, h, 1, d->Lp, d->DP);
         if (ss) fork_to(ss, (hipStream_t)st);
-        LAUNCH(17, swv2_linear_wgrad(&dy, &x, d->d_proj_w, d->d_proj_b, nullptr, d->proj_map, C, sp, ws));
+        LAUNCH(17, swv2_linear_wgrad_ws(&dy, &x, d->d_proj_w, d->d_proj_b, nullptr, d->proj_map, C, sp, d->wgrad_ws, d->wgrad_ws_bytes, ws));
         swv2_epilogue e = epi(SWV2_EPI_HEADS, d->doh, 0);
         e.p[0] = h; e.p[2] = d->Lp; e.p[3] = d->DP; e.p[4] = d->L;
         LAUNCH(18, swv2_linear(&dy, d->w_projt, &e, h * d->DP, st));
@@ -182,7 +193,7 @@ extern "C" int swv2_block_bwd(const swv2_block_desc* d, void* st) {
     {
         swv2_operand dy = op_heads(d->dqkvh, Bw, h, 3, d->Lp, d->DP), x = op(SWV2_OP_F32, d->x, Mw, C, C, d->rowidx);
         if (ss) fork_to(ss, (hipStream_t)st);
-        LAUNCH(20, swv2_linear_wgrad(&dy, &x, d->d_qkv_w, d->d_qkv_b, d->qkv_map, nullptr, C, sp, ws));
+        LAUNCH(20, swv2_linear_wgrad_ws(&dy, &x, d->d_qkv_w, d->d_qkv_b, d->qkv_map, nullptr, C, sp, d->wgrad_ws, d->wgrad_ws_bytes, ws));
         swv2_epilogue e = epi(SWV2_EPI_F32, d->dx, C, nullptr, d->dx1, nullptr, d->rowidx);
         LAUNCH(21, swv2_linear(&dy, d->w_qkvt, &e, C, st));
     }

@@ -16,7 +16,7 @@ template <int YK, int XK>
 __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(ALoad<YK> yl, ALoad<XK> xl, float* __restrict__ dW,
                                                            float* __restrict__ db, const int32_t* __restrict__ nmap,
                                                            const int32_t* __restrict__ kmap, int ldw, int M, int N,
-                                                           int K, int ntk, int rows_per_split) {
+                                                           int K, int ntk, int rows_per_split, float* __restrict__ ws) {
     __shared__ __attribute__((aligned(16))) uint16_t smem[2 * TM * TP];          // [Y | X][TM][TP], single buffer
     __shared__ float dbs[BN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -117,6 +117,16 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(ALoad<YK> yl, ALoad<X
         __syncthreads();                    // all waves done with the tile before the next commit overwrites it
     }
     // accumulate the tile: rows n = n_base + wr*64 + 16i + 4g + r, cols k = k_base + wc*64 + 16j + fr
+    if (ws) {                               // workspace path: plain partial tile, summed by tn_reduce_kernel
+        float* pt = ws + ((size_t)slice * tiles + tile) * (BN * BN);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    pt[(wr * 64 + 16 * i + 4 * g + r) * BN + wc * 64 + 16 * j + fr] = acc[i][j][r];
+    } else
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -141,186 +151,86 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(ALoad<YK> yl, ALoad<X
 }
 
 // ------------------------------------------------------------------------------------------------
-// TN "full" kernel: one 8-wave workgroup owns the WHOLE [64*WN x 128*WK] output block (WN*WK = 8: 512x128, 128x512 or
-// 256x256) for its row slice, so dY and X are each read exactly once per slice.  The tiled kernel re-reads one operand
-// once per 128-wide output tile, and those re-reads are real HBM traffic (PMC: 415 MB vs 198 MB algorithmic for the fc1
-// weight gradient).  64 rows per step, both operands as transposed LDS reads; wave (wn, wk) accumulates a 64 x 128
-// sub-block in 128 registers.
+// Second stage of the workspace path: dW[nmap(n)][kmap(k)] += sum over row slices of the partial tiles
+// ws[slice][tile][128][128].  Device-scope float atomics resolve beyond the per-XCD L2s and cost ~5 ns each when 64+
+// workgroups hit the same 64 K addresses (measured: the fc1 gradient went 94 -> 177 us from 64 to 256 slices), so with
+// a workspace the slices write plain coalesced partials and this kernel owns every output element exclusively.
+// block = 256 threads = 64 tile entries x 4 slice groups.
 // ------------------------------------------------------------------------------------------------
-constexpr int FR = 64;                      // rows per step
-constexpr int FTHREADS = 512;
-
-template <int YK, int XK, int WN, int WK>
-__global__ __launch_bounds__(FTHREADS) void gemm_tn_full_kernel(ALoad<YK> yl, ALoad<XK> xl, float* __restrict__ dW,
-                                                                float* __restrict__ db, const int32_t* __restrict__ nmap,
-                                                                const int32_t* __restrict__ kmap, int ldw, int M, int N,
-                                                                int K, int ntk, int rows_per_split) {
-    constexpr int NB = 64 * WN, KB = 128 * WK;           // output block
-    constexpr int YP = NB + 8, XP = KB + 8;              // LDS pitches (elements): +16 B
-    constexpr int YCH = NB / 8, XCH = KB / 8;            // chunks per row
-    constexpr int YPT = FR * YCH / FTHREADS, XPT = FR * XCH / FTHREADS;   // chunks per thread per step
-    constexpr int YRS = FTHREADS / YCH, XRS = FTHREADS / XCH;             // row stride between a thread's chunks
-    __shared__ __attribute__((aligned(16))) uint16_t Ys[FR * YP];
-    __shared__ __attribute__((aligned(16))) uint16_t Xs[FR * XP];
-    __shared__ float dbs[NB];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fr = lane & 15, g = lane >> 4;
-    const int wn = wave % WN, wk = wave / WN;
-    const int tn = blockIdx.x / ntk, tk = blockIdx.x - tn * ntk;
-    const int n_base = tn * NB, k_base = tk * KB;
-    const int m_lo = blockIdx.y * rows_per_split;
-    const int m_hi = min(M, m_lo + rows_per_split);
-    const int steps = (m_hi - m_lo + FR - 1) / FR;
-    if (steps <= 0) return;
-    const bool want_db = (db != nullptr) && (tk == 0);
-    for (int i = tid; i < NB; i += FTHREADS) dbs[i] = 0.f;
-
-    const int ycol = tid % YCH, yr0 = tid / YCH;
-    const int xcol = tid % XCH, xr0 = tid / XCH;
-    typename ALoad<YK>::Raw ry[YPT];
-    typename ALoad<XK>::Raw rx[XPT];
-    int yrow[YPT], xrow[XPT];
-    float colsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    auto resolve = [&](int s) {
-#pragma unroll
-        for (int i = 0; i < YPT; ++i) {
-            const int m = m_lo + s * FR + yr0 + i * YRS;
-            yrow[i] = yl.row_of((s < steps && m < m_hi) ? m : M);
-        }
-#pragma unroll
-        for (int i = 0; i < XPT; ++i) {
-            const int m = m_lo + s * FR + xr0 + i * XRS;
-            xrow[i] = xl.row_of((s < steps && m < m_hi) ? m : M);
-        }
-    };
-    auto issue = [&]() {
-#pragma unroll
-        for (int i = 0; i < YPT; ++i) ry[i] = yl.raw_at(yrow[i], n_base + ycol * 8);
-#pragma unroll
-        for (int i = 0; i < XPT; ++i) rx[i] = xl.raw_at(xrow[i], k_base + xcol * 8);
-    };
-    auto commit = [&]() {
-#pragma unroll
-        for (int i = 0; i < YPT; ++i) {
-            const uint4 yv = yl.cvt(ry[i]);
-            *(uint4*)(Ys + (yr0 + i * YRS) * YP + ycol * 8) = yv;
-            if (want_db) {
-                float v[8];
-                unpack8(yv, v);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) colsum[e] += v[e];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < XPT; ++i) *(uint4*)(Xs + (xr0 + i * XRS) * XP + xcol * 8) = xl.cvt(rx[i]);
-    };
-
-    f32x4 acc[4][8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    resolve(0);
-    issue();
-    resolve(1);
-    for (int s = 0; s < steps; ++s) {
-        commit();
-        __syncthreads();
-        if (s + 1 < steps) { issue(); resolve(s + 2); }
-#pragma unroll
-        for (int kk = 0; kk < FR / 32; ++kk) {
-            const int r0 = 32 * kk + 8 * g + (fr >> 2), cc = (fr & 3) * 4;
-            bf16x8 af[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bf16x4 a0 = lds_tr_read(Ys + r0 * YP + wn * 64 + i * 16 + cc);
-                const bf16x4 a1 = lds_tr_read(Ys + (r0 + 4) * YP + wn * 64 + i * 16 + cc);
-                af[i] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const bf16x4 b0 = lds_tr_read(Xs + r0 * XP + wk * 128 + j * 16 + cc);
-                const bf16x4 b1 = lds_tr_read(Xs + (r0 + 4) * XP + wk * 128 + j * 16 + cc);
-                const bf16x8 bf = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i][j] = mfma32(af[i], bf, acc[i][j]);
-            }
-        }
-        __syncthreads();
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW,
+                                                        const int32_t* __restrict__ nmap, const int32_t* __restrict__ kmap,
+                                                        int ldw, int N, int K, int ntk, int tiles, int slices) {
+    __shared__ float part[4][64];
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63), sg = threadIdx.x >> 6, tile = blockIdx.y;
+    const float* src = ws + (size_t)tile * (BN * BN) + e;
+    const size_t stride = (size_t)tiles * (BN * BN);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int sl = sg;
+    for (; sl + 12 < slices; sl += 16) {
+        s0 += src[(size_t)sl * stride];
+        s1 += src[(size_t)(sl + 4) * stride];
+        s2 += src[(size_t)(sl + 8) * stride];
+        s3 += src[(size_t)(sl + 12) * stride];
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int n = n_base + wn * 64 + 16 * i + 4 * g + r, k = k_base + wk * 128 + 16 * j + fr;
-                if (n >= N || k >= K) continue;
-                if (nmap) n = nmap[n];
-                if (kmap) k = kmap[k];
-                if (n >= 0 && k >= 0) atomicAdd(dW + (long)n * ldw + k, acc[i][j][r]);
-            }
-    if (want_db) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) atomicAdd(&dbs[ycol * 8 + e], colsum[e]);
-        __syncthreads();
-        for (int i = tid; i < NB; i += FTHREADS)
-            if (n_base + i < N) {
-                const int n = nmap ? nmap[n_base + i] : n_base + i;
-                if (n >= 0) atomicAdd(db + n, dbs[i]);
-            }
+    for (; sl < slices; sl += 4) s0 += src[(size_t)sl * stride];
+    part[sg][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sg == 0) {
+        const int tn = tile / ntk, tk = tile - tn * ntk;
+        int n = tn * BN + (e >> 7), k = tk * BN + (e & 127);
+        if (n < N && k < K) {
+            if (nmap) n = nmap[n];
+            if (kmap) k = kmap[k];
+            const int l = threadIdx.x;
+            if (n >= 0 && k >= 0) dW[(long)n * ldw + k] += (part[0][l] + part[1][l]) + (part[2][l] + part[3][l]);
+        }
     }
+}
+
+struct TnPlan { int ntn, ntk, tiles, rows, real_slices, slices; size_t ws_bytes; };
+TnPlan tn_plan(int M, int N, int K, int splits) {
+    TnPlan p;
+    p.ntn = cdiv(N, BN); p.ntk = cdiv(K, BN); p.tiles = p.ntn * p.ntk;
+    const int eff = (p.tiles >= 3) ? splits : splits * 2;         // small outputs: more row slices to fill the chip
+    p.rows = cdiv(cdiv(M, eff), TM) * TM;
+    p.real_slices = cdiv(M, p.rows);
+    p.slices = cdiv(p.real_slices, 8) * 8;                        // padded to a multiple of 8 (empty slices exit at once)
+    p.ws_bytes = (size_t)p.real_slices * p.tiles * BN * BN * sizeof(float);
+    return p;
 }
 
 template <int YK, int XK>
 int launch_tn2(const swv2_operand* y, const swv2_operand* x, float* dW, float* db, const int32_t* nmap,
-               const int32_t* kmap, int ldw, int M, int N, int K, int splits, hipStream_t st) {
-    // splits < 0 selects the "full" kernel (operands read once per slice) with -splits row slices; used for outputs wider
-    // than one 128 x 128 tile.  splits > 0: tiled kernel.
-    if (splits < 0 && (N > 128 || K > 128)) {
-        const int nb = (K <= 128) ? 512 : (N <= 128 ? 128 : 256), kb = 65536 / nb;
-        const int ntn = cdiv(N, nb), ntk = cdiv(K, kb);
-        int rows = cdiv(cdiv(M, -splits), FR) * FR;
-        dim3 grid(ntn * ntk, cdiv(M, rows));
-        if (nb == 512)
-            hipLaunchKernelGGL((gemm_tn_full_kernel<YK, XK, 8, 1>), grid, dim3(FTHREADS), 0, st, make_loader<YK>(y),
-                               make_loader<XK>(x), dW, db, nmap, kmap, ldw, M, N, K, ntk, rows);
-        else if (nb == 128)
-            hipLaunchKernelGGL((gemm_tn_full_kernel<YK, XK, 2, 4>), grid, dim3(FTHREADS), 0, st, make_loader<YK>(y),
-                               make_loader<XK>(x), dW, db, nmap, kmap, ldw, M, N, K, ntk, rows);
-        else
-            hipLaunchKernelGGL((gemm_tn_full_kernel<YK, XK, 4, 2>), grid, dim3(FTHREADS), 0, st, make_loader<YK>(y),
-                               make_loader<XK>(x), dW, db, nmap, kmap, ldw, M, N, K, ntk, rows);
-    } else {
-        if (splits < 0) splits = -splits;
-        const int ntn = cdiv(N, BN), ntk = cdiv(K, BN);
-        const int eff = (ntn * ntk >= 3) ? splits : splits * 2;     // small outputs: more row slices to fill the chip
-        int rows = cdiv(cdiv(M, eff), TM) * TM;
-        const int slices = cdiv(cdiv(M, rows), 8) * 8;              // padded to a multiple of 8 (empty slices exit at once)
-        dim3 grid(ntn * ntk * slices);
-        hipLaunchKernelGGL((gemm_tn_kernel<YK, XK>), grid, dim3(NTHREADS), 0, st, make_loader<YK>(y), make_loader<XK>(x), dW,
-                           db, nmap, kmap, ldw, M, N, K, ntk, rows);
+               const int32_t* kmap, int ldw, int M, int N, int K, int splits, float* ws, size_t ws_bytes, hipStream_t st) {
+    const TnPlan p = tn_plan(M, N, K, splits);
+    if (ws && ws_bytes < p.ws_bytes) {
+        swv2_set_error("swv2_linear_wgrad_ws: workspace of %zu bytes, %zu needed (swv2_linear_wgrad_ws_bytes)", ws_bytes, p.ws_bytes);
+        return SWV2_ERR_INVALID;
     }
+    hipLaunchKernelGGL((gemm_tn_kernel<YK, XK>), dim3(p.tiles * p.slices), dim3(NTHREADS), 0, st, make_loader<YK>(y),
+                       make_loader<XK>(x), dW, db, nmap, kmap, ldw, M, N, K, p.ntk, p.rows, ws);
+    if (ws)
+        hipLaunchKernelGGL(tn_reduce_kernel, dim3(BN * BN / 64, p.tiles), dim3(256), 0, st, ws, dW, nmap, kmap, ldw, N, K, p.ntk,
+                           p.tiles, p.real_slices);
     SWV2_CHECK_LAUNCH("swv2_linear_wgrad");
     return SWV2_OK;
 }
 
 template <int YK>
 int launch_tn1(const swv2_operand* y, const swv2_operand* x, float* dW, float* db, const int32_t* nmap,
-               const int32_t* kmap, int ldw, int M, int N, int K, int splits, hipStream_t st) {
+               const int32_t* kmap, int ldw, int M, int N, int K, int splits, float* ws, size_t wsb, hipStream_t st) {
     // only the (dY, X) operand pairs that occur in the model are instantiated (compile time)
-    if (x->kind == SWV2_OP_F32) return launch_tn2<YK, A_F32>(y, x, dW, db, nmap, kmap, ldw, M, N, K, splits, st);
+    if (x->kind == SWV2_OP_F32) return launch_tn2<YK, A_F32>(y, x, dW, db, nmap, kmap, ldw, M, N, K, splits, ws, wsb, st);
     if constexpr (YK == A_BF16) {
         switch (x->kind) {
-            case SWV2_OP_BF16: return launch_tn2<YK, A_BF16>(y, x, dW, db, nmap, kmap, ldw, M, N, K, splits, st);
-            case SWV2_OP_BF16_GELU: return launch_tn2<YK, A_BF16_GELU>(y, x, dW, db, nmap, kmap, ldw, M, N, K, splits, st);
-            case SWV2_OP_HEADS: return launch_tn2<YK, A_HEADS>(y, x, dW, db, nmap, kmap, ldw, M, N, K, splits, st);
-            case SWV2_OP_PATCH: return launch_tn2<YK, A_PATCH>(y, x, dW, db, nmap, kmap, ldw, M, N, K, splits, st);
+            case SWV2_OP_BF16: return launch_tn2<YK, A_BF16>(y, x, dW, db, nmap, kmap, ldw, M, N, K, splits, ws, wsb, st);
+            case SWV2_OP_BF16_GELU: return launch_tn2<YK, A_BF16_GELU>(y, x, dW, db, nmap, kmap, ldw, M, N, K, splits, ws, wsb, st);
+            case SWV2_OP_HEADS: return launch_tn2<YK, A_HEADS>(y, x, dW, db, nmap, kmap, ldw, M, N, K, splits, ws, wsb, st);
+            case SWV2_OP_PATCH: return launch_tn2<YK, A_PATCH>(y, x, dW, db, nmap, kmap, ldw, M, N, K, splits, ws, wsb, st);
         }
     }
     if constexpr (YK == A_F32) {
-        if (x->kind == SWV2_OP_MERGE_LN) return launch_tn2<YK, A_MERGE_LN>(y, x, dW, db, nmap, kmap, ldw, M, N, K, splits, st);
+        if (x->kind == SWV2_OP_MERGE_LN) return launch_tn2<YK, A_MERGE_LN>(y, x, dW, db, nmap, kmap, ldw, M, N, K, splits, ws, wsb, st);
     }
     swv2_set_error("swv2_linear_wgrad: operand pair (dY kind %d, X kind %d) is not instantiated", y->kind, x->kind);
     return SWV2_ERR_UNSUPPORTED;
@@ -328,22 +238,32 @@ int launch_tn1(const swv2_operand* y, const swv2_operand* x, float* dW, float* d
 
 }  // namespace
 
-extern "C" int swv2_linear_wgrad(const swv2_operand* dy, const swv2_operand* x, float* dW, float* db,
-                                 const int32_t* nmap, const int32_t* kmap, int ldw, int splits, void* stream) {
+extern "C" size_t swv2_linear_wgrad_ws_bytes(int M, int N, int K, int splits) {
+    return (M > 0 && N > 0 && K > 0 && splits > 0) ? tn_plan(M, N, K, splits).ws_bytes : 0;
+}
+
+extern "C" int swv2_linear_wgrad_ws(const swv2_operand* dy, const swv2_operand* x, float* dW, float* db, const int32_t* nmap,
+                                    const int32_t* kmap, int ldw, int splits, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_operand(dy, "swv2_linear_wgrad(dy)");
     if (rc) return rc;
     rc = check_operand(x, "swv2_linear_wgrad(x)");
     if (rc) return rc;
-    SWV2_CHECK_ARG(dW && splits != 0 && ldw > 0, "swv2_linear_wgrad: null dW, bad splits or bad pitch");
+    SWV2_CHECK_ARG(dW && splits > 0 && ldw > 0, "swv2_linear_wgrad: null dW, non-positive splits or bad pitch");
     SWV2_CHECK_ARG(dy->rows == x->rows, "swv2_linear_wgrad: row counts differ (%d vs %d)", dy->rows, x->rows);
     const int M = dy->rows, N = dy->cols, K = x->cols;
     hipStream_t st = (hipStream_t)stream;
+    float* w = (float*)ws;
     switch (dy->kind) {
-        case SWV2_OP_F32: return launch_tn1<A_F32>(dy, x, dW, db, nmap, kmap, ldw, M, N, K, splits, st);
-        case SWV2_OP_BF16: return launch_tn1<A_BF16>(dy, x, dW, db, nmap, kmap, ldw, M, N, K, splits, st);
-        case SWV2_OP_HEADS: return launch_tn1<A_HEADS>(dy, x, dW, db, nmap, kmap, ldw, M, N, K, splits, st);
-        case SWV2_OP_PATCH: return launch_tn1<A_PATCH>(dy, x, dW, db, nmap, kmap, ldw, M, N, K, splits, st);
+        case SWV2_OP_F32: return launch_tn1<A_F32>(dy, x, dW, db, nmap, kmap, ldw, M, N, K, splits, w, ws_bytes, st);
+        case SWV2_OP_BF16: return launch_tn1<A_BF16>(dy, x, dW, db, nmap, kmap, ldw, M, N, K, splits, w, ws_bytes, st);
+        case SWV2_OP_HEADS: return launch_tn1<A_HEADS>(dy, x, dW, db, nmap, kmap, ldw, M, N, K, splits, w, ws_bytes, st);
+        case SWV2_OP_PATCH: return launch_tn1<A_PATCH>(dy, x, dW, db, nmap, kmap, ldw, M, N, K, splits, w, ws_bytes, st);
     }
     swv2_set_error("swv2_linear_wgrad: unsupported dY operand kind %d", dy->kind);
     return SWV2_ERR_INVALID;
+}
+
+extern "C" int swv2_linear_wgrad(const swv2_operand* dy, const swv2_operand* x, float* dW, float* db, const int32_t* nmap,
+                                 const int32_t* kmap, int ldw, int splits, void* stream) {
+    return swv2_linear_wgrad_ws(dy, x, dW, db, nmap, kmap, ldw, splits, nullptr, 0, stream);
 }

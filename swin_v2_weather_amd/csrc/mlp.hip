@@ -1,0 +1,251 @@
+// Fused MLP branch of a SwinV2 block, forward (reference swinv2_global.py:492-496 with timm Mlp :381-386):
+//     x2 = x1 + drop_path2 * LayerNorm2( fc2( GELU( fc1(x1) ) ) )
+// as ONE kernel.  The unfused sequence (fc1 GEMM, fc2 GEMM, LN kernel) moves 660 MB per block at the benchmark shape
+// (the [M][hidden] activation is written twice and read once, the fc2 output and x1 are re-read by the LN kernel); here
+// the hidden activation never leaves the registers and HBM sees x1 once in, and (x2, the saved pre-activation, the saved
+// fc2 output, mean / rstd) out: 300 MB.
+//
+// Chained-MFMA layout trick (no LDS round trip for the hidden activation): both products are computed TRANSPOSED,
+//     H^T[hid][m] = W1[hid][c] X^T[c][m]      A = W1 rows (LDS),  B = X rows (registers, loaded once per wave)
+//     Y^T[n][m]   = W2[n][hid] H^T[hid][m]    A = W2 rows (LDS),  B = GELU(H^T) straight from the accumulators:
+// the 16x16 C tile of a wave64 MFMA holds (row 4g+r, col l&15) in lane l, which is exactly the B-operand layout
+// (k = 4g+j, n = l&15) of the next product; two C tiles (32 hidden units) make one K=32 operand, with the matching
+// k-permutation applied to the W2 fragment reads.
+// A wave owns 16*MT rows for the whole kernel (X fragments + Y^T accumulators stay in registers); the weights stream
+// through LDS in chunks of 32 hidden units (W1[32][C] and W2[C][32], double buffered), shared by the 4 waves.
+#include <cstdlib>
+#include "gemm_common.h"
+
+namespace {
+
+constexpr int MLP_MAX_HIDDEN = 2048;
+
+struct MlpFwd {
+    const float* x; const uint16_t* w1; const float* b1; const uint16_t* w2; const float* b2;
+    const float* gamma; const float* beta; const float* scale;
+    uint16_t* hpre; uint16_t* a2; float* mean; float* rstd; float* y;
+    int M, hidden, rows_per_sample; float eps;
+};
+
+template <int C, int MT>
+__global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpFwd a) {
+    constexpr int KS = C / 32, NT = C / 16;
+    constexpr int P1 = C + 8, P2 = 40;                 // LDS row pitches (elements) of the W1 / W2 chunks
+    constexpr int W1E = 32 * P1, W2E = C * P2;
+    constexpr int NCHUNK = 4 * C;                      // 16-byte pieces of either weight chunk
+    constexpr int SPT = (NCHUNK + 255) / 256;
+    constexpr int ROWS = 64 * MT;                      // rows per workgroup
+    constexpr int PX = C + 8;                          // pitch (bf16) of the staged x tile
+    constexpr int PY = C + 4, PA = C + 8;              // pitches of the per-wave epilogue tiles (fp32 / bf16)
+    constexpr int WBYTES = 2 * (W1E + W2E) * 2, XBYTES = ROWS * PX * 2, EBYTES = 4 * 16 * (PY * 4 + PA * 2);
+    constexpr int SBYTES = WBYTES > XBYTES ? (WBYTES > EBYTES ? WBYTES : EBYTES) : (XBYTES > EBYTES ? XBYTES : EBYTES);
+    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SBYTES];
+    // fc1 bias in LDS: a global load inside the chunk loop would make its s_waitcnt drain the (older, in-order) weight
+    // prefetch of the next chunk as well
+    __shared__ __attribute__((aligned(16))) float b1s[MLP_MAX_HIDDEN];
+    uint16_t* smem = (uint16_t*)smem_raw;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4;
+    const int wg_row0 = blockIdx.x * ROWS;
+    const int row0 = wg_row0 + wave * (16 * MT);
+    const int hid = a.hidden, nch = hid / 32;
+
+    // weight-chunk staging (global/L2 -> registers -> LDS), one chunk ahead of the MFMAs
+    u32x4 s1[SPT], s2[SPT];
+    auto issue = [&](int ch) {
+#pragma unroll
+        for (int i = 0; i < SPT; ++i) {
+            const int idx = min(tid + 256 * i, NCHUNK - 1);      // unconditional loads keep the staging in registers
+            s1[i] = *(const u32x4*)(a.w1 + (size_t)(32 * ch + idx / (C / 8)) * C + 8 * (idx % (C / 8)));
+            s2[i] = *(const u32x4*)(a.w2 + (size_t)(idx >> 2) * hid + 32 * ch + 8 * (idx & 3));
+        }
+    };
+    auto commit = [&](int buf) {
+        uint16_t* W1s = smem + buf * (W1E + W2E);
+        uint16_t* W2s = W1s + W1E;
+#pragma unroll
+        for (int i = 0; i < SPT; ++i) {
+            const int idx = tid + 256 * i;
+            if (NCHUNK % 256 == 0 || idx < NCHUNK) {
+                *(u32x4*)(W1s + (idx / (C / 8)) * P1 + 8 * (idx % (C / 8))) = s1[i];
+                *(u32x4*)(W2s + (idx >> 2) * P2 + 8 * (idx & 3)) = s2[i];
+            }
+        }
+    };
+    issue(0);
+    for (int i = tid; i < hid; i += 256) b1s[i] = a.b1[i];
+
+    // x tile -> LDS as bf16 with coalesced 16-byte loads (a lane-per-row fragment load would touch 64 lines per
+    // instruction), then each wave picks up its B fragments: lane (m = fr, g) holds c = 32 ks + 8 g .. + 7
+    {
+        constexpr int UNITS = ROWS * (C / 4);             // f32x4 units of the tile
+#pragma unroll
+        for (int i = 0; i < UNITS / 256; ++i) {
+            const int u = tid + 256 * i, row = u / (C / 4), c4 = u % (C / 4);
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (wg_row0 + row < a.M) v = *(const f32x4*)(a.x + (size_t)(wg_row0 + row) * C + 4 * c4);
+            *(bf16x4*)(smem + row * PX + 4 * c4) = f2bf4(v);
+        }
+    }
+    __syncthreads();
+    bf16x8 xf[MT][KS];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            xf[mt][ks] = *(const bf16x8*)(smem + (wave * 16 * MT + 16 * mt + fr) * PX + 32 * ks + 8 * g);
+    __syncthreads();
+
+    f32x4 yacc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) yacc[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    commit(0);
+    __syncthreads();
+    for (int ch = 0; ch < nch; ++ch) {
+        if (ch + 1 < nch) issue(ch + 1);
+        const uint16_t* W1s = smem + (ch & 1) * (W1E + W2E);
+        const uint16_t* W2s = W1s + W1E;
+        // ---- H^T chunk (32 hidden x 16 MT rows), bias, bf16 round (saved), GELU -> B operand of the second product
+        bf16x4 hb[MT][2];
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht) {
+            const f32x4 bias = *(const f32x4*)(b1s + 32 * ch + 16 * ht + 4 * g);
+            f32x4 hacc[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) hacc[mt] = bias;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 wf = *(const bf16x8*)(W1s + (16 * ht + fr) * P1 + 32 * ks + 8 * g);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) hacc[mt] = mfma32(wf, xf[mt][ks], hacc[mt]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const bf16x4 hr = f2bf4(hacc[mt]);                 // the pre-activation as the backward will read it
+                const int r = row0 + 16 * mt + fr;
+                if (r < a.M) *(bf16x4*)(a.hpre + (size_t)r * hid + 32 * ch + 16 * ht + 4 * g) = hr;
+                f32x4 act;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) act[e] = gelu_f(bf2f(hr[e]));
+                hb[mt][ht] = f2bf4(act);
+            }
+        }
+        // ---- Y^T += W2[:, chunk] GELU(H^T chunk)
+        bf16x8 hop[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) hop[mt] = __builtin_shufflevector(hb[mt][0], hb[mt][1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const bf16x4 lo = *(const bf16x4*)(W2s + (16 * t + fr) * P2 + 4 * g);
+            const bf16x4 hi = *(const bf16x4*)(W2s + (16 * t + fr) * P2 + 16 + 4 * g);
+            const bf16x8 wf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) yacc[mt][t] = mfma32(wf, hop[mt], yacc[mt][t]);
+        }
+        if (ch + 1 < nch) commit((ch + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: + b2, bf16 round (saved fc2 output), LayerNorm over the row, drop-path scale -- in the accumulator
+    // layout (lane (m = fr, g) holds n = 16 t + 4 g + r; a row is spread over the 4 lanes with equal fr) -- then through
+    // a per-wave LDS tile so that the residual read and the stores are whole rows (512 B) per instruction
+    float* Ys = (float*)(smem_raw + wave * 16 * (PY * 4 + PA * 2));
+    uint16_t* As = (uint16_t*)(Ys + 16 * PY);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int r = row0 + 16 * mt + fr;
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const f32x4 b2v = *(const f32x4*)(a.b2 + 16 * t + 4 * g);
+            const bf16x4 ar = f2bf4(yacc[mt][t] + b2v);
+            *(bf16x4*)(As + fr * PA + 16 * t + 4 * g) = ar;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { yacc[mt][t][e] = bf2f(ar[e]); s += yacc[mt][t][e]; }
+        }
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        const float mu = s * (1.f / C);
+        float q = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = yacc[mt][t][e] - mu; q = fmaf(d, d, q); }
+        q += __shfl_xor(q, 16);
+        q += __shfl_xor(q, 32);
+        const float rs = rsqrtf(q * (1.f / C) + a.eps);
+        const bool ok = r < a.M;
+        if (ok && g == 0) { a.mean[r] = mu; a.rstd[r] = rs; }
+        const float sc = (a.scale && ok) ? a.scale[r / a.rows_per_sample] : 1.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int n = 16 * t + 4 * g;
+            const f32x4 gm = *(const f32x4*)(a.gamma + n), bt = *(const f32x4*)(a.beta + n);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = sc * ((yacc[mt][t][e] - mu) * rs * gm[e] + bt[e]);
+            *(f32x4*)(Ys + fr * PY + n) = o;
+        }
+        __syncthreads();
+        const int rbase = row0 + 16 * mt;
+#pragma unroll
+        for (int p = 0; p < 16 * (C / 4) / 64; ++p) {              // fp32 rows: residual + store
+            const int u = lane + 64 * p, row = u / (C / 4), c4 = u % (C / 4);
+            if (rbase + row < a.M) {
+                const size_t off = (size_t)(rbase + row) * C + 4 * c4;
+                *(f32x4*)(a.y + off) = *(const f32x4*)(a.x + off) + *(const f32x4*)(Ys + row * PY + 4 * c4);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < (16 * (C / 8) + 63) / 64; ++p) {       // bf16 rows of the saved fc2 output
+            const int u = lane + 64 * p, row = u / (C / 8), c8 = u % (C / 8);
+            if (u < 16 * (C / 8) && rbase + row < a.M)
+                *(u32x4*)(a.a2 + (size_t)(rbase + row) * C + 8 * c8) = *(const u32x4*)(As + row * PA + 8 * c8);
+        }
+        if (mt + 1 < MT) __syncthreads();
+    }
+}
+
+template <int C, int MT>
+void launch_mlp_fwd(const MlpFwd& k, hipStream_t st) {
+    hipLaunchKernelGGL((mlp_fwd_kernel<C, MT>), dim3(cdiv(k.M, 64 * MT)), dim3(256), 0, st, k);
+}
+
+}  // namespace
+
+extern "C" int swv2_mlp_supported(int C, int hidden) {
+    return (C == 32 || C == 64 || C == 96 || C == 128 || C == 192 || C == 256) && hidden > 0 && hidden % 32 == 0 && hidden <= MLP_MAX_HIDDEN;
+}
+
+extern "C" int swv2_mlp_fwd(const swv2_mlp_args* a, void* stream) {
+    SWV2_CHECK_ARG(a && a->x && a->w1 && a->b1 && a->w2 && a->b2 && a->gamma && a->beta && a->hpre && a->a2 && a->mean &&
+                       a->rstd && a->y, "swv2_mlp_fwd: null pointer");
+    SWV2_CHECK_ARG(a->M > 0 && a->rows_per_sample > 0, "swv2_mlp_fwd: M and rows_per_sample must be positive");
+    if (!swv2_mlp_supported(a->C, a->hidden)) {
+        swv2_set_error("swv2_mlp_fwd: C=%d hidden=%d not instantiated (C in {32,64,96,128,192,256}, hidden %% 32 == 0); "
+                       "use swv2_linear + swv2_ln_residual_fwd", a->C, a->hidden);
+        return SWV2_ERR_UNSUPPORTED;
+    }
+    MlpFwd k = {a->x, (const uint16_t*)a->w1, a->b1, (const uint16_t*)a->w2, a->b2, a->gamma, a->beta, a->scale,
+                (uint16_t*)a->hpre, (uint16_t*)a->a2, a->mean, a->rstd, a->y, a->M, a->hidden, a->rows_per_sample, a->eps};
+    hipStream_t st = (hipStream_t)stream;
+    // rows per workgroup (64 * MT): the kernel is issue-bound, so what matters is how evenly the row tiles fill the
+    // resident-workgroup slots (3 per CU at MT = 1, 2 at MT = 2): time ~ ceil(tiles / slots) * MT
+    static const int force_mt = getenv("SWV2_MLP_MT") ? atoi(getenv("SWV2_MLP_MT")) : 0;
+    const long t1 = cdiv(cdiv(a->M, 64), 256 * 3), t2 = 2L * cdiv(cdiv(a->M, 128), 256 * 2);
+    const bool mt2 = force_mt ? force_mt == 2 : t2 < t1;
+    switch (a->C) {
+        case 32: mt2 ? launch_mlp_fwd<32, 2>(k, st) : launch_mlp_fwd<32, 1>(k, st); break;
+        case 64: mt2 ? launch_mlp_fwd<64, 2>(k, st) : launch_mlp_fwd<64, 1>(k, st); break;
+        case 96: mt2 ? launch_mlp_fwd<96, 2>(k, st) : launch_mlp_fwd<96, 1>(k, st); break;
+        case 128: mt2 ? launch_mlp_fwd<128, 2>(k, st) : launch_mlp_fwd<128, 1>(k, st); break;
+        case 192: launch_mlp_fwd<192, 1>(k, st); break;
+        case 256: launch_mlp_fwd<256, 1>(k, st); break;
+    }
+    SWV2_CHECK_LAUNCH("swv2_mlp_fwd");
+    return SWV2_OK;
+}

@@ -115,7 +115,7 @@ class _BlockRunner:
     """Per (block, batch size, device) launch descriptor: geometry, index tables and buffer offsets are filled once."""
 
     ACTS = ("qkvh", "rnorm", "oh", "lse", "a1", "mean1", "rstd1", "x1", "hpre", "hact", "a2", "mean2", "rstd2")
-    SCRATCH = ("da2", "dh", "da1", "doh", "dqkvh", "dx1", "ln_ws")
+    SCRATCH = ("da2", "dh", "da1", "doh", "dqkvh", "dx1", "ln_ws", "wgrad_ws")
 
     def __init__(self, blk, plan, Cc, hid, device):
         self.plan, self.C, self.hid, self.device = plan, Cc, hid, device
@@ -125,14 +125,20 @@ class _BlockRunner:
         d.B, d.T, d.C, d.heads, d.head_dim, d.hidden = B, T, Cc, h, plan.d, hid
         d.L, d.Lp, d.DP, d.nwh, d.nww, d.mask_thr = Lw, Lp, DP, plan.nwh, plan.nww, plan.mask_thr
         d.rowidx, d.qkv_map, d.proj_map = plan.rowidx.data_ptr(), plan.qkv_map.data_ptr(), plan.proj_map.data_ptr()
-        d.wgrad_splits = 64
+        d.wgrad_splits = int(os.environ.get("SWV2_WGRAD_SPLITS", "128"))
+        lib = L.load()
+        ws_bytes = max(lib.swv2_linear_wgrad_ws_bytes(m, n_, k, d.wgrad_splits)
+                       for m, n_, k in ((BT, Cc, hid), (BT, hid, Cc), (Mw, Cc, h * DP), (Mw, 3 * h * DP, Cc)))
+        d.wgrad_ws_bytes = ws_bytes
         d.wgrad_side_stream = int(os.environ.get("SWV2_WGRAD_SIDE_STREAM", "1"))
+        d.fuse_mlp = int(os.environ.get("SWV2_FUSE_MLP", "1"))
+        fused = bool(d.fuse_mlp) and bool(L.load().swv2_mlp_supported(Cc, hid))
         self.desc = d
         act_sizes = [Bw * h * 3 * Lp * DP * 2, Bw * h * 2 * Lp * 4, Bw * h * Lp * DP * 2, Bw * h * Lp * 4, Mw * Cc * 2, Mw * 4,
-                     Mw * 4, BT * Cc * 4, BT * hid * 2, BT * hid * 2, BT * Cc * 2, BT * 4, BT * 4]
+                     Mw * 4, BT * Cc * 4, BT * hid * 2, 0 if fused else BT * hid * 2, BT * Cc * 2, BT * 4, BT * 4]
         self.act_off, self.act_bytes = _carve(act_sizes)
         scr_sizes = [BT * Cc * 2, BT * hid * 2, Mw * Cc * 2, Bw * h * Lp * DP * 2, Bw * h * 3 * Lp * DP * 2, BT * Cc * 4,
-                     L.LN_BWD_MAX_BLOCKS * 2 * Cc * 4]
+                     L.LN_BWD_MAX_BLOCKS * 2 * Cc * 4, ws_bytes]
         self.scr_off, self.scr_bytes = _carve(scr_sizes)
         self.grad_shapes = [(h,), (3 * Cc, Cc), (3 * Cc,), (Cc, Cc), (Cc,), (Cc,), (Cc,), (hid, Cc), (hid,), (Cc, hid), (Cc,),
                             (Cc,), (Cc,)]

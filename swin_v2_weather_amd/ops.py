@@ -143,11 +143,20 @@ def linear(a: L.Operand, w_bf16: torch.Tensor, e: L.Epilogue, N: int, tag: str =
 
 
 def linear_wgrad(dy: L.Operand, x: L.Operand, dW: torch.Tensor, db: Optional[torch.Tensor], nmap=None, kmap=None,
-                 splits: int = 64):
+                 splits: int = 128, workspace: bool = True):
+    """dW += dY^T X.  workspace=True: per-slice partial tiles + reduce kernel (deterministic, no atomics on dW), the
+    partials live in a torch allocation that is released (stream-ordered) after the call; False: fp32 atomics on dW."""
     _chk(dW, torch.float32, "dW")
     ldw = dW.shape[-1] if dW.dim() == 2 else dW[0].numel()
-    L.check(L.load().swv2_linear_wgrad(C.byref(dy), C.byref(x), _p(dW), _p(db), _p(nmap), _p(kmap), ldw, splits,
-                                       _stream()), "swv2_linear_wgrad")
+    lib = L.load()
+    if not workspace:
+        L.check(lib.swv2_linear_wgrad(C.byref(dy), C.byref(x), _p(dW), _p(db), _p(nmap), _p(kmap), ldw, splits, _stream()),
+                "swv2_linear_wgrad")
+        return
+    nbytes = lib.swv2_linear_wgrad_ws_bytes(dy.rows, dy.cols, x.cols, splits)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dW.device)
+    L.check(lib.swv2_linear_wgrad_ws(C.byref(dy), C.byref(x), _p(dW), _p(db), _p(nmap), _p(kmap), ldw, splits, _p(ws), nbytes,
+                                     _stream()), "swv2_linear_wgrad_ws")
 
 
 def prep_weight(w: torch.Tensor, transpose=False, row_map=None, out_rows=None, col_map=None, out_cols=None):
@@ -229,6 +238,24 @@ def loss_grad(prd, tar, qw, coef, dprd):
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_inv_scale=1.0):
     L.check(L.load().swv2_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, step, grad_inv_scale,
                                     _stream()), "swv2_adam_step")
+
+
+def mlp_fwd(x, w1, b1, w2, b2, gamma, beta, scale, rows_per_sample, eps=1e-5):
+    """Fused fc1 -> GELU -> fc2 -> LayerNorm -> drop-path -> +x.  Returns (y, hpre, a2, mean, rstd)."""
+    M, Cc = x.shape
+    hid = w1.shape[0]
+    _chk(x, torch.float32, "mlp x"); _chk(w1, BF16, "mlp w1"); _chk(w2, BF16, "mlp w2")
+    dev = x.device
+    y = torch.empty(M, Cc, dtype=torch.float32, device=dev)
+    hpre = torch.empty(M, hid, dtype=BF16, device=dev)
+    a2 = torch.empty(M, Cc, dtype=BF16, device=dev)
+    mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    a = L.MlpArgs()
+    a.x, a.w1, a.b1, a.w2, a.b2, a.gamma, a.beta, a.scale = (_p(t) for t in (x, w1, b1, w2, b2, gamma, beta, scale))
+    a.hpre, a.a2, a.mean, a.rstd, a.y = (_p(t) for t in (hpre, a2, mean, rstd, y))
+    a.M, a.C, a.hidden, a.rows_per_sample, a.eps = M, Cc, hid, rows_per_sample, eps
+    L.check(_timed("mlp_fwd", L.load().swv2_mlp_fwd, C.byref(a), _stream()), "swv2_mlp_fwd")
+    return y, hpre, a2, mean, rstd
 
 
 def cpb_fwd(w1, b1, w2, b2, keep, bias, wh, ww, heads, hidden, drop_p):

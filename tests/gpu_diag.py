@@ -187,7 +187,7 @@ def t_linear():
     # weight gradient
     dW = torch.zeros(Nn, K, device=dev)
     db = torch.zeros(Nn, device=dev)
-    ops.linear_wgrad(ops.op_bf16(dy.to(BF).to(dev)), ops.op_bf16(hpre.to(BF).to(dev)), dW, db, splits=7)
+    ops.linear_wgrad(ops.op_bf16(dy.to(BF).to(dev)), ops.op_bf16(hpre.to(BF).to(dev)), dW, db, splits=7, workspace=False)
     say(f"wgrad bf16xbf16 M={M}: dW rel {rel(dW, rb(dy).T @ rb(hpre)):.3e} db rel {rel(db, rb(dy).sum(0)):.3e}")
     dW = torch.zeros(Nn, K, device=dev)
     ops.linear_wgrad(ops.op_bf16(dy.to(BF).to(dev)), ops.op_bf16(hpre.to(BF).to(dev), gelu=True), dW, None, splits=3)

@@ -80,18 +80,21 @@ def probe_gemm(B=2):
     say(f"linear gelu(bf16[{M},512]) -> bf16 N=128: {t:.1f} us")
     dW = torch.zeros(512, Cc, device=dev)
     db = torch.zeros(512, device=dev)
-    for splits in (64, 128, -64, -128, -256):
-        t = timeit(lambda: ops.linear_wgrad(ops.op_bf16(hb), ops.op_f32(x), dW, db, splits=splits))
-        say(f"wgrad dY bf16[{M},512] x X f32[{M},128] splits={splits}: {t:.1f} us")
+    for splits in (64, 128, 256, 512):
+      for wsp in (False, True):
+        t = timeit(lambda: ops.linear_wgrad(ops.op_bf16(hb), ops.op_f32(x), dW, db, splits=splits, workspace=wsp))
+        say(f"wgrad dY bf16[{M},512] x X f32[{M},128] splits={splits} ws={wsp}: {t:.1f} us ({M * (1024 + 512) / t / 1e3:.0f} GB/s)")
     da2 = torch.randn(M, Cc, device=dev).to(BF)
     dW2 = torch.zeros(Cc, 512, device=dev)
-    for splits in (64, -64, -128, -256):
-        t = timeit(lambda: ops.linear_wgrad(ops.op_bf16(da2), ops.op_bf16(hb), dW2, None, splits=splits))
-        say(f"wgrad dY bf16[{M},128] x X bf16[{M},512] splits={splits}: {t:.1f} us")
-    for splits in (64, 128, 256):
+    for splits in (64, 128, 256, 512):
+      for wsp in (False, True):
+        t = timeit(lambda: ops.linear_wgrad(ops.op_bf16(da2), ops.op_bf16(hb), dW2, None, splits=splits, workspace=wsp))
+        say(f"wgrad dY bf16[{M},128] x X bf16[{M},512] splits={splits} ws={wsp}: {t:.1f} us ({M * (1024 + 256) / t / 1e3:.0f} GB/s)")
+    for splits in (64, 128, 256, 512):
+      for wsp in (False, True):
         dWp = torch.zeros(Cc, Cc, device=dev)
-        t = timeit(lambda: ops.linear_wgrad(ops.op_bf16(da2), ops.op_bf16(xb), dWp, None, splits=splits))
-        say(f"wgrad dY bf16[{M},128] x X bf16[{M},128] splits={splits}: {t:.1f} us")
+        t = timeit(lambda: ops.linear_wgrad(ops.op_bf16(da2), ops.op_bf16(xb), dWp, None, splits=splits, workspace=wsp))
+        say(f"wgrad dY bf16[{M},128] x X bf16[{M},128] splits={splits} ws={wsp}: {t:.1f} us ({M * 512 / t / 1e3:.0f} GB/s)")
     a = xb
     y = torch.empty(M, Cc, device=dev)
     mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
@@ -104,7 +107,27 @@ def probe_gemm(B=2):
     say(f"ln_residual_bwd: {t:.1f} us ({M * Cc * (2 + 4 + 2) / t / 1e3:.0f} GB/s)")
 
 
+def probe_mlp(B=2):
+    import ctypes
+    T, Cc, hid = 64800, 128, 512
+    M = B * T
+    x = torch.randn(M, Cc, device=dev)
+    w1, w2 = ops.prep_weight(torch.randn(hid, Cc, device=dev) * 0.1), ops.prep_weight(torch.randn(Cc, hid, device=dev) * 0.1)
+    b1, b2, g, bt = torch.zeros(hid, device=dev), torch.zeros(Cc, device=dev), torch.ones(Cc, device=dev), torch.zeros(Cc, device=dev)
+    y, hpre, a2 = torch.empty(M, Cc, device=dev), torch.empty(M, hid, dtype=BF, device=dev), torch.empty(M, Cc, dtype=BF, device=dev)
+    mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    a = L.MlpArgs()
+    a.x, a.w1, a.b1, a.w2, a.b2, a.gamma, a.beta = (t.data_ptr() for t in (x, w1, b1, w2, b2, g, bt))
+    a.hpre, a.a2, a.mean, a.rstd, a.y = (t.data_ptr() for t in (hpre, a2, mean, rstd, y))
+    a.M, a.C, a.hidden, a.rows_per_sample, a.eps = M, Cc, hid, T, 1e-5
+    fn, st = L.load().swv2_mlp_fwd, torch.cuda.current_stream().cuda_stream
+    t = timeit(lambda: fn(ctypes.byref(a), st), n=20)
+    say(f"mlp_fwd M={M}: {t:.1f} us ({M * (Cc * 4 * 2 + hid * 2 + Cc * 2) / t / 1e3:.0f} GB/s)")
+
+
 if __name__ == "__main__":
+    if "mlp" in (sys.argv[1] if len(sys.argv) > 1 else ""):
+        probe_mlp(2)
     flt = sys.argv[1] if len(sys.argv) > 1 else ""
     if "attn" in flt or not flt:
         probe_attn(2, False)

@@ -7,6 +7,7 @@ accumulation and stores inter-kernel activations as bf16, like the reference und
   * against the fp32 golden vectors of the real reference: the stated bf16 tolerance of the north star.
 """
 import json
+import ctypes
 import os
 
 import numpy as np
@@ -122,9 +123,22 @@ def test_gelu_paths_and_weight_gradients(dev, K):
     O.gelu_erf(hp).backward((rb(dy) @ rb(w)).double())
     assert rel(dh.float(), hp.grad) < 4e-3
     for splits in (1, 7, 64):
-        dW, db = torch.zeros(Nn, Kd, device=dev), torch.zeros(Nn, device=dev)
-        ops.linear_wgrad(ops.op_bf16(dy.to(BF).to(dev)), ops.op_bf16(hpre.to(BF).to(dev)), dW, db, splits=splits)
-        assert rel(dW, rb(dy).T @ rb(hpre)) < 1e-5 and rel(db, rb(dy).sum(0)) < 1e-5
+        for workspace in (False, True):          # fp32 atomics on dW / per-slice partial tiles + reduce kernel
+            dW, db = torch.ones(Nn, Kd, device=dev), torch.zeros(Nn, device=dev)       # dW is accumulated into
+            ops.linear_wgrad(ops.op_bf16(dy.to(BF).to(dev)), ops.op_bf16(hpre.to(BF).to(dev)), dW, db, splits=splits,
+                             workspace=workspace)
+            assert rel(dW - 1.0, rb(dy).T @ rb(hpre)) < 1e-5 and rel(db, rb(dy).sum(0)) < 1e-5
+    # the workspace path is deterministic (no atomics on dW): two runs agree bit for bit
+    outs = []
+    for _ in range(2):
+        dW = torch.zeros(Nn, Kd, device=dev)
+        ops.linear_wgrad(ops.op_bf16(dy.to(BF).to(dev)), ops.op_bf16(hpre.to(BF).to(dev)), dW, None, splits=16)
+        outs.append(dW.clone())
+    assert torch.equal(outs[0], outs[1])
+    with pytest.raises(L.Swv2Error):             # undersized workspace is refused, not overrun
+        dyo, xo = ops.op_bf16(dy.to(BF).to(dev)), ops.op_bf16(hpre.to(BF).to(dev))
+        L.check(L.load().swv2_linear_wgrad_ws(ctypes.byref(dyo), ctypes.byref(xo), dW.data_ptr(), None, None, None, Kd, 8,
+                                              dW.data_ptr(), 16, None), "swv2_linear_wgrad_ws")
 
 
 def test_patch_embed_conv_and_unpatchify(dev, K):
@@ -600,3 +614,66 @@ def test_cpb_kernels_match_oracle(dev, K, wh, ww, heads, hidden, train):
                 heads, hidden, 0.125)
     for gk, k in zip(gs, ("a.meta_mlp.fc1.weight", "a.meta_mlp.fc1.bias", "a.meta_mlp.fc2.weight", "a.meta_mlp.fc2.bias")):
         assert rel(gk, p[k].grad) < 2e-5, k
+
+
+@pytest.mark.parametrize("M,Cc,hid,T", [(300, 128, 512, 100), (77, 32, 128, 77), (130, 96, 384, 65), (50, 192, 96, 25), (64, 256, 64, 64),
+                                         (129, 64, 32, 43)])
+def test_fused_mlp_forward_matches_oracle(dev, K, M, Cc, hid, T):
+    """swv2_mlp_fwd = fc1 + GELU + fc2 + LayerNorm + drop-path + residual in one kernel (swinv2_global.py:492-496): against
+    the oracle with the kernel's rounding points (bf16 operands, bf16 pre-activation / GELU / fc2 output)."""
+    ops, L = K["ops"], K["L"]
+    g = torch.Generator().manual_seed(M + Cc)
+    x = torch.randn(M, Cc, generator=g)
+    w1, b1 = torch.randn(hid, Cc, generator=g) * 0.2, torch.randn(hid, generator=g) * 0.1
+    w2, b2 = torch.randn(Cc, hid, generator=g) * 0.2, torch.randn(Cc, generator=g) * 0.1
+    gm, bt = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.1
+    sc = torch.tensor([0.0, 1.25, 1.0, 1.25][: (M + T - 1) // T])
+    y, hpre, a2, mean, rstd = ops.mlp_fwd(x.to(dev), ops.prep_weight(w1.to(dev)), b1.to(dev), ops.prep_weight(w2.to(dev)), b2.to(dev),
+                                          gm.to(dev), bt.to(dev), sc.to(dev), T)
+    pre = rb(rb(x) @ rb(w1).T + b1)
+    act = rb(O.gelu_erf(pre))
+    a2r = rb(act @ rb(w2).T + b2)
+    ln = O.layer_norm(a2r, gm, bt)
+    ref = x + sc[torch.arange(M) // T].view(-1, 1) * ln
+    assert rel(hpre.float(), pre) < 3e-3 and rel(a2.float(), a2r) < 4e-3
+    assert rel(mean, a2r.mean(-1)) < 4e-3 and rel(rstd, torch.rsqrt(a2r.var(-1, unbiased=False) + 1e-5)) < 4e-3
+    assert rel(y, ref) < 3e-3
+    # the unfused sequence (same rounding points) agrees to accumulation-order noise
+    pre2 = torch.empty(M, hid, dtype=BF, device=dev)
+    act2 = torch.empty(M, hid, dtype=BF, device=dev)
+    ops.linear(ops.op_f32(x.to(dev)), ops.prep_weight(w1.to(dev)), ops.epilogue(L.EPI_BF16_GELU, pre2, ld=hid, bias=b1.to(dev), aux_out=act2), hid)
+    assert rel(hpre.float(), pre2.float()) < 1e-3
+    if not L.load().swv2_mlp_supported(Cc + 8, hid):
+        a = L.MlpArgs()
+        for f in ("x", "w1", "b1", "w2", "b2", "gamma", "beta", "hpre", "a2", "mean", "rstd", "y"):
+            setattr(a, f, y.data_ptr())
+        a.M, a.C, a.hidden, a.rows_per_sample = 8, Cc + 8, hid, 8
+        assert L.load().swv2_mlp_fwd(ctypes.byref(a), None) != 0          # unsupported shape is refused, never mis-run
+
+
+@pytest.mark.parametrize("fuse", ["0", "1"])
+def test_block_fused_and_unfused_mlp_paths(dev, K, monkeypatch, fuse):
+    """Both forward paths of the MLP branch (SWV2_FUSE_MLP = 1: swv2_mlp_fwd, hact recomputed on load in the backward;
+    0: three launches) against the bf16-emulating oracle on a reference block fixture, forward and backward."""
+    monkeypatch.setenv("SWV2_FUSE_MLP", fuse)
+    N = K["N"]
+    fx = np.load(os.path.join(GOLD, "block_nopos_shift_3x3_eval.npz"))
+    gh, gw, wh, ww, sh, sw, Cc, h, B, seed, rng_seed, train = [int(v) for v in fx["meta"]]
+    blk = N.SwinTransformerV2CrBlock(dim=Cc, num_heads=h, feat_size=(gh, gw), window_size=(wh, ww), shift_size=(sh, sw),
+                                     rel_pos=False, drop_path=0.0)
+    load_params(blk, fx)
+    blk = blk.to(dev).eval()
+    x = torch.from_numpy(fx["x"]).to(dev).requires_grad_(True)
+    y = blk(x)
+    y.backward(torch.from_numpy(fx["gy"]).to(dev))
+    assert blk._runner(B, x.device).desc.fuse_mlp == int(fuse)
+    p = {"b." + k[2:]: torch.from_numpy(fx[k]).clone().requires_grad_(True) for k in fx.files if k.startswith("p:")}
+    xo = torch.from_numpy(fx["x"]).clone().requires_grad_(True)
+    O.set_rounding(O.bf16_round)
+    try:
+        yo = O.block_forward(xo, p, "b.", block_cfg(gh, gw, wh, ww, sh, sw, Cc, h, False), 1, training=False)
+        yo.backward(torch.from_numpy(fx["gy"]))
+    finally:
+        O.set_rounding(None)
+    assert rel(y, yo) < 1e-3 and rel(x.grad, xo.grad) < 1.5e-2
+    assert worst_grad(blk, {k[2:]: v.grad for k, v in p.items()}) < 3e-2

@@ -227,6 +227,32 @@ typedef struct {
 int swv2_mlp_supported(int C, int hidden);
 int swv2_mlp_fwd(const swv2_mlp_args* a, void* stream);
 
+/* Fused MLP branch, backward (the autograd of swv2_mlp_fwd w.r.t. x and the data-path intermediates):
+ *   da2 = LayerNorm backward of scale[b] * dy (saved a2, mean, rstd);  dh = (da2 W2) * GELU'(hpre);  dx = dy + dh W1
+ * in one kernel (replaces swv2_ln_residual_bwd + swv2_linear(EPI_GELU_GRAD) + swv2_linear(EPI_F32)).  da2 and dh are
+ * written for the weight gradients (swv2_linear_wgrad: d fc2 = da2^T GELU(hpre), d fc1 = dh^T x).  dgamma / dbeta are
+ * ACCUMULATED.  ws: >= swv2_mlp_bwd_ws_floats(M, C) floats, contents undefined afterwards. */
+typedef struct {
+    const float* dy;       /* [M][C] gradient of y */
+    const void* a2;        /* bf16 [M][C]      saved by the forward */
+    const float* mean;     /* [M] */
+    const float* rstd;
+    const float* gamma;    /* [C] */
+    const float* scale;    /* per-sample drop-path factor or NULL */
+    const void* hpre;      /* bf16 [M][hidden] saved by the forward */
+    const void* w2t;       /* bf16 [hidden][C] = fc2.weight^T (swv2_prep_weight, transpose) */
+    const void* w1t;       /* bf16 [C][hidden] = fc1.weight^T */
+    void* da2;             /* out bf16 [M][C] */
+    void* dh;              /* out bf16 [M][hidden] */
+    float* dx;             /* out fp32 [M][C] */
+    float* dgamma;         /* [C], accumulated */
+    float* dbeta;
+    float* ws;
+    int M, C, hidden, rows_per_sample;
+} swv2_mlp_bwd_args;
+size_t swv2_mlp_bwd_ws_floats(int M, int C);
+int swv2_mlp_bwd(const swv2_mlp_bwd_args* a, void* stream);
+
 /* Continuous position bias (swinv2_global.py:240-261,274-287): bias[heads][L][L] = meta_mlp(log-spaced relative
  * coordinates), meta_mlp = Linear(2,hidden) -> ReLU -> Dropout(drop_p) -> Linear(hidden,heads); the relative-coordinate
  * table is generated in-kernel.  keep_bf16: [L*L][hidden] keep-mask drawn by the caller (any non-zero = keep; the kernel
@@ -264,7 +290,7 @@ typedef struct swv2_block_desc {
     const float* dx2;        /* grad of x2 */
     void *da2, *dh, *da1, *doh, *dqkvh;   /* bf16 scratch: [BT][C], [BT][hid], [Bw*Lp][C], [Bw][h][Lp][DP], [Bw][h][3][Lp][DP] */
     float* dx1;              /* fp32 scratch [BT][C] */
-    float* ln_ws;            /* SWV2_LN_BWD_MAX_BLOCKS*2*C floats */
+    float* ln_ws;            /* max(SWV2_LN_BWD_MAX_BLOCKS*2*C, swv2_mlp_bwd_ws_floats(B*T, C)) floats */
     float* dx;               /* out: grad of x */
     /* parameter gradients, ACCUMULATED (caller zeroes) */
     float *d_logit_scale, *d_bias, *d_qkv_w, *d_qkv_b, *d_proj_w, *d_proj_b, *d_n1_w, *d_n1_b, *d_fc1_w, *d_fc1_b,
@@ -278,7 +304,8 @@ typedef struct swv2_block_desc {
     void* ev_start;
     void* ev_stop;
     int fuse_mlp;            /* 1: forward steps 5-7 run as swv2_mlp_fwd when the shape is supported (hact is then neither
-                                written nor read: the backward applies GELU to hpre on load); 0: three launches */
+                                written nor read: the backward applies GELU to hpre on load); 0: three launches.  The backward
+                                likewise runs steps 11, 13, 15 as swv2_mlp_bwd */
     void* wgrad_ws;          /* optional workspace of the weight-gradient products (swv2_linear_wgrad_ws), shared by the four
                                 products of the block (they are ordered on one stream); NULL = atomic accumulation */
     size_t wgrad_ws_bytes;

@@ -75,6 +75,11 @@ class MlpArgs(C.Structure):
                [(n, C.c_int) for n in ("M", "C", "hidden", "rows_per_sample")] + [("eps", C.c_float)]
 
 
+class MlpBwdArgs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("dy", "a2", "mean", "rstd", "gamma", "scale", "hpre", "w2t", "w1t", "da2", "dh", "dx",
+                                           "dgamma", "dbeta", "ws")] + [(n, C.c_int) for n in ("M", "C", "hidden", "rows_per_sample")]
+
+
 class LnArgs(C.Structure):
     _fields_ = [("a", C.c_void_p), ("res", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
                 ("scale", C.c_void_p), ("rowidx", C.c_void_p), ("y", C.c_void_p), ("mean", C.c_void_p),
@@ -125,6 +130,8 @@ SYMBOLS = {
     "swv2_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P]),
     "swv2_mlp_supported": (_I, [_I, _I]),
     "swv2_mlp_fwd": (_I, [C.POINTER(MlpArgs), _P]),
+    "swv2_mlp_bwd_ws_floats": (C.c_size_t, [_I, _I]),
+    "swv2_mlp_bwd": (_I, [C.POINTER(MlpBwdArgs), _P]),
     "swv2_cpb_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "swv2_cpb_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "swv2_block_fwd": (_I, [C.POINTER(BlockDesc), _P]),

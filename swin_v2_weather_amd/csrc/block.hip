@@ -139,6 +139,21 @@ extern "C" int swv2_block_bwd(const swv2_block_desc* d, void* st) {
     const int sp = d->wgrad_splits > 0 ? d->wgrad_splits : 64;
     SideStream* ss = d->wgrad_side_stream ? side_stream() : nullptr;
     void* ws = ss ? (void*)ss->s : st;            // stream of the weight-gradient products
+    const bool fused = d->fuse_mlp && swv2_mlp_supported(C, hid);
+    if (fused) {
+        // 7', 6', 5' data path fused: LN2 backward, dh = (da2 W2) * GELU'(hpre), dx1 = dx2 + dh W1 in one kernel
+        swv2_mlp_bwd_args m = {};
+        m.dy = d->dx2; m.a2 = d->a2; m.mean = d->mean2; m.rstd = d->rstd2; m.gamma = d->n2_w; m.scale = d->dp2; m.hpre = d->hpre;
+        m.w2t = d->w_fc2t; m.w1t = d->w_fc1t; m.da2 = d->da2; m.dh = d->dh; m.dx = d->dx1; m.dgamma = d->d_n2_w;
+        m.dbeta = d->d_n2_b; m.ws = d->ln_ws; m.M = BT; m.C = C; m.hidden = hid; m.rows_per_sample = d->T;
+        LAUNCH(13, swv2_mlp_bwd(&m, st));
+        // weight gradients (hact was not stored: GELU(hpre) on load)
+        swv2_operand dy2 = op(SWV2_OP_BF16, d->da2, BT, C, C), x2 = op(SWV2_OP_BF16_GELU, d->hpre, BT, hid, hid);
+        swv2_operand dy1 = op(SWV2_OP_BF16, d->dh, BT, hid, hid), x1 = op(SWV2_OP_F32, d->x1, BT, C, C);
+        if (ss) fork_to(ss, (hipStream_t)st);
+        LAUNCH(12, swv2_linear_wgrad_ws(&dy2, &x2, d->d_fc2_w, d->d_fc2_b, nullptr, nullptr, hid, sp, d->wgrad_ws, d->wgrad_ws_bytes, ws));
+        LAUNCH(14, swv2_linear_wgrad_ws(&dy1, &x1, d->d_fc1_w, d->d_fc1_b, nullptr, nullptr, C, sp, d->wgrad_ws, d->wgrad_ws_bytes, ws));
+    } else {
     // 7'. LN2 backward
     {
         swv2_ln_args l = {};
@@ -148,9 +163,8 @@ extern "C" int swv2_block_bwd(const swv2_block_desc* d, void* st) {
     }
     // 6'. fc2: dW = da2^T GELU(h) ; dh = (da2 W2) * GELU'(h)
     {
-        const bool fused = d->fuse_mlp && swv2_mlp_supported(C, hid);     // hact was not stored: GELU(hpre) on load
         swv2_operand dy = op(SWV2_OP_BF16, d->da2, BT, C, C),
-                     x = fused ? op(SWV2_OP_BF16_GELU, d->hpre, BT, hid, hid) : op(SWV2_OP_BF16, d->hact, BT, hid, hid);
+                     x = op(SWV2_OP_BF16, d->hact, BT, hid, hid);
         if (ss) fork_to(ss, (hipStream_t)st);
         LAUNCH(12, swv2_linear_wgrad_ws(&dy, &x, d->d_fc2_w, d->d_fc2_b, nullptr, nullptr, hid, sp, d->wgrad_ws, d->wgrad_ws_bytes, ws));
         swv2_epilogue e = epi(SWV2_EPI_GELU_GRAD, d->dh, hid, nullptr, d->hpre);
@@ -163,6 +177,7 @@ extern "C" int swv2_block_bwd(const swv2_block_desc* d, void* st) {
         LAUNCH(14, swv2_linear_wgrad_ws(&dy, &x, d->d_fc1_w, d->d_fc1_b, nullptr, nullptr, C, sp, d->wgrad_ws, d->wgrad_ws_bytes, ws));
         swv2_epilogue e = epi(SWV2_EPI_F32, d->dx1, C, nullptr, d->dx2);
         LAUNCH(15, swv2_linear(&dy, d->w_fc1t, &e, C, st));
+    }
     }
     // 4'. LN1 backward (gathers dx1 rows through the window table; padded rows -> 0)
     {

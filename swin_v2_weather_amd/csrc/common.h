@@ -68,4 +68,6 @@ void swv2_set_error(const char* fmt, ...);
         }                                                                            \
     } while (0)
 
+void swv2_launch_ln_partials_reduce(const float* ws, float* dgamma, float* dbeta, int nblocks, int C, hipStream_t st);
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -73,6 +73,12 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpFwd a) {
             }
         }
     };
+#ifdef SWV2_MLP_STAMPS
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#define STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[i] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define STAMP(i)
+#endif
     issue(0);
     for (int i = tid; i < hid; i += 256) b1s[i] = a.b1[i];
 
@@ -83,8 +89,9 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpFwd a) {
 #pragma unroll
         for (int i = 0; i < UNITS / 256; ++i) {
             const int u = tid + 256 * i, row = u / (C / 4), c4 = u % (C / 4);
-            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (wg_row0 + row < a.M) v = *(const f32x4*)(a.x + (size_t)(wg_row0 + row) * C + 4 * c4);
+            // rows past M repeat row M - 1: every later load / store of such a row is then an unconditional duplicate of
+            // that row's (identical) values -- no exec-masked memory ops, so the compiler can count them (s_waitcnt)
+            const f32x4 v = *(const f32x4*)(a.x + (size_t)min(wg_row0 + row, a.M - 1) * C + 4 * c4);
             *(bf16x4*)(smem + row * PX + 4 * c4) = f2bf4(v);
         }
     }
@@ -105,35 +112,39 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpFwd a) {
 
     commit(0);
     __syncthreads();
+    STAMP(0);
     for (int ch = 0; ch < nch; ++ch) {
         if (ch + 1 < nch) issue(ch + 1);
         const uint16_t* W1s = smem + (ch & 1) * (W1E + W2E);
         const uint16_t* W2s = W1s + W1E;
         // ---- H^T chunk (32 hidden x 16 MT rows), bias, bf16 round (saved), GELU -> B operand of the second product
-        bf16x4 hb[MT][2];
+        f32x4 hacc[2][MT];
 #pragma unroll
         for (int ht = 0; ht < 2; ++ht) {
             const f32x4 bias = *(const f32x4*)(b1s + 32 * ch + 16 * ht + 4 * g);
-            f32x4 hacc[MT];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) hacc[mt] = bias;
+            for (int mt = 0; mt < MT; ++mt) hacc[ht][mt] = bias;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const bf16x8 wf = *(const bf16x8*)(W1s + (16 * ht + fr) * P1 + 32 * ks + 8 * g);
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) hacc[mt] = mfma32(wf, xf[mt][ks], hacc[mt]);
+                for (int mt = 0; mt < MT; ++mt) hacc[ht][mt] = mfma32(wf, xf[mt][ks], hacc[ht][mt]);
             }
+        }
+        STAMP(1);
+        bf16x4 hb[MT][2], hrs[MT][2];
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const bf16x4 hr = f2bf4(hacc[mt]);                 // the pre-activation as the backward will read it
-                const int r = row0 + 16 * mt + fr;
-                if (r < a.M) *(bf16x4*)(a.hpre + (size_t)r * hid + 32 * ch + 16 * ht + 4 * g) = hr;
+                const bf16x4 hr = f2bf4(hacc[ht][mt]);             // the pre-activation as the backward will read it
+                hrs[mt][ht] = hr;
                 f32x4 act;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) act[e] = gelu_f(bf2f(hr[e]));
                 hb[mt][ht] = f2bf4(act);
             }
-        }
+        STAMP(2);
         // ---- Y^T += W2[:, chunk] GELU(H^T chunk)
         bf16x8 hop[MT];
 #pragma unroll
@@ -146,8 +157,21 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpFwd a) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) yacc[mt][t] = mfma32(wf, hop[mt], yacc[mt][t]);
         }
+        // next chunk's weights -> the other LDS buffer, then this chunk's stores: a wait for those loads placed after
+        // the stores would also wait for the stores' acknowledgements (one in-order vmcnt counter)
+        STAMP(3);
         if (ch + 1 < nch) commit((ch + 1) & 1);
+        STAMP(4);
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int r = min(row0 + 16 * mt + fr, a.M - 1);
+                *(bf16x4*)(a.hpre + (size_t)r * hid + 32 * ch + 16 * ht + 4 * g) = hrs[mt][ht];
+            }
+        STAMP(5);
         __syncthreads();
+        STAMP(6);
     }
 
     // ---- epilogue: + b2, bf16 round (saved fc2 output), LayerNorm over the row, drop-path scale -- in the accumulator
@@ -178,9 +202,9 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpFwd a) {
         q += __shfl_xor(q, 16);
         q += __shfl_xor(q, 32);
         const float rs = rsqrtf(q * (1.f / C) + a.eps);
-        const bool ok = r < a.M;
-        if (ok && g == 0) { a.mean[r] = mu; a.rstd[r] = rs; }
-        const float sc = (a.scale && ok) ? a.scale[r / a.rows_per_sample] : 1.f;
+        const int rc = min(r, a.M - 1);
+        if (g == 0) { a.mean[rc] = mu; a.rstd[rc] = rs; }
+        const float sc = a.scale ? a.scale[rc / a.rows_per_sample] : 1.f;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int n = 16 * t + 4 * g;
@@ -195,24 +219,278 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpFwd a) {
 #pragma unroll
         for (int p = 0; p < 16 * (C / 4) / 64; ++p) {              // fp32 rows: residual + store
             const int u = lane + 64 * p, row = u / (C / 4), c4 = u % (C / 4);
-            if (rbase + row < a.M) {
-                const size_t off = (size_t)(rbase + row) * C + 4 * c4;
-                *(f32x4*)(a.y + off) = *(const f32x4*)(a.x + off) + *(const f32x4*)(Ys + row * PY + 4 * c4);
-            }
+            const size_t off = (size_t)min(rbase + row, a.M - 1) * C + 4 * c4;
+            *(f32x4*)(a.y + off) = *(const f32x4*)(a.x + off) + *(const f32x4*)(Ys + row * PY + 4 * c4);
         }
 #pragma unroll
         for (int p = 0; p < (16 * (C / 8) + 63) / 64; ++p) {       // bf16 rows of the saved fc2 output
             const int u = lane + 64 * p, row = u / (C / 8), c8 = u % (C / 8);
-            if (u < 16 * (C / 8) && rbase + row < a.M)
-                *(u32x4*)(a.a2 + (size_t)(rbase + row) * C + 8 * c8) = *(const u32x4*)(As + row * PA + 8 * c8);
+            if ((16 * (C / 8)) % 64 == 0 || u < 16 * (C / 8))
+                *(u32x4*)(a.a2 + (size_t)min(rbase + row, a.M - 1) * C + 8 * c8) = *(const u32x4*)(As + row * PA + 8 * c8);
         }
         if (mt + 1 < MT) __syncthreads();
     }
+#ifdef SWV2_MLP_STAMPS
+    STAMP(7);
+    if (lane == 0 && (blockIdx.x % 97) == 0) {       // a sample of waves: y[...] is overwritten with the stamps (probe only)
+        unsigned long long* o = (unsigned long long*)a.mean + ((blockIdx.x / 97) * 4 + wave) * 8;
+        for (int i = 0; i < 8; ++i) o[i] = tacc[i];
+    }
+#endif
 }
 
 template <int C, int MT>
 void launch_mlp_fwd(const MlpFwd& k, hipStream_t st) {
     hipLaunchKernelGGL((mlp_fwd_kernel<C, MT>), dim3(cdiv(k.M, 64 * MT)), dim3(256), 0, st, k);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Fused MLP branch, backward (autograd of the above): per row tile
+//     da2 = LayerNorm2 backward of (scale * dy)                     (row statistics from the saved mean / rstd)
+//     dH  = (da2 W2) * GELU'(hpre)        dH^T[hid][m] = W2^T[hid][n] da2^T[n][m]     A = W2^T rows (LDS), B = da2 (regs)
+//     dx  = dy + dH W1                    dx^T[c][m]   = W1^T[c][hid] dH^T[hid][m]    A = W1^T rows (LDS), B = dH (accs)
+// The same chained-MFMA skeleton as the forward: da2 fragments and the dx^T accumulators stay in registers, the
+// weights stream through LDS in chunks of 32 hidden units, dH is written once (bf16, for the fc1 weight gradient) and
+// never re-read here.  Replaces LN backward + two GEMM launches (693 MB -> 462 MB at the benchmark shape).
+// d gamma / d beta: per-lane column sums -> DPP reduction over the 16 rows of a tile -> LDS over the 4 waves -> one
+// partial row per workgroup in `ws`, folded by swv2_launch_ln_partials_reduce.
+// ------------------------------------------------------------------------------------------------------------------
+struct MlpBwd {
+    const float* dy; const uint16_t* a2; const float* mean; const float* rstd; const float* gamma; const float* scale;
+    const uint16_t* hpre; const uint16_t* w2t; const uint16_t* w1t;
+    uint16_t* da2; uint16_t* dh; float* dx; float* ws;
+    int M, hidden, rows_per_sample;
+};
+
+template <int C, int MT>
+__global__ __launch_bounds__(256) void mlp_bwd_kernel(const MlpBwd a) {
+    constexpr int KS = C / 32, NT = C / 16;
+    constexpr int P1 = C + 8, P2 = 40;
+    constexpr int W1E = 32 * P1, W2E = C * P2;
+    constexpr int NCHUNK = 4 * C;
+    constexpr int SPT = (NCHUNK + 255) / 256;
+    constexpr int PY = C + 4;
+    constexpr int WBYTES = 2 * (W1E + W2E) * 2, EBYTES = 4 * 16 * PY * 4, GBYTES = 4 * 2 * C * 4;
+    constexpr int SBYTES = WBYTES > EBYTES ? (WBYTES > GBYTES ? WBYTES : GBYTES) : (EBYTES > GBYTES ? EBYTES : GBYTES);
+    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SBYTES];
+    uint16_t* smem = (uint16_t*)smem_raw;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4;
+    const int row0 = blockIdx.x * (64 * MT) + wave * (16 * MT);
+    const int hid = a.hidden, nch = hid / 32;
+
+    u32x4 s1[SPT], s2[SPT];
+    auto issue = [&](int ch) {          // W2^T chunk: rows 32 ch .. + 32 of [hid][C];  W1^T chunk: columns of [C][hid]
+#pragma unroll
+        for (int i = 0; i < SPT; ++i) {
+            const int idx = min(tid + 256 * i, NCHUNK - 1);
+            s1[i] = *(const u32x4*)(a.w2t + (size_t)(32 * ch + idx / (C / 8)) * C + 8 * (idx % (C / 8)));
+            s2[i] = *(const u32x4*)(a.w1t + (size_t)(idx >> 2) * hid + 32 * ch + 8 * (idx & 3));
+        }
+    };
+    auto commit = [&](int buf) {
+        uint16_t* W1s = smem + buf * (W1E + W2E);
+        uint16_t* W2s = W1s + W1E;
+#pragma unroll
+        for (int i = 0; i < SPT; ++i) {
+            const int idx = tid + 256 * i;
+            if (NCHUNK % 256 == 0 || idx < NCHUNK) {
+                *(u32x4*)(W1s + (idx / (C / 8)) * P1 + 8 * (idx % (C / 8))) = s1[i];
+                *(u32x4*)(W2s + (idx >> 2) * P2 + 8 * (idx & 3)) = s2[i];
+            }
+        }
+    };
+    // saved pre-activation of the NEXT chunk, in the accumulator layout (lane (m = fr, g): hidden 16 ht + 4 g .. + 3)
+    u32x2 hp[MT][2], hpn[MT][2];
+    auto issue_h = [&](int ch, u32x2 (&dst)[MT][2]) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int r = min(row0 + 16 * mt + fr, a.M - 1);
+#pragma unroll
+            for (int ht = 0; ht < 2; ++ht) dst[mt][ht] = *(const u32x2*)(a.hpre + (size_t)r * hid + 32 * ch + 16 * ht + 4 * g);
+        }
+    };
+#ifdef SWV2_MLP_STAMPS
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#endif
+    issue(0);
+    issue_h(0, hp);
+
+    // ---- LayerNorm backward in the B-fragment layout: lane (m = fr, g) holds columns c = 32 ks + 8 g .. + 7 of its row
+    bf16x8 xf[MT][KS];
+    float dgm[KS][8], dbt[KS][8];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { dgm[ks][e] = 0.f; dbt[ks][e] = 0.f; }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int r = row0 + 16 * mt + fr;
+        const bool ok = r < a.M;
+        const int rc = ok ? r : a.M - 1;
+        const float mu = a.mean[rc], rs = a.rstd[rc];
+        const float sc = a.scale ? a.scale[rc / a.rows_per_sample] : 1.f;
+        const float once = ok ? 1.f : 0.f;           // duplicate rows (past M) compute row M - 1 again but count once
+        float gg[KS][8], xh[KS][8];
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int c0 = 32 * ks + 8 * g;
+            float av[8];
+            unpack8(*(const uint4*)(a.a2 + (size_t)rc * C + c0), av);
+#pragma unroll
+            for (int hlf = 0; hlf < 2; ++hlf) {
+                const f32x4 d4 = *(const f32x4*)(a.dy + (size_t)rc * C + c0 + 4 * hlf);
+                const f32x4 gm = *(const f32x4*)(a.gamma + c0 + 4 * hlf);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = 4 * hlf + e;
+                    const float d = sc * d4[e];
+                    xh[ks][k] = (av[k] - mu) * rs;
+                    gg[ks][k] = d * gm[e];
+                    dgm[ks][k] = fmaf(once * d, xh[ks][k], dgm[ks][k]);
+                    dbt[ks][k] = fmaf(once, d, dbt[ks][k]);
+                    t1 += gg[ks][k];
+                    t2 = fmaf(gg[ks][k], xh[ks][k], t2);
+                }
+            }
+        }
+        t1 += __shfl_xor(t1, 16); t1 += __shfl_xor(t1, 32);
+        t2 += __shfl_xor(t2, 16); t2 += __shfl_xor(t2, 32);
+        t1 *= (1.f / C); t2 *= (1.f / C);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = rs * (gg[ks][e] - t1 - xh[ks][e] * t2);
+            const uint4 pk = pack8(o);
+            *(uint4*)(a.da2 + (size_t)rc * C + 32 * ks + 8 * g) = pk;
+            xf[mt][ks] = __builtin_bit_cast(bf16x8, pk);
+        }
+    }
+    STAMP(0);
+    // column sums over the 16 rows of the wave's tiles (lanes with equal g), then over the 4 waves
+    {
+        float* gs = (float*)smem_raw;                          // [4 waves][2][C]
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = dgm[ks][e], w = dbt[ks][e];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { v += __shfl_xor(v, o); w += __shfl_xor(w, o); }
+                if (fr == 0) {
+                    gs[(wave * 2 + 0) * C + 32 * ks + 8 * g + e] = v;
+                    gs[(wave * 2 + 1) * C + 32 * ks + 8 * g + e] = w;
+                }
+            }
+        __syncthreads();
+        for (int i = tid; i < 2 * C; i += 256)
+            a.ws[(size_t)blockIdx.x * 2 * C + i] = (gs[i] + gs[2 * C + i]) + (gs[4 * C + i] + gs[6 * C + i]);
+        __syncthreads();
+    }
+
+    f32x4 yacc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) yacc[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    commit(0);
+    __syncthreads();
+    STAMP(1);
+    // one chunk; `cur` holds this chunk's saved pre-activation, `nxt` receives the next chunk's (two register sets used
+    // alternately: a copy between them would wait for the loads right where it is written)
+    auto chunk = [&](int ch, u32x2 (&cur)[MT][2], u32x2 (&nxt)[MT][2]) {
+        if (ch + 1 < nch) { issue(ch + 1); issue_h(ch + 1, nxt); }
+        const uint16_t* W1s = smem + (ch & 1) * (W1E + W2E);
+        const uint16_t* W2s = W1s + W1E;
+        f32x4 hacc[2][MT];
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) hacc[ht][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 wf = *(const bf16x8*)(W1s + (16 * ht + fr) * P1 + 32 * ks + 8 * g);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) hacc[ht][mt] = mfma32(wf, xf[mt][ks], hacc[ht][mt]);
+            }
+        }
+        STAMP(2);
+        bf16x4 hb[MT][2];
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const uint32_t w0 = cur[mt][ht][0], w1 = cur[mt][ht][1];
+                f32x4 dv;
+                dv[0] = hacc[ht][mt][0] * gelu_grad_f(__uint_as_float(w0 << 16));
+                dv[1] = hacc[ht][mt][1] * gelu_grad_f(__uint_as_float(w0 & 0xffff0000u));
+                dv[2] = hacc[ht][mt][2] * gelu_grad_f(__uint_as_float(w1 << 16));
+                dv[3] = hacc[ht][mt][3] * gelu_grad_f(__uint_as_float(w1 & 0xffff0000u));
+                hb[mt][ht] = f2bf4(dv);
+            }
+        bf16x8 hop[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) hop[mt] = __builtin_shufflevector(hb[mt][0], hb[mt][1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const bf16x4 lo = *(const bf16x4*)(W2s + (16 * t + fr) * P2 + 4 * g);
+            const bf16x4 hi = *(const bf16x4*)(W2s + (16 * t + fr) * P2 + 16 + 4 * g);
+            const bf16x8 wf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) yacc[mt][t] = mfma32(wf, hop[mt], yacc[mt][t]);
+        }
+        STAMP(3);
+        if (ch + 1 < nch) commit((ch + 1) & 1);       // before this chunk's stores (see the forward kernel)
+        STAMP(4);
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int r = min(row0 + 16 * mt + fr, a.M - 1);
+                *(bf16x4*)(a.dh + (size_t)r * hid + 32 * ch + 16 * ht + 4 * g) = hb[mt][ht];
+            }
+        STAMP(5);
+        __syncthreads();
+        STAMP(6);
+    };
+    for (int ch = 0; ch < nch; ch += 2) {
+        chunk(ch, hp, hpn);
+        if (ch + 1 < nch) chunk(ch + 1, hpn, hp);
+    }
+
+    // ---- dx = dy + (dH W1): accumulators -> per-wave LDS tile -> whole rows
+    float* Ys = (float*)smem_raw + wave * 16 * PY;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) *(f32x4*)(Ys + fr * PY + 16 * t + 4 * g) = yacc[mt][t];
+        __syncthreads();
+        const int rbase = row0 + 16 * mt;
+#pragma unroll
+        for (int p = 0; p < 16 * (C / 4) / 64; ++p) {
+            const int u = lane + 64 * p, row = u / (C / 4), c4 = u % (C / 4);
+            const size_t off = (size_t)min(rbase + row, a.M - 1) * C + 4 * c4;
+            *(f32x4*)(a.dx + off) = *(const f32x4*)(a.dy + off) + *(const f32x4*)(Ys + row * PY + 4 * c4);
+        }
+        if (mt + 1 < MT) __syncthreads();
+    }
+#ifdef SWV2_MLP_STAMPS
+    STAMP(7);
+    if (lane == 0 && (blockIdx.x % 97) == 0) {
+        unsigned long long* o = (unsigned long long*)(a.ws + (size_t)gridDim.x * 2 * C) + ((blockIdx.x / 97) * 4 + wave) * 8;
+        for (int i = 0; i < 8; ++i) o[i] = tacc[i];
+    }
+#endif
+}
+
+template <int C, int MT>
+void launch_mlp_bwd(const MlpBwd& k, hipStream_t st) {
+    hipLaunchKernelGGL((mlp_bwd_kernel<C, MT>), dim3(cdiv(k.M, 64 * MT)), dim3(256), 0, st, k);
 }
 
 }  // namespace
@@ -233,11 +511,10 @@ extern "C" int swv2_mlp_fwd(const swv2_mlp_args* a, void* stream) {
     MlpFwd k = {a->x, (const uint16_t*)a->w1, a->b1, (const uint16_t*)a->w2, a->b2, a->gamma, a->beta, a->scale,
                 (uint16_t*)a->hpre, (uint16_t*)a->a2, a->mean, a->rstd, a->y, a->M, a->hidden, a->rows_per_sample, a->eps};
     hipStream_t st = (hipStream_t)stream;
-    // rows per workgroup (64 * MT): the kernel is issue-bound, so what matters is how evenly the row tiles fill the
-    // resident-workgroup slots (3 per CU at MT = 1, 2 at MT = 2): time ~ ceil(tiles / slots) * MT
+    // rows per workgroup (64 * MT): two tiles per wave halve the LDS fragment reads per MFMA (measured at C = 128,
+    // M = 129600: 113 us vs 138 us), one tile keeps small problems spread over the CUs
     static const int force_mt = getenv("SWV2_MLP_MT") ? atoi(getenv("SWV2_MLP_MT")) : 0;
-    const long t1 = cdiv(cdiv(a->M, 64), 256 * 3), t2 = 2L * cdiv(cdiv(a->M, 128), 256 * 2);
-    const bool mt2 = force_mt ? force_mt == 2 : t2 < t1;
+    const bool mt2 = force_mt ? force_mt == 2 : a->M >= 128 * 256;
     switch (a->C) {
         case 32: mt2 ? launch_mlp_fwd<32, 2>(k, st) : launch_mlp_fwd<32, 1>(k, st); break;
         case 64: mt2 ? launch_mlp_fwd<64, 2>(k, st) : launch_mlp_fwd<64, 1>(k, st); break;
@@ -247,5 +524,36 @@ extern "C" int swv2_mlp_fwd(const swv2_mlp_args* a, void* stream) {
         case 256: launch_mlp_fwd<256, 1>(k, st); break;
     }
     SWV2_CHECK_LAUNCH("swv2_mlp_fwd");
+    return SWV2_OK;
+}
+
+extern "C" size_t swv2_mlp_bwd_ws_floats(int M, int C) { return (M > 0 && C > 0) ? (size_t)cdiv(M, 64) * 2 * C : 0; }
+
+extern "C" int swv2_mlp_bwd(const swv2_mlp_bwd_args* a, void* stream) {
+    SWV2_CHECK_ARG(a && a->dy && a->a2 && a->mean && a->rstd && a->gamma && a->hpre && a->w2t && a->w1t && a->da2 && a->dh &&
+                       a->dx && a->dgamma && a->dbeta && a->ws, "swv2_mlp_bwd: null pointer");
+    SWV2_CHECK_ARG(a->M > 0 && a->rows_per_sample > 0, "swv2_mlp_bwd: M and rows_per_sample must be positive");
+    if (!swv2_mlp_supported(a->C, a->hidden)) {
+        swv2_set_error("swv2_mlp_bwd: C=%d hidden=%d not instantiated; use swv2_ln_residual_bwd + swv2_linear", a->C, a->hidden);
+        return SWV2_ERR_UNSUPPORTED;
+    }
+    MlpBwd k = {a->dy, (const uint16_t*)a->a2, a->mean, a->rstd, a->gamma, a->scale, (const uint16_t*)a->hpre,
+                (const uint16_t*)a->w2t, (const uint16_t*)a->w1t, (uint16_t*)a->da2, (uint16_t*)a->dh, a->dx, a->ws, a->M,
+                a->hidden, a->rows_per_sample};
+    hipStream_t st = (hipStream_t)stream;
+    static const int force_mt = getenv("SWV2_MLP_MT") ? atoi(getenv("SWV2_MLP_MT")) : 0;
+    const long t1 = cdiv(cdiv(a->M, 64), 256 * 3), t2 = 2L * cdiv(cdiv(a->M, 128), 256 * 2);
+    const bool mt2 = force_mt ? force_mt == 2 : (a->C <= 64 && t2 < t1);   // wider rows: two tiles per wave cost occupancy
+    switch (a->C) {
+        case 32: mt2 ? launch_mlp_bwd<32, 2>(k, st) : launch_mlp_bwd<32, 1>(k, st); break;
+        case 64: mt2 ? launch_mlp_bwd<64, 2>(k, st) : launch_mlp_bwd<64, 1>(k, st); break;
+        case 96: mt2 ? launch_mlp_bwd<96, 2>(k, st) : launch_mlp_bwd<96, 1>(k, st); break;
+        case 128: mt2 ? launch_mlp_bwd<128, 2>(k, st) : launch_mlp_bwd<128, 1>(k, st); break;
+        case 192: launch_mlp_bwd<192, 1>(k, st); break;
+        case 256: launch_mlp_bwd<256, 1>(k, st); break;
+    }
+    const bool two = (a->C <= 128) && mt2;
+    swv2_launch_ln_partials_reduce(a->ws, a->dgamma, a->dbeta, cdiv(a->M, two ? 128 : 64), a->C, st);
+    SWV2_CHECK_LAUNCH("swv2_mlp_bwd");
     return SWV2_OK;
 }

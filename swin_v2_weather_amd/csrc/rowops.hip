@@ -389,6 +389,11 @@ int ln_check(const swv2_ln_args* a, bool bwd) {
 
 }  // namespace
 
+// shared with mlp.hip (fused MLP backward): dgamma[j] += sum_b ws[b][0][j], dbeta[j] += sum_b ws[b][1][j]
+void swv2_launch_ln_partials_reduce(const float* ws, float* dgamma, float* dbeta, int nblocks, int C, hipStream_t st) {
+    hipLaunchKernelGGL(ln_partials_reduce_kernel, dim3(cdiv(2 * C, 32)), dim3(256), 0, st, ws, dgamma, dbeta, nblocks, C);
+}
+
 #define LN_DISPATCH(FN)                                              \
     const int chunks = a->C / 8;                                     \
     if (chunks <= 16) FN<16, 1>(a, st);                              \

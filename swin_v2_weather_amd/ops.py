@@ -258,6 +258,23 @@ def mlp_fwd(x, w1, b1, w2, b2, gamma, beta, scale, rows_per_sample, eps=1e-5):
     return y, hpre, a2, mean, rstd
 
 
+def mlp_bwd(dy, a2, mean, rstd, gamma, scale, hpre, w2t, w1t, dgamma, dbeta, rows_per_sample):
+    """Fused LN backward -> dh = (da2 W2) * GELU'(hpre) -> dx = dy + dh W1.  Returns (dx, da2, dh); dgamma/dbeta accumulated."""
+    M, Cc = dy.shape
+    hid = hpre.shape[1]
+    dev = dy.device
+    da2 = torch.empty(M, Cc, dtype=BF16, device=dev)
+    dh = torch.empty(M, hid, dtype=BF16, device=dev)
+    dx = torch.empty(M, Cc, dtype=torch.float32, device=dev)
+    ws = torch.empty(L.load().swv2_mlp_bwd_ws_floats(M, Cc), dtype=torch.float32, device=dev)
+    a = L.MlpBwdArgs()
+    a.dy, a.a2, a.mean, a.rstd, a.gamma, a.scale, a.hpre, a.w2t, a.w1t = (_p(t) for t in (dy, a2, mean, rstd, gamma, scale, hpre, w2t, w1t))
+    a.da2, a.dh, a.dx, a.dgamma, a.dbeta, a.ws = (_p(t) for t in (da2, dh, dx, dgamma, dbeta, ws))
+    a.M, a.C, a.hidden, a.rows_per_sample = M, Cc, hid, rows_per_sample
+    L.check(_timed("mlp_bwd", L.load().swv2_mlp_bwd, C.byref(a), _stream()), "swv2_mlp_bwd")
+    return dx, da2, dh
+
+
 def cpb_fwd(w1, b1, w2, b2, keep, bias, wh, ww, heads, hidden, drop_p):
     L.check(L.load().swv2_cpb_fwd(_p(w1), _p(b1), _p(w2), _p(b2), _p(keep), _p(bias), wh, ww, heads, hidden, drop_p, _stream()),
             "swv2_cpb_fwd")

@@ -123,6 +123,18 @@ def probe_mlp(B=2):
     fn, st = L.load().swv2_mlp_fwd, torch.cuda.current_stream().cuda_stream
     t = timeit(lambda: fn(ctypes.byref(a), st), n=20)
     say(f"mlp_fwd M={M}: {t:.1f} us ({M * (Cc * 4 * 2 + hid * 2 + Cc * 2) / t / 1e3:.0f} GB/s)")
+    dy, da2, dh, dx = torch.randn(M, Cc, device=dev), torch.empty(M, Cc, dtype=BF, device=dev), torch.empty(M, hid, dtype=BF, device=dev), torch.empty(M, Cc, device=dev)
+    dg, db = torch.zeros(Cc, device=dev), torch.zeros(Cc, device=dev)
+    ws = torch.empty(L.load().swv2_mlp_bwd_ws_floats(M, Cc), device=dev)
+    w2t, w1t = ops.prep_weight(torch.randn(Cc, hid, device=dev) * 0.1, transpose=True), ops.prep_weight(torch.randn(hid, Cc, device=dev) * 0.1, transpose=True)
+    fn(ctypes.byref(a), st)
+    b = L.MlpBwdArgs()
+    b.dy, b.a2, b.mean, b.rstd, b.gamma, b.hpre, b.w2t, b.w1t = (t_.data_ptr() for t_ in (dy, a2, mean, rstd, g, hpre, w2t, w1t))
+    b.da2, b.dh, b.dx, b.dgamma, b.dbeta, b.ws = (t_.data_ptr() for t_ in (da2, dh, dx, dg, db, ws))
+    b.M, b.C, b.hidden, b.rows_per_sample = M, Cc, hid, T
+    fb = L.load().swv2_mlp_bwd
+    t = timeit(lambda: fb(ctypes.byref(b), st), n=20)
+    say(f"mlp_bwd M={M}: {t:.1f} us ({M * (Cc * 4 * 2 + hid * 2 * 2 + Cc * 2 * 2) / t / 1e3:.0f} GB/s)")
 
 
 if __name__ == "__main__":

@@ -651,6 +651,43 @@ def test_fused_mlp_forward_matches_oracle(dev, K, M, Cc, hid, T):
         assert L.load().swv2_mlp_fwd(ctypes.byref(a), None) != 0          # unsupported shape is refused, never mis-run
 
 
+@pytest.mark.parametrize("M,Cc,hid,T", [(300, 128, 512, 100), (77, 32, 128, 77), (130, 96, 384, 65), (50, 192, 96, 25), (64, 256, 64, 64),
+                                         (129, 64, 32, 43)])
+def test_fused_mlp_backward_matches_autograd(dev, K, M, Cc, hid, T):
+    """swv2_mlp_bwd against torch autograd (fp64) of the forward formula evaluated at the SAVED tensors: LN backward from
+    (a2, mean, rstd), GELU' at the saved bf16 pre-activation, bf16 operands for both products."""
+    ops, L = K["ops"], K["L"]
+    g = torch.Generator().manual_seed(7 * M + Cc)
+    x = torch.randn(M, Cc, generator=g)
+    w1, b1 = torch.randn(hid, Cc, generator=g) * 0.2, torch.randn(hid, generator=g) * 0.1
+    w2, b2 = torch.randn(Cc, hid, generator=g) * 0.2, torch.randn(Cc, generator=g) * 0.1
+    gm, bt = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.1
+    sc = torch.tensor([0.0, 1.25, 1.0, 1.25][: (M + T - 1) // T])
+    dy = torch.randn(M, Cc, generator=g)
+    xd, w1d, w2d = x.to(dev), w1.to(dev), w2.to(dev)
+    y, hpre, a2, mean, rstd = ops.mlp_fwd(xd, ops.prep_weight(w1d), b1.to(dev), ops.prep_weight(w2d), b2.to(dev), gm.to(dev), bt.to(dev),
+                                          sc.to(dev), T)
+    dgm, dbt = torch.zeros(Cc, device=dev), torch.zeros(Cc, device=dev)
+    dx, da2, dh = ops.mlp_bwd(dy.to(dev), a2, mean, rstd, gm.to(dev), sc.to(dev), hpre, ops.prep_weight(w2d, transpose=True),
+                              ops.prep_weight(w1d, transpose=True), dgm, dbt, T)
+    # reference: the same graph from the saved bf16 tensors, in fp64
+    a2r = a2.float().cpu().double().requires_grad_(True)
+    gmr, btr = gm.double().requires_grad_(True), bt.double().requires_grad_(True)
+    scr = sc.double()[torch.arange(M) // T].view(-1, 1)
+    ln = (a2r - mean.cpu().double().view(-1, 1)) * rstd.cpu().double().view(-1, 1)
+    # LN backward through the statistics as functions of a2 (autograd of the true LayerNorm at the saved a2)
+    lnf = torch.nn.functional.layer_norm(a2r, (Cc,), gmr, btr, 1e-5)
+    (scr * lnf).backward(dy.double())
+    da2_ref = a2r.grad
+    assert rel(da2.float(), da2_ref) < 6e-3
+    assert rel(dgm, gmr.grad) < 1e-4 and rel(dbt, btr.grad) < 1e-4
+    hp = hpre.float().cpu().double().requires_grad_(True)
+    O.gelu_erf(hp).backward(rb(da2.float().cpu()).double() @ rb(w2).double())
+    assert rel(dh.float(), hp.grad) < 5e-3
+    dx_ref = dy.double() + rb(dh.float().cpu()).double() @ rb(w1).double()
+    assert rel(dx, dx_ref) < 1e-5
+
+
 @pytest.mark.parametrize("fuse", ["0", "1"])
 def test_block_fused_and_unfused_mlp_paths(dev, K, monkeypatch, fuse):
     """Both forward paths of the MLP branch (SWV2_FUSE_MLP = 1: swv2_mlp_fwd, hact recomputed on load in the backward;

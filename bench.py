@@ -193,6 +193,9 @@ def main():
             "roofline": {"kernel": a.roofline_kernel, "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "launches_timed": n_l, "avg_ms": k_ms,
                          "algorithmic_bytes_per_launch": alg,
+                         "co_running": ("weight-gradient GEMMs of the same block on the library's side stream overlap this kernel "
+                                        "(SWV2_WGRAD_SIDE_STREAM=0 times it alone)")
+                                       if os.environ.get("SWV2_WGRAD_SIDE_STREAM", "1") != "0" and "bwd" in a.roofline_kernel else None,
                          "flops_per_launch": {"attn_fwd": 4.0, "attn_bwd": 8.0}.get(a.roofline_kernel, 0.0) * T * Lw * a.embed_dim * B},
         }
         if world == 1 and not a.no_cpu_baseline:

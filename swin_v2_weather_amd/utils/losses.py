@@ -51,6 +51,19 @@ def auto_channel_weights(channel_names, n_out):
     return w
 
 
+def load_stats(params):
+    """(global_stds, time_diff_stds) as [1, N, 1, 1] float32 arrays (losses.py:91-92 loads them from params.*_path).
+    Without the ERA5 statistics files (synthetic-data runs: no dataset in the image) the stand-ins of SURVEY.md 8(d) are
+    used: unit global stds and a fixed, seeded positive vector of time-difference stds."""
+    import os
+    gp, tp = str(getattr(params, 'global_stds_path', '')), str(getattr(params, 'time_diff_stds_path', ''))
+    if os.path.isfile(gp) and os.path.isfile(tp):
+        return np.load(gp).astype(np.float32), np.load(tp).astype(np.float32)
+    n = max(len(getattr(params, 'channel_names', [])), int(np.max(np.asarray(params.out_channels))) + 1)
+    rng = np.random.RandomState(333)
+    return np.ones((1, n, 1, 1), np.float32), (0.05 + 0.45 * rng.rand(1, n, 1, 1)).astype(np.float32)
+
+
 class LossHandler(nn.Module):
     """Wrapper class that handles computing losses: `LossHandler(params)(prd, tar, inp)` (losses.py:30-150)."""
 
@@ -79,8 +92,9 @@ class LossHandler(nn.Module):
         if 'temp-std' in flags:
             eps = 1e-6
             oc = np.asarray(params.out_channels)
-            gstd = torch.from_numpy(np.load(params.global_stds_path)).reshape(1, -1, 1, 1)[:, oc]
-            tstd = np.sqrt(params.dt) * torch.from_numpy(np.load(params.time_diff_stds_path)).reshape(1, -1, 1, 1)[:, oc]
+            gs_np, td_np = load_stats(params)
+            gstd = torch.from_numpy(gs_np).reshape(1, -1, 1, 1)[:, oc]
+            tstd = np.sqrt(params.dt) * torch.from_numpy(td_np).reshape(1, -1, 1, 1)[:, oc]
             tvw = gstd / (tstd + eps)
             if 'squared' in flags:
                 tvw = tvw ** 2

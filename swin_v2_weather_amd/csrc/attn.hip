@@ -106,10 +106,16 @@ __global__ __launch_bounds__(64 * LT) void attn_fwd_kernel(
 
     constexpr int CHUNKS_PER_T = DK;         // K + V slabs = 64*LT*DK 16-byte chunks over 64*LT threads
     uint4 stage[CHUNKS_PER_T];
+    // Q fragment (B operand: B[k = d 4g+j][n = query fr]) straight from global, 512 B contiguous per wave; the NEXT
+    // window's fragment is fetched with its K / V slabs: a load issued after the prefetch and needed at once would make
+    // its s_waitcnt drain the (in-order) prefetch too and expose one HBM round trip per window
+    bf16x4 qf[DK], qn[DK];
     auto issue_loads = [&](int bw) {
         const uint16_t* base = qkvh + ((size_t)bw * h + hd) * 3 * SLAB + SLAB;   // K slab, V slab follows
 #pragma unroll
         for (int j = 0; j < CHUNKS_PER_T; ++j) stage[j] = *(const uint4*)(base + (size_t)(tid + j * C::NT) * 8);
+#pragma unroll
+        for (int kk = 0; kk < DK; ++kk) qn[kk] = *(const bf16x4*)(base - SLAB + (size_t)q * DP + 16 * kk + 4 * g);
     };
     auto write_stage = [&](int buf) {
         uint16_t* dst = smem + buf * 2 * SLAB;
@@ -121,6 +127,8 @@ __global__ __launch_bounds__(64 * LT) void attn_fwd_kernel(
     if (bw >= Bw) return;
     issue_loads(bw);
     write_stage(0);
+#pragma unroll
+    for (int kk = 0; kk < DK; ++kk) qf[kk] = qn[kk];
     __syncthreads();
 
     for (int it = 0; bw < Bw; bw += gridDim.x, ++it) {
@@ -131,11 +139,6 @@ __global__ __launch_bounds__(64 * LT) void attn_fwd_kernel(
         const uint16_t* Ks = smem + buf * 2 * SLAB;
         const uint16_t* Vs = Ks + SLAB;
         const size_t slab0 = ((size_t)bw * h + hd) * 3 * SLAB;
-
-        // Q fragment (B operand: B[k = d 4g+j][n = query fr]) straight from global: 512 B contiguous per wave
-        bf16x4 qf[DK];
-#pragma unroll
-        for (int kk = 0; kk < DK; ++kk) qf[kk] = *(const bf16x4*)(qkvh + slab0 + (size_t)q * DP + 16 * kk + 4 * g);
 
         // S^T tiles: rows = keys 16t + 4g + r, column = query fr
         f32x4 acc[LT];
@@ -180,6 +183,13 @@ __global__ __launch_bounds__(64 * LT) void attn_fwd_kernel(
                 o[dt] = mfma16(vf, pb, o[dt]);
             }
         }
+        // next window's K / V -> the other LDS buffer BEFORE this window's stores are issued: a wait for the prefetch
+        // placed after (exec-masked) stores would also wait for their acknowledgements
+        if (bw_next < Bw) {
+            write_stage(buf ^ 1);
+#pragma unroll
+            for (int kk = 0; kk < DK; ++kk) qf[kk] = qn[kk];
+        }
         const float inv = (q < L) ? 1.f / sum : 0.f;
         uint16_t* orow = oh + ((size_t)bw * h + hd) * SLAB + (size_t)q * DP;
 #pragma unroll
@@ -189,8 +199,6 @@ __global__ __launch_bounds__(64 * LT) void attn_fwd_kernel(
             *(bf16x4*)(orow + 16 * dt + 4 * g) = f2bf4(v);
         }
         if (g == 0) lse[((size_t)bw * h + hd) * Lp + q] = (q < L) ? mx + __log2f(sum) : 0.f;
-
-        if (bw_next < Bw) write_stage(buf ^ 1);
         __syncthreads();
     }
 }
@@ -228,7 +236,7 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
     constexpr int DSP = Lp + 4;                              // row pitch (elements) of the [key][q] bf16 images
     // rows of the dcos image: all Lp keys, or (compile-time L, no bias) the real keys rounded up to a 4-row block plus
     // one block of zeros that stands in for every padded-key block in phase 2
-    constexpr bool COMPACT = (LFIX > 0) && !HAS_BIAS;
+    constexpr bool COMPACT = (LFIX > 0) && !HAS_BIAS && TPW > 1;
     constexpr int IREAL = COMPACT ? (LFIX + 3) / 4 * 4 : Lp;
     constexpr int IROWS = COMPACT ? IREAL + 4 : Lp;
     constexpr bool BIAS_LDS = HAS_BIAS && (LT * DK <= 11);   // 145 KB at LT=11, DK=1
@@ -238,6 +246,7 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
     __shared__ __attribute__((aligned(16))) uint16_t Qs[SLAB];
     __shared__ __attribute__((aligned(16))) uint16_t Ks[SLAB];
     __shared__ __attribute__((aligned(16))) uint16_t dOs[SLAB];
+    __shared__ __attribute__((aligned(16))) uint16_t Vs[SLAB];
     __shared__ __attribute__((aligned(16))) uint16_t dSb[IROWS * DSP];
     __shared__ __attribute__((aligned(16))) uint16_t biasS[BIAS_LDS ? Lp * DSP : 8];
     __shared__ __attribute__((aligned(16))) float LSEs[Lp];
@@ -286,7 +295,7 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
     float dsig = 0.f;
 
     // ---- staging registers: chunk c = tid + j*NT of the q, k, dO, o slabs
-    uint4 sq[CPT], sk[CPT], sdo[CPT], so[CPT];
+    uint4 sq[CPT], sk[CPT], sv[CPT], sdo[CPT], so[CPT];
     float slse = 0.f;
     auto issue = [&](int bw) {
         const size_t slab0 = ((size_t)bw * h + hd) * 3 * SLAB, oslab = ((size_t)bw * h + hd) * SLAB;
@@ -296,6 +305,7 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
             if (c < CH) {
                 sq[j] = *(const uint4*)(qkvh + slab0 + (size_t)c * 8);
                 sk[j] = *(const uint4*)(qkvh + slab0 + SLAB + (size_t)c * 8);
+                sv[j] = *(const uint4*)(qkvh + slab0 + 2 * SLAB + (size_t)c * 8);
                 sdo[j] = *(const uint4*)(doh + oslab + (size_t)c * 8);
                 so[j] = *(const uint4*)(oh + oslab + (size_t)c * 8);
             }
@@ -309,6 +319,7 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
             if (c < CH) {
                 *(uint4*)(Qs + c * 8) = sq[j];
                 *(uint4*)(Ks + c * 8) = sk[j];
+                *(uint4*)(Vs + c * 8) = sv[j];
                 *(uint4*)(dOs + c * 8) = sdo[j];
             }
             // delta partial over this chunk's 8 channels, reduced over the CPR chunks of the row (adjacent lanes)
@@ -349,15 +360,17 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
 #pragma unroll
             for (int kk = 0; kk < DK; ++kk) {
                 kf[i][kk] = *(const bf16x4*)(Ks + key * DP + 16 * kk + 4 * g);
-                vf[i][kk] = *(const bf16x4*)(qkvh + slab0 + 2 * SLAB + (size_t)key * DP + 16 * kk + 4 * g);
+                vf[i][kk] = *(const bf16x4*)(Vs + key * DP + 16 * kk + 4 * g);   // (a global load here would drain the prefetch)
                 dk[i][kk] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 dv[i][kk] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
         const bool do_mask = (mask_thr > 0) && (((bw % nW) / nww) == nwh - 1);
         // one q-tile step; `br` / `dbrow`: this lane's bias row / bias-gradient row of the tile (TPW = 1 only)
-        auto step = [&](const int qt, const f32x4 br, f32x4& dbrow, auto masked_c) {
-            constexpr bool MASKED = decltype(masked_c)::value;
+        // MASKED / PADT (shift-mask window / a key tile with padded keys) are wave-uniform and loop-invariant: separate
+        // instantiations, so the common case carries no per-element selects
+        auto step = [&](const int qt, const f32x4 br, f32x4& dbrow, auto masked_c, auto pad_c) {
+            constexpr bool MASKED = decltype(masked_c)::value, PADT = decltype(pad_c)::value;
             bf16x4 qa[DK], da[DK], tq[DK], td[DK];
 #pragma unroll
             for (int kk = 0; kk < DK; ++kk) {
@@ -375,7 +388,7 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
                 if (TPW > 1 && kt >= LT) continue;                      // wave-uniform
                 const int key = 16 * kt + fr;
                 const bool kid = key >= mask_thr;
-                const bool pad_tile = 16 * kt + 16 > Lc, key_ok = key < Lc;
+                const bool key_ok = key < Lc;
                 // S = Q K^T and dP = dO V^T : rows q = 16qt + 4g + r, column = key fr
                 f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -392,7 +405,7 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
                         x = fmaf(s[r], sc2, br[r]) - l4[r];
                     } else {
                         x = fmaf(s[r], sc2, -l4[r]);
-                        if (pad_tile) x = key_ok ? x : SWV2_NEG_BIG;
+                        if (PADT) x = key_ok ? x : SWV2_NEG_BIG;
                     }
                     if (MASKED) x += ((q >= mask_thr) != kid) ? (-100.f * SWV2_LOG2E) : 0.f;
                     const float pr = __builtin_amdgcn_exp2f(x);
@@ -402,7 +415,8 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
                     dsig = fmaf(dsr, s[r], dsig);
                     if (HAS_BIAS) dbrow[r] += dsr;
                 }
-                const bf16x4 pb = f2bf4(p);
+                const uint32_t pk2[2] = {f2bf2(p[0], p[1]), f2bf2(p[2], p[3])};      // explicit pairs: one cvt_pk each
+                const bf16x4 pb = __builtin_bit_cast(bf16x4, pk2);
                 const bf16x4 dsb = f2bf4(ds);
                 if (!COMPACT || key < IREAL) *(bf16x4*)(dSb + key * DSP + 16 * qt + 4 * g) = dsb;   // image [key][q] for phase 2
                 // dV^T += dO^T P ; dK^T += Q^T dcos     (A operands: transposed reads of the staged dO / Q tiles)
@@ -431,7 +445,8 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
 #undef SWV2_CASE
                 }
                 f32x4 dsrow = {0.f, 0.f, 0.f, 0.f};
-                if (do_mask) step(qt, br, dsrow, std::true_type{}); else step(qt, br, dsrow, std::false_type{});
+                if (do_mask) step(qt, br, dsrow, std::true_type{}, std::false_type{});
+                else step(qt, br, dsrow, std::false_type{}, std::false_type{});
 #define SWV2_CASE(I) case I: if (I < LT) dbr[I < LT ? I : 0] += dsrow; break;
                 switch (qt) { SWV2_CASE(0) SWV2_CASE(1) SWV2_CASE(2) SWV2_CASE(3) SWV2_CASE(4) SWV2_CASE(5)
                               SWV2_CASE(6) SWV2_CASE(7) SWV2_CASE(8) SWV2_CASE(9) SWV2_CASE(10) }
@@ -439,12 +454,18 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
             }
         } else {
             f32x4 dummy = {0.f, 0.f, 0.f, 0.f};
+            // a wave's tiles contain padded keys only in the last tile (with TPW > 1 the test stays per element)
+            const bool pad_wave = TPW > 1 || 16 * tw + 16 > Lc;
+            // rolled loops: unrolling (2 or full) spills at the 168-VGPR budget of 11 waves (measured 164 -> 203 us)
             if (do_mask) {
 #pragma unroll 1
-                for (int qt = 0; qt < LT; ++qt) step(qt, dummy, dummy, std::true_type{});
+                for (int qt = 0; qt < LT; ++qt) step(qt, dummy, dummy, std::true_type{}, std::true_type{});
+            } else if (pad_wave) {
+#pragma unroll 1
+                for (int qt = 0; qt < LT; ++qt) step(qt, dummy, dummy, std::false_type{}, std::true_type{});
             } else {
-#pragma unroll 1                        // measured: unrolling (2 or full) spills at the 168-VGPR budget: 164 -> 203 us
-                for (int qt = 0; qt < LT; ++qt) step(qt, dummy, dummy, std::false_type{});
+#pragma unroll 1
+                for (int qt = 0; qt < LT; ++qt) step(qt, dummy, dummy, std::false_type{}, std::false_type{});
             }
         }
         // ---- dK (through the L2-normalisation) and dV of this wave's key tile(s)

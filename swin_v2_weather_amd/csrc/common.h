@@ -22,10 +22,15 @@ __device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float(((uin
 __device__ __forceinline__ float bf2f(short v) { return __uint_as_float(((uint32_t)(uint16_t)v) << 16); }
 // plain casts: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN-preserving) on gfx950
 __device__ __forceinline__ uint16_t f2bf(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
-__device__ __forceinline__ bf16x4 f2bf4(f32x4 v) { return __builtin_bit_cast(bf16x4, __builtin_convertvector(v, bf4_t)); }
 __device__ __forceinline__ uint32_t f2bf2(float lo, float hi) {
     f32x2 v = {lo, hi};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf2_t));
+}
+// two explicit pairs: a 4-wide convertvector of values produced one by one (v_exp results) compiled to four single
+// v_cvt_pk + two v_perm instead of two v_cvt_pk
+__device__ __forceinline__ bf16x4 f2bf4(f32x4 v) {
+    const uint32_t p[2] = {f2bf2(v[0], v[1]), f2bf2(v[2], v[3])};
+    return __builtin_bit_cast(bf16x4, p);
 }
 
 // ---- MFMA wrappers (wave64) ---------------------------------------------------------------

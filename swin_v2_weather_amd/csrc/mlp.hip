@@ -28,7 +28,7 @@ struct MlpFwd {
 };
 
 template <int C, int MT>
-__global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpFwd a) {
+__global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(const MlpFwd a) {
     constexpr int KS = C / 32, NT = C / 16;
     constexpr int P1 = C + 8, P2 = 40;                 // LDS row pitches (elements) of the W1 / W2 chunks
     constexpr int W1E = 32 * P1, W2E = C * P2;
@@ -36,13 +36,15 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpFwd a) {
     constexpr int SPT = (NCHUNK + 255) / 256;
     constexpr int ROWS = 64 * MT;                      // rows per workgroup
     constexpr int PX = C + 8;                          // pitch (bf16) of the staged x tile
-    constexpr int PY = C + 4, PA = C + 8;              // pitches of the per-wave epilogue tiles (fp32 / bf16)
-    constexpr int WBYTES = 2 * (W1E + W2E) * 2, XBYTES = ROWS * PX * 2, EBYTES = 4 * 16 * (PY * 4 + PA * 2);
+    constexpr int PA = C + 8;                          // pitch of the per-wave epilogue tile (bf16)
+    constexpr int EWAVE = 16 * PA * 2 + 16 * 2 * 4;    // per wave: bf16 tile + (mean, rstd) of its 16 rows
+    constexpr int WBYTES = 2 * (W1E + W2E) * 2, XBYTES = ROWS * PX * 2, EBYTES = 4 * EWAVE;
     constexpr int SBYTES = WBYTES > XBYTES ? (WBYTES > EBYTES ? WBYTES : EBYTES) : (XBYTES > EBYTES ? XBYTES : EBYTES);
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SBYTES];
     // fc1 bias in LDS: a global load inside the chunk loop would make its s_waitcnt drain the (older, in-order) weight
     // prefetch of the next chunk as well
     __shared__ __attribute__((aligned(16))) float b1s[MLP_MAX_HIDDEN];
+    __shared__ __attribute__((aligned(16))) float cs[3 * C];          // fc2 bias | LayerNorm gamma | beta
     uint16_t* smem = (uint16_t*)smem_raw;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -81,6 +83,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpFwd a) {
 #endif
     issue(0);
     for (int i = tid; i < hid; i += 256) b1s[i] = a.b1[i];
+    for (int i = tid; i < C; i += 256) { cs[i] = a.b2[i]; cs[C + i] = a.gamma[i]; cs[2 * C + i] = a.beta[i]; }
 
     // x tile -> LDS as bf16 with coalesced 16-byte loads (a lane-per-row fragment load would touch 64 lines per
     // instruction), then each wave picks up its B fragments: lane (m = fr, g) holds c = 32 ks + 8 g .. + 7
@@ -174,18 +177,18 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpFwd a) {
         STAMP(6);
     }
 
-    // ---- epilogue: + b2, bf16 round (saved fc2 output), LayerNorm over the row, drop-path scale -- in the accumulator
-    // layout (lane (m = fr, g) holds n = 16 t + 4 g + r; a row is spread over the 4 lanes with equal fr) -- then through
-    // a per-wave LDS tile so that the residual read and the stores are whole rows (512 B) per instruction
-    float* Ys = (float*)(smem_raw + wave * 16 * (PY * 4 + PA * 2));
-    uint16_t* As = (uint16_t*)(Ys + 16 * PY);
+    // ---- epilogue.  Accumulator layout (lane (m = fr, g) holds n = 16 t + 4 g + r; a row is spread over the 4 lanes
+    // with equal fr): + b2, bf16 round (the saved fc2 output), row mean / rstd (2 shuffle steps each).  The bf16 tile
+    // and the statistics go through a per-wave LDS tile; normalisation, drop-path scale and residual then run in ROW
+    // layout (a lane owns 8 consecutive columns), so the residual read and both stores are whole rows per instruction.
+    uint16_t* As = (uint16_t*)(smem_raw + wave * EWAVE);
+    float* St = (float*)(As + 16 * PA);                       // [16 rows][mean, rstd]
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const int r = row0 + 16 * mt + fr;
         float s = 0.f;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const f32x4 b2v = *(const f32x4*)(a.b2 + 16 * t + 4 * g);
+            const f32x4 b2v = *(const f32x4*)(cs + 16 * t + 4 * g);
             const bf16x4 ar = f2bf4(yacc[mt][t] + b2v);
             *(bf16x4*)(As + fr * PA + 16 * t + 4 * g) = ar;
 #pragma unroll
@@ -202,31 +205,37 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpFwd a) {
         q += __shfl_xor(q, 16);
         q += __shfl_xor(q, 32);
         const float rs = rsqrtf(q * (1.f / C) + a.eps);
-        const int rc = min(r, a.M - 1);
-        if (g == 0) { a.mean[rc] = mu; a.rstd[rc] = rs; }
-        const float sc = a.scale ? a.scale[rc / a.rows_per_sample] : 1.f;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int n = 16 * t + 4 * g;
-            const f32x4 gm = *(const f32x4*)(a.gamma + n), bt = *(const f32x4*)(a.beta + n);
-            f32x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = sc * ((yacc[mt][t][e] - mu) * rs * gm[e] + bt[e]);
-            *(f32x4*)(Ys + fr * PY + n) = o;
+        if (g == 0) {
+            const int rc = min(row0 + 16 * mt + fr, a.M - 1);
+            a.mean[rc] = mu;
+            a.rstd[rc] = rs;
+            St[2 * fr] = mu;
+            St[2 * fr + 1] = rs;
         }
         __syncthreads();
         const int rbase = row0 + 16 * mt;
+        constexpr int UNITS = 16 * (C / 8);
 #pragma unroll
-        for (int p = 0; p < 16 * (C / 4) / 64; ++p) {              // fp32 rows: residual + store
-            const int u = lane + 64 * p, row = u / (C / 4), c4 = u % (C / 4);
-            const size_t off = (size_t)min(rbase + row, a.M - 1) * C + 4 * c4;
-            *(f32x4*)(a.y + off) = *(const f32x4*)(a.x + off) + *(const f32x4*)(Ys + row * PY + 4 * c4);
-        }
-#pragma unroll
-        for (int p = 0; p < (16 * (C / 8) + 63) / 64; ++p) {       // bf16 rows of the saved fc2 output
+        for (int p = 0; p < (UNITS + 63) / 64; ++p) {
             const int u = lane + 64 * p, row = u / (C / 8), c8 = u % (C / 8);
-            if ((16 * (C / 8)) % 64 == 0 || u < 16 * (C / 8))
-                *(u32x4*)(a.a2 + (size_t)min(rbase + row, a.M - 1) * C + 8 * c8) = *(const u32x4*)(As + row * PA + 8 * c8);
+            if (UNITS % 64 == 0 || u < UNITS) {
+                const int rc = min(rbase + row, a.M - 1);
+                const u32x4 av = *(const u32x4*)(As + row * PA + 8 * c8);
+                const float mu_r = St[2 * row], rs_r = St[2 * row + 1];
+                const float sc = a.scale ? a.scale[rc / a.rows_per_sample] : 1.f;
+                const size_t off = (size_t)rc * C + 8 * c8;
+                *(u32x4*)(a.a2 + off) = av;
+                float v[8];
+                unpack8(__builtin_bit_cast(uint4, av), v);
+#pragma unroll
+                for (int hlf = 0; hlf < 2; ++hlf) {
+                    const f32x4 gm = *(const f32x4*)(cs + C + 8 * c8 + 4 * hlf), bt = *(const f32x4*)(cs + 2 * C + 8 * c8 + 4 * hlf);
+                    f32x4 o = *(const f32x4*)(a.x + off + 4 * hlf);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] += sc * ((v[4 * hlf + e] - mu_r) * rs_r * gm[e] + bt[e]);
+                    *(f32x4*)(a.y + off + 4 * hlf) = o;
+                }
+            }
         }
         if (mt + 1 < MT) __syncthreads();
     }
@@ -263,22 +272,26 @@ struct MlpBwd {
 };
 
 template <int C, int MT>
-__global__ __launch_bounds__(256) void mlp_bwd_kernel(const MlpBwd a) {
+__global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const MlpBwd a) {
     constexpr int KS = C / 32, NT = C / 16;
     constexpr int P1 = C + 8, P2 = 40;
     constexpr int W1E = 32 * P1, W2E = C * P2;
     constexpr int NCHUNK = 4 * C;
     constexpr int SPT = (NCHUNK + 255) / 256;
     constexpr int PY = C + 4;
-    constexpr int WBYTES = 2 * (W1E + W2E) * 2, EBYTES = 4 * 16 * PY * 4, GBYTES = 4 * 2 * C * 4;
-    constexpr int SBYTES = WBYTES > EBYTES ? (WBYTES > GBYTES ? WBYTES : GBYTES) : (EBYTES > GBYTES ? EBYTES : GBYTES);
+    constexpr int ROWS = 64 * MT, PX = C + 8;          // rows per workgroup, pitch (bf16) of the staged da2 tile
+    constexpr int XBYTES = ROWS * PX * 2;
+    constexpr int GBYTES = (256 / (C <= 32 ? 8 : C <= 64 ? 16 : C <= 128 ? 32 : 64)) * 2 * C * 4;      // d gamma / d beta row groups
+    constexpr int WBYTES = 2 * (W1E + W2E) * 2, EBYTES = 4 * 16 * PY * 4, PBYTES = XBYTES + GBYTES;
+    constexpr int SBYTES = WBYTES > EBYTES ? (WBYTES > PBYTES ? WBYTES : PBYTES) : (EBYTES > PBYTES ? EBYTES : PBYTES);
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SBYTES];
     uint16_t* smem = (uint16_t*)smem_raw;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4;
-    const int row0 = blockIdx.x * (64 * MT) + wave * (16 * MT);
+    const int wg_row0 = blockIdx.x * ROWS;
+    const int row0 = wg_row0 + wave * (16 * MT);
     const int hid = a.hidden, nch = hid / 32;
 
     u32x4 s1[SPT], s2[SPT];
@@ -318,79 +331,86 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const MlpBwd a) {
     issue(0);
     issue_h(0, hp);
 
-    // ---- LayerNorm backward in the B-fragment layout: lane (m = fr, g) holds columns c = 32 ks + 8 g .. + 7 of its row
+    // ---- LayerNorm backward in ROW layout: LPR lanes per row (4 columns each), the workgroup's rows in passes of RPP
+    // rows.  A thread keeps the same 4 columns in every pass, so d gamma / d beta are private register sums over the
+    // rows (one LDS reduction over the RPP row groups at the end) and all global accesses are whole rows.  da2 goes to
+    // global (bf16, for the fc2 weight gradient) and to an LDS tile from which the waves pick up their B fragments.
     bf16x8 xf[MT][KS];
-    float dgm[KS][8], dbt[KS][8];
+    {
+        constexpr int LPR = C <= 32 ? 8 : C <= 64 ? 16 : C <= 128 ? 32 : 64;      // lanes per row (power of two >= C / 4)
+        constexpr int RPP = 256 / LPR, NPASS = ROWS / RPP;
+        constexpr int BATCH = NPASS < 4 ? NPASS : 4;                               // passes whose loads are in flight together
+        static_assert(NPASS % BATCH == 0, "row passes must come in whole batches");
+        const int lr = tid % LPR, rg = tid / LPR;
+        const bool act = 4 * lr < C;
+        const int c0 = act ? 4 * lr : 0;
+        const f32x4 gm = *(const f32x4*)(a.gamma + c0);
+        f32x4 dgm = {0.f, 0.f, 0.f, 0.f}, dbt = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int pb = 0; pb < NPASS; pb += BATCH) {
+            f32x4 d4[BATCH];
+            u32x2 a4[BATCH];
+            float mu[BATCH], rs[BATCH], sc[BATCH];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
+            for (int i = 0; i < BATCH; ++i) {
+                const int rc = min(wg_row0 + (pb + i) * RPP + rg, a.M - 1);
+                d4[i] = *(const f32x4*)(a.dy + (size_t)rc * C + c0);
+                a4[i] = *(const u32x2*)(a.a2 + (size_t)rc * C + c0);
+                mu[i] = a.mean[rc];
+                rs[i] = a.rstd[rc];
+                sc[i] = a.scale ? a.scale[rc / a.rows_per_sample] : 1.f;
+            }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { dgm[ks][e] = 0.f; dbt[ks][e] = 0.f; }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int r = row0 + 16 * mt + fr;
-        const bool ok = r < a.M;
-        const int rc = ok ? r : a.M - 1;
-        const float mu = a.mean[rc], rs = a.rstd[rc];
-        const float sc = a.scale ? a.scale[rc / a.rows_per_sample] : 1.f;
-        const float once = ok ? 1.f : 0.f;           // duplicate rows (past M) compute row M - 1 again but count once
-        float gg[KS][8], xh[KS][8];
-        float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int c0 = 32 * ks + 8 * g;
-            float av[8];
-            unpack8(*(const uint4*)(a.a2 + (size_t)rc * C + c0), av);
-#pragma unroll
-            for (int hlf = 0; hlf < 2; ++hlf) {
-                const f32x4 d4 = *(const f32x4*)(a.dy + (size_t)rc * C + c0 + 4 * hlf);
-                const f32x4 gm = *(const f32x4*)(a.gamma + c0 + 4 * hlf);
+            for (int i = 0; i < BATCH; ++i) {
+                const int row = (pb + i) * RPP + rg;
+                const float once = (act && wg_row0 + row < a.M) ? 1.f : 0.f;   // duplicate rows (past M) count once
+                const float av[4] = {__uint_as_float(a4[i][0] << 16), __uint_as_float(a4[i][0] & 0xffff0000u),
+                                     __uint_as_float(a4[i][1] << 16), __uint_as_float(a4[i][1] & 0xffff0000u)};
+                float gg[4], xh[4], t1 = 0.f, t2 = 0.f;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int k = 4 * hlf + e;
-                    const float d = sc * d4[e];
-                    xh[ks][k] = (av[k] - mu) * rs;
-                    gg[ks][k] = d * gm[e];
-                    dgm[ks][k] = fmaf(once * d, xh[ks][k], dgm[ks][k]);
-                    dbt[ks][k] = fmaf(once, d, dbt[ks][k]);
-                    t1 += gg[ks][k];
-                    t2 = fmaf(gg[ks][k], xh[ks][k], t2);
+                    const float d = act ? sc[i] * d4[i][e] : 0.f;
+                    xh[e] = (av[e] - mu[i]) * rs[i];
+                    gg[e] = d * gm[e];
+                    dgm[e] = fmaf(once * d, xh[e], dgm[e]);
+                    dbt[e] = fmaf(once, d, dbt[e]);
+                    t1 += gg[e];
+                    t2 = fmaf(gg[e], xh[e], t2);
+                }
+#pragma unroll
+                for (int o = 1; o < LPR; o <<= 1) { t1 += __shfl_xor(t1, o); t2 += __shfl_xor(t2, o); }
+                t1 *= (1.f / C); t2 *= (1.f / C);
+                f32x4 o4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o4[e] = rs[i] * (gg[e] - t1 - xh[e] * t2);
+                const bf16x4 ob = f2bf4(o4);
+                if (act) {
+                    *(bf16x4*)(a.da2 + (size_t)min(wg_row0 + row, a.M - 1) * C + c0) = ob;
+                    *(bf16x4*)(smem + row * PX + c0) = ob;
                 }
             }
         }
-        t1 += __shfl_xor(t1, 16); t1 += __shfl_xor(t1, 32);
-        t2 += __shfl_xor(t2, 16); t2 += __shfl_xor(t2, 32);
-        t1 *= (1.f / C); t2 *= (1.f / C);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            float o[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = rs * (gg[ks][e] - t1 - xh[ks][e] * t2);
-            const uint4 pk = pack8(o);
-            *(uint4*)(a.da2 + (size_t)rc * C + 32 * ks + 8 * g) = pk;
-            xf[mt][ks] = __builtin_bit_cast(bf16x8, pk);
+        float* gs = (float*)(smem_raw + XBYTES);                   // [RPP row groups][2][C]
+        if (act) {
+            *(f32x4*)(gs + (rg * 2 + 0) * C + c0) = dgm;
+            *(f32x4*)(gs + (rg * 2 + 1) * C + c0) = dbt;
         }
+        __syncthreads();
+        for (int i = tid; i < 2 * C; i += 256) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < RPP; ++r) t += gs[r * 2 * C + i];
+            a.ws[(size_t)blockIdx.x * 2 * C + i] = t;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                xf[mt][ks] = *(const bf16x8*)(smem + (wave * 16 * MT + 16 * mt + fr) * PX + 32 * ks + 8 * g);
+        __syncthreads();
     }
     STAMP(0);
-    // column sums over the 16 rows of the wave's tiles (lanes with equal g), then over the 4 waves
-    {
-        float* gs = (float*)smem_raw;                          // [4 waves][2][C]
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float v = dgm[ks][e], w = dbt[ks][e];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) { v += __shfl_xor(v, o); w += __shfl_xor(w, o); }
-                if (fr == 0) {
-                    gs[(wave * 2 + 0) * C + 32 * ks + 8 * g + e] = v;
-                    gs[(wave * 2 + 1) * C + 32 * ks + 8 * g + e] = w;
-                }
-            }
-        __syncthreads();
-        for (int i = tid; i < 2 * C; i += 256)
-            a.ws[(size_t)blockIdx.x * 2 * C + i] = (gs[i] + gs[2 * C + i]) + (gs[4 * C + i] + gs[6 * C + i]);
-        __syncthreads();
-    }
+    STAMP(1);
 
     f32x4 yacc[MT][NT];
 #pragma unroll
@@ -400,7 +420,6 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const MlpBwd a) {
 
     commit(0);
     __syncthreads();
-    STAMP(1);
     // one chunk; `cur` holds this chunk's saved pre-activation, `nxt` receives the next chunk's (two register sets used
     // alternately: a copy between them would wait for the loads right where it is written)
     auto chunk = [&](int ch, u32x2 (&cur)[MT][2], u32x2 (&nxt)[MT][2]) {
@@ -542,8 +561,7 @@ extern "C" int swv2_mlp_bwd(const swv2_mlp_bwd_args* a, void* stream) {
                 a->hidden, a->rows_per_sample};
     hipStream_t st = (hipStream_t)stream;
     static const int force_mt = getenv("SWV2_MLP_MT") ? atoi(getenv("SWV2_MLP_MT")) : 0;
-    const long t1 = cdiv(cdiv(a->M, 64), 256 * 3), t2 = 2L * cdiv(cdiv(a->M, 128), 256 * 2);
-    const bool mt2 = force_mt ? force_mt == 2 : (a->C <= 64 && t2 < t1);   // wider rows: two tiles per wave cost occupancy
+    const bool mt2 = force_mt ? force_mt == 2 : a->M >= 128 * 256;      // measured at C = 128, M = 129600: 170 us vs 185 us
     switch (a->C) {
         case 32: mt2 ? launch_mlp_bwd<32, 2>(k, st) : launch_mlp_bwd<32, 1>(k, st); break;
         case 64: mt2 ? launch_mlp_bwd<64, 2>(k, st) : launch_mlp_bwd<64, 1>(k, st); break;

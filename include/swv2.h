@@ -52,6 +52,8 @@ typedef struct swv2_attn_args {
     const void* qkvh;         /* in  */
     const float* logit_scale; /* in  [heads] raw tau; sigma = exp(min(tau, ln 100))   (swinv2_global.py:305) */
     const float* bias;        /* in  [heads][L][L] continuous position bias (swinv2_global.py:274-287) or NULL */
+    const void* bias_pack;    /* optional: the same table pre-packed by swv2_attn_pack_bias (kernel register / LDS-image
+                                 layouts, coalesced loads); NULL = the kernels convert `bias` themselves */
     void* oh;                 /* fwd: out; bwd: in */
     float* lse;               /* fwd: out; bwd: in */
     const void* doh;          /* bwd in : grad of oh, same layout */
@@ -68,6 +70,10 @@ typedef struct swv2_attn_args {
     int max_chunks;           /* workgroups per head (each loops over windows); 64 is a good default */
     int dbg;                  /* must be 0 (kernel-ablation switches used by tests/perf_probe.py only) */
 } swv2_attn_args;
+
+/* bias table -> the kernels' layouts (bf16, log2 domain); out: swv2_attn_pack_bias_bytes(heads, L) bytes */
+size_t swv2_attn_pack_bias_bytes(int heads, int L);
+int swv2_attn_pack_bias(const float* bias, int heads, int L, void* out, void* stream);
 
 /* cosine window attention core, forward: swinv2_global.py:304-318 (q,k normalisation is in the QKV epilogue) */
 int swv2_attn_fwd(const swv2_attn_args* a, void* stream);
@@ -280,6 +286,7 @@ typedef struct swv2_block_desc {
     /* per-call inputs */
     const float* x;          /* [B*T][C] block input (residual stream) */
     const float* bias;       /* [heads][L][L] CPB table or NULL */
+    void* bias_pack;         /* with bias: swv2_attn_pack_bias_bytes(heads, L) bytes, written by the forward, read by both */
     const float* dp1;        /* [B] drop-path scales or NULL */
     const float* dp2;
     /* saved activations: written by forward, read by backward */

@@ -52,7 +52,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
 
 # ---- structures (mirror include/swv2.h) ---------------------------------------------------------------------
 class AttnArgs(C.Structure):
-    _fields_ = [("qkvh", C.c_void_p), ("logit_scale", C.c_void_p), ("bias", C.c_void_p), ("oh", C.c_void_p),
+    _fields_ = [("qkvh", C.c_void_p), ("logit_scale", C.c_void_p), ("bias", C.c_void_p), ("bias_pack", C.c_void_p), ("oh", C.c_void_p),
                 ("lse", C.c_void_p), ("doh", C.c_void_p), ("rnorm", C.c_void_p), ("dqkvh", C.c_void_p),
                 ("dlogit_scale", C.c_void_p), ("dbias", C.c_void_p),
                 ("Bw", C.c_int), ("heads", C.c_int), ("L", C.c_int), ("head_dim", C.c_int),
@@ -95,7 +95,7 @@ class BlockDesc(C.Structure):
                     "rowidx", "qkv_map", "proj_map",
                     "logit_scale", "qkv_b_pad", "proj_b", "n1_w", "n1_b", "fc1_b", "fc2_b", "n2_w", "n2_b",
                     "w_qkv", "w_proj", "w_fc1", "w_fc2", "w_qkvt", "w_projt", "w_fc1t", "w_fc2t",
-                    "x", "bias", "dp1", "dp2",
+                    "x", "bias", "bias_pack", "dp1", "dp2",
                     "qkvh", "rnorm", "oh", "lse", "a1", "mean1", "rstd1", "x1", "hpre", "hact", "a2", "mean2", "rstd2", "x2",
                     "dx2", "da2", "dh", "da1", "doh", "dqkvh", "dx1", "ln_ws", "dx",
                     "d_logit_scale", "d_bias", "d_qkv_w", "d_qkv_b", "d_proj_w", "d_proj_b", "d_n1_w", "d_n1_b", "d_fc1_w",
@@ -113,6 +113,8 @@ SYMBOLS = {
     "swv2_version": (_I, []),
     "swv2_last_error": (C.c_char_p, []),
     "swv2_attn_geometry": (_I, [_I, _I, C.POINTER(_I), C.POINTER(_I)]),
+    "swv2_attn_pack_bias_bytes": (C.c_size_t, [_I, _I]),
+    "swv2_attn_pack_bias": (_I, [_P, _I, _I, _P, _P]),
     "swv2_attn_fwd": (_I, [C.POINTER(AttnArgs), _P]),
     "swv2_attn_bwd": (_I, [C.POINTER(AttnArgs), _P]),
     "swv2_linear": (_I, [C.POINTER(Operand), _P, C.POINTER(Epilogue), _I, _P]),

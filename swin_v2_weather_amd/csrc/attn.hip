@@ -67,11 +67,50 @@ __device__ __forceinline__ float score_pass(f32x4 (&acc)[LT], const uint32_t (&b
 }
 
 // ------------------------------------------------------------------------------------------------
+// CPB bias table, pre-packed once per block call for both kernels (swv2_attn_pack_bias): log2 domain, bf16,
+// -1e30 on padded keys, 0 on padded queries.
+//   forward part : u32 [h][LT q-tiles][LT key-tiles][2][64 lanes]: the packed pair (r = 2j, 2j+1) of lane (fr = query,
+//                  g) -- exactly the registers of attn_fwd_kernel, so its load is one coalesced dword per register
+//                  (the fp32 [h][L][L] table read in register layout touches one cache line per lane: 31 K lines =
+//                  ~15 us per workgroup, measured 26 us)
+//   backward part: bf16 [h][Lp keys][Lp + 4]: the LDS image of attn_bwd_kernel, copied with 16-byte loads (the
+//                  in-kernel transposing conversion cost ~30 us per workgroup)
+// ------------------------------------------------------------------------------------------------
+template <int LT>
+struct BiasPack {
+    static constexpr int Lp = 16 * LT, DSP = Lp + 4;
+    static constexpr size_t FWD_U32 = (size_t)LT * LT * 2 * 64;       // per head
+    static constexpr size_t BWD_BF16 = (size_t)Lp * DSP;              // per head
+    static size_t bytes(int heads) { return heads * (FWD_U32 * 4 + BWD_BF16 * 2); }
+};
+
+template <int LT>
+__global__ void attn_pack_bias_kernel(const float* __restrict__ bias, int heads, int L, uint32_t* __restrict__ fwd,
+                                      uint16_t* __restrict__ bwd) {
+    using P = BiasPack<LT>;
+    const int hd = blockIdx.y;
+    auto val = [&](int q, int key) -> float {
+        if (key >= L) return SWV2_NEG_BIG;
+        return (q < L) ? bias[((size_t)hd * L + q) * L + key] * SWV2_LOG2E : 0.f;
+    };
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < P::FWD_U32; i += (size_t)gridDim.x * blockDim.x) {
+        const int lane = i & 63, j = (i >> 6) & 1, t = (int)((i >> 7) % LT), qt = (int)((i >> 7) / LT);
+        const int q = 16 * qt + (lane & 15), key = 16 * t + 4 * (lane >> 4) + 2 * j;
+        fwd[(size_t)hd * P::FWD_U32 + i] = f2bf2(val(q, key), val(q, key + 1));
+    }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < P::BWD_BF16; i += (size_t)gridDim.x * blockDim.x) {
+        const int key = (int)(i / P::DSP), q = (int)(i % P::DSP);
+        bwd[(size_t)hd * P::BWD_BF16 + i] = (q < P::Lp) ? f2bf(val(q, key)) : (uint16_t)0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
 template <int LT, int DK, bool HAS_BIAS, int LFIX>
 __global__ __launch_bounds__(64 * LT) void attn_fwd_kernel(
     const uint16_t* __restrict__ qkvh, const float* __restrict__ logit_scale, const float* __restrict__ bias,
+    const uint32_t* __restrict__ bpack,   // swv2_attn_pack_bias forward part or null
     uint16_t* __restrict__ oh, float* __restrict__ lse, int Bw, int h, int L, int nW, int nww, int nwh, int mask_thr) {
     using C = AttnCfg<LT, DK>;
     constexpr int Lp = C::Lp, DP = C::DP, SLAB = C::SLAB;
@@ -90,17 +129,34 @@ __global__ __launch_bounds__(64 * LT) void attn_fwd_kernel(
     // (identical P in both passes), held as packed pairs: 2 x LT registers
     uint32_t biasp[LT][2];
     if (HAS_BIAS) {
+        if (bpack) {
+            const uint32_t* src = bpack + (((size_t)hd * LT + qt) * LT) * 128 + lane;
 #pragma unroll
-        for (int t = 0; t < LT; ++t) {
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = 16 * t + 4 * g + r;
-                v[r] = SWV2_NEG_BIG;
-                if (key < L) v[r] = (q < L) ? bias[((size_t)hd * L + q) * L + key] * SWV2_LOG2E : 0.f;
+            for (int t = 0; t < LT; ++t) {
+                biasp[t][0] = src[t * 128];
+                biasp[t][1] = src[t * 128 + 64];
             }
-            biasp[t][0] = f2bf2(v[0], v[1]);
-            biasp[t][1] = f2bf2(v[2], v[3]);
+        } else {
+            // unconditional (clamped) loads, selection afterwards (exec-masked loads are serialised by the compiler)
+            float bv[LT][4];
+#pragma unroll
+            for (int t = 0; t < LT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = 16 * t + 4 * g + r;
+                    bv[t][r] = bias[((size_t)hd * L + min(q, L - 1)) * L + min(key, L - 1)];
+                }
+#pragma unroll
+            for (int t = 0; t < LT; ++t) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = 16 * t + 4 * g + r;
+                    v[r] = (key < L) ? ((q < L) ? bv[t][r] * SWV2_LOG2E : 0.f) : SWV2_NEG_BIG;
+                }
+                biasp[t][0] = f2bf2(v[0], v[1]);
+                biasp[t][1] = f2bf2(v[2], v[3]);
+            }
         }
     }
 
@@ -223,6 +279,7 @@ __global__ __launch_bounds__(64 * LT) void attn_fwd_kernel(
 template <int LT, int DK, bool HAS_BIAS, int LFIX, int TPW>
 __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
     const uint16_t* __restrict__ qkvh, const float* __restrict__ logit_scale, const float* __restrict__ bias,
+    const uint16_t* __restrict__ bimg,     // swv2_attn_pack_bias backward part ([h][Lp][Lp + 4] bf16) or null
     const uint16_t* __restrict__ oh, const uint16_t* __restrict__ doh, const float* __restrict__ lse,
     const float* __restrict__ rnorm,       // [Bw][h][2][Lp]  1/max(|q|,eps), 1/max(|k|,eps)
     uint16_t* __restrict__ dqkvh,          // [Bw][h][3][Lp][DP]  grads w.r.t. the UN-normalised q, k and v
@@ -273,12 +330,24 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
         const int key = 16 * tw + fr;
 #pragma unroll
         for (int qt = 0; qt < LT; ++qt) dbr[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (BIAS_LDS) {
-            for (int i = tid; i < Lp * Lp; i += NT) {
-                const int q = i / Lp, k = i - q * Lp;       // k fastest: coalesced global reads
-                float v = SWV2_NEG_BIG;
-                if (k < L) v = (q < L) ? bias[((size_t)hd * L + q) * L + k] * SWV2_LOG2E : 0.f;
-                biasS[k * DSP + q] = f2bf(v);
+        if (BIAS_LDS && bimg) {
+            const uint4* src = (const uint4*)(bimg + (size_t)hd * Lp * DSP);       // Lp * DSP * 2 bytes, multiple of 16
+            for (int i = tid; i < Lp * DSP / 8; i += NT) ((uint4*)biasS)[i] = src[i];
+        } else if (BIAS_LDS) {
+            // 8 loads in flight per thread (a load -> LDS-write loop exposes one memory round trip per element: 44 trips)
+            for (int i0 = 0; i0 < Lp * Lp; i0 += 8 * NT) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + u * NT + tid, q = i / Lp, k = i - q * Lp;       // k fastest: coalesced global reads
+                    const bool in = (i < Lp * Lp) && (k < L) && (q < L);
+                    v[u] = bias[in ? ((size_t)hd * L + q) * L + k : (size_t)hd * L * L];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + u * NT + tid, q = i / Lp, k = i - q * Lp;
+                    if (i < Lp * Lp) biasS[k * DSP + q] = f2bf((k < L) ? ((q < L) ? v[u] * SWV2_LOG2E : 0.f) : SWV2_NEG_BIG);
+                }
             }
         } else {
 #pragma unroll
@@ -286,8 +355,8 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int q = 16 * qt + 4 * g + r;
-                    float v = SWV2_NEG_BIG;
-                    if (key < L) v = (q < L) ? bias[((size_t)hd * L + q) * L + key] * SWV2_LOG2E : 0.f;
+                    const float b = bias[((size_t)hd * L + min(q, L - 1)) * L + min(key, L - 1)];     // unconditional load
+                    const float v = (key < L) ? ((q < L) ? b * SWV2_LOG2E : 0.f) : SWV2_NEG_BIG;
                     biasr[qt][r] = bf2f(f2bf(v));           // bf16-rounded like the LDS image and the forward
                 }
         }
@@ -578,11 +647,12 @@ int launch_fwd(const swv2_attn_args* a, hipStream_t st) {
     const int nW = a->nwh * a->nww;
     if (a->bias)
         hipLaunchKernelGGL((attn_fwd_kernel<LT, DK, true, LFIX>), grid, block, 0, st, (const uint16_t*)a->qkvh, a->logit_scale,
-                           a->bias, (uint16_t*)a->oh, a->lse, a->Bw, a->heads, a->L, nW, a->nww, a->nwh, a->mask_thr);
+                           a->bias, (const uint32_t*)a->bias_pack, (uint16_t*)a->oh, a->lse, a->Bw, a->heads, a->L, nW, a->nww,
+                           a->nwh, a->mask_thr);
     else
         hipLaunchKernelGGL((attn_fwd_kernel<LT, DK, false, LFIX>), grid, block, 0, st, (const uint16_t*)a->qkvh,
-                           a->logit_scale, a->bias, (uint16_t*)a->oh, a->lse, a->Bw, a->heads, a->L, nW, a->nww,
-                           a->nwh, a->mask_thr);
+                           a->logit_scale, a->bias, (const uint32_t*)nullptr, (uint16_t*)a->oh, a->lse, a->Bw, a->heads, a->L, nW,
+                           a->nww, a->nwh, a->mask_thr);
     SWV2_CHECK_LAUNCH("swv2_attn_fwd");
     return SWV2_OK;
 }
@@ -593,8 +663,10 @@ int launch_bwd(const swv2_attn_args* a, hipStream_t st) {
     const int nW = a->nwh * a->nww;
     if (a->bias) {
         dim3 grid(nchunk, a->heads), block(64 * LT);
+        const uint16_t* bimg = a->bias_pack ? (const uint16_t*)((const char*)a->bias_pack + a->heads * BiasPack<LT>::FWD_U32 * 4)
+                                            : nullptr;
         hipLaunchKernelGGL((attn_bwd_kernel<LT, DK, true, LFIX, 1>), grid, block, 0, st, (const uint16_t*)a->qkvh, a->logit_scale,
-                           a->bias, (const uint16_t*)a->oh, (const uint16_t*)a->doh, a->lse, a->rnorm,
+                           a->bias, bimg, (const uint16_t*)a->oh, (const uint16_t*)a->doh, a->lse, a->rnorm,
                            (uint16_t*)a->dqkvh, a->dlogit_scale, a->dbias, a->Bw, a->heads, a->L, nW, a->nww, a->nwh,
                            a->mask_thr, a->dbg);
     } else {
@@ -603,7 +675,7 @@ int launch_bwd(const swv2_attn_args* a, hipStream_t st) {
         constexpr int TPW = 1;
         dim3 grid(nchunk, a->heads), block(64 * ((LT + TPW - 1) / TPW));
         hipLaunchKernelGGL((attn_bwd_kernel<LT, DK, false, LFIX, TPW>), grid, block, 0, st, (const uint16_t*)a->qkvh,
-                           a->logit_scale, a->bias, (const uint16_t*)a->oh, (const uint16_t*)a->doh, a->lse, a->rnorm,
+                           a->logit_scale, a->bias, (const uint16_t*)nullptr, (const uint16_t*)a->oh, (const uint16_t*)a->doh, a->lse, a->rnorm,
                            (uint16_t*)a->dqkvh, a->dlogit_scale, a->dbias, a->Bw, a->heads, a->L, nW, a->nww, a->nwh,
                            a->mask_thr, a->dbg);
     }
@@ -653,6 +725,24 @@ extern "C" int swv2_attn_geometry(int L, int head_dim, int* Lp, int* DP) {
     if (Lp == 176 && DP == 32) return FN<11, 2, 0>(a, st);                             \
     swv2_set_error("attention: no kernel for Lp=%d DP=%d", Lp, DP);                    \
     return SWV2_ERR_UNSUPPORTED;
+
+extern "C" size_t swv2_attn_pack_bias_bytes(int heads, int L) {
+    if (heads <= 0 || L <= 0) return 0;
+    return L <= 64 ? BiasPack<4>::bytes(heads) : (L <= 176 ? BiasPack<11>::bytes(heads) : 0);
+}
+
+extern "C" int swv2_attn_pack_bias(const float* bias, int heads, int L, void* out, void* stream) {
+    SWV2_CHECK_ARG(bias && out && heads > 0 && L > 0 && L <= 176, "swv2_attn_pack_bias: null pointer or L=%d out of range", L);
+    hipStream_t st = (hipStream_t)stream;
+    if (L <= 64)
+        hipLaunchKernelGGL((attn_pack_bias_kernel<4>), dim3(16, heads), dim3(256), 0, st, bias, heads, L, (uint32_t*)out,
+                           (uint16_t*)((char*)out + heads * BiasPack<4>::FWD_U32 * 4));
+    else
+        hipLaunchKernelGGL((attn_pack_bias_kernel<11>), dim3(64, heads), dim3(256), 0, st, bias, heads, L, (uint32_t*)out,
+                           (uint16_t*)((char*)out + heads * BiasPack<11>::FWD_U32 * 4));
+    SWV2_CHECK_LAUNCH("swv2_attn_pack_bias");
+    return SWV2_OK;
+}
 
 extern "C" int swv2_attn_fwd(const swv2_attn_args* a, void* stream) {
     int rc0 = check_args(a, false);

@@ -22,7 +22,8 @@ swv2_epilogue epi(int kind, void* out, long ld, const float* bias = nullptr, con
 }
 swv2_attn_args attn(const swv2_block_desc* d) {
     swv2_attn_args a = {};
-    a.qkvh = d->qkvh; a.logit_scale = d->logit_scale; a.bias = d->bias; a.oh = d->oh; a.lse = d->lse;
+    a.qkvh = d->qkvh; a.logit_scale = d->logit_scale; a.bias = d->bias; a.bias_pack = d->bias ? d->bias_pack : nullptr;
+    a.oh = d->oh; a.lse = d->lse;
     a.Bw = d->B * d->nwh * d->nww; a.heads = d->heads; a.L = d->L; a.head_dim = d->head_dim; a.nwh = d->nwh; a.nww = d->nww;
     a.mask_thr = d->mask_thr; a.max_chunks = 64;
     return a;
@@ -84,9 +85,11 @@ extern "C" int swv2_block_fwd(const swv2_block_desc* d, void* st) {
         e.p[0] = h; e.p[2] = d->Lp; e.p[3] = d->DP; e.p[4] = d->L;
         LAUNCH(1, swv2_linear(&a, d->w_qkv, &e, 3 * h * d->DP, st));
     }
-    // 2. cosine attention core
+    // 2. cosine attention core (the CPB table is packed once into the kernels' layouts; the backward reuses it)
     {
+        if (d->bias && d->bias_pack) TRY(swv2_attn_pack_bias(d->bias, h, d->L, d->bias_pack, st));
         swv2_attn_args a = attn(d);
+        if (d->bias) a.max_chunks = 32;          // per-workgroup table load: fewer, longer-lived workgroups
         LAUNCH(2, swv2_attn_fwd(&a, st));
     }
     // 3. merge heads | proj GEMM

@@ -114,7 +114,7 @@ def _carve(sizes, align=256):
 class _BlockRunner:
     """Per (block, batch size, device) launch descriptor: geometry, index tables and buffer offsets are filled once."""
 
-    ACTS = ("qkvh", "rnorm", "oh", "lse", "a1", "mean1", "rstd1", "x1", "hpre", "hact", "a2", "mean2", "rstd2")
+    ACTS = ("qkvh", "rnorm", "oh", "lse", "a1", "mean1", "rstd1", "x1", "hpre", "hact", "a2", "mean2", "rstd2", "bias_pack")
     SCRATCH = ("da2", "dh", "da1", "doh", "dqkvh", "dx1", "ln_ws", "wgrad_ws")
 
     def __init__(self, blk, plan, Cc, hid, device):
@@ -135,7 +135,8 @@ class _BlockRunner:
         fused = bool(d.fuse_mlp) and bool(L.load().swv2_mlp_supported(Cc, hid))
         self.desc = d
         act_sizes = [Bw * h * 3 * Lp * DP * 2, Bw * h * 2 * Lp * 4, Bw * h * Lp * DP * 2, Bw * h * Lp * 4, Mw * Cc * 2, Mw * 4,
-                     Mw * 4, BT * Cc * 4, BT * hid * 2, 0 if fused else BT * hid * 2, BT * Cc * 2, BT * 4, BT * 4]
+                     Mw * 4, BT * Cc * 4, BT * hid * 2, 0 if fused else BT * hid * 2, BT * Cc * 2, BT * 4, BT * 4,
+                     lib.swv2_attn_pack_bias_bytes(h, Lw)]
         self.act_off, self.act_bytes = _carve(act_sizes)
         scr_sizes = [BT * Cc * 2, BT * hid * 2, Mw * Cc * 2, Bw * h * Lp * DP * 2, Bw * h * 3 * Lp * DP * 2, BT * Cc * 4,
                      max(L.LN_BWD_MAX_BLOCKS * 2 * Cc, lib.swv2_mlp_bwd_ws_floats(BT, Cc)) * 4, ws_bytes]

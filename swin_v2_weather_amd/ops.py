@@ -192,12 +192,21 @@ def ln_residual_bwd(a, dy, gamma, scale, rowidx, mean, rstd, da, dgamma, dbeta, 
 
 
 def attn_args(qkvh, logit_scale, bias, oh, lse, Bw, heads, Lwin, head_dim, nwh, nww, mask_thr, doh=None, rnorm=None,
-              dqkvh=None, dlogit=None, dbias=None, max_chunks=64) -> L.AttnArgs:
+              dqkvh=None, dlogit=None, dbias=None, max_chunks=64, bias_pack=None) -> L.AttnArgs:
     a = L.AttnArgs()
     a.qkvh, a.logit_scale, a.bias, a.oh, a.lse = _p(qkvh), _p(logit_scale), _p(bias), _p(oh), _p(lse)
+    a.bias_pack = _p(bias_pack)
     a.doh, a.rnorm, a.dqkvh, a.dlogit_scale, a.dbias = _p(doh), _p(rnorm), _p(dqkvh), _p(dlogit), _p(dbias)
     a.Bw, a.heads, a.L, a.head_dim, a.nwh, a.nww, a.mask_thr, a.max_chunks = Bw, heads, Lwin, head_dim, nwh, nww, mask_thr, max_chunks
     return a
+
+
+def attn_pack_bias(bias: torch.Tensor) -> torch.Tensor:
+    """[heads][L][L] fp32 CPB table -> the attention kernels' pre-packed layouts (one uint8 buffer)."""
+    heads, Lw = bias.shape[0], bias.shape[1]
+    out = torch.empty(L.load().swv2_attn_pack_bias_bytes(heads, Lw), dtype=torch.uint8, device=bias.device)
+    L.check(L.load().swv2_attn_pack_bias(_p(bias), heads, Lw, _p(out), _stream()), "swv2_attn_pack_bias")
+    return out
 
 
 def attn_fwd(a: L.AttnArgs):

@@ -48,13 +48,14 @@ def probe_attn(B=2, rel_pos=False):
     dq = torch.empty(Bw, h, 3, Lp, DP, dtype=BF, device=dev)
     dls = torch.zeros(h, device=dev)
     dbias = torch.zeros(h, Lw, Lw, device=dev) if rel_pos else None
+    pk = ops.attn_pack_bias(bias) if rel_pos else None
     for chunks in (32, 64, 128):
-        a = ops.attn_args(qkvh, ls, bias, oh, lse, Bw, h, Lw, 16, plan.nwh, plan.nww, plan.mask_thr, max_chunks=chunks)
+        a = ops.attn_args(qkvh, ls, bias, oh, lse, Bw, h, Lw, 16, plan.nwh, plan.nww, plan.mask_thr, max_chunks=chunks, bias_pack=pk)
         say(f"attn_fwd  B={B} bias={rel_pos} chunks={chunks}: {timeit(lambda: ops.attn_fwd(a)):.1f} us")
     for chunks in (32, 64, 128):
         for dbg in (0, 1, 2, 4, 5):
             a = ops.attn_args(qkvh, ls, bias, oh, lse, Bw, h, Lw, 16, plan.nwh, plan.nww, plan.mask_thr, doh=doh, rnorm=rnorm,
-                              dqkvh=dq, dlogit=dls, dbias=dbias, max_chunks=chunks)
+                              dqkvh=dq, dlogit=dls, dbias=dbias, max_chunks=chunks, bias_pack=pk)
             a.dbg = dbg
             say(f"attn_bwd  B={B} bias={rel_pos} chunks={chunks} dbg={dbg}: {timeit(lambda: ops.attn_bwd(a)):.1f} us")
 

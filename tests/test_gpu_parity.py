@@ -260,6 +260,15 @@ def test_attention_core_fwd_bwd(dev, K, wh, ww, h, d, nwh, nww, shifted, use_bia
     assert rel(got[:, :, 2], g[:, :, 2]) < 6e-3
     assert float(dls[-1]) == 0.0 and rel(dls, ls_ref.grad) < 0.12       # clamp gate; sum with heavy cancellation
     if use_bias:
+        # the pre-packed table (swv2_attn_pack_bias) holds the same bf16 values: forward and dq/dk/dv are bit-identical
+        pk = ops.attn_pack_bias(bd)
+        oh2, lse2 = torch.empty_like(oh), torch.empty_like(lse)
+        ops.attn_fwd(ops.attn_args(qkvh, lsd, bd, oh2, lse2, Bw, h, Lw, d, nwh, nww, mask_thr, bias_pack=pk))
+        assert torch.equal(oh2, oh) and torch.equal(lse2, lse)
+        dq2, dls2, db2 = torch.empty_like(dqkvh), torch.zeros_like(dls), torch.zeros_like(dbias)
+        ops.attn_bwd(ops.attn_args(qkvh, lsd, bd, oh, lse, Bw, h, Lw, d, nwh, nww, mask_thr, doh=doh, rnorm=rnorm.to(dev).contiguous(),
+                                   dqkvh=dq2, dlogit=dls2, dbias=db2, bias_pack=pk))
+        assert torch.equal(dq2, dqkvh) and rel(db2, dbias) < 1e-5
         assert rel(dbias, bias_ref.grad) < 8e-3
 
 

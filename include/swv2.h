@@ -208,6 +208,33 @@ int swv2_loss_grad(const float* prd, const float* tar, const float* quad_w, cons
 int swv2_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                    int step, float grad_inv_scale, void* stream);
 
+/* Fused attention branch, forward, for blocks WITHOUT the CPB bias (rel_pos = False, the yaml default):
+ *   y = x + scale[b] * LayerNorm1(proj(W-MSA(roll / partition(x))))   scattered back through window-reverse / un-roll
+ * (swinv2_global.py:446-478, 170-198, 490) as one kernel.  Writes everything the unfused kernels save for the backward
+ * in the same layouts (qkvh, rnorm, oh, lse, a1, mean, rstd), so swv2_attn_bwd etc. run unchanged.  C in {32,64,96,128},
+ * head_dim <= 16, an even number of heads with heads * 16 <= 128, L <= 176 (swv2_attn_branch_supported), else SWV2_ERR_UNSUPPORTED. */
+typedef struct {
+    const float* x;            /* [B*T][C] fp32 block input, image order: GEMM input (gathered) and residual */
+    const int32_t* rowidx;     /* [Bw*Lp] window row -> image row, negative = padding */
+    const void* wqkv;          /* bf16 [3*heads*16][C], rows (part, head, j) with the head dim padded to 16 */
+    const float* bqkv;         /* [3*heads*16] padded alike */
+    const void* wproj;         /* bf16 [C][heads*16] */
+    const float* bproj;        /* [C] */
+    const float* logit_scale;  /* [heads] */
+    const float* gamma;        /* LayerNorm1 weight / bias [C] */
+    const float* beta;
+    const float* scale;        /* per-sample drop-path factor or NULL */
+    void* qkvh; float* rnorm; void* oh; float* lse;   /* out: saved for swv2_attn_bwd (layouts above) */
+    void* a1;                  /* out bf16 [Bw*Lp][C] proj output, window order */
+    float* mean;               /* out [Bw*Lp] */
+    float* rstd;
+    float* y;                  /* out fp32 [B*T][C] */
+    int Bw, heads, L, head_dim, C, nwh, nww, mask_thr, rows_per_sample;
+    float eps;
+} swv2_attn_branch_args;
+int swv2_attn_branch_supported(int C, int heads, int L, int head_dim);
+int swv2_attn_branch_fwd(const swv2_attn_branch_args* a, void* stream);
+
 /* Fused MLP branch, forward: y = x + scale[b] * LayerNorm(fc2(GELU(fc1(x))))  (swinv2_global.py:492-496, timm Mlp
  * :381-386) in one kernel; the [M][hidden] activation stays in registers.  Saves for the backward: hpre = bf16(fc1(x)),
  * a2 = bf16(fc2 output), mean / rstd of the LayerNorm.  Same results as swv2_linear(EPI_BF16_GELU) + swv2_linear +
@@ -310,6 +337,7 @@ typedef struct swv2_block_desc {
     int ev_kernel;
     void* ev_start;
     void* ev_stop;
+    int fuse_attn;           /* 1: forward steps 1-4 run as swv2_attn_branch_fwd when there is no bias and the shape is supported */
     int fuse_mlp;            /* 1: forward steps 5-7 run as swv2_mlp_fwd when the shape is supported (hact is then neither
                                 written nor read: the backward applies GELU to hpre on load); 0: three launches.  The backward
                                 likewise runs steps 11, 13, 15 as swv2_mlp_bwd */

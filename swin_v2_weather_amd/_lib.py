@@ -13,7 +13,7 @@ import threading
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libswv2.so")
-SOURCES = ["capi.hip", "attn.hip", "gemm.hip", "gemm_tn.hip", "rowops.hip", "block.hip", "cpb.hip", "mlp.hip"]
+SOURCES = ["capi.hip", "attn.hip", "gemm.hip", "gemm_tn.hip", "rowops.hip", "block.hip", "cpb.hip", "mlp.hip", "attn_fused.hip"]
 
 _lib = None
 _lock = threading.Lock()
@@ -26,7 +26,7 @@ class Swv2Error(RuntimeError):
 def build_library(force: bool = False, verbose: bool = False) -> str:
     """Compile csrc/*.hip for gfx950 into swin_v2_weather_amd/libswv2.so (cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(HERE, "..", "include", "swv2.h")]
+    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(CSRC, "attn_common.h"), os.path.join(HERE, "..", "include", "swv2.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -70,6 +70,13 @@ class Epilogue(C.Structure):
                 ("aux_out", C.c_void_p), ("rowidx", C.c_void_p), ("ld", C.c_long), ("p", C.c_int * 5)]
 
 
+class AttnBranchArgs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("x", "rowidx", "wqkv", "bqkv", "wproj", "bproj", "logit_scale", "gamma", "beta", "scale",
+                                           "qkvh", "rnorm", "oh", "lse", "a1", "mean", "rstd", "y")] + \
+               [(n, C.c_int) for n in ("Bw", "heads", "L", "head_dim", "C", "nwh", "nww", "mask_thr", "rows_per_sample")] + \
+               [("eps", C.c_float)]
+
+
 class MlpArgs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("x", "w1", "b1", "w2", "b2", "gamma", "beta", "scale", "hpre", "a2", "mean", "rstd", "y")] + \
                [(n, C.c_int) for n in ("M", "C", "hidden", "rows_per_sample")] + [("eps", C.c_float)]
@@ -101,7 +108,7 @@ class BlockDesc(C.Structure):
                     "d_logit_scale", "d_bias", "d_qkv_w", "d_qkv_b", "d_proj_w", "d_proj_b", "d_n1_w", "d_n1_b", "d_fc1_w",
                     "d_fc1_b", "d_fc2_w", "d_fc2_b", "d_n2_w", "d_n2_b")] +
                 [("wgrad_splits", C.c_int), ("ev_kernel", C.c_int), ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p),
-                 ("fuse_mlp", C.c_int), ("wgrad_ws", C.c_void_p), ("wgrad_ws_bytes", C.c_size_t), ("wgrad_side_stream", C.c_int)])
+                 ("fuse_attn", C.c_int), ("fuse_mlp", C.c_int), ("wgrad_ws", C.c_void_p), ("wgrad_ws_bytes", C.c_size_t), ("wgrad_side_stream", C.c_int)])
 
 
 OP_F32, OP_BF16, OP_BF16_GELU, OP_HEADS, OP_PATCH, OP_MERGE_LN = range(6)
@@ -130,6 +137,8 @@ SYMBOLS = {
     "swv2_loss_sums": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "swv2_loss_grad": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "swv2_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P]),
+    "swv2_attn_branch_supported": (_I, [_I, _I, _I, _I]),
+    "swv2_attn_branch_fwd": (_I, [C.POINTER(AttnBranchArgs), _P]),
     "swv2_mlp_supported": (_I, [_I, _I]),
     "swv2_mlp_fwd": (_I, [C.POINTER(MlpArgs), _P]),
     "swv2_mlp_bwd_ws_floats": (C.c_size_t, [_I, _I]),

@@ -723,3 +723,61 @@ def test_block_fused_and_unfused_mlp_paths(dev, K, monkeypatch, fuse):
         O.set_rounding(None)
     assert rel(y, yo) < 1e-3 and rel(x.grad, xo.grad) < 1.5e-2
     assert worst_grad(blk, {k[2:]: v.grad for k, v in p.items()}) < 3e-2
+
+
+@pytest.mark.parametrize("gh,gw,wh,ww,sh,sw,Cc,h,fixture", [
+    (18, 36, 9, 18, 0, 0, 32, 2, "nopos_noshift_eval"),     # reference fixture: also checked against the oracle
+    (18, 36, 9, 18, 4, 9, 128, 8, None),                    # benchmark window / width, shifted (mask in the last window row)
+    (12, 27, 6, 9, 3, 4, 64, 4, None),                      # small window (LT = 4), shifted
+    (12, 18, 6, 9, 0, 0, 96, 8, None),                      # head_dim 12 padded to 16
+])
+def test_block_fused_attention_branch(dev, K, monkeypatch, gh, gw, wh, ww, sh, sw, Cc, h, fixture):
+    """SWV2_FUSE_ATTN=1: gather + qkv + cosine attention + proj + LN1 + residual scatter as ONE kernel
+    (swv2_attn_branch_fwd) against the unfused path (same saved tensors, so the unchanged backward must give the same
+    gradients) and, on the reference fixture, against the bf16-emulating oracle."""
+    N = K["N"]
+    B = 2
+    assert K["L"].load().swv2_attn_branch_supported(Cc, h, wh * ww, Cc // h) == 1
+    if fixture:
+        fx = np.load(os.path.join(GOLD, f"block_{fixture}.npz"))
+        assert [int(v) for v in fx["meta"]][:8] == [gh, gw, wh, ww, sh, sw, Cc, h]
+        x0, gy0 = torch.from_numpy(fx["x"]), torch.from_numpy(fx["gy"])
+    else:
+        g = torch.Generator().manual_seed(gh * 7 + Cc)
+        x0, gy0 = torch.randn(B, gh, gw, Cc, generator=g), torch.randn(B, gh, gw, Cc, generator=g)
+    outs, state = {}, None
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("SWV2_FUSE_ATTN", fuse)
+        torch.manual_seed(5)
+        blk = N.SwinTransformerV2CrBlock(dim=Cc, num_heads=h, feat_size=(gh, gw), window_size=(wh, ww), shift_size=(sh, sw),
+                                         rel_pos=False, drop_path=0.0)
+        if fixture:
+            load_params(blk, fx)
+        else:
+            if state is None:
+                with torch.no_grad():
+                    for n_, p_ in blk.named_parameters():
+                        if n_.startswith("norm"):
+                            p_.copy_(torch.rand_like(p_) + 0.5 if n_.endswith("weight") else 0.1 * torch.randn_like(p_))
+                state = {k_: v_.clone() for k_, v_ in blk.state_dict().items()}
+            blk.load_state_dict(state)
+        blk = blk.to(dev).eval()
+        x = x0.to(dev).requires_grad_(True)
+        y = blk(x)
+        y.backward(gy0.to(dev))
+        assert blk._runner(B, x.device).desc.fuse_attn == int(fuse)
+        outs[fuse] = (y.detach(), x.grad.detach(), {n_: p_.grad.detach().clone() for n_, p_ in blk.named_parameters()})
+    assert rel(outs["1"][0], outs["0"][0]) < 2e-3 and rel(outs["1"][1], outs["0"][1]) < 1.5e-2
+    for n_ in outs["0"][2]:
+        tol = 0.15 if "logit_scale" in n_ else 3e-2
+        assert rel(outs["1"][2][n_], outs["0"][2][n_]) < tol, n_
+    if fixture:
+        p = {"b." + k[2:]: torch.from_numpy(fx[k]).clone().requires_grad_(True) for k in fx.files if k.startswith("p:")}
+        xo = x0.clone().requires_grad_(True)
+        O.set_rounding(O.bf16_round)
+        try:
+            yo = O.block_forward(xo, p, "b.", block_cfg(gh, gw, wh, ww, sh, sw, Cc, h, False), 1, training=False)
+            yo.backward(gy0)
+        finally:
+            O.set_rounding(None)
+        assert rel(outs["1"][0], yo) < 1e-3 and rel(outs["1"][1], xo.grad) < 1.5e-2

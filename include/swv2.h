@@ -235,6 +235,39 @@ typedef struct {
 int swv2_attn_branch_supported(int C, int heads, int L, int head_dim);
 int swv2_attn_branch_fwd(const swv2_attn_branch_args* a, void* stream);
 
+/* Output projection of the attention branch fused with LayerNorm1 (swinv2_global.py:318-319, 468-476, 490):
+ *   forward : y[dst] = x[dst] + scale[b] * LN(merge_heads(oh) Wp^T + bp),  dst = rowidx[m] (negative = padded row, skipped);
+ *             saves a1 = bf16(proj output) [Bw*Lp][C] (window order), mean, rstd            (replaces swv2_linear + swv2_ln_residual_fwd)
+ *   backward: da1 = LN backward of scale * dy[dst] (zeros for padded rows), d(oh) = split_heads(da1 Wp), head-major;
+ *             dgamma / dbeta ACCUMULATED; ws >= swv2_proj_ln_bwd_ws_floats(Bw*Lp, C) floats   (replaces swv2_ln_residual_bwd + swv2_linear)
+ * C in {32,64,96,128}, head dim padded to 16, an even number of heads with heads * 16 <= 128 (swv2_proj_ln_supported). */
+typedef struct {
+    const void* oh;        /* bf16 [Bw][heads][Lp][16] */
+    const void* wp;        /* bf16 [C][heads*16] (swv2_prep_weight with the head-padding column map) */
+    const float* bp;       /* [C] */
+    const float* gamma; const float* beta; const float* scale;
+    const int32_t* rowidx; /* [Bw*Lp] or NULL (identity) */
+    const float* x;        /* fp32 [rows][C] residual, destination order */
+    void* a1; float* mean; float* rstd;     /* out, window order */
+    float* y;              /* out fp32 [rows][C], destination order */
+    int Bw, Lp, heads, C, rows_per_sample;
+    float eps;
+} swv2_proj_ln_args;
+typedef struct {
+    const float* dy;       /* fp32 [rows][C] gradient of y, destination order */
+    const void* a1; const float* mean; const float* rstd; const float* gamma; const float* scale;
+    const int32_t* rowidx;
+    const void* wpt;       /* bf16 [heads*16][C] = proj.weight^T (swv2_prep_weight, transpose, head-padding row map) */
+    void* da1;             /* out bf16 [Bw*Lp][C] */
+    void* doh;             /* out bf16 [Bw][heads][Lp][16] */
+    float* dgamma; float* dbeta; float* ws;
+    int Bw, Lp, heads, C, rows_per_sample;
+} swv2_proj_ln_bwd_args;
+int swv2_proj_ln_supported(int C, int heads, int head_pad);
+size_t swv2_proj_ln_bwd_ws_floats(int Mw, int C);
+int swv2_proj_ln_fwd(const swv2_proj_ln_args* a, void* stream);
+int swv2_proj_ln_bwd(const swv2_proj_ln_bwd_args* a, void* stream);
+
 /* Fused MLP branch, forward: y = x + scale[b] * LayerNorm(fc2(GELU(fc1(x))))  (swinv2_global.py:492-496, timm Mlp
  * :381-386) in one kernel; the [M][hidden] activation stays in registers.  Saves for the backward: hpre = bf16(fc1(x)),
  * a2 = bf16(fc2 output), mean / rstd of the LayerNorm.  Same results as swv2_linear(EPI_BF16_GELU) + swv2_linear +
@@ -324,7 +357,7 @@ typedef struct swv2_block_desc {
     const float* dx2;        /* grad of x2 */
     void *da2, *dh, *da1, *doh, *dqkvh;   /* bf16 scratch: [BT][C], [BT][hid], [Bw*Lp][C], [Bw][h][Lp][DP], [Bw][h][3][Lp][DP] */
     float* dx1;              /* fp32 scratch [BT][C] */
-    float* ln_ws;            /* max(SWV2_LN_BWD_MAX_BLOCKS*2*C, swv2_mlp_bwd_ws_floats(B*T, C)) floats */
+    float* ln_ws;            /* max(SWV2_LN_BWD_MAX_BLOCKS*2*C, swv2_mlp_bwd_ws_floats(B*T, C), swv2_proj_ln_bwd_ws_floats(Bw*Lp, C)) floats */
     float* dx;               /* out: grad of x */
     /* parameter gradients, ACCUMULATED (caller zeroes) */
     float *d_logit_scale, *d_bias, *d_qkv_w, *d_qkv_b, *d_proj_w, *d_proj_b, *d_n1_w, *d_n1_b, *d_fc1_w, *d_fc1_b,
@@ -337,6 +370,8 @@ typedef struct swv2_block_desc {
     int ev_kernel;
     void* ev_start;
     void* ev_stop;
+    int fuse_proj_ln;        /* 1: proj + LN1 run as swv2_proj_ln_fwd / _bwd when the shape is supported (forward steps 3-4,
+                                backward steps 16, 18) */
     int fuse_attn;           /* 1: forward steps 1-4 run as swv2_attn_branch_fwd when there is no bias and the shape is supported */
     int fuse_mlp;            /* 1: forward steps 5-7 run as swv2_mlp_fwd when the shape is supported (hact is then neither
                                 written nor read: the backward applies GELU to hpre on load); 0: three launches.  The backward

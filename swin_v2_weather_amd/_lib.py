@@ -13,7 +13,7 @@ import threading
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libswv2.so")
-SOURCES = ["capi.hip", "attn.hip", "gemm.hip", "gemm_tn.hip", "rowops.hip", "block.hip", "cpb.hip", "mlp.hip", "attn_fused.hip"]
+SOURCES = ["capi.hip", "attn.hip", "gemm.hip", "gemm_tn.hip", "rowops.hip", "block.hip", "cpb.hip", "mlp.hip", "attn_fused.hip", "proj_ln.hip"]
 
 _lib = None
 _lock = threading.Lock()
@@ -77,6 +77,16 @@ class AttnBranchArgs(C.Structure):
                [("eps", C.c_float)]
 
 
+class ProjLnArgs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("oh", "wp", "bp", "gamma", "beta", "scale", "rowidx", "x", "a1", "mean", "rstd", "y")] + \
+               [(n, C.c_int) for n in ("Bw", "Lp", "heads", "C", "rows_per_sample")] + [("eps", C.c_float)]
+
+
+class ProjLnBwdArgs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("dy", "a1", "mean", "rstd", "gamma", "scale", "rowidx", "wpt", "da1", "doh", "dgamma", "dbeta",
+                                           "ws")] + [(n, C.c_int) for n in ("Bw", "Lp", "heads", "C", "rows_per_sample")]
+
+
 class MlpArgs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("x", "w1", "b1", "w2", "b2", "gamma", "beta", "scale", "hpre", "a2", "mean", "rstd", "y")] + \
                [(n, C.c_int) for n in ("M", "C", "hidden", "rows_per_sample")] + [("eps", C.c_float)]
@@ -108,7 +118,7 @@ class BlockDesc(C.Structure):
                     "d_logit_scale", "d_bias", "d_qkv_w", "d_qkv_b", "d_proj_w", "d_proj_b", "d_n1_w", "d_n1_b", "d_fc1_w",
                     "d_fc1_b", "d_fc2_w", "d_fc2_b", "d_n2_w", "d_n2_b")] +
                 [("wgrad_splits", C.c_int), ("ev_kernel", C.c_int), ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p),
-                 ("fuse_attn", C.c_int), ("fuse_mlp", C.c_int), ("wgrad_ws", C.c_void_p), ("wgrad_ws_bytes", C.c_size_t), ("wgrad_side_stream", C.c_int)])
+                 ("fuse_proj_ln", C.c_int), ("fuse_attn", C.c_int), ("fuse_mlp", C.c_int), ("wgrad_ws", C.c_void_p), ("wgrad_ws_bytes", C.c_size_t), ("wgrad_side_stream", C.c_int)])
 
 
 OP_F32, OP_BF16, OP_BF16_GELU, OP_HEADS, OP_PATCH, OP_MERGE_LN = range(6)
@@ -139,6 +149,10 @@ SYMBOLS = {
     "swv2_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P]),
     "swv2_attn_branch_supported": (_I, [_I, _I, _I, _I]),
     "swv2_attn_branch_fwd": (_I, [C.POINTER(AttnBranchArgs), _P]),
+    "swv2_proj_ln_supported": (_I, [_I, _I, _I]),
+    "swv2_proj_ln_bwd_ws_floats": (C.c_size_t, [_I, _I]),
+    "swv2_proj_ln_fwd": (_I, [C.POINTER(ProjLnArgs), _P]),
+    "swv2_proj_ln_bwd": (_I, [C.POINTER(ProjLnBwdArgs), _P]),
     "swv2_mlp_supported": (_I, [_I, _I]),
     "swv2_mlp_fwd": (_I, [C.POINTER(MlpArgs), _P]),
     "swv2_mlp_bwd_ws_floats": (C.c_size_t, [_I, _I]),

@@ -103,6 +103,14 @@ extern "C" int swv2_block_fwd(const swv2_block_desc* d, void* st) {
         if (d->bias) a.max_chunks = 32;          // per-workgroup table load: fewer, longer-lived workgroups
         LAUNCH(2, swv2_attn_fwd(&a, st));
     }
+    if (d->fuse_proj_ln && swv2_proj_ln_supported(C, h, d->DP)) {
+        // 3-4 fused: merge heads, proj GEMM, LN1 + drop-path + residual + reverse / un-roll scatter in one kernel
+        swv2_proj_ln_args m = {};
+        m.oh = d->oh; m.wp = d->w_proj; m.bp = d->proj_b; m.gamma = d->n1_w; m.beta = d->n1_b; m.scale = d->dp1; m.rowidx = d->rowidx;
+        m.x = d->x; m.a1 = d->a1; m.mean = d->mean1; m.rstd = d->rstd1; m.y = d->x1; m.Bw = Bw; m.Lp = d->Lp; m.heads = h; m.C = C;
+        m.rows_per_sample = d->T; m.eps = 1e-5f;
+        LAUNCH(3, swv2_proj_ln_fwd(&m, st));
+    } else {
     // 3. merge heads | proj GEMM
     {
         swv2_operand a = op_heads(d->oh, Bw, h, 1, d->Lp, d->DP);
@@ -115,6 +123,7 @@ extern "C" int swv2_block_fwd(const swv2_block_desc* d, void* st) {
         l.a = d->a1; l.res = d->x; l.gamma = d->n1_w; l.beta = d->n1_b; l.scale = d->dp1; l.rowidx = d->rowidx; l.y = d->x1;
         l.mean = d->mean1; l.rstd = d->rstd1; l.M = Mw; l.C = C; l.res_mod = 0; l.rows_per_sample = d->T; l.eps = 1e-5f;
         LAUNCH(4, swv2_ln_residual_fwd(&l, st));
+    }
     }
     }
     // 5-7 fused: fc1, GELU, fc2, LN2 + drop-path + residual in one kernel (the hidden activation stays in registers)
@@ -194,6 +203,17 @@ extern "C" int swv2_block_bwd(const swv2_block_desc* d, void* st) {
         LAUNCH(15, swv2_linear(&dy, d->w_fc1t, &e, C, st));
     }
     }
+    if (d->fuse_proj_ln && swv2_proj_ln_supported(C, h, d->DP)) {
+        // 4' + the data path of 3' fused: LN1 backward (row gather) and d(oh) = split(da1 Wp) in one kernel
+        swv2_proj_ln_bwd_args m = {};
+        m.dy = d->dx1; m.a1 = d->a1; m.mean = d->mean1; m.rstd = d->rstd1; m.gamma = d->n1_w; m.scale = d->dp1; m.rowidx = d->rowidx;
+        m.wpt = d->w_projt; m.da1 = d->da1; m.doh = d->doh; m.dgamma = d->d_n1_w; m.dbeta = d->d_n1_b; m.ws = d->ln_ws;
+        m.Bw = Bw; m.Lp = d->Lp; m.heads = h; m.C = C; m.rows_per_sample = d->T;
+        LAUNCH(16, swv2_proj_ln_bwd(&m, st));
+        swv2_operand dy = op(SWV2_OP_BF16, d->da1, Mw, C, C), x = op_heads(d->oh, Bw, h, 1, d->Lp, d->DP);
+        if (ss) fork_to(ss, (hipStream_t)st);
+        LAUNCH(17, swv2_linear_wgrad_ws(&dy, &x, d->d_proj_w, d->d_proj_b, nullptr, d->proj_map, C, sp, d->wgrad_ws, d->wgrad_ws_bytes, ws));
+    } else {
     // 4'. LN1 backward (gathers dx1 rows through the window table; padded rows -> 0)
     {
         swv2_ln_args l = {};
@@ -209,6 +229,7 @@ extern "C" int swv2_block_bwd(const swv2_block_desc* d, void* st) {
         swv2_epilogue e = epi(SWV2_EPI_HEADS, d->doh, 0);
         e.p[0] = h; e.p[2] = d->Lp; e.p[3] = d->DP; e.p[4] = d->L;
         LAUNCH(18, swv2_linear(&dy, d->w_projt, &e, h * d->DP, st));
+    }
     }
     // 2'. attention backward (incl. the backward of the q / k normalisation)
     {

@@ -1,0 +1,331 @@
+// Output projection of the attention branch fused with LayerNorm1, forward and backward (reference
+// swinv2_global.py:318-319 + 468-476 + 490):
+//   forward : x1[dst] = x[dst] + scale * LN1( merge_heads(oh) Wp^T + b )          (dst = window-reverse / un-roll row table)
+//   backward: da1 = LN1 backward of (scale * dx1[dst]) ; d(oh) = split_heads(da1 Wp)
+// Each replaces a GEMM launch + a LayerNorm launch (forward 72 + 168 MB -> 204 MB, backward 140 + 72 MB -> 174 MB).  The
+// products are single-pass (K, N <= 128): the whole weight sits in LDS, a wave owns 16 * MT rows, products are computed
+// transposed (accumulator tile = rows of the next layout, see mlp.hip).  The forward's A rows come straight from the
+// head-major attention output (16 tokens x 32 B = 512 B contiguous per head), its epilogue is the LN + scatter epilogue
+// of attn_fused.hip; the backward's prologue is the row-layout LayerNorm backward of mlp_bwd_kernel with a row gather,
+// and its output tiles (rows = one head's 16 channels, column = token) store directly as 512-byte head-major runs.
+#include "gemm_common.h"
+
+namespace {
+
+constexpr int PL_MAX_HDP = 128;
+
+struct ProjLnFwd {
+    const uint16_t* oh; const uint16_t* wp; const float* bp; const float* gamma; const float* beta; const float* scale;
+    const int32_t* rowidx; const float* x; uint16_t* a1; float* mean; float* rstd; float* y;
+    int Mw, Lp, h, rows_per_sample; float eps;
+};
+
+template <int C, int MT>
+__global__ __launch_bounds__(256, 2) void proj_ln_fwd_kernel(const ProjLnFwd a) {
+    constexpr int NTC = C / 16;
+    constexpr int PWP = PL_MAX_HDP + 8, PA = C + 8;
+    constexpr int EWAVE = 16 * PA * 2 + 16 * 2 * 4;
+    constexpr int KSM = PL_MAX_HDP / 32;
+    __shared__ __attribute__((aligned(16))) uint16_t Wps[C * PWP];
+    __shared__ __attribute__((aligned(16))) unsigned char epi[4 * EWAVE];
+    __shared__ __attribute__((aligned(16))) float cs[3 * C];
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4;
+    const int hdp = a.h * 16, ksn = hdp / 32;
+    const int row0 = blockIdx.x * (64 * MT) + wave * (16 * MT);
+
+    // A^T fragments straight from the head-major attention output: lane (m = fr, g) holds k = 32 ks + 8 g .. + 7,
+    // i.e. 8 channels of head 2 ks + (g >> 1)
+    bf16x8 xf[MT][KSM];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = min(row0 + 16 * mt + fr, a.Mw - 1), w = m / a.Lp, t = m - w * a.Lp;
+#pragma unroll
+        for (int ks = 0; ks < KSM; ++ks) {
+            const int k0 = 32 * ks + 8 * g, kc = min(k0, hdp - 8);
+            xf[mt][ks] = *(const bf16x8*)(a.oh + (((size_t)w * a.h + (kc >> 4)) * a.Lp + t) * 16 + (kc & 15));
+        }
+    }
+    for (int i = tid; i < C * (hdp / 8); i += 256) {
+        const int r = i / (hdp / 8), c8 = i % (hdp / 8);
+        *(u32x4*)(Wps + r * PWP + 8 * c8) = *(const u32x4*)(a.wp + (size_t)r * hdp + 8 * c8);
+    }
+    for (int i = tid; i < C; i += 256) { cs[i] = a.bp[i]; cs[C + i] = a.gamma[i]; cs[2 * C + i] = a.beta[i]; }
+    __syncthreads();
+
+    f32x4 yacc[MT][NTC];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int tn = 0; tn < NTC; ++tn) yacc[mt][tn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KSM; ++ks) {
+        if (ks < ksn) {
+#pragma unroll
+            for (int tn = 0; tn < NTC; ++tn) {
+                const bf16x8 wf = *(const bf16x8*)(Wps + (16 * tn + fr) * PWP + 32 * ks + 8 * g);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) yacc[mt][tn] = mfma32(wf, xf[mt][ks], yacc[mt][tn]);
+            }
+        }
+    }
+
+    // epilogue: + bias, bf16 round (saved), LayerNorm in the accumulator layout, row layout through a per-wave LDS tile
+    uint16_t* As = (uint16_t*)(epi + wave * EWAVE);
+    float* St = (float*)(As + 16 * PA);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        float s = 0.f;
+#pragma unroll
+        for (int tn = 0; tn < NTC; ++tn) {
+            const f32x4 bv = *(const f32x4*)(cs + 16 * tn + 4 * g);
+            const bf16x4 ar = f2bf4(yacc[mt][tn] + bv);
+            *(bf16x4*)(As + fr * PA + 16 * tn + 4 * g) = ar;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { yacc[mt][tn][e] = bf2f(ar[e]); s += yacc[mt][tn][e]; }
+        }
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        const float mu = s * (1.f / C);
+        float q = 0.f;
+#pragma unroll
+        for (int tn = 0; tn < NTC; ++tn)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = yacc[mt][tn][e] - mu; q = fmaf(d, d, q); }
+        q += __shfl_xor(q, 16);
+        q += __shfl_xor(q, 32);
+        const float rs = rsqrtf(q * (1.f / C) + a.eps);
+        if (g == 0) {
+            const int m = min(row0 + 16 * mt + fr, a.Mw - 1);
+            a.mean[m] = mu;
+            a.rstd[m] = rs;
+            St[2 * fr] = mu;
+            St[2 * fr + 1] = rs;
+        }
+        constexpr int UNITS = 16 * (C / 8), NP = (UNITS + 63) / 64;
+        // row table and residual rows of all passes first, unconditionally (clamped): a load under `if (dst >= 0)` is
+        // exec-masked and gets serialised behind s_waitcnt vmcnt(0) -- two dependent memory round trips per pass
+        int dstv[NP];
+        f32x4 xr[NP][2];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int u = min(lane + 64 * p, UNITS - 1), row = u / (C / 8);
+            const int m = min(row0 + 16 * mt + row, a.Mw - 1);
+            dstv[p] = a.rowidx ? a.rowidx[m] : m;
+        }
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int u = min(lane + 64 * p, UNITS - 1), c8 = u % (C / 8);
+            const size_t off = (size_t)max(dstv[p], 0) * C + 8 * c8;
+            xr[p][0] = *(const f32x4*)(a.x + off);
+            xr[p][1] = *(const f32x4*)(a.x + off + 4);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int u = lane + 64 * p, row = u / (C / 8), c8 = u % (C / 8);
+            if (UNITS % 64 == 0 || u < UNITS) {
+                const int m = min(row0 + 16 * mt + row, a.Mw - 1);
+                const u32x4 av = *(const u32x4*)(As + row * PA + 8 * c8);
+                *(u32x4*)(a.a1 + (size_t)m * C + 8 * c8) = av;
+                const int dst = dstv[p];
+                if (dst >= 0) {
+                    const float mu_r = St[2 * row], rs_r = St[2 * row + 1];
+                    const float sc = a.scale ? a.scale[dst / a.rows_per_sample] : 1.f;
+                    const size_t off = (size_t)dst * C + 8 * c8;
+                    float v[8];
+                    unpack8(__builtin_bit_cast(uint4, av), v);
+#pragma unroll
+                    for (int hlf = 0; hlf < 2; ++hlf) {
+                        const f32x4 gm = *(const f32x4*)(cs + C + 8 * c8 + 4 * hlf), bt = *(const f32x4*)(cs + 2 * C + 8 * c8 + 4 * hlf);
+                        f32x4 o = xr[p][hlf];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] += sc * ((v[4 * hlf + e] - mu_r) * rs_r * gm[e] + bt[e]);
+                        *(f32x4*)(a.y + off + 4 * hlf) = o;
+                    }
+                }
+            }
+        }
+        if (mt + 1 < MT) __syncthreads();
+    }
+}
+
+struct ProjLnBwd {
+    const float* dy; const uint16_t* a1; const float* mean; const float* rstd; const float* gamma; const float* scale;
+    const int32_t* rowidx; const uint16_t* wpt; uint16_t* da1; uint16_t* doh; float* ws;
+    int Mw, Lp, h, rows_per_sample;
+};
+
+template <int C, int MT>
+__global__ __launch_bounds__(256, 2) void proj_ln_bwd_kernel(const ProjLnBwd a) {
+    constexpr int KS = C / 32;
+    constexpr int ROWS = 64 * MT, PX = C + 8, PW = C + 8;
+    constexpr int LPR = C <= 32 ? 8 : C <= 64 ? 16 : C <= 128 ? 32 : 64;
+    constexpr int RPP = 256 / LPR, NPASS = ROWS / RPP;
+    constexpr int BATCH = NPASS < 4 ? NPASS : 4;
+    static_assert(NPASS % BATCH == 0, "row passes must come in whole batches");
+    __shared__ __attribute__((aligned(16))) uint16_t Wts[PL_MAX_HDP * PW];        // Wp^T rows: [heads * 16][C]
+    __shared__ __attribute__((aligned(16))) uint16_t Xs[ROWS * PX];               // da1 tile
+    __shared__ __attribute__((aligned(16))) float gs[RPP * 2 * C];
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4;
+    const int hdp = a.h * 16;
+    const int wg_row0 = blockIdx.x * ROWS;
+
+    for (int i = tid; i < hdp * (C / 8); i += 256) {
+        const int r = i / (C / 8), c8 = i % (C / 8);
+        *(u32x4*)(Wts + r * PW + 8 * c8) = *(const u32x4*)(a.wpt + (size_t)r * C + 8 * c8);
+    }
+    // ---- LayerNorm backward in row layout (see mlp_bwd_kernel), dy rows gathered through the row table; padded rows
+    // (table < 0) give da1 = 0 and count nothing
+    {
+        const int lr = tid % LPR, rg = tid / LPR;
+        const bool act = 4 * lr < C;
+        const int c0 = act ? 4 * lr : 0;
+        const f32x4 gm = *(const f32x4*)(a.gamma + c0);
+        f32x4 dgm = {0.f, 0.f, 0.f, 0.f}, dbt = {0.f, 0.f, 0.f, 0.f};
+        int srcv[NPASS];                       // the row table of all passes first: one (L2) round trip instead of one per batch
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const int m = min(wg_row0 + i * RPP + rg, a.Mw - 1);
+            srcv[i] = a.rowidx ? a.rowidx[m] : m;
+        }
+#pragma unroll
+        for (int pb = 0; pb < NPASS; pb += BATCH) {
+            f32x4 d4[BATCH];
+            u32x2 a4[BATCH];
+            float mu[BATCH], rs[BATCH], sc[BATCH];
+            int ok[BATCH];
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i) {
+                const int m = min(wg_row0 + (pb + i) * RPP + rg, a.Mw - 1);
+                const int src = srcv[(pb + i) % NPASS];
+                ok[i] = src >= 0;
+                const int sr = max(src, 0);
+                d4[i] = *(const f32x4*)(a.dy + (size_t)sr * C + c0);
+                a4[i] = *(const u32x2*)(a.a1 + (size_t)m * C + c0);
+                mu[i] = a.mean[m];
+                rs[i] = a.rstd[m];
+                sc[i] = a.scale ? a.scale[sr / a.rows_per_sample] : 1.f;
+            }
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i) {
+                const int row = (pb + i) * RPP + rg;
+                const bool live = act && ok[i];
+                const float once = (live && wg_row0 + row < a.Mw) ? 1.f : 0.f;
+                const float av[4] = {__uint_as_float(a4[i][0] << 16), __uint_as_float(a4[i][0] & 0xffff0000u),
+                                     __uint_as_float(a4[i][1] << 16), __uint_as_float(a4[i][1] & 0xffff0000u)};
+                float gg[4], xh[4], t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = live ? sc[i] * d4[i][e] : 0.f;
+                    xh[e] = (av[e] - mu[i]) * rs[i];
+                    gg[e] = d * gm[e];
+                    dgm[e] = fmaf(once * d, xh[e], dgm[e]);
+                    dbt[e] = fmaf(once, d, dbt[e]);
+                    t1 += gg[e];
+                    t2 = fmaf(gg[e], xh[e], t2);
+                }
+#pragma unroll
+                for (int o = 1; o < LPR; o <<= 1) { t1 += __shfl_xor(t1, o); t2 += __shfl_xor(t2, o); }
+                t1 *= (1.f / C); t2 *= (1.f / C);
+                f32x4 o4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o4[e] = ok[i] ? rs[i] * (gg[e] - t1 - xh[e] * t2) : 0.f;
+                const bf16x4 ob = f2bf4(o4);
+                if (act) {
+                    *(bf16x4*)(a.da1 + (size_t)min(wg_row0 + row, a.Mw - 1) * C + c0) = ob;
+                    *(bf16x4*)(Xs + row * PX + c0) = ob;
+                }
+            }
+        }
+        if (act) {
+            *(f32x4*)(gs + (rg * 2 + 0) * C + c0) = dgm;
+            *(f32x4*)(gs + (rg * 2 + 1) * C + c0) = dbt;
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * C; i += 256) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < RPP; ++r) t += gs[r * 2 * C + i];
+            a.ws[(size_t)blockIdx.x * 2 * C + i] = t;
+        }
+    }
+    // ---- d(oh)^T[k][m] = sum_c Wp^T[k][c] da1[m][c]: one 16 x 16 tile per (head, row tile), stored head-major
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        bf16x8 xf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xf[ks] = *(const bf16x8*)(Xs + (wave * 16 * MT + 16 * mt + fr) * PX + 32 * ks + 8 * g);
+        const int m = min(wg_row0 + wave * 16 * MT + 16 * mt + fr, a.Mw - 1), w = m / a.Lp, t = m - w * a.Lp;
+        for (int hd = 0; hd < a.h; ++hd) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 wf = *(const bf16x8*)(Wts + (16 * hd + fr) * PW + 32 * ks + 8 * g);
+                acc = mfma32(wf, xf[ks], acc);
+            }
+            *(bf16x4*)(a.doh + (((size_t)w * a.h + hd) * a.Lp + t) * 16 + 4 * g) = f2bf4(acc);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int swv2_proj_ln_supported(int C, int heads, int head_pad) {
+    return (C == 32 || C == 64 || C == 96 || C == 128) && head_pad == 16 && heads >= 2 && heads % 2 == 0 && heads * 16 <= PL_MAX_HDP;
+}
+
+extern "C" size_t swv2_proj_ln_bwd_ws_floats(int Mw, int C) { return (Mw > 0 && C > 0) ? (size_t)cdiv(Mw, 64) * 2 * C : 0; }
+
+extern "C" int swv2_proj_ln_fwd(const swv2_proj_ln_args* a, void* stream) {
+    SWV2_CHECK_ARG(a && a->oh && a->wp && a->bp && a->gamma && a->beta && a->x && a->a1 && a->mean && a->rstd && a->y,
+                   "swv2_proj_ln_fwd: null pointer");
+    SWV2_CHECK_ARG(a->Bw > 0 && a->Lp > 0 && a->Lp % 16 == 0 && a->rows_per_sample > 0, "swv2_proj_ln_fwd: bad geometry");
+    if (!swv2_proj_ln_supported(a->C, a->heads, 16)) {
+        swv2_set_error("swv2_proj_ln_fwd: C=%d heads=%d not instantiated; use swv2_linear + swv2_ln_residual_fwd", a->C, a->heads);
+        return SWV2_ERR_UNSUPPORTED;
+    }
+    const int Mw = a->Bw * a->Lp;
+    ProjLnFwd k = {(const uint16_t*)a->oh, (const uint16_t*)a->wp, a->bp, a->gamma, a->beta, a->scale, a->rowidx, a->x,
+                   (uint16_t*)a->a1, a->mean, a->rstd, a->y, Mw, a->Lp, a->heads, a->rows_per_sample, a->eps};
+    hipStream_t st = (hipStream_t)stream;
+    const bool mt2 = Mw >= 128 * 256;
+#define PL_CASE(CC)                                                                                                  \
+    case CC:                                                                                                         \
+        if (mt2) hipLaunchKernelGGL((proj_ln_fwd_kernel<CC, 2>), dim3(cdiv(Mw, 128)), dim3(256), 0, st, k);          \
+        else hipLaunchKernelGGL((proj_ln_fwd_kernel<CC, 1>), dim3(cdiv(Mw, 64)), dim3(256), 0, st, k);               \
+        break;
+    switch (a->C) { PL_CASE(32) PL_CASE(64) PL_CASE(96) PL_CASE(128) }
+#undef PL_CASE
+    SWV2_CHECK_LAUNCH("swv2_proj_ln_fwd");
+    return SWV2_OK;
+}
+
+extern "C" int swv2_proj_ln_bwd(const swv2_proj_ln_bwd_args* a, void* stream) {
+    SWV2_CHECK_ARG(a && a->dy && a->a1 && a->mean && a->rstd && a->gamma && a->wpt && a->da1 && a->doh && a->dgamma && a->dbeta &&
+                       a->ws, "swv2_proj_ln_bwd: null pointer");
+    SWV2_CHECK_ARG(a->Bw > 0 && a->Lp > 0 && a->Lp % 16 == 0 && a->rows_per_sample > 0, "swv2_proj_ln_bwd: bad geometry");
+    if (!swv2_proj_ln_supported(a->C, a->heads, 16)) {
+        swv2_set_error("swv2_proj_ln_bwd: C=%d heads=%d not instantiated; use swv2_ln_residual_bwd + swv2_linear", a->C, a->heads);
+        return SWV2_ERR_UNSUPPORTED;
+    }
+    const int Mw = a->Bw * a->Lp;
+    ProjLnBwd k = {a->dy, (const uint16_t*)a->a1, a->mean, a->rstd, a->gamma, a->scale, a->rowidx, (const uint16_t*)a->wpt,
+                   (uint16_t*)a->da1, (uint16_t*)a->doh, a->ws, Mw, a->Lp, a->heads, a->rows_per_sample};
+    hipStream_t st = (hipStream_t)stream;
+    const bool mt2 = Mw >= 128 * 256;
+#define PL_CASE(CC)                                                                                                  \
+    case CC:                                                                                                         \
+        if (mt2) hipLaunchKernelGGL((proj_ln_bwd_kernel<CC, 2>), dim3(cdiv(Mw, 128)), dim3(256), 0, st, k);          \
+        else hipLaunchKernelGGL((proj_ln_bwd_kernel<CC, 1>), dim3(cdiv(Mw, 64)), dim3(256), 0, st, k);               \
+        break;
+    switch (a->C) { PL_CASE(32) PL_CASE(64) PL_CASE(96) PL_CASE(128) }
+#undef PL_CASE
+    swv2_launch_ln_partials_reduce(a->ws, a->dgamma, a->dbeta, cdiv(Mw, mt2 ? 128 : 64), a->C, st);
+    SWV2_CHECK_LAUNCH("swv2_proj_ln_bwd");
+    return SWV2_OK;
+}

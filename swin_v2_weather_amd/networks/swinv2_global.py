@@ -132,6 +132,7 @@ class _BlockRunner:
         d.wgrad_ws_bytes = ws_bytes
         d.wgrad_side_stream = int(os.environ.get("SWV2_WGRAD_SIDE_STREAM", "1"))
         d.fuse_mlp = int(os.environ.get("SWV2_FUSE_MLP", "1"))
+        d.fuse_proj_ln = int(os.environ.get("SWV2_FUSE_PROJ_LN", "1"))
         # fused attention branch (swv2_attn_branch_fwd): parity-green but not yet faster than the four separate kernels
         # (B = 2: 213 vs 210 us per block; B = 8: -8 % of the block forward) -- opt-in
         d.fuse_attn = int(os.environ.get("SWV2_FUSE_ATTN", "0"))
@@ -142,7 +143,7 @@ class _BlockRunner:
                      lib.swv2_attn_pack_bias_bytes(h, Lw)]
         self.act_off, self.act_bytes = _carve(act_sizes)
         scr_sizes = [BT * Cc * 2, BT * hid * 2, Mw * Cc * 2, Bw * h * Lp * DP * 2, Bw * h * 3 * Lp * DP * 2, BT * Cc * 4,
-                     max(L.LN_BWD_MAX_BLOCKS * 2 * Cc, lib.swv2_mlp_bwd_ws_floats(BT, Cc)) * 4, ws_bytes]
+                     max(L.LN_BWD_MAX_BLOCKS * 2 * Cc, lib.swv2_mlp_bwd_ws_floats(BT, Cc), lib.swv2_proj_ln_bwd_ws_floats(Mw, Cc)) * 4, ws_bytes]
         self.scr_off, self.scr_bytes = _carve(scr_sizes)
         self.grad_shapes = [(h,), (3 * Cc, Cc), (3 * Cc,), (Cc, Cc), (Cc,), (Cc,), (Cc,), (hid, Cc), (hid,), (Cc, hid), (Cc,),
                             (Cc,), (Cc,)]

@@ -697,14 +697,17 @@ def test_fused_mlp_backward_matches_autograd(dev, K, M, Cc, hid, T):
     assert rel(dx, dx_ref) < 1e-5
 
 
-@pytest.mark.parametrize("fuse", ["0", "1"])
-def test_block_fused_and_unfused_mlp_paths(dev, K, monkeypatch, fuse):
-    """Both forward paths of the MLP branch (SWV2_FUSE_MLP = 1: swv2_mlp_fwd, hact recomputed on load in the backward;
-    0: three launches) against the bf16-emulating oracle on a reference block fixture, forward and backward."""
-    monkeypatch.setenv("SWV2_FUSE_MLP", fuse)
-    N = K["N"]
-    fx = np.load(os.path.join(GOLD, "block_nopos_shift_3x3_eval.npz"))
+@pytest.mark.parametrize("knob,value", [("SWV2_FUSE_MLP", "0"), ("SWV2_FUSE_MLP", "1"), ("SWV2_FUSE_PROJ_LN", "0"),
+                                        ("SWV2_FUSE_PROJ_LN", "1")])
+def test_block_fused_and_unfused_paths(dev, K, monkeypatch, knob, value):
+    """Both variants of the MLP branch (SWV2_FUSE_MLP: swv2_mlp_fwd / _bwd vs. LN + GEMM launches) and of proj + LN1
+    (SWV2_FUSE_PROJ_LN: swv2_proj_ln_fwd / _bwd) against the bf16-emulating oracle on a reference block fixture whose
+    shape (C = 32, 2 heads of 16, 9 x 18 window) all fused kernels support, forward and backward."""
+    monkeypatch.setenv(knob, value)
+    N, L = K["N"], K["L"]
+    fx = np.load(os.path.join(GOLD, "block_nopos_noshift_eval.npz"))
     gh, gw, wh, ww, sh, sw, Cc, h, B, seed, rng_seed, train = [int(v) for v in fx["meta"]]
+    assert L.load().swv2_mlp_supported(Cc, 4 * Cc) == 1 and L.load().swv2_proj_ln_supported(Cc, h, 16) == 1
     blk = N.SwinTransformerV2CrBlock(dim=Cc, num_heads=h, feat_size=(gh, gw), window_size=(wh, ww), shift_size=(sh, sw),
                                      rel_pos=False, drop_path=0.0)
     load_params(blk, fx)
@@ -712,7 +715,8 @@ def test_block_fused_and_unfused_mlp_paths(dev, K, monkeypatch, fuse):
     x = torch.from_numpy(fx["x"]).to(dev).requires_grad_(True)
     y = blk(x)
     y.backward(torch.from_numpy(fx["gy"]).to(dev))
-    assert blk._runner(B, x.device).desc.fuse_mlp == int(fuse)
+    desc = blk._runner(B, x.device).desc
+    assert {"SWV2_FUSE_MLP": desc.fuse_mlp, "SWV2_FUSE_PROJ_LN": desc.fuse_proj_ln}[knob] == int(value)
     p = {"b." + k[2:]: torch.from_numpy(fx[k]).clone().requires_grad_(True) for k in fx.files if k.startswith("p:")}
     xo = torch.from_numpy(fx["x"]).clone().requires_grad_(True)
     O.set_rounding(O.bf16_round)

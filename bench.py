@@ -157,7 +157,7 @@ def main():
     ktimes = ops.stop_kernel_timing()
     # after the timed region (not part of `value`): the same kernel without the co-running weight-gradient stream
     alone_ms = None
-    if world == 1 and os.environ.get("SWV2_WGRAD_SIDE_STREAM", "1") != "0":
+    if world == 1 and os.environ.get("SWV2_WGRAD_SIDE_STREAM", "0") != "0":
         for m_ in model.modules():
             for r_ in getattr(m_, "_runners", {}).values():
                 r_.desc.wgrad_side_stream = 0
@@ -206,7 +206,7 @@ def main():
                          "algorithmic_bytes_per_launch": alg,
                          "co_running": ("weight-gradient GEMMs of the same block on the library's side stream overlap this kernel "
                                         "(SWV2_WGRAD_SIDE_STREAM=0 times it alone)")
-                                       if os.environ.get("SWV2_WGRAD_SIDE_STREAM", "1") != "0" and "bwd" in a.roofline_kernel else None,
+                                       if os.environ.get("SWV2_WGRAD_SIDE_STREAM", "0") != "0" and "bwd" in a.roofline_kernel else None,
                          "avg_ms_alone": alone_ms, "frac_alone": (alg / (alone_ms * 1e-3) / 1e9 / 8000.0) if alone_ms else None,
                          "flops_per_launch": {"attn_fwd": 4.0, "attn_bwd": 8.0}.get(a.roofline_kernel, 0.0) * T * Lw * a.embed_dim * B},
         }

@@ -130,7 +130,10 @@ class _BlockRunner:
         ws_bytes = max(lib.swv2_linear_wgrad_ws_bytes(m, n_, k, d.wgrad_splits)
                        for m, n_, k in ((BT, Cc, hid), (BT, hid, Cc), (Mw, Cc, h * DP), (Mw, 3 * h * DP, Cc)))
         d.wgrad_ws_bytes = ws_bytes
-        d.wgrad_side_stream = int(os.environ.get("SWV2_WGRAD_SIDE_STREAM", "1"))
+        # weight-gradient GEMMs on the library's side stream: +8 % when they took 4 x 130 us per block with atomics; since
+        # the partial-tile kernels (4 x 30-70 us) the overlap only slows the co-running dX chain down (143.3 vs 144.2
+        # samples/s, attention backward 0.216 vs 0.134 ms) -- opt-in
+        d.wgrad_side_stream = int(os.environ.get("SWV2_WGRAD_SIDE_STREAM", "0"))
         d.fuse_mlp = int(os.environ.get("SWV2_FUSE_MLP", "1"))
         d.fuse_proj_ln = int(os.environ.get("SWV2_FUSE_PROJ_LN", "1"))
         # fused attention branch (swv2_attn_branch_fwd): parity-green but not yet faster than the four separate kernels

@@ -441,8 +441,7 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
                     const float pr = __builtin_amdgcn_exp2f(x);
                     const float dsr = pr * (dp[r] - d4[r]);
                     p[r] = pr;
-                    ds[r] = dsr * sigma;                      // d(cos) = sigma * dS
-                    dsig = fmaf(dsr, s[r], dsig);
+                    ds[r] = dsr;                              // dS; d(cos) = sigma * dS is applied once per tile at the end
                     if (HAS_BIAS) dbrow[r] += dsr;
                 }
                 const uint32_t pk2[2] = {f2bf2(p[0], p[1]), f2bf2(p[2], p[3])};      // explicit pairs: one cvt_pk each
@@ -512,11 +511,15 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
                 for (int r = 0; r < 4; ++r) dot = fmaf(dk[i][dt][r], bf2f(kf[i][dt][r]), dot);
             dot += __shfl_xor(dot, 16);
             dot += __shfl_xor(dot, 32);
+            // d logit_scale: sigma sum_{q,k} dS cos = sigma sum_k (sum_q dS[q][k] q^[q]) . k^[k] = sigma sum_k dot_k -- the same dot
+            // product the normalisation backward needs, so the per-element accumulation in the step loop is gone
+            if (g == 0) dsig += dot;
+            const float rks = rk * sigma;                     // the accumulators hold sum_q q^ dS: d(cos) = sigma dS
 #pragma unroll
             for (int dt = 0; dt < DK; ++dt) {
                 f32x4 v;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = rk * (dk[i][dt][r] - bf2f(kf[i][dt][r]) * dot);
+                for (int r = 0; r < 4; ++r) v[r] = rks * (dk[i][dt][r] - bf2f(kf[i][dt][r]) * dot);
                 *(bf16x4*)(dqkvh + slab0 + SLAB + (size_t)key * DP + 16 * dt + 4 * g) = f2bf4(v);
                 *(bf16x4*)(dqkvh + slab0 + 2 * SLAB + (size_t)key * DP + 16 * dt + 4 * g) = f2bf4(dv[i][dt]);
             }
@@ -552,7 +555,7 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
                 const int qt = tw * TPW + i;
                 if (TPW > 1 && qt >= LT) continue;
                 const int q = 16 * qt + fr;
-                const float rq = rnorm[(((size_t)bw * h + hd) * 2 + 0) * Lp + q];
+                const float rq = rnorm[(((size_t)bw * h + hd) * 2 + 0) * Lp + q] * sigma;
                 bf16x4 qn[DK];
                 float dot = 0.f;
 #pragma unroll

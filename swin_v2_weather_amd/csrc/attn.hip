@@ -261,15 +261,24 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
     constexpr int CH = SLAB / 8;                             // 16-byte chunks per slab
     constexpr int CPT = (CH + NT - 1) / NT;                  // chunks per thread
     constexpr int CPR = 2 * DK;                              // chunks per row
-    __shared__ __attribute__((aligned(16))) uint16_t Qs[SLAB];
-    __shared__ __attribute__((aligned(16))) uint16_t Ks[SLAB];
-    __shared__ __attribute__((aligned(16))) uint16_t dOs[SLAB];
-    __shared__ __attribute__((aligned(16))) uint16_t Vs[SLAB];
-    __shared__ __attribute__((aligned(16))) uint16_t dSb[IROWS * DSP];
-    __shared__ __attribute__((aligned(16))) uint16_t biasS[BIAS_LDS ? Lp * DSP : 8];
-    __shared__ __attribute__((aligned(16))) float LSEs[Lp];
-    __shared__ __attribute__((aligned(16))) float DLs[Lp];
-    __shared__ float red[WAVES];
+    // ONE LDS object with the per-step arrays first: their addresses are then (one running lane offset) + (a constant below
+    // 64 KB that fits the ds_read / ds_write offset field).  As separate __shared__ arrays beyond the first 64 KB each
+    // access needed its own v_add per step (9 address adds in a ~45-instruction loop).
+    constexpr int OFF_Q = 0, OFF_DO = OFF_Q + SLAB * 2, OFF_LSE = OFF_DO + SLAB * 2, OFF_DL = OFF_LSE + Lp * 4,
+                  OFF_K = OFF_DL + Lp * 4, OFF_V = OFF_K + SLAB * 2, OFF_DS = OFF_V + SLAB * 2,
+                  OFF_BIAS = OFF_DS + IROWS * DSP * 2, OFF_RED = OFF_BIAS + (BIAS_LDS ? Lp * DSP * 2 : 16),
+                  LDS_BYTES = OFF_RED + ((WAVES * 4 + 15) / 16) * 16;
+    static_assert(OFF_DS % 16 == 0 && OFF_BIAS % 16 == 0 && OFF_RED % 16 == 0, "16-byte aligned sub-arrays");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+    uint16_t* const Qs = (uint16_t*)(lds + OFF_Q);
+    uint16_t* const dOs = (uint16_t*)(lds + OFF_DO);
+    float* const LSEs = (float*)(lds + OFF_LSE);
+    float* const DLs = (float*)(lds + OFF_DL);
+    uint16_t* const Ks = (uint16_t*)(lds + OFF_K);
+    uint16_t* const Vs = (uint16_t*)(lds + OFF_V);
+    uint16_t* const dSb = (uint16_t*)(lds + OFF_DS);
+    uint16_t* const biasS = (uint16_t*)(lds + OFF_BIAS);
+    float* const red = (float*)(lds + OFF_RED);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -481,20 +490,79 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
                               SWV2_CASE(6) SWV2_CASE(7) SWV2_CASE(8) SWV2_CASE(9) SWV2_CASE(10) }
 #undef SWV2_CASE
             }
+        } else if constexpr (TPW == 1) {
+            // software-pipelined over the q tiles (two register sets used alternately): stage A of step qt + 1 (fragment
+            // reads, S and dP MFMAs) is issued before stage B of step qt (softmax backward on the vector ALU, dV / dK
+            // MFMAs), so a wave has independent work while its MFMA results and LDS reads are in flight.  A plain
+            // `#pragma unroll 2` of the one-piece step made the compiler hoist far more and spill (164 -> 203 us).
+            struct St { f32x4 s, dp, l4, d4; bf16x4 tq[DK], td[DK]; };
+            const int key = 16 * tw + fr;
+            const bool kid = key >= mask_thr, key_ok = key < Lc;
+            auto stageA = [&](const int qt, St& o) {
+                bf16x4 qa[DK], da[DK];
+#pragma unroll
+                for (int kk = 0; kk < DK; ++kk) {
+                    qa[kk] = *(const bf16x4*)(Qs + (16 * qt + fr) * DP + 16 * kk + 4 * g);
+                    da[kk] = *(const bf16x4*)(dOs + (16 * qt + fr) * DP + 16 * kk + 4 * g);
+                    const int off = (16 * qt + 4 * g + (fr >> 2)) * DP + 16 * kk + (fr & 3) * 4;
+                    o.td[kk] = lds_tr_read(dOs + off);
+                    o.tq[kk] = lds_tr_read(Qs + off);
+                }
+                o.l4 = *(const f32x4*)(LSEs + 16 * qt + 4 * g);
+                o.d4 = *(const f32x4*)(DLs + 16 * qt + 4 * g);
+                o.s = (f32x4){0.f, 0.f, 0.f, 0.f};
+                o.dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < DK; ++kk) {
+                    o.s = mfma16(qa[kk], kf[0][kk], o.s);
+                    o.dp = mfma16(da[kk], vf[0][kk], o.dp);
+                }
+            };
+            auto stageB = [&](const int qt, const St& in, auto masked_c, auto pad_c) {
+                constexpr bool MASKED = decltype(masked_c)::value, PADT = decltype(pad_c)::value;
+                f32x4 p, ds;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = 16 * qt + 4 * g + r;
+                    float x = fmaf(in.s[r], sc2, -in.l4[r]);
+                    if (PADT) x = key_ok ? x : SWV2_NEG_BIG;
+                    if (MASKED) x += ((q >= mask_thr) != kid) ? (-100.f * SWV2_LOG2E) : 0.f;
+                    const float pr = __builtin_amdgcn_exp2f(x);
+                    p[r] = pr;
+                    ds[r] = pr * (in.dp[r] - in.d4[r]);
+                }
+                const bf16x4 pb = f2bf4(p), dsb = f2bf4(ds);
+                *(bf16x4*)(dSb + key * DSP + 16 * qt + 4 * g) = dsb;
+#pragma unroll
+                for (int dt = 0; dt < DK; ++dt) {
+                    dv[0][dt] = mfma16(in.td[dt], pb, dv[0][dt]);
+                    dk[0][dt] = mfma16(in.tq[dt], dsb, dk[0][dt]);
+                }
+            };
+            auto run = [&](auto masked_c, auto pad_c) {
+                St sa, sb;
+                stageA(0, sa);
+#pragma unroll 1
+                for (int qt = 0; qt + 1 < LT; qt += 2) {
+                    stageA(qt + 1, sb);
+                    stageB(qt, sa, masked_c, pad_c);
+                    if (qt + 2 < LT) stageA(qt + 2, sa);
+                    stageB(qt + 1, sb, masked_c, pad_c);
+                }
+                if (LT & 1) stageB(LT - 1, sa, masked_c, pad_c);
+            };
+            const bool pad_wave = 16 * tw + 16 > Lc;            // padded keys only in the last tile
+            if (do_mask) run(std::true_type{}, std::true_type{});
+            else if (pad_wave) run(std::false_type{}, std::true_type{});
+            else run(std::false_type{}, std::false_type{});
         } else {
             f32x4 dummy = {0.f, 0.f, 0.f, 0.f};
-            // a wave's tiles contain padded keys only in the last tile (with TPW > 1 the test stays per element)
-            const bool pad_wave = TPW > 1 || 16 * tw + 16 > Lc;
-            // rolled loops: unrolling (2 or full) spills at the 168-VGPR budget of 11 waves (measured 164 -> 203 us)
             if (do_mask) {
 #pragma unroll 1
                 for (int qt = 0; qt < LT; ++qt) step(qt, dummy, dummy, std::true_type{}, std::true_type{});
-            } else if (pad_wave) {
-#pragma unroll 1
-                for (int qt = 0; qt < LT; ++qt) step(qt, dummy, dummy, std::false_type{}, std::true_type{});
             } else {
 #pragma unroll 1
-                for (int qt = 0; qt < LT; ++qt) step(qt, dummy, dummy, std::false_type{}, std::false_type{});
+                for (int qt = 0; qt < LT; ++qt) step(qt, dummy, dummy, std::false_type{}, std::true_type{});
             }
         }
         // ---- dK (through the L2-normalisation) and dV of this wave's key tile(s)

@@ -124,6 +124,9 @@ def main():
     if use_ddp:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], output_device=local_rank,
                                                         broadcast_buffers=False, gradient_as_bucket_view=True)
+        if os.environ.get("SWV2_DDP_BUCKET_GRADS", "1") != "0":
+            from swin_v2_weather_amd.networks.helpers import enable_ddp_bucket_grads
+            enable_ddp_bucket_grads(net)
     g = torch.Generator(device=dev).manual_seed(333 + rank)
     B = a.local_batch
     pool = [(torch.randn(B, 73, a.height, a.width, device=dev, generator=g),

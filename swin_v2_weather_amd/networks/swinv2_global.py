@@ -227,10 +227,21 @@ class _BlockFn(torch.autograd.Function):
         sb = scratch.data_ptr()
         for name, off in zip(run.SCRATCH, run.scr_off):
             setattr(d, name, sb + off)
-        grads = torch.zeros(run.grad_bytes // 4, dtype=torch.float32, device=dev)       # ONE memset for all param grads
-        gb = grads.data_ptr()
-        for name, off in zip(run.grad_names, run.grad_off):
-            setattr(d, name, gb + off)
+        params = (logit_scale, qkv_w, qkv_b, proj_w, proj_b, n1_w, n1_b, fc1_w, fc1_b, fc2_w, fc2_b, n2_w, n2_b)
+        views = blk._bucket_views(params) if blk._ddp_bucket_grads else None
+        if views is not None:
+            # DDP (gradient_as_bucket_view): write the gradients straight into the reducer's bucket memory and hand autograd
+            # aliases of it, so the reducer finds them in place instead of launching one copy kernel per parameter
+            torch._foreach_zero_(views)
+            for name, v in zip(run.grad_names, views):
+                setattr(d, name, v.data_ptr())
+        else:
+            grads = torch.zeros(run.grad_bytes // 4, dtype=torch.float32, device=dev)   # ONE memset for all param grads
+            gb = grads.data_ptr()
+            for name, off in zip(run.grad_names, run.grad_off):
+                setattr(d, name, gb + off)
+        if blk._ddp_bucket_grads:
+            blk._queue_view_refresh(params)
         dbias = torch.zeros_like(bias_c) if ctx.has_bias else None
         dx = torch.empty_like(x)
         d.x, d.dx2, d.dx = x.data_ptr(), dx2.data_ptr(), dx.data_ptr()
@@ -241,7 +252,10 @@ class _BlockFn(torch.autograd.Function):
         ops.block_event_pair("bwd", d)
         L.check(ops._timed("block_bwd", L.load().swv2_block_bwd, run.desc, ops._stream()), "swv2_block_bwd")
         del keep
-        g = [grads[o // 4:o // 4 + int(torch.Size(s).numel())].view(*s) for o, s in zip(run.grad_off, run.grad_shapes)]
+        if views is not None:
+            g = [v.detach() for v in views]
+        else:
+            g = [grads[o // 4:o // 4 + int(torch.Size(s).numel())].view(*s) for o, s in zip(run.grad_off, run.grad_shapes)]
         (dlogit, dqkvw, dqkvb, dprojw, dprojb, dn1w, dn1b, dfc1w, dfc1b, dfc2w, dfc2b, dn2w, dn2b) = g
         return (dx, dbias, None, None, dlogit, dqkvw, dqkvb, dprojw, dprojb, dn1w, dn1b, dfc1w, dfc1b, dfc2w, dfc2b, dn2w,
                 dn2b, None)
@@ -442,6 +456,30 @@ class SwinTransformerV2CrBlock(nn.Module):
         gh, gw = self.feat_size
         return ops.window_plan(B, gh, gw, self.window_size[0], self.window_size[1], self.shift_size[0], self.shift_size[1],
                                self.attn.num_heads, self.dim // self.attn.num_heads, device.index or 0)
+
+    # ---- DDP bucket-view gradients (enabled by helpers.enable_ddp_bucket_grads after the DDP wrap) -----------------
+    _ddp_bucket_grads = False
+
+    @staticmethod
+    def _bucket_views(params):
+        """The reducer's bucket views of this block's parameters (cached from the previous backward), or None when any of
+        them is unknown / stale-shaped or a gradient is already present (accumulation over micro-batches: normal path)."""
+        views = []
+        for p in params:
+            bv = getattr(p, "_swv2_bv", None)
+            if bv is None or p.grad is not None or bv.shape != p.shape or not bv.is_contiguous() or bv.device != p.device:
+                return None
+            views.append(bv)
+        return views
+
+    def _queue_view_refresh(self, params):
+        """At the end of this backward pass p.grad IS the reducer's bucket view (gradient_as_bucket_view=True): remember it."""
+        def refresh():
+            for p in params:
+                g_ = p.grad
+                if g_ is not None and g_.shape == p.shape and g_.is_contiguous():
+                    p._swv2_bv = g_
+        torch.autograd.Variable._execution_engine.queue_callback(refresh)
 
     def _runner(self, B: int, device) -> "_BlockRunner":
         key = (B, device.index or 0, self.feat_size, self.window_size, self.shift_size)

@@ -148,6 +148,9 @@ class Trainer():
                           static_graph=bool(params['checkpointing']) if 'checkpointing' in params else False)
             if self.device.type == 'cuda':
                 self.model = DistributedDataParallel(self.model, device_ids=[self.local_rank], output_device=self.local_rank, **ddp_kw)
+                if self._model_factory is get_model and os.environ.get("SWV2_DDP_BUCKET_GRADS", "1") != "0":
+                    from .networks.helpers import enable_ddp_bucket_grads
+                    enable_ddp_bucket_grads(self.model)     # gradients written straight into the reducer's buckets
             else:
                 self.model = DistributedDataParallel(self.model, **ddp_kw)
 

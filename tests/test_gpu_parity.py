@@ -9,6 +9,7 @@ accumulation and stores inter-kernel activations as bf16, like the reference und
 import json
 import ctypes
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -785,3 +786,15 @@ def test_block_fused_attention_branch(dev, K, monkeypatch, gh, gw, wh, ww, sh, s
         finally:
             O.set_rounding(None)
         assert rel(outs["1"][0], yo) < 1e-3 and rel(outs["1"][1], xo.grad) < 1.5e-2
+
+
+def test_ddp_bucket_view_gradients(dev, K):
+    """helpers.enable_ddp_bucket_grads: the blocks write their parameter gradients straight into the DDP reducer's bucket
+    views (no per-parameter copy kernels).  One rank over RCCL in a child process (own process group): same losses and
+    parameters as plain DDP and as no DDP, and every block picks up its cached bucket views."""
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "ddp_alias_check.py")], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0 and b"ddp alias check ok" in r.stdout, r.stdout.decode()[-2000:]

@@ -42,6 +42,38 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     return fmaf(x * 0.3989422804014327f, gs, 0.5f * (1.f + e));
 }
 
+// ------------------------------------------------------------------------------------------------
+// Table-driven GELU for bf16 inputs.  The argument of every GELU / GELU' on this path is a STORED bf16 pre-activation, so
+// the function has at most 65536 distinct arguments; for |x| in [2^-14, 2^4) (18 binades x 128 mantissas x 2 signs =
+// 4608 entries) the value is looked up in an LDS table that each workgroup fills once with the formulas above -- the
+// results are bit-identical to evaluating them per element (~14 vector-issue slots incl. two transcendentals), at ~5
+// slots + one 2-byte LDS gather.  Arguments outside the table (|x| < 6.1e-5: probability ~5e-5; |x| >= 16) make the
+// caller fall back to the formula for that group of values (wave-uniform branch).
+// ------------------------------------------------------------------------------------------------
+constexpr int GT_LO = (127 - 14) << 7;       // bf16 bits of 2^-14
+constexpr int GT_HALF = 18 * 128;            // entries per sign
+constexpr int GT_N = 2 * GT_HALF;
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+
+// entry i <-> bf16 bits ((i / GT_HALF) << 15) | (GT_LO + i % GT_HALF)
+__device__ __forceinline__ uint16_t gelu_tab_arg(int i) { return (uint16_t)(((i / GT_HALF) << 15) | (GT_LO + i % GT_HALF)); }
+
+// two packed bf16 arguments -> byte offsets (packed u16 pair) into a table of `ESZ`-byte entries; `bad` is set when either
+// argument is outside the table (the offsets are then clamped and the caller must not use the looked-up values)
+template <int ESZ>
+__device__ __forceinline__ uint32_t gelu_tab_off2(uint32_t w, bool& bad) {
+    const u16x2_t a = __builtin_bit_cast(u16x2_t, w & 0x7fff7fffu);
+    const u16x2_t lo = {(unsigned short)GT_LO, (unsigned short)GT_LO};
+    const u16x2_t mx = {(unsigned short)(GT_HALF - 1), (unsigned short)(GT_HALF - 1)};
+    const u16x2_t idx = a - lo;                                      // wraps for arguments below the table
+    const u16x2_t idc = __builtin_elementwise_min(idx, mx);
+    bad = bad || (__builtin_bit_cast(uint32_t, idx) != __builtin_bit_cast(uint32_t, idc));
+    const u16x2_t sg = __builtin_bit_cast(u16x2_t, w) >> 15;         // 0 / 1 per half
+    const u16x2_t half = {(unsigned short)GT_HALF, (unsigned short)GT_HALF};
+    const u16x2_t off = (idc + sg * half) * (unsigned short)ESZ;
+    return __builtin_bit_cast(uint32_t, off);
+}
+
 __device__ __forceinline__ uint4 pack8(const float* v) {
     uint4 r;
     r.x = f2bf2(v[0], v[1]); r.y = f2bf2(v[2], v[3]); r.z = f2bf2(v[4], v[5]); r.w = f2bf2(v[6], v[7]);
@@ -129,7 +161,21 @@ template <> struct ALoad<A_BF16_GELU> {
         if (m >= d.M || k0 >= d.K) return make_uint4(0, 0, 0, 0);
         return *(const uint4*)((const uint16_t*)d.ptr + (long)m * d.ld + k0);
     }
+    const uint16_t* tab = nullptr;      // LDS table of bf16(GELU(x)) (see gelu_tab_off2), set by the kernel; null = formula
     __device__ __forceinline__ uint4 cvt(const Raw& r) const {
+        if (tab) {
+            bool bad = false;
+            const uint32_t o[4] = {gelu_tab_off2<2>(r.x, bad), gelu_tab_off2<2>(r.y, bad), gelu_tab_off2<2>(r.z, bad),
+                                   gelu_tab_off2<2>(r.w, bad)};
+            if (!__builtin_expect(__any((int)bad), 0)) {
+                const unsigned char* tb = (const unsigned char*)tab;
+                uint32_t q[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    q[i] = (uint32_t)*(const uint16_t*)(tb + (o[i] & 0xffffu)) | ((uint32_t)*(const uint16_t*)(tb + (o[i] >> 16)) << 16);
+                return make_uint4(q[0], q[1], q[2], q[3]);
+            }
+        }
         float v[8];
         unpack8(r, v);
 #pragma unroll

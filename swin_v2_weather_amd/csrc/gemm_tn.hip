@@ -13,12 +13,19 @@ constexpr int TP = 136;                     // LDS row pitch (elements) of the [
 constexpr int TCH = TM * 16 / NTHREADS;     // 16-byte chunks per thread per operand per step (8)
 
 template <int YK, int XK>
-__global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(ALoad<YK> yl, ALoad<XK> xl, float* __restrict__ dW,
+__global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(ALoad<YK> yl, ALoad<XK> xl_arg, float* __restrict__ dW,
                                                            float* __restrict__ db, const int32_t* __restrict__ nmap,
                                                            const int32_t* __restrict__ kmap, int ldw, int M, int N,
                                                            int K, int ntk, int rows_per_split, float* __restrict__ ws) {
     __shared__ __attribute__((aligned(16))) uint16_t smem[2 * TM * TP];          // [Y | X][TM][TP], single buffer
     __shared__ float dbs[BN];
+    __shared__ __attribute__((aligned(16))) uint16_t gtab[XK == A_BF16_GELU ? GT_N : 8];
+    ALoad<XK> xl = xl_arg;
+    if constexpr (XK == A_BF16_GELU) {          // GELU-on-load of the stored bf16 pre-activation through a lookup table
+        for (int i = threadIdx.x; i < GT_N; i += NTHREADS) gtab[i] = f2bf(gelu_f(bf2f(gelu_tab_arg(i))));
+        xl.tab = gtab;
+        __syncthreads();
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, g = lane >> 4;
     const int wr = wave >> 1, wc = wave & 1;

@@ -45,8 +45,10 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(const MlpFwd a) {
     // prefetch of the next chunk as well
     __shared__ __attribute__((aligned(16))) float b1s[MLP_MAX_HIDDEN];
     __shared__ __attribute__((aligned(16))) float cs[3 * C];          // fc2 bias | LayerNorm gamma | beta
+    __shared__ __attribute__((aligned(16))) uint16_t gtab[GT_N];      // bf16(GELU(x)) for every bf16 x in the table range
     uint16_t* smem = (uint16_t*)smem_raw;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4;
     const int wg_row0 = blockIdx.x * ROWS;
@@ -84,6 +86,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(const MlpFwd a) {
     issue(0);
     for (int i = tid; i < hid; i += 256) b1s[i] = a.b1[i];
     for (int i = tid; i < C; i += 256) { cs[i] = a.b2[i]; cs[C + i] = a.gamma[i]; cs[2 * C + i] = a.beta[i]; }
+    for (int i = tid; i < GT_N; i += 256) gtab[i] = f2bf(gelu_f(bf2f(gelu_tab_arg(i))));
 
     // x tile -> LDS as bf16 with coalesced 16-byte loads (a lane-per-row fragment load would touch 64 lines per
     // instruction), then each wave picks up its B fragments: lane (m = fr, g) holds c = 32 ks + 8 g .. + 7
@@ -142,10 +145,23 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(const MlpFwd a) {
             for (int mt = 0; mt < MT; ++mt) {
                 const bf16x4 hr = f2bf4(hacc[ht][mt]);             // the pre-activation as the backward will read it
                 hrs[mt][ht] = hr;
-                f32x4 act;
+                // GELU of the stored bf16 value: table lookup (bit-identical to the formula), formula for the rare group
+                // with an argument outside the table
+                const uint32_t w0 = __builtin_bit_cast(u32x2, hr)[0], w1 = __builtin_bit_cast(u32x2, hr)[1];
+                bool bad = false;
+                const uint32_t o0 = gelu_tab_off2<2>(w0, bad), o1 = gelu_tab_off2<2>(w1, bad);
+                if (__builtin_expect(__any((int)bad), 0)) {
+                    f32x4 act;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) act[e] = gelu_f(bf2f(hr[e]));
-                hb[mt][ht] = f2bf4(act);
+                    for (int e = 0; e < 4; ++e) act[e] = gelu_f(bf2f(hr[e]));
+                    hb[mt][ht] = f2bf4(act);
+                } else {
+                    const unsigned char* tb = (const unsigned char*)gtab;
+                    const uint32_t r0 = (uint32_t)*(const uint16_t*)(tb + (o0 & 0xffffu)) | ((uint32_t)*(const uint16_t*)(tb + (o0 >> 16)) << 16);
+                    const uint32_t r1 = (uint32_t)*(const uint16_t*)(tb + (o1 & 0xffffu)) | ((uint32_t)*(const uint16_t*)(tb + (o1 >> 16)) << 16);
+                    const u32x2 rr = {r0, r1};
+                    hb[mt][ht] = __builtin_bit_cast(bf16x4, rr);
+                }
             }
         STAMP(2);
         // ---- Y^T += W2[:, chunk] GELU(H^T chunk)

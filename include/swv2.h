@@ -68,7 +68,7 @@ typedef struct swv2_attn_args {
                                  different regions get -100.  (wh - sh) * ww for a block shifted by sh > 0 rows;
                                  0 = no mask. */
     int max_chunks;           /* workgroups per head (each loops over windows); 64 is a good default */
-    int dbg;                  /* must be 0 (kernel-ablation switches used by tests/perf_probe.py only) */
+    int dbg;                  /* must be 0 (kernel-ablation switches used by tools/perf_probe.py only) */
 } swv2_attn_args;
 
 /* bias table -> the kernels' layouts (bf16, log2 domain); out: swv2_attn_pack_bias_bytes(heads, L) bytes */

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-kernel timing probe at the benchmark shape (GPU box): python tests/perf_probe.py [filter]"""
+"""Per-kernel timing probe at the benchmark shape (GPU box): python tools/perf_probe.py [filter]"""
 import os
 import sys
 import time

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run a few optimisation steps of a named yaml config through the Trainer on one GPU and report ms/step (GPU box).
-   python tests/run_cfg.py bench_geo_depth24_e192_invar [local_batch] [steps]"""
+   python tools/run_cfg.py bench_geo_depth24_e192_invar [local_batch] [steps]"""
 import os, sys, time, torch
 from types import SimpleNamespace
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)

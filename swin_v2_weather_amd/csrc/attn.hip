@@ -601,22 +601,44 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
             for (int i = 0; i < TPW; ++i)
 #pragma unroll
                 for (int dt = 0; dt < DK; ++dt) dq[i][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int t = 0; t < LT; ++t) {
+            // key tiles in pairs: the two tiles' transposed fragments concatenate to one K = 32 operand (same k order on
+            // both sides), which halves the MFMA count and the length of the dependent accumulation chain
+            auto frag = [&](int t, bf16x4 (&kt_)[DK], bf16x4 (&ds_)[TPW]) {
                 const int row = 16 * t + 4 * g + (fr >> 2);
                 // padded-key blocks of the compact image read the zero block
                 const int irow = (COMPACT && 16 * t + 4 * g >= IREAL) ? IREAL + (fr >> 2) : row;
-                bf16x4 kt_[DK];
 #pragma unroll
                 for (int dt = 0; dt < DK; ++dt) kt_[dt] = lds_tr_read(Ks + row * DP + 16 * dt + (fr & 3) * 4);   // rows d, col key
 #pragma unroll
                 for (int i = 0; i < TPW; ++i) {
-                    const int qt = tw * TPW + i;
-                    if (TPW > 1 && qt >= LT) continue;
-                    const bf16x4 dsT = lds_tr_read(dSb + irow * DSP + 16 * qt + (fr & 3) * 4);   // B[k = key][n = q]
-#pragma unroll
-                    for (int dt = 0; dt < DK; ++dt) dq[i][dt] = mfma16(kt_[dt], dsT, dq[i][dt]);
+                    const int qt = min(tw * TPW + i, LT - 1);
+                    ds_[i] = lds_tr_read(dSb + irow * DSP + 16 * qt + (fr & 3) * 4);                // B[k = key][n = q]
                 }
+            };
+#pragma unroll
+            for (int t = 0; t + 1 < LT; t += 2) {
+                bf16x4 k0[DK], k1[DK], d0[TPW], d1[TPW];
+                frag(t, k0, d0);
+                frag(t + 1, k1, d1);
+#pragma unroll
+                for (int i = 0; i < TPW; ++i)
+#pragma unroll
+                    for (int dt = 0; dt < DK; ++dt)
+                        dq[i][dt] = mfma32(__builtin_shufflevector(k0[dt], k1[dt], 0, 1, 2, 3, 4, 5, 6, 7),
+                                           __builtin_shufflevector(d0[i], d1[i], 0, 1, 2, 3, 4, 5, 6, 7), dq[i][dt]);
+            }
+            if (LT & 1) {
+                bf16x4 k0[DK], d0[TPW];
+                frag(LT - 1, k0, d0);
+#pragma unroll
+                for (int i = 0; i < TPW; ++i)
+#pragma unroll
+                    for (int dt = 0; dt < DK; ++dt) {
+                        // own accumulator: a K = 16 MFMA chained directly onto the K = 32 accumulator gave wrong sums
+                        // (measured; the same pair as two K = 16 MFMAs, or with this separate accumulator, is exact)
+                        const f32x4 tail = mfma16(k0[dt], d0[i], (f32x4){0.f, 0.f, 0.f, 0.f});
+                        dq[i][dt] += tail;
+                    }
             }
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {

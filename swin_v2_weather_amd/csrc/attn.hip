@@ -170,20 +170,44 @@ __global__ __launch_bounds__(64 * LT) void attn_fwd_kernel(
         }
 
         const bool do_mask = (mask_thr > 0) && (((bw % nW) / nww) == nwh - 1);
-        float mx;
-        if (do_mask) mx = score_pass<LT, HAS_BIAS, true, LFIX>(acc, biasp, sc2, L, g, mask_thr, q >= mask_thr);
-        else         mx = score_pass<LT, HAS_BIAS, false, LFIX>(acc, biasp, sc2, L, g, mask_thr, false);
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        float sum = 0.f;
+        float mx, sum = 0.f;
+        if (!HAS_BIAS && !do_mask) {
+            // no bias, no mask: sigma > 0 commutes with the maximum, so the row maximum is taken over the raw cosines and
+            // the scale is folded into the exponent's fma -- one vector instruction per element less
+            const int Lc = LFIX > 0 ? LFIX : L;
+            mx = SWV2_NEG_BIG;
 #pragma unroll
-        for (int t = 0; t < LT; ++t)
+            for (int t = 0; t < LT; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = __builtin_amdgcn_exp2f(acc[t][r] - mx);
-                acc[t][r] = p;
-                sum += p;
-            }
+                for (int r = 0; r < 4; ++r) {
+                    if (16 * t + 16 > Lc) acc[t][r] = (16 * t + 4 * g + r < Lc) ? acc[t][r] : SWV2_NEG_BIG;
+                    mx = fmaxf(mx, acc[t][r]);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            mx *= sc2;
+#pragma unroll
+            for (int t = 0; t < LT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(acc[t][r], sc2, -mx));
+                    acc[t][r] = p;
+                    sum += p;
+                }
+        } else {
+            if (do_mask) mx = score_pass<LT, HAS_BIAS, true, LFIX>(acc, biasp, sc2, L, g, mask_thr, q >= mask_thr);
+            else         mx = score_pass<LT, HAS_BIAS, false, LFIX>(acc, biasp, sc2, L, g, mask_thr, false);
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+#pragma unroll
+            for (int t = 0; t < LT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(acc[t][r] - mx);
+                    acc[t][r] = p;
+                    sum += p;
+                }
+        }
         sum += __shfl_xor(sum, 16);
         sum += __shfl_xor(sum, 32);
 

@@ -123,7 +123,8 @@ def main():
     net = model
     if use_ddp:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], output_device=local_rank,
-                                                        broadcast_buffers=False, gradient_as_bucket_view=True)
+                                                        broadcast_buffers=False, gradient_as_bucket_view=True,
+                                                        bucket_cap_mb=12)      # the 12.4 MB pos_embed gradient (ready last) alone
         if os.environ.get("SWV2_DDP_BUCKET_GRADS", "1") != "0":
             from swin_v2_weather_amd.networks.helpers import enable_ddp_bucket_grads
             enable_ddp_bucket_grads(net)

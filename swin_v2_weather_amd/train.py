@@ -144,7 +144,7 @@ class Trainer():
 
         if dist.is_initialized():
             ddp_kw = dict(broadcast_buffers=False, gradient_as_bucket_view=True,
-                          bucket_cap_mb=params['ddp_bucket_cap_mb'] if 'ddp_bucket_cap_mb' in params else 25,
+                          bucket_cap_mb=params['ddp_bucket_cap_mb'] if 'ddp_bucket_cap_mb' in params else 12,
                           static_graph=bool(params['checkpointing']) if 'checkpointing' in params else False)
             if self.device.type == 'cuda':
                 self.model = DistributedDataParallel(self.model, device_ids=[self.local_rank], output_device=self.local_rank, **ddp_kw)

@@ -190,23 +190,30 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_residual_bwd_kernel(
     }
 }
 
-// dgamma[j] += sum_b ws[b][0][j], dbeta[j] += sum_b ws[b][1][j] : 32 columns x 8 slices of blocks per workgroup
-__global__ __launch_bounds__(256) void ln_partials_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dgamma,
-                                                                 float* __restrict__ dbeta, int nblocks, int C) {
-    __shared__ float part[8][32];
-    const int col = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int j = blockIdx.x * 32 + col;
+// dgamma[j] += sum_b ws[b][0][j], dbeta[j] += sum_b ws[b][1][j] : 16 columns x 64 slices of blocks per workgroup (a
+// launch of 2 C / 16 workgroups; the per-thread chain over ~1000 partial rows is what this tiny kernel's time is, so it is
+// spread over 64 slices: 11 -> ~4 us, 25 launches per step)
+constexpr int LNR_COLS = 16, LNR_SLICES = 64;
+__global__ __launch_bounds__(LNR_COLS * LNR_SLICES) void ln_partials_reduce_kernel(const float* __restrict__ ws,
+                                                                                   float* __restrict__ dgamma,
+                                                                                   float* __restrict__ dbeta, int nblocks,
+                                                                                   int C) {
+    __shared__ float part[LNR_SLICES][LNR_COLS];
+    const int col = threadIdx.x % LNR_COLS, sl = threadIdx.x / LNR_COLS;
+    const int j = blockIdx.x * LNR_COLS + col;
     float s = 0.f;
     if (j < 2 * C) {
-#pragma unroll 8
-        for (int b = sl; b < nblocks; b += 8) s += ws[(size_t)b * 2 * C + j];
+#pragma unroll 4
+        for (int b = sl; b < nblocks; b += LNR_SLICES) s += ws[(size_t)b * 2 * C + j];
     }
     part[sl][col] = s;
     __syncthreads();
+    for (int h = LNR_SLICES / 2; h > 0; h >>= 1) {            // fixed-order tree: deterministic
+        if (sl < h) part[sl][col] += part[sl + h][col];
+        __syncthreads();
+    }
     if (sl == 0 && j < 2 * C) {
-#pragma unroll
-        for (int i = 1; i < 8; ++i) s += part[i][col];
-        if (j < C) dgamma[j] += s; else dbeta[j - C] += s;
+        if (j < C) dgamma[j] += part[0][col]; else dbeta[j - C] += part[0][col];
     }
 }
 
@@ -374,8 +381,8 @@ void launch_ln_bwd(const swv2_ln_args* a, hipStream_t st) {
     hipLaunchKernelGGL((ln_residual_bwd_kernel<G, CH>), dim3(grid), dim3(LN_BLOCK), 0, st, (const uint16_t*)a->a, a->dy,
                        a->gamma, a->scale, a->rowidx, a->mean, a->rstd, (uint16_t*)a->da, a->ws, a->M, a->C,
                        a->rows_per_sample);
-    hipLaunchKernelGGL(ln_partials_reduce_kernel, dim3(cdiv(2 * a->C, 32)), dim3(256), 0, st, a->ws, a->dgamma, a->dbeta,
-                       grid, a->C);
+    hipLaunchKernelGGL(ln_partials_reduce_kernel, dim3(cdiv(2 * a->C, LNR_COLS)), dim3(LNR_COLS * LNR_SLICES), 0, st, a->ws,
+                       a->dgamma, a->dbeta, grid, a->C);
 }
 
 int ln_check(const swv2_ln_args* a, bool bwd) {
@@ -391,7 +398,8 @@ int ln_check(const swv2_ln_args* a, bool bwd) {
 
 // shared with mlp.hip (fused MLP backward): dgamma[j] += sum_b ws[b][0][j], dbeta[j] += sum_b ws[b][1][j]
 void swv2_launch_ln_partials_reduce(const float* ws, float* dgamma, float* dbeta, int nblocks, int C, hipStream_t st) {
-    hipLaunchKernelGGL(ln_partials_reduce_kernel, dim3(cdiv(2 * C, 32)), dim3(256), 0, st, ws, dgamma, dbeta, nblocks, C);
+    hipLaunchKernelGGL(ln_partials_reduce_kernel, dim3(cdiv(2 * C, LNR_COLS)), dim3(LNR_COLS * LNR_SLICES), 0, st, ws, dgamma,
+                       dbeta, nblocks, C);
 }
 
 #define LN_DISPATCH(FN)                                              \

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""torch.profiler view of one benchmark step: which aten ops launch the non-swv2 kernels (GPU box)."""
+import os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import bench
+from types import SimpleNamespace
+from torch.profiler import profile, ProfilerActivity
+from swin_v2_weather_amd.networks.helpers import get_model
+from swin_v2_weather_amd.utils.losses import LossHandler
+
+dev = torch.device("cuda:0")
+import argparse
+ns = SimpleNamespace(depth=12, embed_dim=128, heads=8, height=720, width=1440, window_ratio=80, rel_pos=0, drop_path_rate=0.1)
+p = bench.model_params(ns)
+model = get_model(p).to(dev).train()
+lp = SimpleNamespace(n_future=0, img_shape_x=720, img_shape_y=1440, loss="l2", channel_weights="none", n_out_channels=73, model_grid_type="equiangular")
+loss_obj = LossHandler(lp).to(dev)
+opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.95), fused=True)
+x, y = torch.randn(2, 73, 720, 1440, device=dev), torch.randn(2, 73, 720, 1440, device=dev)
+def step():
+    model.zero_grad(); l = loss_obj(model(x), y, x); l.backward(); opt.step()
+for _ in range(4): step()
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    step(); torch.cuda.synchronize()
+rows = [e for e in prof.key_averages() if e.device_time_total > 0 or e.self_device_time_total > 0]
+rows.sort(key=lambda e: -e.self_device_time_total)
+for e in rows[:40]:
+    if not any(k in e.key for k in ("gemm_", "mlp_", "attn_", "proj_ln", "tn_reduce", "ln_")):
+        print(f"{e.key[:90]:90s} n={e.count:4d} self_dev={e.self_device_time_total:9.1f} us")

@@ -51,8 +51,30 @@ def pmc(dfetch, dwrite, out):
         print(f"{res[n]['hbm_bytes_per_launch'] / 1e6:10.1f} MB/launch  {n}")
 
 
+def counters(root, out):
+    """mean per-launch value of every counter of every pass directory under `root` -> {kernel: {counter: mean}}"""
+    res = {}
+    for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+        acc = {}
+        for r in csv.DictReader(open(f)):
+            k = (short(r["Kernel_Name"]), r["Counter_Name"])
+            a = acc.setdefault(k, [0, 0.0])
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+        for (n, c), (cnt, val) in acc.items():
+            res.setdefault(n, {})[c] = val / cnt
+    json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+    for n, v in sorted(res.items()):
+        if "SQ_BUSY_CYCLES" in v or "SQ_WAVE_CYCLES" in v:
+            print(n)
+            for c in sorted(v):
+                print(f"    {c:28s} {v[c]:16.0f}")
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "stats":
+    if sys.argv[1] == "counters":
+        counters(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "stats":
         stats(sys.argv[2], int(sys.argv[3]), sys.argv[4])
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4])

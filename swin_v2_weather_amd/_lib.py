@@ -13,7 +13,7 @@ import threading
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libswv2.so")
-SOURCES = ["capi.hip", "attn.hip", "gemm.hip", "gemm_tn.hip", "rowops.hip", "block.hip", "cpb.hip", "mlp.hip", "attn_fused.hip", "proj_ln.hip"]
+SOURCES = ["capi.hip", "attn.hip", "attn2.hip", "gemm.hip", "gemm_tn.hip", "rowops.hip", "block.hip", "cpb.hip", "mlp.hip", "attn_fused.hip", "proj_ln.hip"]
 
 _lib = None
 _lock = threading.Lock()

@@ -20,7 +20,10 @@
 //   backward: wave = key tile, product S = Q K^T so P / dS accumulators are directly the B operands of
 //             dV^T = dO^T P and dK^T = Q^T dS; dK, dV need no cross-wave reduction, the bias gradient of
 //             (head, key-tile) accumulates in registers across all windows of the workgroup, and only dQ crosses
-//             waves (LDS float atomics, one 16x16 tile per step).
+//             waves: the bf16 dS tiles go to an LDS image [key][q] and a second, barrier-separated phase (wave = query
+//             tile) reads them back transposed -- no atomics (see the phase description above attn_bwd_kernel).
+// These first-generation kernels now serve the shapes / options attn2.hip does not cover (window areas <= 64, the
+// backward with a CPB bias); attn2.hip holds the small-workgroup kernels used at the benchmark shape.
 #include <type_traits>
 
 #include "attn_common.h"
@@ -822,14 +825,32 @@ extern "C" int swv2_attn_pack_bias(const float* bias, int heads, int L, void* ou
     return SWV2_OK;
 }
 
+// second-generation kernels (attn2.hip): 0 / negative = handled (ok / error), 1 = shape not covered
+int swv2_attn2_fwd(const swv2_attn_args* a, int Lp, int DP, void* stream);
+int swv2_attn2_bwd(const swv2_attn_args* a, int Lp, int DP, void* stream);
+
 extern "C" int swv2_attn_fwd(const swv2_attn_args* a, void* stream) {
     int rc0 = check_args(a, false);
     if (rc0) return rc0;
+    if (!(a->dbg & 16)) {                     // dbg bit 4: force the first-generation kernel (tools/perf_probe.py A/B runs)
+        int Lp2, DP2;
+        int rc2 = swv2_attn_geometry(a->L, a->head_dim, &Lp2, &DP2);
+        if (rc2) return rc2;
+        rc2 = swv2_attn2_fwd(a, Lp2, DP2, stream);
+        if (rc2 <= 0) return rc2;
+    }
     SWV2_ATTN_DISPATCH(launch_fwd)
 }
 
 extern "C" int swv2_attn_bwd(const swv2_attn_args* a, void* stream) {
     int rc0 = check_args(a, true);
     if (rc0) return rc0;
+    if (!(a->dbg & 16)) {
+        int Lp2, DP2;
+        int rc2 = swv2_attn_geometry(a->L, a->head_dim, &Lp2, &DP2);
+        if (rc2) return rc2;
+        rc2 = swv2_attn2_bwd(a, Lp2, DP2, stream);
+        if (rc2 <= 0) return rc2;
+    }
     SWV2_ATTN_DISPATCH(launch_bwd)
 }

@@ -228,8 +228,12 @@ class _BlockFn(torch.autograd.Function):
         for name, off in zip(run.SCRATCH, run.scr_off):
             setattr(d, name, sb + off)
         params = (logit_scale, qkv_w, qkv_b, proj_w, proj_b, n1_w, n1_b, fc1_w, fc1_b, fc2_w, fc2_b, n2_w, n2_b)
-        views = blk._bucket_views(params) if blk._ddp_bucket_grads else None
+        # the views are handed out at most ONCE per backward pass: a multi-step rollout (MultiStepWrapper) runs this node
+        # n_future + 1 times per pass while p.grad is still None, and a second hand-out would zero / overwrite the gradient
+        # autograd's input buffer still holds as an alias (g_last twice instead of g_1 + ... + g_k)
+        views = blk._bucket_views(params) if (blk._ddp_bucket_grads and not blk._bv_in_use) else None
         if views is not None:
+            blk._bv_in_use = True
             # DDP (gradient_as_bucket_view): write the gradients straight into the reducer's bucket memory and hand autograd
             # aliases of it, so the reducer finds them in place instead of launching one copy kernel per parameter
             torch._foreach_zero_(views)
@@ -383,7 +387,7 @@ class WindowMultiHeadAttention(WindowMultiHeadAttentionNoPos):
         m = self.meta_mlp
         wh, ww = self.window_size
         keep = None
-        if self.training:
+        if m.drop1.training:          # the reference's nn.Dropout follows ITS module's flag (meta_mlp.eval() switches it off)
             ones = torch.ones(wh * ww * wh * ww, m.fc1.weight.shape[0], dtype=BF16, device=m.fc1.weight.device)
             keep = F.dropout(ones, 0.125, True)
         if not m.fc1.weight.is_cuda:
@@ -459,6 +463,7 @@ class SwinTransformerV2CrBlock(nn.Module):
 
     # ---- DDP bucket-view gradients (enabled by helpers.enable_ddp_bucket_grads after the DDP wrap) -----------------
     _ddp_bucket_grads = False
+    _bv_in_use = False          # the cached bucket views were handed to autograd in the current backward pass
 
     @staticmethod
     def _bucket_views(params):
@@ -475,6 +480,7 @@ class SwinTransformerV2CrBlock(nn.Module):
     def _queue_view_refresh(self, params):
         """At the end of this backward pass p.grad IS the reducer's bucket view (gradient_as_bucket_view=True): remember it."""
         def refresh():
+            self._bv_in_use = False
             for p in params:
                 g_ = p.grad
                 if g_ is not None and g_.shape == p.shape and g_.is_contiguous():

@@ -161,6 +161,97 @@ def fx_block():
             dp=np.array(dp), **params_of(blk), **grads_of(blk))
 
 
+def strided_grads(module, big=20000, step=5):
+    """parameter gradients; tensors above `big` elements keep every `step`-th element of the flattened gradient"""
+    out = {}
+    for n, p in module.named_parameters():
+        if p.grad is None:
+            continue
+        g = p.grad.detach()
+        out["g:" + n] = g.flatten()[::step].half() if g.numel() > big else g     # reference OUTPUTS may be fp16, inputs never
+    return out
+
+
+def fx_block_cfg():
+    """a11 at the BASELINE head geometries: cfg 4 (C = 192, 8 heads, d = 24 -> padded to 32, hidden 768) and
+    cfg 2 (C = 128, 8 heads, d = 16) with and without CPB, all on 9x18 windows, shifted (4, 9), 2x2 windows per sample.
+    Large parameter gradients are stored strided (every 5th element) to keep the fixtures small."""
+    for tag, relpos, C, h in [("cfg4_nopos", False, 192, 8), ("cfg2_relpos", True, 128, 8)]:
+        feat, win, shift = (18, 36), (9, 18), (4, 9)
+        seed = 2100 + len(tag) + C
+        torch.manual_seed(seed)
+        blk = sw.SwinTransformerV2CrBlock(dim=C, num_heads=h, feat_size=feat, window_size=win, shift_size=shift,
+                                          rel_pos=relpos, drop_path=0.0)
+        randomize(blk, seed, clamp_head=False)
+        blk.eval()
+        x = torch.randn(1, feat[0], feat[1], C, requires_grad=True)
+        y = blk(x)
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        cfg = O.SwinCfg(img_size=(feat[0] * 4, feat[1] * 4), patch_size=4, depth=2, num_heads=h, in_chans=1,
+                        out_chans=1, embed_dim=C, window_ratio=1, rel_pos=relpos, drop_path_rate=0.0)
+
+        class _C(O.SwinCfg):
+            window = property(lambda s: win)
+
+            def shift(s, i):
+                return shift
+
+            def drop_path(s, i):
+                return 0.0
+        cfg.__class__ = _C
+        p = {"b." + n: v.detach() for n, v in blk.named_parameters()}
+        yo = O.block_forward(x.detach(), p, "b.", cfg, 1, training=False)
+        print(f"block[{tag}] oracle max err {maxerr(yo, y):.2e}")
+        npz(f"block_{tag}.npz", x=x, y=y.half(), gy=gy, gx=x.grad.half(),
+            meta=np.array([feat[0], feat[1], win[0], win[1], shift[0], shift[1], C, h, 1, seed, 0, 0]),
+            dp=np.array(0.0), gstep=np.array(5), gbig=np.array(20000), **params_of(blk), **strided_grads(blk))
+
+
+def fx_model_cfg4():
+    """cfg-4-shaped whole model + loss: 77 -> 73 channels (73 fields + zenith + 2 landmask + orography),
+    d = 24 heads, residual skip, 2 blocks (plain + shifted), and the channel-weighted loss string of the *_chweight configs
+    ('weighted absolute temp-std squared geometric l2'): forward, loss value, and all gradients THROUGH the loss."""
+    seed = 4400
+    cin, cout, img, C, h = 77, 73, (24, 72), 96, 4
+    torch.manual_seed(seed)
+    m = sw.SwinTransformerV2Cr(img_size=img, patch_size=4, depths=(2,), num_heads=(h,), in_chans=cin, out_chans=cout,
+                               embed_dim=C, img_window_ratio=8, drop_path_rate=0.0, full_pos_embed=True, rel_pos=False,
+                               mlp_ratio=4, residual=True)
+    randomize(m, seed, clamp_head=False)
+    m.eval()
+    g = torch.Generator().manual_seed(seed + 1)
+    gstd = (0.5 + torch.rand(1, cout, 1, 1, generator=g)).numpy()
+    tdstd = (0.2 + torch.rand(1, cout, 1, 1, generator=g)).numpy()
+    tmp = "/tmp/_golden_stats4"
+    os.makedirs(tmp, exist_ok=True)
+    np.save(tmp + "/gs.npy", gstd)
+    np.save(tmp + "/td.npy", tdstd)
+    loss = "weighted absolute temp-std squared geometric l2"
+    params = fake_params(n_future=0, img_shape_x=img[0], img_shape_y=img[1], loss=loss, channel_weights="auto",
+                         n_out_channels=cout, channel_names=CHANNEL_NAMES, out_channels=np.arange(cout),
+                         global_stds_path=tmp + "/gs.npy", time_diff_stds_path=tmp + "/td.npy", dt=1,
+                         model_grid_type="equiangular")
+    lh = ls.LossHandler(params)
+    x = torch.randn(1, cin, *img, generator=g).requires_grad_(True)
+    tar = torch.randn(1, cout, *img, generator=g)
+    y = m(x)
+    val = lh(y, tar, x)
+    val.backward()
+    cfg = O.SwinCfg(img_size=img, patch_size=4, depth=2, num_heads=h, in_chans=cin, out_chans=cout, embed_dim=C,
+                    window_ratio=8, drop_path_rate=0.0, full_pos_embed=True, rel_pos=False, residual=True)
+    p = {n: v.detach() for n, v in m.named_parameters()}
+    yo = O.model_forward(x.detach(), p, cfg, training=False)
+    chw = O.loss_channel_weights(loss, cout, 0, CHANNEL_NAMES, "auto", torch.from_numpy(gstd), torch.from_numpy(tdstd), 1,
+                                 training=True)
+    vo = O.geometric_l2_loss(yo, tar, chw, loss)
+    print(f"model[cfg4] oracle max err {maxerr(yo, y):.2e}; loss ref {float(val):.6f} oracle rel err "
+          f"{abs(float(vo) - float(val)) / abs(float(val)):.1e}")
+    npz("model_cfg4.npz", x=x, tar=tar, y=y.half(), gx=x.grad.half(), loss=np.array(float(val)), global_stds=gstd, time_diff_stds=tdstd,
+        meta=np.array([cin, cout, img[0], img[1], C, h, 2, 8, 0, 1, seed]), gstep=np.array(5), gbig=np.array(20000),
+        **params_of(m), **strided_grads(m))
+
+
 def fx_patch_ops():
     seed = 3001
     torch.manual_seed(seed)
@@ -384,14 +475,53 @@ def fx_losscurve(steps=100):
                    "curve": curve}, f)
 
 
+def fx_losscurve_relpos(steps=100):
+    """Second 100-step curve (the first one is low-sensitivity -- zero LN weights keep the blocks near the
+    identity, no CPB): randomised LayerNorm weights and logit scales from step 0, rel_pos=True (CPB meta-MLP trained through
+    d bias), residual skip, targets correlated with the input (tar = 0.5 x + noise) so the loss actually falls.  The only
+    stochastic piece of the model, the meta-MLP's hard-coded Dropout(0.125), is switched off by putting the meta_mlp
+    sub-modules in eval mode (CPU and GPU generators cannot be made to agree); drop_path 0."""
+    seed = 777
+    torch.manual_seed(seed)
+    m = sw.SwinTransformerV2Cr(img_size=(96, 144), patch_size=4, depths=(2,), num_heads=(4,), in_chans=20,
+                               out_chans=20, embed_dim=64, img_window_ratio=8, drop_path_rate=0.0,
+                               full_pos_embed=True, rel_pos=True, mlp_ratio=4, residual=True)
+    randomize(m, seed, clamp_head=False)
+    init = {n: v.detach().clone() for n, v in m.named_parameters()}
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, betas=(0.9, 0.95))
+    chw = O.loss_channel_weights("l2", 20, 0)
+    curve = []
+    m.train()
+    for mod in m.modules():
+        if isinstance(mod, sw.WindowMultiHeadAttention):
+            mod.meta_mlp.eval()
+    for it in range(steps):
+        x, n_ = synthetic_batch(it % 4, 2, 20, 20, 96, 144, seed)
+        t = 0.5 * x + 0.5 * n_
+        opt.zero_grad()
+        y = m(x)
+        loss = O.geometric_l2_loss(y, t, chw, "l2")
+        loss.backward()
+        opt.step()
+        curve.append(float(loss))
+        if it % 10 == 0:
+            print(f"  curve2 step {it}: {curve[-1]:.6f}", flush=True)
+    npz("losscurve_relpos_init.npz", **{k: v for k, v in init.items()})
+    with open(os.path.join(HERE, "losscurve_relpos.json"), "w") as f:
+        json.dump({"seed": seed, "steps": steps, "lr": 1e-3, "betas": [0.9, 0.95], "pool": 4, "loss": "l2", "batch": 2,
+                   "cfg": {"img_size": [96, 144], "depth": 2, "num_heads": 4, "embed_dim": 64, "window_ratio": 8,
+                           "in_chans": 20, "out_chans": 20, "rel_pos": True, "residual": True},
+                   "curve": curve}, f)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-curve", action="store_true")
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
-    todo = [fx_masks, fx_window_attn, fx_block, fx_patch_ops, fx_model, fx_loss, fx_multistep]
+    todo = [fx_masks, fx_window_attn, fx_block, fx_block_cfg, fx_patch_ops, fx_model, fx_model_cfg4, fx_loss, fx_multistep]
     if not a.skip_curve:
-        todo.append(fx_losscurve)
+        todo += [fx_losscurve, fx_losscurve_relpos]
     for f in todo:
         if a.only and a.only not in f.__name__:
             continue

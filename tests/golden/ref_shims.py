@@ -1,8 +1,8 @@
 """Import shims that let the read-only reference (/root/reference) be imported in the build
 container, where `timm`, `ruamel.yaml`, `torch_harmonics` ... are not installed.
 
-Only used by `make_golden.py` (fixture generation) and by the optional
-`tests/test_reference_live.py` (skipped when /root/reference is absent, e.g. on the GPU box).
+Only used by `make_golden.py` (fixture generation in the build container, where /root/reference exists); nothing under
+`tests/test_*.py` imports it, so no test reads /root/reference at run time.
 
 The `timm.layers` stand-ins are our restatement of timm's published semantics
 (timm >= 0.9): see oracle/swin_oracle.py header.  They are NOT part of the product.

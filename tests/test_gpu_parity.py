@@ -51,16 +51,19 @@ def load_params(module, fx):
     module.load_state_dict({k[2:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("p:")}, strict=True)
 
 
-def worst_grad(module, ref_grads, floor=1e-3, logit_tol=0.15):
+def worst_grad(module, ref_grads, floor=1e-3, logit_tol=0.15, big=None, step=1):
     """worst relative l2 error over the parameter gradients.  `logit_scale` gets its own (looser) bar: its gradient is
     sigma * sum(dS * cos) over every (window, query, key) -- a sum with heavy cancellation, so bf16 rounding of the
     stored attention output shows up an order of magnitude more than in any other gradient."""
     worst = 0.0
     for n, p in module.named_parameters():
         r = ref_grads.get(n)
-        if r is None or p.grad is None or float(r.abs().max()) < floor:
+        if r is None or p.grad is None or float(r.float().abs().max()) < floor:
             continue
-        e = rel(p.grad, r)
+        got = p.grad
+        if big is not None and got.numel() > big:          # fixture keeps every `step`-th element of large gradients
+            got = got.flatten()[::step]
+        e = rel(got, r.float())
         if n.endswith("logit_scale"):
             assert e < logit_tol, (n, e)
             continue
@@ -261,10 +264,16 @@ def test_attention_core_fwd_bwd(dev, K, wh, ww, h, d, nwh, nww, shifted, use_bia
     assert rel(got[:, :, 2], g[:, :, 2]) < 6e-3
     assert float(dls[-1]) == 0.0 and rel(dls, ls_ref.grad) < 0.12       # clamp gate; sum with heavy cancellation
     if use_bias:
-        # the pre-packed table (swv2_attn_pack_bias) holds the same bf16 values: forward and dq/dk/dv are bit-identical
+        # the pre-packed table (swv2_attn_pack_bias) holds the same bf16 values.  With it the forward may run the
+        # second-generation kernel (pairs of key tiles per K = 32 MFMA: another summation order), so the outputs agree to
+        # bf16 rounding rather than bit for bit; the (first-generation) bias backward is bit-identical either way
         pk = ops.attn_pack_bias(bd)
         oh2, lse2 = torch.empty_like(oh), torch.empty_like(lse)
         ops.attn_fwd(ops.attn_args(qkvh, lsd, bd, oh2, lse2, Bw, h, Lw, d, nwh, nww, mask_thr, bias_pack=pk))
+        assert rel(oh2, oh) < 4e-3 and float((lse2 - lse).abs().max()) < 1e-4
+        a1 = ops.attn_args(qkvh, lsd, bd, oh2, lse2, Bw, h, Lw, d, nwh, nww, mask_thr, bias_pack=pk)
+        a1.dbg = 16                                     # first-generation kernel on the packed table: bit-identical
+        ops.attn_fwd(a1)
         assert torch.equal(oh2, oh) and torch.equal(lse2, lse)
         dq2, dls2, db2 = torch.empty_like(dqkvh), torch.zeros_like(dls), torch.zeros_like(dbias)
         ops.attn_bwd(ops.attn_args(qkvh, lsd, bd, oh, lse, Bw, h, Lw, d, nwh, nww, mask_thr, doh=doh, rnorm=rnorm.to(dev).contiguous(),
@@ -318,6 +327,108 @@ def test_block_against_reference_fixture(dev, K, tag):
     # (2) bf16 tolerance against the fp32 reference.  These fixtures carry one head at the sigma = 100 clamp, where the
     # softmax is an arg-max and bf16 operand rounding moves logits by ~0.3: the worst case for reduced precision.
     assert rel(y, torch.from_numpy(fx["y"])) < 3e-2 and rel(x.grad, torch.from_numpy(fx["gx"])) < 0.15
+
+
+@pytest.mark.parametrize("tag", ["cfg4_nopos", "cfg2_relpos"])
+def test_block_at_baseline_head_geometry(dev, K, tag):
+    """Blocks at the BASELINE head geometries against the real reference (VERDICT r1 'cfg 4 is untested'): cfg 4 = C 192, 8
+    heads, d = 24 (padded to 32 in the attention layout), hidden 768 -- the shape where swv2_proj_ln_supported says no and the
+    unfused proj + LN path runs; cfg 2 = C 128, 8 heads, d = 16 with the CPB bias.  9x18 windows, shifted (4, 9)."""
+    N = K["N"]
+    fx = np.load(os.path.join(GOLD, f"block_{tag}.npz"))
+    gh, gw, wh, ww, sh, sw, Cc, h, B, seed, _, _ = [int(v) for v in fx["meta"]]
+    relpos = "relpos" in tag
+    blk = N.SwinTransformerV2CrBlock(dim=Cc, num_heads=h, feat_size=(gh, gw), window_size=(wh, ww), shift_size=(sh, sw),
+                                     rel_pos=relpos, drop_path=0.0)
+    load_params(blk, fx)
+    blk = blk.to(dev).eval()
+    x = torch.from_numpy(fx["x"]).to(dev).requires_grad_(True)
+    y = blk(x)
+    y.backward(torch.from_numpy(fx["gy"]).to(dev))
+    big, step = int(fx["gbig"]), int(fx["gstep"])
+    # bf16 tolerance against the fp32 reference (logit scales near their ln 10 init: no arg-max head in these fixtures)
+    assert rel(y, torch.from_numpy(fx["y"]).float()) < 1.5e-2 and rel(x.grad, torch.from_numpy(fx["gx"]).float()) < 4e-2
+    assert worst_grad(blk, {k[2:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("g:")}, big=big, step=step,
+                      logit_tol=0.05) < 6e-2
+    # kernel correctness against the bf16-emulating oracle
+    p = {"b." + k[2:]: torch.from_numpy(fx[k]).clone().requires_grad_(True) for k in fx.files if k.startswith("p:")}
+    xo = torch.from_numpy(fx["x"]).clone().requires_grad_(True)
+    O.set_rounding(O.bf16_round)
+    try:
+        yo = O.block_forward(xo, p, "b.", block_cfg(gh, gw, wh, ww, sh, sw, Cc, h, relpos), 1, training=False)
+        yo.backward(torch.from_numpy(fx["gy"]))
+    finally:
+        O.set_rounding(None)
+    assert rel(y, yo) < 1e-3 and rel(x.grad, xo.grad) < 1.5e-2
+    assert worst_grad(blk, {k[2:]: v.grad for k, v in p.items()}, logit_tol=0.05) < 3e-2
+
+
+def test_model_cfg4_shape_with_channel_weighted_loss(dev, K):
+    """cfg-4-shaped model (77 -> 73 channels, d = 24 heads, residual skip, plain + shifted block) through the channel-weighted
+    loss of the *_chweight configs (config/swin.yaml:160-173): forward, loss value and every gradient THROUGH the loss,
+    against the real reference."""
+    from types import SimpleNamespace
+    from swin_v2_weather_amd.utils.losses import LossHandler
+    import tempfile
+    fx = np.load(os.path.join(GOLD, "model_cfg4.npz"))
+    cin, cout, H, W, Cc, h, depth, ratio, relpos, residual, seed = [int(v) for v in fx["meta"]]
+    m = K["N"].SwinTransformerV2Cr(img_size=(H, W), patch_size=4, depths=(depth,), num_heads=(h,), in_chans=cin, out_chans=cout,
+                                   embed_dim=Cc, img_window_ratio=ratio, full_pos_embed=True, rel_pos=bool(relpos),
+                                   residual=bool(residual))
+    load_params(m, fx)
+    m = m.to(dev).eval()
+    names = (["u10m", "v10m", "u100m", "v100m", "t2m", "sp", "msl", "tcwv"] +
+             [f"{v}{l}" for v in "uvztq" for l in (50, 100, 150, 200, 250, 300, 400, 500, 600, 700, 850, 925, 1000)])
+    tmp = tempfile.mkdtemp()
+    np.save(tmp + "/gs.npy", fx["global_stds"])
+    np.save(tmp + "/td.npy", fx["time_diff_stds"])
+    lh = LossHandler(SimpleNamespace(n_future=0, img_shape_x=H, img_shape_y=W, loss="weighted absolute temp-std squared geometric l2",
+                                     channel_weights="auto", n_out_channels=cout, channel_names=names, out_channels=np.arange(cout),
+                                     global_stds_path=tmp + "/gs.npy", time_diff_stds_path=tmp + "/td.npy", dt=1,
+                                     model_grid_type="equiangular")).to(dev)
+    x = torch.from_numpy(fx["x"]).to(dev).requires_grad_(True)
+    y = m(x)
+    val = lh(y, torch.from_numpy(fx["tar"]).to(dev), x)
+    val.backward()
+    assert rel(y, torch.from_numpy(fx["y"]).float()) < 1.5e-2
+    assert abs(float(val) - float(fx["loss"])) < 1e-2 * float(fx["loss"])
+    assert rel(x.grad, torch.from_numpy(fx["gx"]).float()) < 4e-2
+    assert worst_grad(m, {k[2:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("g:")}, big=int(fx["gbig"]),
+                      step=int(fx["gstep"]), logit_tol=0.05) < 8e-2
+
+
+def test_full_size_block_forward_backward_against_oracle(dev, K):
+    """ONE block at the BASELINE size (B = 2, 180 x 360 tokens, 800 windows of 9 x 18, 40 of them with the shift mask, C = 128,
+    8 heads) forward AND backward against the bf16-emulating oracle (the 400-window backward -- chunking over
+    windows, XCD slice maps, partial-tile weight gradients -- was only ever run by bench.py, unchecked)."""
+    N = K["N"]
+    torch.manual_seed(11)
+    gh, gw, wh, ww, sh, sw, Cc, h, B = 180, 360, 9, 18, 4, 9, 128, 8, 2
+    blk = N.SwinTransformerV2CrBlock(dim=Cc, num_heads=h, feat_size=(gh, gw), window_size=(wh, ww), shift_size=(sh, sw),
+                                     rel_pos=False, drop_path=0.0)
+    with torch.no_grad():
+        for n_, p_ in blk.named_parameters():
+            if n_.endswith("norm1.weight") or n_.endswith("norm2.weight"):
+                p_.uniform_(0.5, 1.5)
+            elif n_.endswith("logit_scale"):
+                p_.copy_(torch.log(torch.tensor(10.0)) + 0.25 * torch.randn(h))
+    x = torch.randn(B, gh, gw, Cc)
+    gy = torch.randn(B, gh, gw, Cc)
+    p = {"b." + n_: v.detach().clone().requires_grad_(True) for n_, v in blk.named_parameters()}
+    blk = blk.to(dev).eval()
+    xd = x.to(dev).requires_grad_(True)
+    y = blk(xd)
+    y.backward(gy.to(dev))
+    xo = x.clone().requires_grad_(True)
+    O.set_rounding(O.bf16_round)
+    try:
+        yo = O.block_forward(xo, p, "b.", block_cfg(gh, gw, wh, ww, sh, sw, Cc, h, False), 1, training=False)
+        yo.backward(gy)
+    finally:
+        O.set_rounding(None)
+    assert rel(y, yo) < 1e-3 and rel(xd.grad, xo.grad) < 1.5e-2
+    # weight gradients are sums over 129 600 rows: bf16 rounding noise averages out, systematic errors would not
+    assert worst_grad(blk, {k[2:]: v.grad for k, v in p.items()}, logit_tol=0.05) < 3e-2
 
 
 def test_block_train_mode_replays_droppath_and_cpb_dropout(dev, K):
@@ -494,6 +605,50 @@ def test_loss_curve_tiny_100_steps(dev, K):
     err = np.abs(np.array(curve) - ref) / np.abs(ref)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump({"max_rel_err": float(err.max()), "curve": curve}, open(os.path.join(ROOT, "gpurun_out", "losscurve_gpu.json"), "w"))
+    assert float(err.max()) < 1e-3, f"loss curve deviates: max rel err {err.max():.2e} at step {int(err.argmax())}"
+
+
+def test_loss_curve_relpos_randomised_ln_100_steps(dev, K):
+    """Second curve (the first is low-sensitivity): LayerNorm weights / logit scales randomised from step 0, CPB
+    bias trained through d(bias), residual skip, targets correlated with the input -- the loss falls 4.47 -> 1.93.  The
+    meta-MLP's hard-coded Dropout(0.125) is off (its sub-modules in eval mode, as when the reference curve was recorded)."""
+    from types import SimpleNamespace
+    from swin_v2_weather_amd.utils.losses import LossHandler
+    meta = json.load(open(os.path.join(GOLD, "losscurve_relpos.json")))
+    init = np.load(os.path.join(GOLD, "losscurve_relpos_init.npz"))
+    c = meta["cfg"]
+    N = K["N"]
+    m = N.SwinTransformerV2Cr(img_size=tuple(c["img_size"]), patch_size=4, depths=(c["depth"],), num_heads=(c["num_heads"],),
+                              in_chans=c["in_chans"], out_chans=c["out_chans"], embed_dim=c["embed_dim"],
+                              img_window_ratio=c["window_ratio"], drop_path_rate=0.0, full_pos_embed=True, rel_pos=True,
+                              mlp_ratio=4, residual=True)
+    m.load_state_dict({k: torch.from_numpy(init[k]) for k in init.files}, strict=True)
+    m = m.to(dev).train()
+    for mod in m.modules():
+        if isinstance(mod, N.WindowMultiHeadAttention):
+            mod.meta_mlp.eval()
+    lh = LossHandler(SimpleNamespace(n_future=0, img_shape_x=c["img_size"][0], img_shape_y=c["img_size"][1], loss="l2",
+                                     channel_weights="none", n_out_channels=c["out_chans"], model_grid_type="equiangular")).to(dev)
+    opt = torch.optim.Adam(m.parameters(), lr=meta["lr"], betas=tuple(meta["betas"]))
+    H, W = c["img_size"]
+
+    def batch(step):
+        g = torch.Generator().manual_seed(meta["seed"] * 100003 + step)
+        x = torch.randn(meta["batch"], c["in_chans"], H, W, generator=g)
+        n_ = torch.randn(meta["batch"], c["out_chans"], H, W, generator=g)
+        return x, 0.5 * x + 0.5 * n_
+    curve = []
+    for it in range(meta["steps"]):
+        x, t = batch(it % meta["pool"])
+        opt.zero_grad()
+        loss = lh(m(x.to(dev)), t.to(dev))
+        loss.backward()
+        opt.step()
+        curve.append(float(loss))
+    ref = np.array(meta["curve"])
+    err = np.abs(np.array(curve) - ref) / np.abs(ref)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump({"max_rel_err": float(err.max()), "curve": curve}, open(os.path.join(ROOT, "gpurun_out", "losscurve_relpos_gpu.json"), "w"))
     assert float(err.max()) < 1e-3, f"loss curve deviates: max rel err {err.max():.2e} at step {int(err.argmax())}"
 
 
@@ -788,13 +943,48 @@ def test_block_fused_attention_branch(dev, K, monkeypatch, gh, gw, wh, ww, sh, s
         assert rel(outs["1"][0], yo) < 1e-3 and rel(outs["1"][1], xo.grad) < 1.5e-2
 
 
-def test_ddp_bucket_view_gradients(dev, K):
-    """helpers.enable_ddp_bucket_grads: the blocks write their parameter gradients straight into the DDP reducer's bucket
-    views (no per-parameter copy kernels).  One rank over RCCL in a child process (own process group): same losses and
-    parameters as plain DDP and as no DDP, and every block picks up its cached bucket views."""
+def _ddp_run(tmp_path, tag, world, backend, mode, n_future, port):
+    """spawn `world` worker processes (tests/ddp_alias_check.py), all on cuda:0; returns rank 0's record"""
     import subprocess
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
-               HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "ddp_alias_check.py")], env=env, stdout=subprocess.PIPE,
-                       stderr=subprocess.STDOUT, timeout=600)
-    assert r.returncode == 0 and b"ddp alias check ok" in r.stdout, r.stdout.decode()[-2000:]
+    out = os.path.join(str(tmp_path), f"{tag}.pt")
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", SWV2_DDP_BACKEND=backend, SWV2_DDP_MODE=mode, SWV2_DDP_NFUTURE=str(n_future),
+                   SWV2_DDP_STEPS="3", SWV2_DDP_OUT=out)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ddp_alias_check.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = [p_.communicate(timeout=900)[0].decode() for p_ in procs]
+    assert all(p_.returncode == 0 for p_ in procs), "\n".join(l[-1500:] for l in logs)
+    return torch.load(out)
+
+
+def _ddp_close(a, b, tol=2e-3):
+    worst = max(float((x - y).abs().max() / (y.abs().max() + 1e-12)) for x, y in zip(a["params"], b["params"]))
+    assert worst < tol, worst
+    assert all(abs(x - y) < 5e-4 * abs(y) + 1e-6 for x, y in zip(a["losses"], b["losses"])), (a["losses"], b["losses"])
+
+
+def test_ddp_bucket_view_gradients(dev, K, tmp_path):
+    """helpers.enable_ddp_bucket_grads on one rank over RCCL: the blocks write their parameter gradients straight into the
+    DDP reducer's bucket views.  Same losses / parameters as no DDP at all -- also through a 2-step MultiStepWrapper rollout,
+    where every block's backward node runs twice per pass and the views may be handed out only once."""
+    for nf in (0, 1):
+        ref = _ddp_run(tmp_path, f"plain{nf}", 1, "nccl", "plain", nf, 29531)
+        al = _ddp_run(tmp_path, f"alias{nf}", 1, "nccl", "alias", nf, 29533 + nf)
+        assert al["used"] == 4 and al["stuck"] == 0 and al["nranks"] == 1, (al["used"], al["stuck"])
+        _ddp_close(al, ref)
+
+
+def test_ddp_two_ranks_hip_model(dev, K, tmp_path):
+    """The HIP model under REAL multi-rank DDP (train.py:186-190): two processes share cuda:0 (backend gloo: CUDA tensors are
+    staged through the host), each on its half of the batch, with the bucket-view gradient path -- covers the reducer's
+    bucket rebuild after the first step and the mark-ready logic with > 1 rank.  Invariant (tests/test_ddp_gloo.py): after 3
+    Adam steps the parameters equal the 1-process run on the whole batch."""
+    for nf in (0, 1):
+        ref = _ddp_run(tmp_path, f"plain{nf}", 1, "gloo", "plain", nf, 29541)
+        two = _ddp_run(tmp_path, f"two{nf}", 2, "gloo", "alias", nf, 29543 + nf)
+        assert two["nranks"] == 2 and two["stuck"] == 0
+        _ddp_close(two, ref)
+    stock = _ddp_run(tmp_path, "stock0", 2, "gloo", "ddp", 0, 29547)
+    _ddp_close(stock, _ddp_run(tmp_path, "plain0b", 1, "gloo", "plain", 0, 29549))

@@ -39,6 +39,36 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert lib.swv2_version() == 100
 
 
+def header_struct_fields(name):
+    """member names of `struct <name>` in include/swv2.h, in declaration order"""
+    txt = open(os.path.join(ROOT, "include", "swv2.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    body = re.search(r"typedef struct(?: %s)? \{([^{}]*)\} %s;" % (name, name), txt, flags=re.S).group(1)
+    out = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        first, *rest = decl.split(",")
+        out.append(re.findall(r"([A-Za-z_][A-Za-z0-9_]*)\s*(?:\[[^\]]*\])?\s*$", first.strip())[0])
+        out += [re.sub(r"\[.*", "", r_).replace("*", "").strip() for r_ in rest]
+    return out
+
+
+def test_ctypes_structs_follow_the_header_field_order():
+    """the ctypes mirrors (swin_v2_weather_amd/_lib.py) and the stub printed in INTEGRATION.md list exactly the members of
+    the C structs, in order -- a missing member shifts every later pointer by one slot (`bias_pack`)"""
+    pairs = {"swv2_attn_args": L.AttnArgs, "swv2_operand": L.Operand, "swv2_epilogue": L.Epilogue, "swv2_block_desc": L.BlockDesc,
+             "swv2_mlp_args": L.MlpArgs, "swv2_mlp_bwd_args": L.MlpBwdArgs, "swv2_proj_ln_args": L.ProjLnArgs,
+             "swv2_proj_ln_bwd_args": L.ProjLnBwdArgs, "swv2_attn_branch_args": L.AttnBranchArgs, "swv2_ln_args": L.LnArgs}
+    for cname, cls in pairs.items():
+        assert [f[0] for f in cls._fields_] == header_struct_fields(cname), cname
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    stub = doc[doc.index("class AttnArgs(C.Structure)"):doc.index("lib.swv2_attn_fwd.argtypes")]
+    names = re.findall(r'"([A-Za-z_][A-Za-z0-9_]*)"', stub)
+    assert names == header_struct_fields("swv2_attn_args")
+
+
 def test_argument_errors_are_reported_without_touching_the_gpu():
     lib = L.load()
     assert lib.swv2_attn_fwd(None, None) == -1            # SWV2_ERR_INVALID

@@ -49,15 +49,14 @@ def probe_attn(B=2, rel_pos=False):
     dls = torch.zeros(h, device=dev)
     dbias = torch.zeros(h, Lw, Lw, device=dev) if rel_pos else None
     pk = ops.attn_pack_bias(bias) if rel_pos else None
-    for chunks in (32, 64, 128):
-        a = ops.attn_args(qkvh, ls, bias, oh, lse, Bw, h, Lw, 16, plan.nwh, plan.nww, plan.mask_thr, max_chunks=chunks, bias_pack=pk)
-        say(f"attn_fwd  B={B} bias={rel_pos} chunks={chunks}: {timeit(lambda: ops.attn_fwd(a)):.1f} us")
-    for chunks in (32, 64, 128):
-        for dbg in (0, 1, 2, 4, 5):
-            a = ops.attn_args(qkvh, ls, bias, oh, lse, Bw, h, Lw, 16, plan.nwh, plan.nww, plan.mask_thr, doh=doh, rnorm=rnorm,
-                              dqkvh=dq, dlogit=dls, dbias=dbias, max_chunks=chunks, bias_pack=pk)
-            a.dbg = dbg
-            say(f"attn_bwd  B={B} bias={rel_pos} chunks={chunks} dbg={dbg}: {timeit(lambda: ops.attn_bwd(a)):.1f} us")
+    for gen, dbg in (("gen1", 16), ("gen2", 0), ("gen2-occ3", 32)):
+        a = ops.attn_args(qkvh, ls, bias, oh, lse, Bw, h, Lw, 16, plan.nwh, plan.nww, plan.mask_thr, max_chunks=32 if rel_pos else 64, bias_pack=pk)
+        a.dbg = dbg
+        say(f"attn_fwd  {gen} B={B} bias={rel_pos}: {timeit(lambda: ops.attn_fwd(a), n=20):.1f} us")
+        a = ops.attn_args(qkvh, ls, bias, oh, lse, Bw, h, Lw, 16, plan.nwh, plan.nww, plan.mask_thr, doh=doh, rnorm=rnorm,
+                          dqkvh=dq, dlogit=dls, dbias=dbias, max_chunks=32 if rel_pos else 64, bias_pack=pk)
+        a.dbg = dbg
+        say(f"attn_bwd  {gen} B={B} bias={rel_pos}: {timeit(lambda: ops.attn_bwd(a), n=20):.1f} us")
 
 
 def probe_gemm(B=2):
@@ -161,6 +160,7 @@ if __name__ == "__main__":
     if "attn" in flt or not flt:
         probe_attn(2, False)
         probe_attn(2, True)
+        probe_attn(8, False)
     if "gemm" in flt or not flt:
         probe_gemm(2)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)

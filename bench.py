@@ -41,9 +41,10 @@ def train_flops_per_sample(a):
 
 
 def cpu_baseline(a):
-    """Oracle (oracle/swin_oracle.py, fp32 torch on the host cores) on a bounded sample of the same workload: one
-    sample at the full 73 x H x W shape through patch-embed + ONE block + head, forward + backward, and the same with
-    zero blocks; the per-sample time for depth D is extrapolated as t0 + D * (t1 - t0)."""
+    """Oracle (oracle/swin_oracle.py, fp32 torch on the host cores) on a BOUNDED sample of the same workload (the full
+    depth-12 step is ~40 s per sample on 128 host threads): one sample at the full 73 x H x W shape through patch-embed +
+    ONE block + head, forward + backward, and the same with zero blocks -- one warm-up and two timed iterations each -- and
+    the per-sample time for depth D extrapolated as t0 + D * (t1 - t0) (the blocks are identical).  Labelled as such."""
     from oracle import swin_oracle as O
     from swin_v2_weather_amd.networks.helpers import get_model
     torch.manual_seed(0)
@@ -61,15 +62,52 @@ def cpu_baseline(a):
         cfg.depth = depth
         net = O.OracleNet(cfg, sd)
         x = torch.randn(1, 73, a.height, a.width)
-        t0 = time.time()
-        y = net(x)
-        y.square().mean().backward()
-        times[depth] = time.time() - t0
-        del net, y
+        ts = []
+        for it in range(3):                                 # 1 warm-up (allocator, thread pool) + 2 timed
+            t0 = time.time()
+            y = net(x)
+            y.square().mean().backward()
+            ts.append(time.time() - t0)
+            del y
+        times[depth] = min(ts[1:])
+        del net
     per_sample = times[0] + a.depth * (times[1] - times[0])
-    return {"value": 1.0 / per_sample, "unit": "samples/sec", "cores": threads, "kind": "port",
-            "sample": f"oracle fp32 fwd+bwd of 1 sample 73x{a.height}x{a.width}: embed+head {times[0]:.1f}s, +1 block "
-                      f"{times[1] - times[0]:.1f}s, extrapolated to depth {a.depth} ({per_sample:.0f}s/sample); optimizer excluded"}
+    return {"value": 1.0 / per_sample, "unit": "samples/sec", "cores": threads, "kind": "port", "extrapolated": True,
+            "sample": f"oracle fp32 fwd+bwd of 1 sample 73x{a.height}x{a.width}, 1 warm + 2 timed iterations: embed+head "
+                      f"{times[0]:.1f}s, +1 block {times[1] - times[0]:.1f}s, EXTRAPOLATED linearly to depth {a.depth} "
+                      f"({per_sample:.0f}s/sample); optimizer excluded"}
+
+
+# kernels timed with HIP events inside the timed region (round robin over the 12 blocks of every step):
+#   name -> (rocprof kernel-name fragment, bound, algorithmic bytes per token-channel and sample, MFMA flops per T*L*C*B)
+ROOFLINE_KERNELS = {
+    "attn_bwd": ("attn_bwd_kernel", "hbm", 16.0, 8.0),      # bf16 q, k, v, o, do in; dq, dk, dv out
+    "attn_fwd": ("attn_fwd3_kernel", "hbm", 8.0, 4.0),      # bf16 q, k, v in; o out
+    "mlp_bwd": ("mlp_bwd_kernel", "hbm", 28.0, 0.0),        # dx2, x-stats, a2, hpre in; da2, dh, dx1 out
+    "mlp_fwd": ("mlp_fwd_kernel", "hbm", 18.0, 0.0),
+}
+
+
+def roofline_entry(name, ktimes, a, pmc, B):
+    frag, bound, bpe, fpe = ROOFLINE_KERNELS[name]
+    T = (a.height // 4) * (a.width // 4)
+    Lw = (a.height // a.window_ratio) * (a.width // a.window_ratio)
+    n_l, k_ms = ktimes.get(name, (0, 0.0))
+    alg = bpe * T * a.embed_dim * B
+    achieved = alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    traffic, src = None, None
+    if pmc is not None and B == pmc[1].get("_local_batch", 2):
+        for k, v in pmc[1].items():
+            if frag in k and isinstance(v, dict) and "hbm_bytes_per_launch" in v:
+                traffic, src = v["hbm_bytes_per_launch"], pmc[0]
+                break
+    e = {"kernel": name, "bound": bound, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+         "traffic": traffic, "traffic_source": src, "launches_timed": n_l, "avg_ms": k_ms, "algorithmic_bytes_per_launch": alg}
+    if fpe:
+        fl = fpe * T * Lw * a.embed_dim * B
+        e["flops_per_launch"] = fl
+        e["mfma_frac"] = fl / (k_ms * 1e-3) / 2.5e15 if k_ms > 0 else 0.0
+    return e
 
 
 def main():
@@ -91,6 +129,9 @@ def main():
     ap.add_argument("--settle", type=int, default=8, help="untimed set-up steps before the W warm-up steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-kernel", default="attn_bwd")
+    ap.add_argument("--data", default="resident", choices=["resident", "host"],
+                    help="host: after the timed (HBM-resident) region, time the same step fed from HOST-resident fields through the "
+                         "input pipeline (pinned staging, async H2D, assembly kernels) and report it as `host_pipeline`")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -152,7 +193,8 @@ def main():
     for i in range(a.warmup):
         step(i)
     fence()
-    ops.start_kernel_timing([a.roofline_kernel])
+    timed_kernels = [a.roofline_kernel] + [k for k in ROOFLINE_KERNELS if k != a.roofline_kernel]
+    ops.start_kernel_timing(timed_kernels)
     t0 = time.perf_counter()
     for i in range(a.steps):
         loss = step(a.warmup + i)
@@ -170,6 +212,36 @@ def main():
             step(i)
         fence()
         alone_ms = ops.stop_kernel_timing().get(a.roofline_kernel, (0, None))[1]
+    host_leg = None
+    if a.data == "host":
+        # PCIe-inclusive rate (never `value`): host-resident fp32 fields [N, 73, 721, 1440] -> staging ring -> H2D -> assembly
+        from swin_v2_weather_amd.utils.host_pipeline import Era5HostPipeline, SyntheticYearSource
+
+        class P(dict):
+            __getattr__ = dict.__getitem__
+        host_leg = {}
+        for label, pinned in (("staged", False), ("zero_copy_pinned_source", True)):
+            src = SyntheticYearSource(n_years=1, n_samples=6, seed=333 + rank, pinned=pinned)
+            hp_params = P(local_batch_size=B, dt=1, n_future=0, img_size=(a.height, a.width), in_channels=list(range(73)),
+                          out_channels=list(range(73)), add_zenith=False, seed=333, data_num_shards=1, data_shard_id=0,
+                          num_data_workers=16)
+            pipe = Era5HostPipeline(hp_params, src, dev, train=True, steps_per_epoch=a.steps + 2)
+            fence()
+            n_done, t1 = 0, None
+            for bi, (inp, tar, _) in enumerate(pipe):
+                if bi == 2:                                  # two untimed steps fill the ring
+                    fence()
+                    t1 = time.perf_counter()
+                net.zero_grad()
+                loss_h = loss_obj(net(inp), tar, inp)
+                loss_h.backward()
+                opt.step()
+                n_done += int(bi >= 2)
+            fence()
+            dth = time.perf_counter() - t1
+            host_leg[label] = {"samples_per_s": world * B * n_done / dth, "ms_per_step": 1e3 * dth / n_done,
+                               "h2d_gb_per_s_per_gpu": B * n_done * 2 * 73 * 721 * 1440 * 4 / dth / 1e9}
+            del pipe, src
     if use_ddp:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -177,23 +249,18 @@ def main():
     if rank == 0:
         value = world * B * a.steps / dt
         flops = train_flops_per_sample(a)
-        T = (a.height // 4) * (a.width // 4)
-        Lw = (a.height // a.window_ratio) * (a.width // a.window_ratio)
-        n_l, k_ms = ktimes.get(a.roofline_kernel, (0, 0.0))
-        # algorithmic bytes per attention-core launch: fwd 8 T C, bwd 16 T C bytes per sample
-        per_sample = {"attn_fwd": 8.0, "attn_bwd": 16.0}.get(a.roofline_kernel, 0.0) * T * a.embed_dim
-        alg = per_sample * B
-        achieved = alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        traffic = None
-        try:        # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, see profiles/)
-            import glob
-            pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.json")))[-1]))
-            key = [k for k in pm if a.roofline_kernel.replace("attn_", "attn_").split("_")[0] in k and
-                   ("bwd" in k) == ("bwd" in a.roofline_kernel)]
-            if key and a.local_batch == 2:
-                traffic = pm[key[0]]["hbm_bytes_per_launch"]
+        pmc = None
+        try:        # HBM bytes per launch from the committed rocprofv3 --pmc passes (2 x FETCH_SIZE + WRITE_SIZE, see profiles/);
+            import glob   # measured at local batch 2 for the kernels of that round -- reported with its source, null otherwise
+            f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.json")))[-1]
+            pmc = (os.path.relpath(f, ROOT), json.load(open(f)))
         except Exception:
-            traffic = None
+            pmc = None
+        main_rf = roofline_entry(a.roofline_kernel, ktimes, a, pmc, B)
+        main_rf["co_running"] = None
+        if alone_ms:
+            main_rf["avg_ms_alone"] = alone_ms
+            main_rf["frac_alone"] = main_rf["algorithmic_bytes_per_launch"] / (alone_ms * 1e-3) / 1e9 / 8000.0
         out = {
             "metric": "ERA5 samples/sec (73x721x1440) swin_73var depth12", "value": value, "unit": "samples/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
@@ -205,14 +272,10 @@ def main():
                        "final_loss": float(loss)},
             "model_tflops_per_gpu": value * flops / world / 1e12,
             "mfma_frac_end_to_end": value * flops / world / 2.5e15,
-            "roofline": {"kernel": a.roofline_kernel, "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": traffic, "launches_timed": n_l, "avg_ms": k_ms,
-                         "algorithmic_bytes_per_launch": alg,
-                         "co_running": ("weight-gradient GEMMs of the same block on the library's side stream overlap this kernel "
-                                        "(SWV2_WGRAD_SIDE_STREAM=0 times it alone)")
-                                       if os.environ.get("SWV2_WGRAD_SIDE_STREAM", "0") != "0" and "bwd" in a.roofline_kernel else None,
-                         "avg_ms_alone": alone_ms, "frac_alone": (alg / (alone_ms * 1e-3) / 1e9 / 8000.0) if alone_ms else None,
-                         "flops_per_launch": {"attn_fwd": 4.0, "attn_bwd": 8.0}.get(a.roofline_kernel, 0.0) * T * Lw * a.embed_dim * B},
+            "host_pipeline": host_leg,
+            "rccl_nranks": dist.get_world_size() if use_ddp else None,   # self-check: ranks in the RCCL group that all-reduced
+            "roofline": main_rf,
+            "roofline_others": [roofline_entry(k, ktimes, a, pmc, B) for k in ROOFLINE_KERNELS if k != a.roofline_kernel],
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a)

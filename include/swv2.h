@@ -208,6 +208,23 @@ int swv2_loss_grad(const float* prd, const float* tar, const float* quad_w, cons
 int swv2_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                    int step, float grad_inv_scale, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * ERA5 input assembly (the step BEFORE the model): raw time slabs staged on the device by async H2D copies
+ * -> the model's input / target buffers, one pass each.
+ *   raw  [B][S][Craw][Hraw][Wraw] fp32   S time slabs per sample as stored in the year files (721 x 1440 rows, uncropped)
+ *   out  [B][Cout_total][H][W]    fp32   channels coff .. coff + S*Csel - 1 are written:
+ *        out[b][coff + s*Csel + c][i][j] = (raw[b][s][chan[c]][i][j] - mean[c]) / std[c]        i < H, j < W
+ * replaces the host-side crop + channel select + z-score of utils/data_loader_era5.py:163-171,98-107 (bit-identical: same
+ * operation order, IEEE division) and DALI's fn.normalize (utils/data_loader_era5_dali.py:77-90).
+ * swv2_era5_zenith writes nz cos-zenith channels (hours[b*nz + k] = hours since Jan 1st 00:00 of the sample's year;
+ * data_loader_era5.py:109-146 -- closed form on the 0.25 degree grid, stand-in for the absent modulus routine);
+ * swv2_era5_static broadcasts Cs static feature planes [Cs][H][W] over the batch (utils/preprocess_utils.py:50-68).
+ * ------------------------------------------------------------------------------------------------------------ */
+int swv2_era5_select_normalize(const float* raw, float* out, const int* chan, const float* mean, const float* stdv, int B, int S,
+                               int Csel, int Craw, int Hraw, int Wraw, int H, int W, int Cout_total, int coff, void* stream);
+int swv2_era5_zenith(float* out, const float* hours, int B, int nz, int H, int W, int Cout_total, int coff, void* stream);
+int swv2_era5_static(const float* stat, float* out, int B, int Cs, int H, int W, int Cout_total, int coff, void* stream);
+
 /* Fused attention branch, forward, for blocks WITHOUT the CPB bias (rel_pos = False, the yaml default):
  *   y = x + scale[b] * LayerNorm1(proj(W-MSA(roll / partition(x))))   scattered back through window-reverse / un-roll
  * (swinv2_global.py:446-478, 170-198, 490) as one kernel.  Writes everything the unfused kernels save for the backward

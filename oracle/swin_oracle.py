@@ -232,8 +232,23 @@ def attention_core(qkv: Tensor, logit_scale: Tensor, heads: int,
     if _ROUND is None:
         P = torch.softmax(S, dim=-1)
         return torch.einsum("bhqk,bhkd->bqhd", P, v).reshape(Bw, L, C)
-    # HIP path: un-normalised exp rounded to bf16 for the P.V product, fp32 row sum, one division at the end
-    E = torch.exp(S - S.max(dim=-1, keepdim=True).values)
+    # HIP path: un-normalised exp rounded to bf16 for the P.V product, one division at the end.
+    rowmax = S.max(dim=-1, keepdim=True).values
+    if bias is None and 64 < L <= 176 and d <= 16:
+        # third-form forward kernel (csrc/attn2.hip, attn_fwd3_kernel): the exponent's reference point is sigma itself
+        # ("fixed maximum", cosines are bounded) while sigma log2(e) <= 40 and the window carries no shift mask, the row
+        # maximum otherwise; the normaliser is the sum of the bf16-ROUNDED exponentials (an all-ones MFMA operand)
+        sig = torch.exp(torch.clamp(logit_scale.detach(), max=LOGIT_MAX))
+        fixed = (sig * math.log2(math.e) <= 40.0).view(1, heads, 1, 1)
+        if mask is not None:
+            nW = mask.shape[0]
+            masked_w = (mask != 0).flatten(1).any(1).repeat(Bw // nW).view(Bw, 1, 1, 1)
+            fixed = fixed & ~masked_w
+        ref = torch.where(fixed, sig.view(1, heads, 1, 1).to(S.dtype).expand_as(rowmax), rowmax)
+        Er = _r(torch.exp(S - ref.detach()))
+        return _r(torch.einsum("bhqk,bhkd->bqhd", Er, v) / Er.sum(-1).permute(0, 2, 1).unsqueeze(-1)).reshape(Bw, L, C)
+    # first-generation kernels (csrc/attn.hip): row maximum, fp32 row sum
+    E = torch.exp(S - rowmax)
     return _r(torch.einsum("bhqk,bhkd->bqhd", _r(E), v) / E.sum(-1).permute(0, 2, 1).unsqueeze(-1)).reshape(Bw, L, C)
 
 

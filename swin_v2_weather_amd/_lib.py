@@ -13,7 +13,7 @@ import threading
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libswv2.so")
-SOURCES = ["capi.hip", "attn.hip", "attn2.hip", "gemm.hip", "gemm_tn.hip", "rowops.hip", "block.hip", "cpb.hip", "mlp.hip", "attn_fused.hip", "proj_ln.hip"]
+SOURCES = ["capi.hip", "attn.hip", "attn2.hip", "gemm.hip", "gemm_tn.hip", "rowops.hip", "block.hip", "cpb.hip", "mlp.hip", "attn_fused.hip", "proj_ln.hip", "dataio.hip"]
 
 _lib = None
 _lock = threading.Lock()
@@ -147,6 +147,9 @@ SYMBOLS = {
     "swv2_loss_sums": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "swv2_loss_grad": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "swv2_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P]),
+    "swv2_era5_select_normalize": (_I, [_P, _P, _P, _P, _P] + [_I] * 10 + [_P]),
+    "swv2_era5_zenith": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "swv2_era5_static": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "swv2_attn_branch_supported": (_I, [_I, _I, _I, _I]),
     "swv2_attn_branch_fwd": (_I, [C.POINTER(AttnBranchArgs), _P]),
     "swv2_proj_ln_supported": (_I, [_I, _I, _I]),

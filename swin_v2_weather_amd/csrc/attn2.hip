@@ -24,6 +24,20 @@ namespace {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+// In-kernel phase timing (diagnostic builds only, -DSWV2_ATTN_STAMPS, tools/probe_attn_stamps.py): wave 0 of every workgroup
+// accumulates s_memtime deltas per phase and leaves them in the padded tail of its first item's lse row.  `dep` orders the
+// stamp behind the value that ends the phase.
+#ifdef SWV2_ATTN_STAMPS
+#define STAMP_DECL unsigned long long st_prev = 0, st_acc[7] = {0, 0, 0, 0, 0, 0, 0};
+#define STAMP_START() do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev) : : "memory"); } while (0)
+#define STAMP(k, dep) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : "v"(dep) : "memory"); \
+                           st_acc[k] += t_ - st_prev; st_prev = t_; } while (0)
+#else
+#define STAMP_DECL
+#define STAMP_START() do {} while (0)
+#define STAMP(k, dep) do {} while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // forward: wave = q tiles {w, w + WAVES, ...}; swapped product S^T = K Q^T (lane = query column), O^T = V^T P^T with
 // pairs of key tiles as one K = 32 operand.  K / V slabs double-buffered in LDS (register-staged prefetch of the next
@@ -75,10 +89,13 @@ __global__ __launch_bounds__(64 * WAVES, 3) void attn_fwd2_kernel(
 
     int bw = blockIdx.x;
     if (bw >= Bw) return;
+    const int bw_first = bw;
+    STAMP_DECL
     issue_loads(bw);
     load_q(bw, wave);
     write_stage(0);
     __syncthreads();
+    STAMP_START();
 
     for (int it = 0; bw < Bw; bw += gridDim.x, ++it) {
         const int buf = it & 1;
@@ -94,6 +111,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void attn_fwd2_kernel(
             const int q = 16 * qt + fr;
 #pragma unroll
             for (int kk = 0; kk < DK; ++kk) qf[kk] = qn[kk];
+            STAMP(0, qf[0]);
             {   // next q tile of this item, or this wave's first q tile of the next item
                 const bool wrap = qt + WAVES >= LT;
                 load_q(wrap ? (bw_next < Bw ? bw_next : bw) : bw, wrap ? wave : qt + WAVES);
@@ -126,6 +144,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void attn_fwd2_kernel(
                 mx = fmaxf(mx, __shfl_xor(mx, 16));
                 mx = fmaxf(mx, __shfl_xor(mx, 32));
                 mx *= sc2;
+                STAMP(1, mx);
 #pragma unroll
                 for (int t = 0; t < LT; ++t)
 #pragma unroll
@@ -159,6 +178,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void attn_fwd2_kernel(
             }
             sum += __shfl_xor(sum, 16);
             sum += __shfl_xor(sum, 32);
+            STAMP(2, sum);
 
             // O^T[d][q] = sum_keys V^T[d][key] P^T[key][q]; two key tiles = one K = 32 operand (same k order on both sides)
             f32x4 o[DK];
@@ -194,10 +214,275 @@ __global__ __launch_bounds__(64 * WAVES, 3) void attn_fwd2_kernel(
                 *(bf16x4*)(orow + 16 * dt + 4 * g) = f2bf4(v);
             }
             if (g == 0) lse[((size_t)bw * h + hd) * Lp + q] = (q < L) ? mx + __log2f(sum) : 0.f;
+            STAMP(3, o[0][0]);
         }
         if (bw_next < Bw) write_stage(buf ^ 1);
+        STAMP(4, stage[0][0]);
         __syncthreads();
+        STAMP(5, stage[0][0]);
     }
+#ifdef SWV2_ATTN_STAMPS
+    if (tid == 0 && Lp - L >= 14) {
+        unsigned long long* dst = (unsigned long long*)(lse + ((size_t)bw_first * h + hd) * Lp + L);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) dst[k] = st_acc[k];
+    }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward, third form (head_dim <= 16, no CPB bias): the softmax's per-element vector work is cut from
+// max + fma + exp + add + 1/2 cvt to exp + 1/2 cvt by letting the MFMAs do the rest:
+//   * scale: sigma log2(e) q^ is split into two bf16 parts (hi + lo, exact to ~2^-17) that fill the K = 32 operand against
+//     the key tile repeated twice -- the K = 32 MFMA costs the same 16 cycles as the K = 16 one, so S' = sigma' cos comes
+//     out of the matrix pipe already scaled, at fp32-product accuracy;
+//   * max: cosines are bounded, S' <= sigma', so the accumulator is started at -sigma' and exp2 is applied to the MFMA
+//     result directly ("fixed maximum"); P then spans [2^(-2 sigma'), 1], representable in bf16 / fp32 while
+//     sigma' <= 40 (sigma <= 27.7; tau starts at ln 10).  Larger scales and shift-masked windows take the general path
+//     (row maximum on the vector ALU);
+//   * row sum: one more K = 32 MFMA per key-tile pair with an all-ones A operand (the matrix pipe idles most of the time).
+//     The normaliser is then the sum of the bf16-rounded P -- exactly the values that multiply V.
+// Measured before (tools/probe_attn_stamps.py): ~259 vector instructions per 16-query row at ~5.7 SIMD cycles each.
+// ------------------------------------------------------------------------------------------------
+// KREG: the wave keeps the K (A operand of S^T) and V^T (A operand of O^T) fragments of the whole item in registers (66
+// VGPRs), read from LDS once per item and pinned there (an empty asm makes the values opaque: the compiler otherwise sinks the
+// loop-invariant reads back into the row loop, where -- double-buffered in 8 registers -- every QK MFMA waits a full LDS
+// round trip: 11 x ~80 cycles per row against 11 x 16 for back-to-back MFMAs; measured on one wave per SIMD: ~2000 cycles
+// per row of pure compute).
+template <int LT, int LFIX, int WAVES, int OCC, bool KREG>
+__global__ __launch_bounds__(64 * WAVES, OCC) void attn_fwd3_kernel(
+    const uint16_t* __restrict__ qkvh, const float* __restrict__ logit_scale, uint16_t* __restrict__ oh, float* __restrict__ lse,
+    int Bw, int h, int L, int nW, int nww, int nwh, int mask_thr, int dbg) {
+    constexpr int DP = 16, Lp = 16 * LT, SLAB = Lp * DP;
+    constexpr int NT = 64 * WAVES;
+    constexpr int CH = 2 * SLAB / 8;                  // 16-byte chunks of the K | V slabs (a multiple of 64)
+    constexpr int CPT = (CH + NT - 1) / NT;
+    // LDS per buffer: K image with every 4-value group stored twice ([key][g][d 4g.. | d 4g..], 64 B per key: the A operand of
+    // the K = 32 product against (hi | lo) of sigma' q^ is then ONE 16-byte read per lane), then the V slab as it is
+    // ... and the Q slab: the row loop must not wait on any global load (a vmcnt wait inside it also waits for the row's own
+    // O / lse stores and for the next item's prefetch -- one full memory round trip per row, measured)
+    constexpr int KIMG = 2 * SLAB, BUF = KIMG + 2 * SLAB;
+    constexpr int QCH = SLAB / 8, QPT = (QCH + NT - 1) / NT;   // 16-byte chunks of the Q slab / per thread
+    __shared__ __attribute__((aligned(16))) uint16_t smem[2 * BUF];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, g = lane >> 4;
+    const int hd = blockIdx.y;
+    const bool last_chunk_ok = (wave * 64 + (CPT - 1) * NT) < CH;          // wave-uniform
+    const int Lc = LFIX > 0 ? LFIX : L;
+
+    const float sc2 = __expf(fminf(logit_scale[hd], SWV2_LN100)) * SWV2_LOG2E;
+    const bool bounded = sc2 <= 40.f;
+
+    u32x4 stage[CPT], stageq[QPT];
+    auto issue_loads = [&](int bw) {
+        const uint16_t* base = qkvh + ((size_t)bw * h + hd) * 3 * SLAB;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) stage[j] = *(const u32x4*)(base + SLAB + (size_t)min(tid + j * NT, CH - 1) * 8);
+#pragma unroll
+        for (int j = 0; j < QPT; ++j) stageq[j] = *(const u32x4*)(base + (size_t)min(tid + j * NT, QCH - 1) * 8);
+    };
+    auto write_stage = [&](int buf) {
+        uint16_t* dst = smem + buf * BUF;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j)
+            if (j < CPT - 1 || last_chunk_ok) {
+                const int c = tid + j * NT;                      // chunk c: 8 values, K chunks first (2 per key row), then V
+                if (c < CH / 2) {
+                    const u32x4 lo = {stage[j][0], stage[j][1], stage[j][0], stage[j][1]};
+                    const u32x4 hi = {stage[j][2], stage[j][3], stage[j][2], stage[j][3]};
+                    *(u32x4*)(dst + (size_t)c * 16) = lo;        // key c / 2, groups 2 (c & 1) and 2 (c & 1) + 1: 32 B per chunk
+                    *(u32x4*)(dst + (size_t)c * 16 + 8) = hi;
+                } else {
+                    *(u32x4*)(dst + KIMG + (size_t)(c - CH / 2) * 8) = stage[j];
+                }
+            }
+#pragma unroll
+        for (int j = 0; j < QPT; ++j)
+            if (tid + j * NT < QCH) *(u32x4*)(dst + KIMG + SLAB + (size_t)(tid + j * NT) * 8) = stageq[j];
+    };
+
+    int bw = blockIdx.x;
+    if (bw >= Bw) return;
+    const int bw_first = bw;
+    STAMP_DECL
+    issue_loads(bw);
+    write_stage(0);
+    __syncthreads();
+
+    const bf16x8 ones8 = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    const bf16x4 ones4 = {0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    STAMP_START();
+#ifdef SWV2_ATTN_STAMPS
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(), ct0 = __builtin_amdgcn_s_memtime();
+#endif
+
+    for (int it = 0; bw < Bw; bw += gridDim.x, ++it) {
+        const int buf = it & 1;
+        const int bw_next = bw + gridDim.x;
+        // the next item's K / V are requested AFTER this item's first row fragment has been waited for (a wait for a younger
+        // load would otherwise drain this prefetch too: in-order vmcnt)
+        const uint16_t* Ki = smem + buf * BUF;
+        const uint16_t* Vs = Ki + KIMG;
+        const uint16_t* Qs = Vs + SLAB;
+        if (bw_next < Bw && !(dbg & 512)) issue_loads(bw_next);      // consumed by write_stage at the top of the wave's last row
+        const bool do_mask = (mask_thr > 0) && (((bw % nW) / nww) == nwh - 1);
+        const bool fixed = bounded && !do_mask;                       // wave-uniform
+        const float c0 = fixed ? -sc2 : 0.f;
+        // accumulator start of the last key tile: padded keys (rows of S^T = registers) get -1e30, so P = 0 there
+        f32x4 cpad;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cpad[r] = (16 * (LT - 1) + 4 * g + r < Lc) ? c0 : SWV2_NEG_BIG;
+
+        bf16x8 kreg[KREG ? LT : 1], vreg[KREG ? LT / 2 : 1];
+        bf16x4 vtail = {0, 0, 0, 0};
+        if constexpr (KREG) {
+#pragma unroll
+            for (int t = 0; t < LT; ++t) kreg[t] = *(const bf16x8*)(Ki + (16 * t + fr) * 32 + 8 * g);
+#pragma unroll
+            for (int t = 0; t + 1 < LT; t += 2) {
+                const bf16x4 v0 = lds_tr_read(Vs + (16 * t + 4 * g + (fr >> 2)) * DP + (fr & 3) * 4);
+                const bf16x4 v1 = lds_tr_read(Vs + (16 * (t + 1) + 4 * g + (fr >> 2)) * DP + (fr & 3) * 4);
+                vreg[t / 2] = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+            if (LT & 1) vtail = lds_tr_read(Vs + (16 * (LT - 1) + 4 * g + (fr >> 2)) * DP + (fr & 3) * 4);
+#pragma unroll
+            for (int t = 0; t < LT; ++t) asm volatile("" : "+v"(kreg[t]));
+#pragma unroll
+            for (int t = 0; t < LT / 2; ++t) asm volatile("" : "+v"(vreg[t]));
+            asm volatile("" : "+v"(vtail));
+        }
+
+        STAMP(5, cpad[0]);
+#pragma unroll 1
+        for (int qt = wave; qt < LT; qt += WAVES) {                   // wave-uniform trip count
+            const int q = 16 * qt + fr;
+            // the next item's slabs go to the other LDS buffer before the LAST row's stores are issued: its wait (in-order
+            // vmcnt) then covers only loads issued rows ago and the earlier rows' stores
+            if (qt + WAVES >= LT && bw_next < Bw) write_stage(buf ^ 1);
+            const bf16x4 qraw = *(const bf16x4*)(Qs + (size_t)q * DP + 4 * g);
+
+            // B operand of S^T = K Q^T over k = (part, d): (hi | lo) bf16 split of sigma' q^[4g .. 4g + 3] (exact to ~2^-17)
+            bf16x8 qB;
+            {
+                float x[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[j] = bf2f(qraw[j]) * sc2;
+                uint32_t w[4];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    w[j] = f2bf2(x[2 * j], x[2 * j + 1]);
+                    w[2 + j] = f2bf2(x[2 * j] - __uint_as_float(w[j] << 16), x[2 * j + 1] - __uint_as_float(w[j] & 0xffff0000u));
+                }
+                qB = __builtin_bit_cast(bf16x8, w);
+            }
+            STAMP(0, qB[0]);
+
+            // S'^T tiles: rows = keys 16t + 4g + r, column = query fr; already scaled, and (fixed) already minus sigma'
+            f32x4 acc[LT];
+#pragma unroll
+            for (int t = 0; t < LT; ++t) {
+                bf16x8 kA;
+                if constexpr (KREG) kA = kreg[t];
+                else kA = *(const bf16x8*)(Ki + (16 * t + fr) * 32 + 8 * g);
+                const f32x4 c = (t == LT - 1) ? cpad : (f32x4){c0, c0, c0, c0};
+                acc[t] = mfma32(kA, qB, c);
+            }
+            float mx = sc2;
+            if (!fixed) {
+                mx = SWV2_NEG_BIG;
+                const bool qid = q >= mask_thr;
+#pragma unroll
+                for (int t = 0; t < LT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (do_mask) acc[t][r] += (((16 * t + 4 * g + r) >= mask_thr) != qid) ? (-100.f * SWV2_LOG2E) : 0.f;
+                        mx = fmaxf(mx, acc[t][r]);
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+#pragma unroll
+                for (int t = 0; t < LT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[t][r] -= mx;
+            }
+            STAMP(1, acc[LT - 1][0]);
+#pragma unroll
+            for (int t = 0; t < LT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // registers that can only hold padded keys (compile-time window area) skip the exp
+                    if (LFIX > 0 && 16 * t + 4 * 0 + r >= LFIX && t == LT - 1) acc[t][r] = 0.f;
+                    else acc[t][r] = __builtin_amdgcn_exp2f(acc[t][r]);
+                }
+            STAMP(2, acc[LT - 1][1]);
+
+            // O^T[d][q] = sum_keys V^T[d][key] P^T[key][q] and the row sums (all-ones A operand), pairs of key tiles per K = 32
+            f32x4 o = {0.f, 0.f, 0.f, 0.f}, rs = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t + 1 < LT; t += 2) {
+                const bf16x4 p0 = f2bf4(acc[t]), p1 = f2bf4(acc[t + 1]);
+                const bf16x8 pb = __builtin_shufflevector(p0, p1, 0, 1, 2, 3, 4, 5, 6, 7);
+                bf16x8 vA;
+                if constexpr (KREG) vA = vreg[t / 2];
+                else {
+                    const bf16x4 v0 = lds_tr_read(Vs + (16 * t + 4 * g + (fr >> 2)) * DP + (fr & 3) * 4);
+                    const bf16x4 v1 = lds_tr_read(Vs + (16 * (t + 1) + 4 * g + (fr >> 2)) * DP + (fr & 3) * 4);
+                    vA = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+                o = mfma32(vA, pb, o);
+                rs = mfma32(ones8, pb, rs);
+            }
+            if (LT & 1) {
+                const bf16x4 pb = f2bf4(acc[LT - 1]);
+                bf16x4 vf;
+                if constexpr (KREG) vf = vtail;
+                else vf = lds_tr_read(Vs + (16 * (LT - 1) + 4 * g + (fr >> 2)) * DP + (fr & 3) * 4);
+                // own accumulators for the K = 16 tail (see attn.hip: chaining it onto the K = 32 accumulator was wrong)
+                const f32x4 to = mfma16(vf, pb, (f32x4){0.f, 0.f, 0.f, 0.f});
+                const f32x4 ts = mfma16(ones4, pb, (f32x4){0.f, 0.f, 0.f, 0.f});
+                o += to;
+                rs += ts;
+            }
+            const float sum = rs[0];                                  // every row of the ones product holds the column sums
+            STAMP(3, sum);
+            const float inv = (q < L) ? __builtin_amdgcn_rcpf(sum) : 0.f;
+            uint16_t* orow = oh + ((size_t)bw * h + hd) * SLAB + (size_t)q * DP;
+            f32x4 v = o;
+            v[0] *= inv; v[1] *= inv; v[2] *= inv; v[3] *= inv;
+            if (!(dbg & 1024) || bw_next >= Bw) {                     // dbg 1024 (probe): stores of the last item only
+                *(bf16x4*)(orow + 4 * g) = f2bf4(v);
+                if (g == 0) lse[((size_t)bw * h + hd) * Lp + q] = (q < L) ? mx + __log2f(sum) : 0.f;
+            } else asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(sum));
+            STAMP(4, v[0]);
+        }
+        __syncthreads();
+        STAMP(6, stage[0][0]);
+    }
+#ifdef SWV2_ATTN_STAMPS
+    if (tid == 0 && Lp - L >= 14) {
+        unsigned long long* dst = (unsigned long long*)(lse + ((size_t)bw_first * h + hd) * Lp + L);
+#pragma unroll
+        for (int k_ = 0; k_ < 7; ++k_) dst[k_] = st_acc[k_];
+        (void)rt0; (void)ct0;
+    }
+#endif
+}
+
+template <int LT, int LFIX, int WAVES, int OCC, bool KREG>
+int launch_fwd3(const swv2_attn_args* a, hipStream_t st) {
+    // OCC workgroups per CU on 256 CUs, every workgroup loops over windows
+    int nchunk = (OCC * 256 + a->heads - 1) / a->heads;
+    if (a->dbg & 2048) nchunk = 256 / a->heads;                 // probes: one / two workgroups per CU
+    if (a->dbg & 4096) nchunk = 512 / a->heads;
+    if (nchunk > a->Bw) nchunk = a->Bw;
+    dim3 grid(nchunk, a->heads), block(64 * WAVES);
+    hipLaunchKernelGGL((attn_fwd3_kernel<LT, LFIX, WAVES, OCC, KREG>), grid, block, 0, st, (const uint16_t*)a->qkvh, a->logit_scale,
+                       (uint16_t*)a->oh, a->lse, a->Bw, a->heads, a->L, a->nwh * a->nww, a->nww, a->nwh, a->mask_thr, a->dbg);
+    SWV2_CHECK_LAUNCH("swv2_attn_fwd");
+    return SWV2_OK;
 }
 
 template <int LT, int DK, int LFIX>
@@ -251,7 +536,12 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn_bwd2_kernel(
     constexpr int CH = SLAB / 8;                             // 16-byte chunks per slab
     constexpr int CPT = (CH + NT - 1) / NT;                  // chunks per thread
     constexpr int CPR = 2 * DK;                              // chunks per row
-    constexpr int BUFB = 4 * SLAB + 12 * Lp;                 // one staging buffer: Q, dO (bf16), LSE, delta, sigma/|q| (fp32)
+    // one staging buffer: Q, dO (bf16), LSE, delta, sigma/|q|, sigma/|k| (fp32) and, for head_dim <= 16, the image of
+    // sigma' q^ split into bf16 (hi | lo) parts, [q][g][hi d 4g.. | lo d 4g..] (64 B per q): the A operand of the K = 32 product
+    // S' = (hi | lo) . (k^ | k^) -- scaled logits straight from the matrix pipe, accumulator started at -LSE
+    constexpr bool FOLD = (DK == 1);
+    constexpr int OFF_QHL = 4 * SLAB + 16 * Lp;
+    constexpr int BUFB = OFF_QHL + (FOLD ? 4 * SLAB : 0);
     constexpr int PARTW = 2 * 16 * DP * 4;                   // bytes of one wave's partial dQ tiles of a step ([2][16 q][DP])
     constexpr int OFF_PART = 2 * BUFB, OFF_SCR = OFF_PART + 2 * WAVES * PARTW, SCRW = 2 * 2 * 512,
                   OFF_RED = OFF_SCR + WAVES * SCRW, LDS_BYTES = OFF_RED + 16 * ((WAVES + 3) / 4);
@@ -284,7 +574,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn_bwd2_kernel(
 
     // ---- staging registers: chunk c = tid + j*NT of the q, dO, o slabs (clamped, unconditional loads; native vectors)
     u32x4 sq[CPT], sdo[CPT], so[CPT];
-    float slse = 0.f, srq = 0.f;
+    float slse = 0.f, srq = 0.f, srk = 0.f;
     frag_t kf[KPW], vf[KPW], kfn[KPW], vfn[KPW];
     auto issue = [&](int bw) {
         const size_t slab0 = ((size_t)bw * h + hd) * 3 * SLAB, oslab = ((size_t)bw * h + hd) * SLAB;
@@ -297,6 +587,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn_bwd2_kernel(
         }
         slse = lse[((size_t)bw * h + hd) * Lp + min(tid, Lp - 1)];
         srq = rnorm[(((size_t)bw * h + hd) * 2 + 0) * Lp + min(tid, Lp - 1)];
+        srk = rnorm[(((size_t)bw * h + hd) * 2 + 1) * Lp + min(tid, Lp - 1)];
 #pragma unroll
         for (int j = 0; j < KPW; ++j) {
             const int key = 16 * min(wave + WAVES * j, LT - 1) + fr;
@@ -311,6 +602,8 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn_bwd2_kernel(
         float* LSEs = (float*)(lds + buf * BUFB + 4 * SLAB);
         float* DLs = LSEs + Lp;
         float* RQs = DLs + Lp;
+        float* RKs = RQs + Lp;
+        uint16_t* QHL = (uint16_t*)(lds + buf * BUFB + OFF_QHL);
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
             const int c = tid + j * NT;
@@ -318,6 +611,21 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn_bwd2_kernel(
             if (ok) {
                 *(u32x4*)(Qs + c * 8) = sq[j];
                 *(u32x4*)(dOs + c * 8) = sdo[j];
+                if constexpr (FOLD) {
+                    // chunk c = row c / 2, d = 8 (c & 1) .. + 7 -> groups g = 2 (c & 1), 2 (c & 1) + 1 of that row
+#pragma unroll
+                    for (int gg = 0; gg < 2; ++gg) {
+                        uint32_t w[4];
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const uint32_t pr = sq[j][2 * gg + e];
+                            const float x0 = __uint_as_float(pr << 16) * sc2, x1 = __uint_as_float(pr & 0xffff0000u) * sc2;
+                            w[e] = f2bf2(x0, x1);
+                            w[2 + e] = f2bf2(x0 - __uint_as_float(w[e] << 16), x1 - __uint_as_float(w[e] & 0xffff0000u));
+                        }
+                        *(u32x4*)(QHL + (size_t)c * 16 + gg * 8) = (u32x4){w[0], w[1], w[2], w[3]};
+                    }
+                }
             }
             float dl = 0.f;
 #pragma unroll
@@ -332,6 +640,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn_bwd2_kernel(
         if (tid < Lp) {
             LSEs[tid] = (tid < L) ? slse : 1.0e30f;
             RQs[tid] = srq * sigma;
+            RKs[tid] = srk * sigma;
         }
     };
 
@@ -374,6 +683,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn_bwd2_kernel(
         const int kt = wave + WAVES * j;
         sinit[j] = (kt < LT && 16 * kt + fr < Lc) ? 0.f : SWV2_NEG_BIG;
     }
+    // only a wave's LAST key tile can hold padded keys (or be surplus): the others start their S' accumulators at -LSE alone
     // dQ summation: thread -> (row of the step's 32 q rows, group of DP/8 columns)
     const int srow = tid >> 3, scol = (tid & 7) * (DP / 8);
 
@@ -387,6 +697,8 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn_bwd2_kernel(
         const float* LSEs = (const float*)(lds + buf * BUFB + 4 * SLAB);
         const float* DLs = LSEs + Lp;
         const float* RQs = DLs + Lp;
+        const float* RKs = RQs + Lp;
+        const uint16_t* QHL = (const uint16_t*)(lds + buf * BUFB + OFF_QHL);
         const bool do_mask = (mask_thr > 0) && (((bw % nW) / nww) == nwh - 1);
 
         f32x4 dk[KPW][DK], dv[KPW][DK];
@@ -403,12 +715,14 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn_bwd2_kernel(
             constexpr int NQ = decltype(nq_c)::value;
             constexpr bool MASKED = decltype(masked_c)::value;
             frag_t qa[NQ], da[NQ];
+            bf16x8 qhl[NQ];
             bf16x4 tq[NQ][DK], td[NQ][DK];
             f32x4 l4[NQ], d4[NQ];
 #pragma unroll
             for (int u = 0; u < NQ; ++u) {
                 const int i = i0 + u;
-                qa[u] = *(const frag_t*)(Qs + (16 * i + fr) * DP + (DK == 1 ? 4 : 8) * g);
+                if constexpr (FOLD) qhl[u] = *(const bf16x8*)(QHL + (16 * i + fr) * 32 + 8 * g);
+                else qa[u] = *(const frag_t*)(Qs + (16 * i + fr) * DP + (DK == 1 ? 4 : 8) * g);
                 da[u] = *(const frag_t*)(dOs + (16 * i + fr) * DP + (DK == 1 ? 4 : 8) * g);
 #pragma unroll
                 for (int dt = 0; dt < DK; ++dt) {
@@ -418,6 +732,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn_bwd2_kernel(
                 }
                 l4[u] = *(const f32x4*)(LSEs + 16 * i + 4 * g);
                 d4[u] = *(const f32x4*)(DLs + 16 * i + 4 * g);
+                if constexpr (FOLD) { l4[u] = -l4[u]; d4[u] = -d4[u]; }      // accumulator start values
             }
             const int toff = (4 * g + (fr >> 2)) * 16 + (fr & 3) * 4;
             f32x4 dq[NQ][DK];
@@ -429,17 +744,37 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn_bwd2_kernel(
                 bf16x4 pb[NQ], dsb[NQ];
 #pragma unroll
                 for (int u = 0; u < NQ; ++u) {
-                    f32x4 s = {sinit[j], sinit[j], sinit[j], sinit[j]}, dp = {0.f, 0.f, 0.f, 0.f};
-                    if constexpr (DK == 1) { s = mfma16(qa[u], kf[j], s); dp = mfma16(da[u], vf[j], dp); }
-                    else                   { s = mfma32(qa[u], kf[j], s); dp = mfma32(da[u], vf[j], dp); }
-                    f32x4 p, ds;
+                    f32x4 s, dp, p, ds;
+                    if constexpr (FOLD) {
+                        // x = sigma' cos - LSE and dP - delta come out of the MFMAs (start values -LSE, -delta)
+                        s = l4[u];
+                        if (j == KPW - 1) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float x = fmaf(s[r], sc2, -l4[u][r]);
-                        if (MASKED) x += (((16 * (i0 + u) + 4 * g + r) >= mask_thr) != kid) ? (-100.f * SWV2_LOG2E) : 0.f;
-                        const float pr = __builtin_amdgcn_exp2f(x);
-                        p[r] = pr;
-                        ds[r] = pr * (dp[r] - d4[u][r]);      // dS; d(cos) = sigma dS is applied once at the end
+                            for (int r = 0; r < 4; ++r) s[r] += sinit[j];
+                        }
+                        s = mfma32(qhl[u], __builtin_shufflevector(kf[j], kf[j], 0, 1, 2, 3, 0, 1, 2, 3), s);
+                        dp = mfma16(da[u], vf[j], d4[u]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float x = s[r];
+                            if (MASKED) x += (((16 * (i0 + u) + 4 * g + r) >= mask_thr) != kid) ? (-100.f * SWV2_LOG2E) : 0.f;
+                            const float pr = __builtin_amdgcn_exp2f(x);
+                            p[r] = pr;
+                            ds[r] = pr * dp[r];               // dS; d(cos) = sigma dS is applied once at the end
+                        }
+                    } else {
+                        s = (f32x4){sinit[j], sinit[j], sinit[j], sinit[j]};
+                        dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        s = mfma32(qa[u], kf[j], s);
+                        dp = mfma32(da[u], vf[j], dp);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float x = fmaf(s[r], sc2, -l4[u][r]);
+                            if (MASKED) x += (((16 * (i0 + u) + 4 * g + r) >= mask_thr) != kid) ? (-100.f * SWV2_LOG2E) : 0.f;
+                            const float pr = __builtin_amdgcn_exp2f(x);
+                            p[r] = pr;
+                            ds[r] = pr * (dp[r] - d4[u][r]);
+                        }
                     }
                     pb[u] = f2bf4(p);
                     dsb[u] = f2bf4(ds);
@@ -532,12 +867,15 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn_bwd2_kernel(
         if (do_mask) run(std::true_type{});
         else run(std::false_type{});
 
+        // the next item's slabs go to the other LDS buffer BEFORE this item's dK / dV stores are issued: the wait for the
+        // prefetch (in-order vmcnt) then does not include them
+        if (bw_next < Bw) commit(buf ^ 1);
         // ---- dK (through the L2-normalisation backward) and dV of this wave's key tiles
 #pragma unroll
         for (int j = 0; j < KPW; ++j) {
             if (wave + WAVES * j >= LT) continue;             // wave-uniform
             const int key = 16 * (wave + WAVES * j) + fr;
-            const float rk = rnorm[(((size_t)bw * h + hd) * 2 + 1) * Lp + key];
+            const float rks = RKs[key];
             // k^ in the accumulator layout (rows d = 16 dt + 4g + r, column key): the lane's K fragment for DK = 1; for the
             // 8-wide fragment (d = 8g + j) the matching values are re-read from global (L2 hit)
             float kh[DK][4];
@@ -561,7 +899,6 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn_bwd2_kernel(
             dot += __shfl_xor(dot, 32);
             // d logit_scale = sigma sum_{q,k} dS cos = sigma sum_k (sum_q dS q^) . k^ : the dot product above
             if (g == 0) dsig += dot;
-            const float rks = rk * sigma;
 #pragma unroll
             for (int dt = 0; dt < DK; ++dt) {
                 f32x4 v;
@@ -572,7 +909,6 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn_bwd2_kernel(
             }
         }
         if (bw_next < Bw) {
-            commit(buf ^ 1);
 #pragma unroll
             for (int j = 0; j < KPW; ++j) { kf[j] = kfn[j]; vf[j] = vfn[j]; }
             make_kT();
@@ -613,6 +949,11 @@ int launch_bwd2(const swv2_attn_args* a, hipStream_t st) {
 int swv2_attn2_fwd(const swv2_attn_args* a, int Lp, int DP, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (a->bias && !a->bias_pack) return 1;
+    if (!a->bias && Lp == 176 && DP == 16 && a->L == 162 && !(a->dbg & 64)) {
+        if (a->dbg & 128) return launch_fwd3<11, 162, 4, 2, true>(a, st);      // probe: fragments pinned in registers, 2 workgroups per CU
+        return launch_fwd3<11, 162, 4, 3, false>(a, st);                       // measured best: 51 us at B = 2 (first generation: 72)
+    }
+    if (!a->bias && Lp == 176 && DP == 16 && !(a->dbg & 64)) return launch_fwd3<11, 0, 4, 3, false>(a, st);
     if (Lp == 176 && DP == 16 && a->L == 162) return launch_fwd2<11, 1, 162>(a, st);
     if (Lp == 176 && DP == 16) return launch_fwd2<11, 1, 0>(a, st);
     if (Lp == 176 && DP == 32) return launch_fwd2<11, 2, 0>(a, st);
@@ -622,6 +963,10 @@ int swv2_attn2_fwd(const swv2_attn_args* a, int Lp, int DP, void* stream) {
 int swv2_attn2_bwd(const swv2_attn_args* a, int Lp, int DP, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (a->bias) return 1;                         // the bias-gradient rows need the one-key-tile-per-wave layout (attn.hip)
+    // Measured at the benchmark shape (B = 2): 135-148 us against 121-127 us for the first-generation two-phase kernel -- the
+    // per-step LDS round trips (dS transpose, partial-dQ slots + barrier) are latency-bound at two waves per SIMD.  Kept
+    // selectable (dbg bit 6) and parity-tested; not the default.
+    if (!(a->dbg & 64)) return 1;
     if (Lp == 176 && DP == 16 && a->L == 162) return (a->dbg & 32) ? launch_bwd2<11, 1, 162, 3>(a, st) : launch_bwd2<11, 1, 162, 2>(a, st);
     if (Lp == 176 && DP == 16) return launch_bwd2<11, 1, 0, 2>(a, st);
     if (Lp == 176 && DP == 32) return launch_bwd2<11, 2, 0, 1>(a, st);

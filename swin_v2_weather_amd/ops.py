@@ -43,25 +43,31 @@ def stop_kernel_timing():
 
 BLOCK_KERNEL_IDS = {"qkv": 1, "attn_fwd": 2, "proj": 3, "ln1_fwd": 4, "fc1": 5, "fc2": 6, "ln2_fwd": 7, "ln2_bwd": 11,
                     "wgrad_fc2": 12, "dh": 13, "wgrad_fc1": 14, "dx1": 15, "ln1_bwd": 16, "wgrad_proj": 17, "doh": 18,
-                    "attn_bwd": 19, "wgrad_qkv": 20, "dx": 21}
+                    "attn_bwd": 19, "wgrad_qkv": 20, "dx": 21,
+                    # fused kernels share the launch slot of the first kernel they replace
+                    "proj_ln_fwd": 3, "mlp_fwd": 5, "mlp_bwd": 13, "proj_ln_bwd": 16}
+
+
+_RR = {"fwd": 0, "bwd": 0}
 
 
 def block_event_pair(phase, desc):
-    """If a kernel of this phase ("fwd": launch ids 1-7, "bwd": 11-21) is being timed (start_kernel_timing), attach a
-    fresh HIP event pair to the block descriptor so that swv2_block_fwd/bwd brackets exactly that launch on the launch
-    stream."""
+    """If kernels of this phase ("fwd": launch ids 1-7, "bwd": 11-21) are being timed (start_kernel_timing), attach a
+    fresh HIP event pair to the block descriptor so that swv2_block_fwd/bwd brackets exactly ONE launch on the launch
+    stream; with several requested kernels of a phase the calls take turns (round robin over the blocks of the step)."""
     desc.ev_kernel = 0
     rec = _TIMED
     if rec is None:
         return
-    for n in rec:
-        kid = BLOCK_KERNEL_IDS.get(n, 0)
-        if kid and ((kid < 10) == (phase == "fwd")):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(); b.record()                       # materialise the hipEvent_t handles (re-recorded by the library)
-            desc.ev_kernel, desc.ev_start, desc.ev_stop = kid, a.cuda_event, b.cuda_event
-            rec[n].append((a, b))
-            return
+    mine = [n for n in rec if BLOCK_KERNEL_IDS.get(n, 0) and ((BLOCK_KERNEL_IDS[n] < 10) == (phase == "fwd"))]
+    if not mine:
+        return
+    n = mine[_RR[phase] % len(mine)]
+    _RR[phase] += 1
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); b.record()                       # materialise the hipEvent_t handles (re-recorded by the library)
+    desc.ev_kernel, desc.ev_start, desc.ev_stop = BLOCK_KERNEL_IDS[n], a.cuda_event, b.cuda_event
+    rec[n].append((a, b))
 
 
 def _timed(name, fn, *args):
@@ -242,6 +248,29 @@ def loss_sums(prd, tar, qw, sums):
 def loss_grad(prd, tar, qw, coef, dprd):
     B, Cc, H, W = prd.shape
     L.check(L.load().swv2_loss_grad(_p(prd), _p(tar), _p(qw), _p(coef), _p(dprd), B * Cc, H, W, _stream()), "swv2_loss_grad")
+
+
+def era5_select_normalize(raw, out, chan, mean, std, coff=0, stream=None):
+    """raw [B, S, Craw, Hraw, Wraw] fp32 -> out[:, coff : coff + S*len(chan)] = (raw[:, s, chan] - mean) / std, cropped to out's H, W"""
+    B, S, Craw, Hraw, Wraw = raw.shape
+    _, Ct, H, W = out.shape
+    _chk(raw, torch.float32, "era5 raw"); _chk(out, torch.float32, "era5 out")
+    L.check(L.load().swv2_era5_select_normalize(_p(raw), _p(out), _p(chan), _p(mean), _p(std), B, S, chan.numel(), Craw, Hraw, Wraw,
+                                                H, W, Ct, coff, stream if stream is not None else _stream()), "swv2_era5_select_normalize")
+
+
+def era5_zenith(out, hours, coff, stream=None):
+    """hours [B, nz] fp32 (hours since Jan 1st) -> out[:, coff : coff + nz] = cos zenith"""
+    B, Ct, H, W = out.shape
+    L.check(L.load().swv2_era5_zenith(_p(out), _p(hours), B, hours.shape[1], H, W, Ct, coff,
+                                      stream if stream is not None else _stream()), "swv2_era5_zenith")
+
+
+def era5_static(stat, out, coff, stream=None):
+    """stat [Cs, H, W] fp32 -> out[:, coff : coff + Cs] (broadcast over the batch)"""
+    B, Ct, H, W = out.shape
+    L.check(L.load().swv2_era5_static(_p(stat), _p(out), B, stat.shape[0], H, W, Ct, coff,
+                                      stream if stream is not None else _stream()), "swv2_era5_static")
 
 
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_inv_scale=1.0):

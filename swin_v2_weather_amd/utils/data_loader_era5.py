@@ -4,13 +4,17 @@
 `(loader, dataset)` otherwise, with the reference's tensor contract:
     inp [B, n_in, H, W], tar [B, n_out*(n_future+1), H, W]  (+ zen_inp [B,1,H,W], zen_tar [B,n_future+1,H,W] if add_zenith)
 and the reference's dataset index arithmetic (year / local index, year-boundary wrap :158-160, target slab :164-165).
-There is no HDF5 here (no h5py, no ERA5 files): each "year file" is a virtual array fields[N, 73, 721, 1440] of iid
-N(0,1) values that is a pure function of (seed, year, time index), cropped to img_size like :163-165 and normalised with
-means 0 / stds 1.  Two ways to consume it:
-  * torch DataLoader over `GetDataset` (CPU generation; plumbing / tests), or
-  * `DevicePoolLoader` (params.synthetic_device_pool > 0, default for GPU runs): a pool of K batches generated ON THE
-    DEVICE once and cycled, so the timed loop has no host RNG and no H2D copy (605 MB / sample would otherwise bind the
-    step to PCIe).
+Data sources, in the order `get_data_loader` tries them:
+  * year files under `files_pattern` (`*.npy` memmaps, or `*.h5` with h5py -- the reference's format) -> the host pipeline of
+    utils/host_pipeline.py: pinned staging ring, async H2D, crop / z-score / zenith / invariants assembled by HIP kernels;
+  * `params.synthetic_host_samples > 0`: the same pipeline over an in-memory synthetic year array (PCIe-inclusive benchmarks);
+  * `params.synthetic_device_pool > 0` (default of the bench configs): `DevicePoolLoader`, K batches generated ON THE DEVICE once
+    and cycled, so the timed loop has no host RNG and no H2D copy (605 MB / sample binds a step to PCIe otherwise);
+  * otherwise a torch DataLoader over the synthetic `GetDataset` (CPU generation; plumbing / tests): each "year file" is a
+    virtual array fields[N, 73, 721, 1440] of iid N(0,1) values that is a pure function of (seed, year, time index), cropped to
+    img_size like :163-165 and normalised with means 0 / stds 1.
+Real data is used whenever it is found; the synthetic sources are explicit params flags (no silent fallback when a data path
+was given but holds no files: that raises).
 """
 import logging
 import math
@@ -126,7 +130,43 @@ class DevicePoolLoader:
             yield self.batches[i % len(self.batches)]
 
 
+def _year_files(location):
+    import glob
+    import os
+    loc = str(location or '')
+    return os.path.isdir(loc) and (glob.glob(os.path.join(loc, '*.npy')) or glob.glob(os.path.join(loc, '*.h5')))
+
+
+class _PipelineDataset:
+    """the attributes train.py reads from `dataset` (img_shape_x / _y, n_samples) for a pipeline-backed loader"""
+
+    def __init__(self, pipe):
+        self.img_shape_x, self.img_shape_y = pipe.H, pipe.W
+        self.n_samples_total = pipe.n_total
+        self.n_in_channels = pipe.n_in
+
+    def __len__(self):
+        return self.n_samples_total
+
+
 def get_data_loader(params, files_pattern, distributed, train):
+    host_n = _get(params, 'synthetic_host_samples', 0)
+    if _year_files(files_pattern) or host_n:
+        from .host_pipeline import Era5HostPipeline, SyntheticYearSource, YearArraySource
+        from .preprocess_utils import build_static_features
+        device = torch.device('cuda', torch.cuda.current_device())
+        if _year_files(files_pattern):
+            source = YearArraySource(str(files_pattern))
+        else:
+            source = SyntheticYearSource(n_years=1, n_samples=int(host_n), seed=_get(params, 'seed', None) or 333,
+                                         pinned=bool(_get(params, 'synthetic_host_pinned', False)))
+        stat = build_static_features(params)
+        pipe = Era5HostPipeline(params, source, device, train, static_features=None if stat is None else stat[0],
+                                steps_per_epoch=_get(params, 'synthetic_steps_per_epoch', None))
+        ds = _PipelineDataset(pipe)
+        return (pipe, ds, pipe) if train else (pipe, ds)      # the pipeline is its own "sampler" (set_epoch)
+    if _get(params, 'require_data_files', False):
+        raise FileNotFoundError(f"no year files (*.npy / *.h5) under {files_pattern!r} and require_data_files is set")
     dataset = GetDataset(params, files_pattern, train)
     pool = _get(params, 'synthetic_device_pool', 0)
     if pool:

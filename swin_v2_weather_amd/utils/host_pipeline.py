@@ -1,0 +1,267 @@
+"""Host-resident ERA5 input pipeline for one MI355X per process -- the replacement of the reference's DALI path
+(utils/data_loader_era5_dali.py + utils/dali_era5_es_helper.py) and of the per-sample host work of its PyTorch loader
+(utils/data_loader_era5.py:149-177), SURVEY 8(f) row 3.
+
+    year files (fields[N, 73, 721, 1440] fp32: .npy memmaps, HDF5 if h5py is importable, or an in-memory synthetic array)
+      -> producer threads copy whole, UNCROPPED time slabs into a ring of pinned staging buffers   (dali_era5_es_helper.py:92-103)
+      -> hipMemcpyAsync on a copy stream into a double-buffered device slab
+      -> swv2_era5_select_normalize / _zenith / _static on the same stream: crop + channel select + z-score + cos-zenith +
+         invariant channels written straight into the model's input / target buffers                (data_loader_era5.py:98-107,
+         163-171; data_loader_era5_dali.py:77-90; preprocess_utils.py:50-68)
+      -> the compute stream waits on an event; the copy of batch k+1 overlaps the training step of batch k.
+
+Sample order (one epoch = one pass over this rank's shard): seeded permutation of all samples, re-drawn per epoch, sliced per
+shard -- dali_era5_es_helper.py:163-175; (year, time index) with that file's boundary handling (:178-186).  Targets are the
+n_future + 1 following time slabs (data_loader_era5.py:164-165), so multi-step configs work too (the DALI helper returns one).
+"""
+from __future__ import annotations
+
+import glob
+import logging
+import os
+import queue
+import threading
+from bisect import bisect_right
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import torch
+
+from .. import ops
+
+
+# ---- sources ---------------------------------------------------------------------------------------------------
+class YearArraySource:
+    """Year files under `location`: `*.npy` (np.load(mmap_mode='r'), shape [N, C, H, W] fp32) or `*.h5` with a 'fields'
+    dataset (needs h5py; data_loader_era5.py:65-95).  The year is the last four characters of the file stem."""
+
+    pinned = False
+
+    def __init__(self, location):
+        paths = sorted(glob.glob(os.path.join(location, "*.npy"))) or sorted(glob.glob(os.path.join(location, "*.h5")))
+        if not paths:
+            raise FileNotFoundError(f"no *.npy / *.h5 year files under {location}")
+        self.paths = paths
+        self.years = [int(os.path.splitext(os.path.basename(p))[0][-4:]) for p in paths]
+        self._arrays = [None] * len(paths)
+        first = self._open(0)
+        self.shape = tuple(first.shape[1:])
+        self.n_samples_year = [self._open(i).shape[0] for i in range(len(paths))]
+
+    def _open(self, i):
+        if self._arrays[i] is None:
+            if self.paths[i].endswith(".npy"):
+                self._arrays[i] = np.load(self.paths[i], mmap_mode="r")
+            else:
+                import h5py                                   # optional dependency, absent in the build image
+                self._arrays[i] = h5py.File(self.paths[i], "r")["fields"]
+        return self._arrays[i]
+
+    def read(self, year_idx, t, out):
+        """copy time slab t of year file year_idx ([C, H, W], uncropped) into the (pinned) numpy view `out`"""
+        np.copyto(out, self._open(year_idx)[t])
+
+
+class SyntheticYearSource:
+    """In-memory stand-in for the year files (no ERA5 data in the image): `n_years` arrays of `n_samples` iid N(0,1) slabs
+    [73, 721, 1440] fp32 (seeded).  `pinned=True` allocates them page-locked, so the H2D copy can read them in place (what a
+    deployment gets by hipHostRegister-ing its in-memory cache); `pinned=False` goes through the staging ring like file data."""
+
+    def __init__(self, n_years=1, n_samples=8, shape=(73, 721, 1440), seed=333, pinned=False, first_year=1979):
+        self.years = [first_year + i for i in range(n_years)]
+        self.n_samples_year = [n_samples] * n_years
+        self.shape = tuple(shape)
+        self.pinned = pinned
+        g = torch.Generator().manual_seed(seed)
+        self._t = []
+        for _ in range(n_years):
+            t = torch.empty((n_samples,) + self.shape, dtype=torch.float32, pin_memory=pinned)
+            for i in range(n_samples):
+                torch.randn(self.shape, generator=g, out=t[i])
+            self._t.append(t)
+
+    def slab(self, year_idx, t):
+        return self._t[year_idx][t]
+
+    def read(self, year_idx, t, out):
+        np.copyto(out, self._t[year_idx][t].numpy())
+
+
+# ---- index arithmetic ------------------------------------------------------------------------------------------
+def epoch_order(n_total, n_shards, shard_id, seed, epoch, shuffle):
+    """dali_era5_es_helper.py:163-175: one permutation per epoch (seed + epoch), contiguous shard slice"""
+    perm = np.random.default_rng(seed=seed + epoch).permutation(n_total) if shuffle else np.arange(n_total)
+    n_shard = n_total // n_shards
+    return perm[n_shard * shard_id: n_shard * (shard_id + 1)]
+
+
+def locate(sample_idx, year_offsets, n_samples_year, step, n_future):
+    """dali_era5_es_helper.py:176-186: (year_idx, local_idx) with the boundary handling of that file"""
+    year_idx = bisect_right(year_offsets, sample_idx) - 1
+    local_idx = int(sample_idx - year_offsets[year_idx])
+    if local_idx < step:
+        local_idx += step
+    if local_idx >= (n_samples_year[year_idx] - step * (n_future + 1)):
+        local_idx = n_samples_year[year_idx] - step * (n_future + 1) - 1
+    return year_idx, local_idx
+
+
+class AssembledBatch(tuple):
+    """(inp, tar, tzen | None) already on the device in the model's layout; PreProcessor passes it through"""
+
+
+# ---- the pipeline ----------------------------------------------------------------------------------------------
+class Era5HostPipeline:
+    def __init__(self, params, source, device, train, static_features=None, steps_per_epoch=None, ring=3, workers=None):
+        self.p, self.src, self.dev, self.train = params, source, device, train
+        g = lambda k, d: params[k] if k in params else d
+        self.B = int(params.local_batch_size)
+        self.dt, self.n_future = int(params.dt), int(params.n_future)
+        self.H, self.W = int(params.img_size[0]), int(params.img_size[1])
+        self.Craw, self.Hraw, self.Wraw = source.shape
+        assert self.H <= self.Hraw and self.W <= self.Wraw, 'image shapes are greater than dataset image shapes'
+        in_ch, out_ch = np.asarray(params.in_channels), np.asarray(params.out_channels)
+        self.n_in, self.n_out, self.S = len(in_ch), len(out_ch), self.n_future + 1
+        self.add_zenith = bool(g('add_zenith', False))
+        self.seed = g('seed', None) or 333
+        self.shards, self.shard_id = int(g('data_num_shards', 1)), int(g('data_shard_id', 0))
+        self.year_offsets = list(np.cumsum([0] + list(source.n_samples_year))[:-1])
+        self.n_total = int(sum(source.n_samples_year))
+        n_shard = self.n_total // self.shards
+        self.steps = steps_per_epoch or max(1, n_shard // self.B)
+        self.epoch = 0
+        # normalisation statistics (data_loader_era5.py:55-56): means / stds [1, N, 1, 1] files, or 0 / 1 without them.  The
+        # reference normalises the TARGETS with the input-channel statistics too (quirk 12): reproduced
+        means, stds = np.zeros(self.Craw, np.float32), np.ones(self.Craw, np.float32)
+        gm, gs = str(g('global_means_path', '')), str(g('global_stds_path', ''))
+        if os.path.isfile(gm) and os.path.isfile(gs):
+            means, stds = np.load(gm).reshape(-1)[:self.Craw].astype(np.float32), np.load(gs).reshape(-1)[:self.Craw].astype(np.float32)
+        dev_t = lambda a, dt: torch.as_tensor(a, dtype=dt).to(device)
+        self.in_chan, self.out_chan = dev_t(in_ch, torch.int32), dev_t(out_ch, torch.int32)
+        self.in_mean, self.in_std = dev_t(means[in_ch], torch.float32), dev_t(stds[in_ch], torch.float32)
+        stat_ch = in_ch if len(in_ch) == len(out_ch) else out_ch
+        self.tar_mean, self.tar_std = dev_t(means[stat_ch], torch.float32), dev_t(stds[stat_ch], torch.float32)
+        self.static = None if static_features is None else static_features.to(device).float().contiguous()   # [Cs, H, W]
+        self.Cin_total = self.n_in + int(self.add_zenith) + (0 if self.static is None else self.static.shape[0])
+        # staging: ring of pinned slabs (skipped when the source itself is page-locked), two device slabs, two output sets
+        slab = (self.Craw, self.Hraw, self.Wraw)
+        self.ring = ring
+        self.direct = bool(getattr(source, "pinned", False))
+        if not self.direct:      # per slot: the input slab and the S target slabs of every sample (separate, contiguous tensors)
+            self.pin = [(torch.empty((self.B, 1) + slab, dtype=torch.float32, pin_memory=True),
+                         torch.empty((self.B, self.S) + slab, dtype=torch.float32, pin_memory=True)) for _ in range(ring)]
+        self.raw = [(torch.empty((self.B, 1) + slab, dtype=torch.float32, device=device),
+                     torch.empty((self.B, self.S) + slab, dtype=torch.float32, device=device)) for _ in range(2)]
+        self.out = [(torch.empty(self.B, self.Cin_total, self.H, self.W, device=device),
+                     torch.empty(self.B, self.S * self.n_out, self.H, self.W, device=device),
+                     torch.empty(self.B, self.S, self.H, self.W, device=device) if self.add_zenith else None) for _ in range(2)]
+        self.hours = [torch.empty(self.B, 1 + self.S, dtype=torch.float32, pin_memory=True) for _ in range(ring + 1)]
+        self.copy_stream = torch.cuda.Stream(device=device)
+        self.pool = ThreadPoolExecutor(max_workers=workers or max(1, int(g('num_data_workers', 8))))
+        logging.info("ERA5 host pipeline: %d samples (%d years), shard %d/%d, %d steps/epoch, %s staging",
+                     self.n_total, len(source.years), self.shard_id, self.shards, self.steps,
+                     "zero-copy (page-locked source)" if self.direct else f"{ring} pinned slabs")
+
+    def __len__(self):
+        return self.steps
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    # -- host side: which slabs make up batch i of this epoch
+    def batch_indices(self, order, i):
+        return [locate(int(order[(i * self.B + b) % len(order)]), self.year_offsets, self.src.n_samples_year, self.dt, self.n_future)
+                for b in range(self.B)]
+
+    def _fill(self, slot, locs):
+        """producer: copy the 1 + S slabs of every sample into pinned slot `slot` (channel blocks in parallel)"""
+        jobs = []
+        for b, (y, t) in enumerate(locs):
+            for s in range(1 + self.S):
+                dst = (self.pin[slot][0][b, 0] if s == 0 else self.pin[slot][1][b, s - 1]).numpy()
+                jobs.append(self.pool.submit(self.src.read, y, t + s * self.dt, dst))
+        for j in jobs:
+            j.result()
+
+    def _submit(self, slot_pin, slot_dev, locs):
+        """copy stream: H2D of the batch + assembly kernels into output set `slot_dev`"""
+        cs = self.copy_stream
+        inp, tar, tz = self.out[slot_dev]
+        hrs = self.hours[slot_pin]
+        for b, (y, t) in enumerate(locs):
+            for s in range(1 + self.S):
+                hrs[b, s] = 6.0 * (t + s * self.dt)
+        with torch.cuda.stream(cs):
+            raw_in, raw_tar = self.raw[slot_dev]
+            if self.direct:
+                for b, (y, t) in enumerate(locs):
+                    raw_in[b, 0].copy_(self.src.slab(y, t), non_blocking=True)
+                    for s in range(self.S):
+                        raw_tar[b, s].copy_(self.src.slab(y, t + (s + 1) * self.dt), non_blocking=True)
+            else:
+                raw_in.copy_(self.pin[slot_pin][0], non_blocking=True)
+                raw_tar.copy_(self.pin[slot_pin][1], non_blocking=True)
+            st = cs.cuda_stream
+            ops.era5_select_normalize(raw_in, inp, self.in_chan, self.in_mean, self.in_std, 0, stream=st)
+            ops.era5_select_normalize(raw_tar, tar, self.out_chan, self.tar_mean, self.tar_std, 0, stream=st)
+            c = self.n_in
+            if self.add_zenith:
+                hd = hrs.to(self.dev, non_blocking=True)
+                ops.era5_zenith(inp, hd[:, :1].contiguous(), c, stream=st)
+                ops.era5_zenith(tz, hd[:, 1:].contiguous(), 0, stream=st)
+                c += 1
+            if self.static is not None:
+                ops.era5_static(self.static, inp, c, stream=st)
+            ev = torch.cuda.Event()
+            ev.record(cs)
+        return ev
+
+    def __iter__(self):
+        order = epoch_order(self.n_total, self.shards, self.shard_id, self.seed, self.epoch, self.train)
+        locs = [self.batch_indices(order, i) for i in range(self.steps)]
+        filled: "queue.Queue" = queue.Queue()          # (batch index, pinned slot) in batch order
+        free: "queue.Queue" = queue.Queue()            # pinned slots whose last H2D has completed
+        for s_ in range(self.ring):
+            free.put(s_)
+        stop = threading.Event()
+
+        def producer():
+            for i in range(self.steps):
+                slot = free.get()
+                if stop.is_set() or slot is None:
+                    return
+                if not self.direct:
+                    self._fill(slot, locs[i])
+                filled.put((i, slot))
+
+        th = threading.Thread(target=producer, daemon=True)
+        th.start()
+        compute = torch.cuda.current_stream(self.dev)
+        ready = [None, None]
+        inflight = []                                   # (H2D-done event, pinned slot) of submitted batches, oldest first
+        try:
+            i0_, slot = filled.get()
+            assert i0_ == 0
+            ready[0] = self._submit(slot, 0, locs[0])
+            inflight.append((ready[0], slot))
+            for i in range(self.steps):
+                if i + 1 < self.steps:
+                    j, slot = filled.get()
+                    assert j == i + 1
+                    # output / device slab (i + 1) % 2 was last read by step i - 1, whose kernels are enqueued by now
+                    fr = torch.cuda.Event()
+                    fr.record(compute)
+                    self.copy_stream.wait_event(fr)
+                    ready[(i + 1) % 2] = self._submit(slot, (i + 1) % 2, locs[i + 1])
+                    inflight.append((ready[(i + 1) % 2], slot))
+                compute.wait_event(ready[i % 2])
+                while len(inflight) > 1:                # batch i's copy has been issued a whole step ago: recycle its slab
+                    ev, s_ = inflight.pop(0)
+                    ev.synchronize()
+                    free.put(s_)
+                yield AssembledBatch(self.out[i % 2])
+        finally:
+            stop.set()
+            free.put(None)
+            th.join(timeout=30)
+        self.epoch += 1

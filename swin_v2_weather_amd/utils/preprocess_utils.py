@@ -1,31 +1,81 @@
 """PreProcessor with the reference's surface (utils/preprocess_utils.py:5-69): moves a loader batch to the device as
 fp32, appends the input cos-zenith channel and the static features (one-hot land mask: 2 channels, then standardised
-orography: 1 channel) and returns (inp, tar, target_zenith | None).  The invariant files (orog.nc / lsm.h5) are not
-available here, so the static fields are seeded synthetic stand-ins: land mask ~ Bernoulli(0.3), orography ~ N(0,1)."""
+orography: 1 channel) and returns (inp, tar, target_zenith | None).
+
+The invariant fields are read from `params.landmask_path` / `params.orography_path` when those files exist (lsm.h5["LSM"],
+orog.nc["Z"] -- utils/conditioning_inputs.py:23-40 -- through h5py / netCDF4 if importable, or `.npy` arrays of the same
+content); without them (no ERA5 files in this image) they are seeded synthetic stand-ins: land mask ~ Bernoulli(0.3),
+orography ~ N(0,1).  Batches that the host pipeline (utils/host_pipeline.py) has already assembled on the device pass
+through unchanged."""
+import logging
+import os
+
+import numpy as np
 import torch
 import torch.nn as nn
+
+from .host_pipeline import AssembledBatch
+
+
+def _read_field(path, h5_key, nc_key):
+    """[721, 1440]-like 2-D field from .npy / .h5 / .nc, or None when the file or its reader is missing"""
+    if not path or not os.path.isfile(str(path)):
+        return None
+    path = str(path)
+    try:
+        if path.endswith(".npy"):
+            a = np.load(path)
+        elif path.endswith(".nc"):
+            from netCDF4 import Dataset as DS
+            with DS(path, "r") as f:
+                a = np.asarray(f.variables[nc_key][0, :, :])
+        else:
+            import h5py
+            with h5py.File(path, "r") as f:
+                a = np.asarray(f[h5_key][0, :, :])
+        return np.asarray(a).reshape(a.shape[-2], a.shape[-1])
+    except ImportError as e:                       # optional readers
+        logging.warning("cannot read %s (%s): using the synthetic stand-in", path, e)
+        return None
+
+
+def build_static_features(params):
+    """[1, Cs, imgx, imgy] fp32 or None: one-hot land mask (2 channels) then standardised orography (1 channel), in the
+    reference's order (preprocess_utils.py:15-45)"""
+    imgx, imgy = params.img_size
+    g = torch.Generator().manual_seed(4242)
+    get = lambda k: params[k] if k in params else None
+    static_features = None
+    if params.add_landmask:
+        lsm_np = _read_field(get("landmask_path"), "LSM", "LSM")
+        lsm = torch.tensor(lsm_np, dtype=torch.long) if lsm_np is not None else (torch.rand(721, 1440, generator=g) < 0.3).long()
+        lsm = torch.permute(torch.nn.functional.one_hot(lsm, 2), (2, 0, 1)).to(torch.float32)
+        static_features = lsm.reshape(1, 2, lsm.shape[1], lsm.shape[2])[:, :, :imgx, :imgy]
+    if params.add_orography:
+        oro_np = _read_field(get("orography_path"), "Z", "Z")
+        if oro_np is not None:                      # conditioning_inputs.py:23-31: min-max scaled to [0, 1] first
+            oro = torch.tensor(oro_np, dtype=torch.float32)
+            oro = (oro - oro.min()) / (oro.max() - oro.min())
+        else:
+            oro = torch.randn(721, 1440, generator=g)
+        oro = oro.reshape(1, 1, oro.shape[0], oro.shape[1])[:, :, :imgx, :imgy]
+        oro = (oro - torch.mean(oro)) / (torch.std(oro) + 1.0e-6)
+        static_features = oro if static_features is None else torch.cat([static_features, oro], dim=1)
+    return None if static_features is None else static_features.contiguous()
 
 
 class PreProcessor(nn.Module):
     def __init__(self, params, device):
         super().__init__()
         self.params, self.device = params, device
-        imgx, imgy = params.img_size
-        g = torch.Generator().manual_seed(4242)
-        static_features = None
-        if self.params.add_landmask:
-            lsm = (torch.rand(721, 1440, generator=g) < 0.3).long()
-            lsm = torch.permute(torch.nn.functional.one_hot(lsm, 2), (2, 0, 1)).to(torch.float32)
-            static_features = lsm.reshape(1, 2, 721, 1440)[:, :, :imgx, :imgy]
-        if self.params.add_orography:
-            oro = torch.randn(721, 1440, generator=g).reshape(1, 1, 721, 1440)[:, :, :imgx, :imgy]
-            oro = (oro - torch.mean(oro)) / (torch.std(oro) + 1.0e-6)
-            static_features = oro if static_features is None else torch.cat([static_features, oro], dim=1)
+        static_features = build_static_features(params)
         self.do_add_static_features = static_features is not None
         if self.do_add_static_features:
-            self.register_buffer("static_features", static_features.contiguous(), persistent=False)
+            self.register_buffer("static_features", static_features, persistent=False)
 
     def forward(self, data):
+        if isinstance(data, AssembledBatch):          # host pipeline: zenith + invariants already written by the assembly kernels
+            return tuple(data)
         if self.params.add_zenith:
             inp, tar, izen, tzen = map(lambda x: x.to(self.device, dtype=torch.float), data)
             inp = torch.cat([inp, izen], dim=1)

@@ -483,7 +483,7 @@ def fx_losscurve_relpos(steps=100):
     sub-modules in eval mode (CPU and GPU generators cannot be made to agree); drop_path 0."""
     seed = 777
     torch.manual_seed(seed)
-    m = sw.SwinTransformerV2Cr(img_size=(96, 144), patch_size=4, depths=(2,), num_heads=(4,), in_chans=20,
+    m = sw.SwinTransformerV2Cr(img_size=(72, 144), patch_size=4, depths=(2,), num_heads=(4,), in_chans=20,
                                out_chans=20, embed_dim=64, img_window_ratio=8, drop_path_rate=0.0,
                                full_pos_embed=True, rel_pos=True, mlp_ratio=4, residual=True)
     randomize(m, seed, clamp_head=False)
@@ -496,7 +496,7 @@ def fx_losscurve_relpos(steps=100):
         if isinstance(mod, sw.WindowMultiHeadAttention):
             mod.meta_mlp.eval()
     for it in range(steps):
-        x, n_ = synthetic_batch(it % 4, 2, 20, 20, 96, 144, seed)
+        x, n_ = synthetic_batch(it % 4, 2, 20, 20, 72, 144, seed)
         t = 0.5 * x + 0.5 * n_
         opt.zero_grad()
         y = m(x)
@@ -509,7 +509,7 @@ def fx_losscurve_relpos(steps=100):
     npz("losscurve_relpos_init.npz", **{k: v for k, v in init.items()})
     with open(os.path.join(HERE, "losscurve_relpos.json"), "w") as f:
         json.dump({"seed": seed, "steps": steps, "lr": 1e-3, "betas": [0.9, 0.95], "pool": 4, "loss": "l2", "batch": 2,
-                   "cfg": {"img_size": [96, 144], "depth": 2, "num_heads": 4, "embed_dim": 64, "window_ratio": 8,
+                   "cfg": {"img_size": [72, 144], "depth": 2, "num_heads": 4, "embed_dim": 64, "window_ratio": 8,
                            "in_chans": 20, "out_chans": 20, "rel_pos": True, "residual": True},
                    "curve": curve}, f)
 

@@ -201,6 +201,7 @@ def from_heads(xh, Bw, Lw, h, d, parts):
 @pytest.mark.parametrize("wh,ww,h,d,nwh,nww,shifted,use_bias", [
     (6, 9, 4, 12, 2, 2, False, False), (6, 9, 4, 12, 2, 2, True, True), (6, 9, 3, 32, 2, 2, True, True),
     (9, 18, 8, 16, 2, 3, False, False), (9, 18, 8, 16, 2, 3, True, True), (9, 18, 2, 24, 2, 2, True, False),
+    (9, 18, 8, 16, 2, 3, True, False),   # shifted, no bias: the masked branch of the second-generation kernels
     (9, 18, 2, 16, 1, 2, True, True),   # one window row: every window carries the shift mask
 ])
 def test_attention_core_fwd_bwd(dev, K, wh, ww, h, d, nwh, nww, shifted, use_bias):
@@ -212,6 +213,10 @@ def test_attention_core_fwd_bwd(dev, K, wh, ww, h, d, nwh, nww, shifted, use_bia
     qkv = torch.randn(Bw, Lw, 3 * Cc)
     ls = torch.log(torch.tensor(10.0)) + 0.5 * torch.randn(h)
     ls[-1] = 5.0                                               # above the ln(100) clamp: zero gradient expected
+    if h >= 8:
+        # sigma = 27: just inside the forward's "fixed maximum" regime (sigma log2 e <= 40), where every P of a row may be
+        # as small as 2^-78; sigma = 30: just outside it (row maximum on the vector ALU)
+        ls[0], ls[1] = float(np.log(27.0)), float(np.log(30.0))
     bias = torch.randn(h, Lw, Lw) if use_bias else None
     gh, gw = nwh * wh, nww * ww
     sh = wh // 2 if (shifted and nwh > 1) else 0
@@ -280,6 +285,51 @@ def test_attention_core_fwd_bwd(dev, K, wh, ww, h, d, nwh, nww, shifted, use_bia
                                    dqkvh=dq2, dlogit=dls2, dbias=db2, bias_pack=pk))
         assert torch.equal(dq2, dqkvh) and rel(db2, dbias) < 1e-5
         assert rel(dbias, bias_ref.grad) < 8e-3
+
+
+@pytest.mark.parametrize("shifted", [False, True])
+def test_attention_kernel_generations_agree(dev, K, shifted):
+    """Every attention kernel build selectable through `dbg` (first generation, the small-workgroup forward / backward of
+    csrc/attn2.hip, the MFMA-folded forward with fragments from LDS or pinned in registers) computes the same function: the
+    non-default ones stay parity-tested here.  Shape of the benchmark (9x18 windows, 8 heads of 16), incl. the masked branch."""
+    ops = K["ops"]
+    torch.manual_seed(3)
+    wh, ww, h, d, nwh, nww, B = 9, 18, 8, 16, 2, 3, 2
+    Lw, nW = wh * ww, nwh * nww
+    Lp, DP = ops.attn_geometry(Lw, d)
+    Bw = B * nW
+    qkvh = torch.randn(Bw, h, 3, Lp, DP, device=dev)
+    qkvh[:, :, :2] = torch.nn.functional.normalize(qkvh[:, :, :2], dim=-1)
+    qkvh[:, :, :, Lw:] = 0
+    qkvh = qkvh.to(BF).contiguous()
+    ls = torch.log(torch.tensor([3.0, 8.0, 10.0, 12.0, 20.0, 27.0, 30.0, 200.0], device=dev))
+    rnorm = torch.rand(Bw, h, 2, Lp, device=dev) + 0.5
+    doh = torch.randn(Bw, h, Lp, DP, device=dev).to(BF)
+    doh[:, :, Lw:] = 0
+    mask_thr = (wh - wh // 2) * ww if shifted else 0
+    res = {}
+    for dbg in (16, 64, 0, 128):
+        oh = torch.zeros(Bw, h, Lp, DP, dtype=BF, device=dev)
+        lse = torch.zeros(Bw, h, Lp, device=dev)
+        a = ops.attn_args(qkvh, ls, None, oh, lse, Bw, h, Lw, d, nwh, nww, mask_thr)
+        a.dbg = dbg
+        ops.attn_fwd(a)
+        res[dbg] = (oh, lse)
+    for dbg in (64, 0, 128):
+        assert rel(res[dbg][0], res[16][0]) < 5e-3, dbg
+        assert float((res[dbg][1][:, :, :Lw] - res[16][1][:, :, :Lw]).abs().max()) < 2e-2, dbg
+    oh, lse = res[16]
+    grads = {}
+    for dbg in (16, 64, 96):
+        dq = torch.zeros(Bw, h, 3, Lp, DP, dtype=BF, device=dev)
+        dls = torch.zeros(h, device=dev)
+        a = ops.attn_args(qkvh, ls, None, oh, lse, Bw, h, Lw, d, nwh, nww, mask_thr, doh=doh, rnorm=rnorm, dqkvh=dq, dlogit=dls)
+        a.dbg = dbg
+        ops.attn_bwd(a)
+        grads[dbg] = (dq, dls)
+    for dbg in (64, 96):
+        assert rel(grads[dbg][0], grads[16][0]) < 1e-2, dbg
+        assert float(grads[dbg][1][-1]) == 0.0 and rel(grads[dbg][1], grads[16][1]) < 5e-2, dbg
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -927,7 +977,9 @@ def test_block_fused_attention_branch(dev, K, monkeypatch, gh, gw, wh, ww, sh, s
         y.backward(gy0.to(dev))
         assert blk._runner(B, x.device).desc.fuse_attn == int(fuse)
         outs[fuse] = (y.detach(), x.grad.detach(), {n_: p_.grad.detach().clone() for n_, p_ in blk.named_parameters()})
-    assert rel(outs["1"][0], outs["0"][0]) < 2e-3 and rel(outs["1"][1], outs["0"][1]) < 1.5e-2
+    # (the unfused path's forward normalises by the sum of the bf16-rounded exponentials with a fixed reference point, the
+    # fused branch kernel by the fp32 sum around the row maximum: two bf16-level roundings of the same softmax)
+    assert rel(outs["1"][0], outs["0"][0]) < 4e-3 and rel(outs["1"][1], outs["0"][1]) < 1.5e-2, (rel(outs["1"][0], outs["0"][0]), rel(outs["1"][1], outs["0"][1]))
     for n_ in outs["0"][2]:
         tol = 0.15 if "logit_scale" in n_ else 3e-2
         assert rel(outs["1"][2][n_], outs["0"][2][n_]) < tol, n_
@@ -940,7 +992,7 @@ def test_block_fused_attention_branch(dev, K, monkeypatch, gh, gw, wh, ww, sh, s
             yo.backward(gy0)
         finally:
             O.set_rounding(None)
-        assert rel(outs["1"][0], yo) < 1e-3 and rel(outs["1"][1], xo.grad) < 1.5e-2
+        assert rel(outs["1"][0], yo) < 3e-3 and rel(outs["1"][1], xo.grad) < 1.5e-2
 
 
 def _ddp_run(tmp_path, tag, world, backend, mode, n_future, port):
@@ -960,9 +1012,11 @@ def _ddp_run(tmp_path, tag, world, backend, mode, n_future, port):
 
 
 def _ddp_close(a, b, tol=2e-3):
-    worst = max(float((x - y).abs().max() / (y.abs().max() + 1e-12)) for x, y in zip(a["params"], b["params"]))
+    """parameters after 3 SGD steps: the UPDATE (p - p0 is not available, so: difference relative to the parameter's scale,
+    floored at the size of an update) must agree"""
+    worst = max(float((x - y).abs().max() / max(float(y.abs().max()), 1e-2)) for x, y in zip(a["params"], b["params"]))
     assert worst < tol, worst
-    assert all(abs(x - y) < 5e-4 * abs(y) + 1e-6 for x, y in zip(a["losses"], b["losses"])), (a["losses"], b["losses"])
+    assert all(abs(x - y) < 1e-4 * abs(y) + 1e-6 for x, y in zip(a["losses"], b["losses"])), (a["losses"], b["losses"])
 
 
 def test_ddp_bucket_view_gradients(dev, K, tmp_path):
@@ -985,6 +1039,84 @@ def test_ddp_two_ranks_hip_model(dev, K, tmp_path):
         ref = _ddp_run(tmp_path, f"plain{nf}", 1, "gloo", "plain", nf, 29541)
         two = _ddp_run(tmp_path, f"two{nf}", 2, "gloo", "alias", nf, 29543 + nf)
         assert two["nranks"] == 2 and two["stuck"] == 0
+        # (two ranks sum the weight-gradient partial tiles in another order than one process on the whole batch: rounding level)
         _ddp_close(two, ref)
     stock = _ddp_run(tmp_path, "stock0", 2, "gloo", "ddp", 0, 29547)
     _ddp_close(stock, _ddp_run(tmp_path, "plain0b", 1, "gloo", "plain", 0, 29549))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# host input pipeline: assembly kernels bit-exact against the reference's host arithmetic, and the
+# double-buffered pipeline end to end
+# ---------------------------------------------------------------------------------------------------------------
+def test_era5_assembly_kernels(dev, K):
+    ops = K["ops"]
+    from swin_v2_weather_amd.utils.data_loader_era5 import cos_zenith
+    rng = np.random.default_rng(1)
+    B, S, Craw, Hraw, Wraw, H, W = 2, 2, 7, 21, 40, 20, 36
+    raw = rng.standard_normal((B, S, Craw, Hraw, Wraw)).astype(np.float32) * 50 + 10
+    chan = np.array([5, 0, 3, 6], np.int32)
+    mean = rng.standard_normal(4).astype(np.float32) * 10
+    std = (0.5 + rng.random(4)).astype(np.float32)
+    out = torch.full((B, 11, H, W), -7.0, device=dev)
+    ops.era5_select_normalize(torch.from_numpy(raw).to(dev), out, torch.from_numpy(chan).to(dev), torch.from_numpy(mean).to(dev),
+                              torch.from_numpy(std).to(dev), coff=1)
+    ref = raw[:, :, chan, :H, :W].copy()                      # data_loader_era5.py:163-171 crop / select, :98-107 z-score
+    ref -= mean.reshape(1, 1, -1, 1, 1)
+    ref /= std.reshape(1, 1, -1, 1, 1)
+    got = out.cpu().numpy()
+    assert np.array_equal(got[:, 1:9], ref.reshape(B, S * 4, H, W))                 # bit-exact
+    assert np.all(got[:, 0] == -7.0) and np.all(got[:, 9:] == -7.0)                 # other channels untouched
+    hours = torch.tensor([[6.0, 12.0], [4380.0, 8754.0]], device=dev)
+    ops.era5_zenith(out, hours, 9)
+    for b in range(2):
+        for k in range(2):
+            z = cos_zenith(1979, float(hours[b, k]), H, W)
+            assert float((out[b, 9 + k].cpu() - z).abs().max()) < 2e-5
+    stat = torch.randn(1, H, W, device=dev)
+    ops.era5_static(stat, out, 0)
+    assert torch.equal(out[:, 0], stat.expand(B, H, W))
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_host_pipeline_end_to_end(dev, K, pinned):
+    """every batch of two epochs equals the synchronous host computation (index order, crop, z-score with the INPUT-channel
+    statistics on inputs and targets, zenith of input / target times, invariant channels), through the staging ring / the
+    zero-copy path, while a consumer keeps the compute stream busy"""
+    from swin_v2_weather_amd.utils import host_pipeline as hp
+    from swin_v2_weather_amd.utils.data_loader_era5 import cos_zenith
+    import tempfile
+
+    class P(dict):
+        __getattr__ = dict.__getitem__
+    Craw, Hraw, Wraw, H, W, B, nf = 6, 21, 40, 20, 40, 2, 1
+    src = hp.SyntheticYearSource(n_years=2, n_samples=9, shape=(Craw, Hraw, Wraw), seed=5, pinned=pinned)
+    tmp = tempfile.mkdtemp()
+    means = np.arange(Craw, dtype=np.float32).reshape(1, Craw, 1, 1) * 0.1
+    stds = (1.0 + np.arange(Craw, dtype=np.float32)).reshape(1, Craw, 1, 1)
+    np.save(tmp + "/m.npy", means)
+    np.save(tmp + "/s.npy", stds)
+    chans = np.array([0, 2, 3, 5])
+    params = P(local_batch_size=B, dt=1, n_future=nf, img_size=(H, W), in_channels=chans, out_channels=chans, add_zenith=True,
+               seed=11, data_num_shards=2, data_shard_id=1, global_means_path=tmp + "/m.npy", global_stds_path=tmp + "/s.npy",
+               num_data_workers=4)
+    stat = torch.randn(3, H, W)
+    pipe = hp.Era5HostPipeline(params, src, dev, train=True, static_features=stat, ring=3)
+    assert len(pipe) == (18 // 2) // B
+    busy = torch.randn(2048, 2048, device=dev)
+    for epoch in range(2):
+        order = hp.epoch_order(18, 2, 1, 11, epoch, True)
+        for i, batch in enumerate(pipe):
+            inp, tar, tz = batch
+            for b in range(B):
+                y, t = hp.locate(int(order[i * B + b]), [0, 9], [9, 9], 1, nf)
+                x = (src.slab(y, t).numpy()[chans, :H, :W] - means[0, chans]) / stds[0, chans]
+                assert np.array_equal(inp[b, :4].cpu().numpy(), x)
+                assert float((inp[b, 4].cpu() - cos_zenith(src.years[y], 6.0 * t, H, W)).abs().max()) < 2e-5
+                assert torch.equal(inp[b, 5:].cpu(), stat)
+                for s_ in range(nf + 1):
+                    tt = (src.slab(y, t + 1 + s_).numpy()[chans, :H, :W] - means[0, chans]) / stds[0, chans]
+                    assert np.array_equal(tar[b, 4 * s_: 4 * s_ + 4].cpu().numpy(), tt)
+                    assert float((tz[b, s_].cpu() - cos_zenith(src.years[y], 6.0 * (t + 1 + s_), H, W)).abs().max()) < 2e-5
+            busy = busy @ busy * 1e-3                          # keep the compute stream busy past the next __next__
+        assert i == len(pipe) - 1

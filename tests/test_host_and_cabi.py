@@ -233,3 +233,55 @@ def test_dataset_index_arithmetic_and_tensor_contract():
     loader, dataset, sampler = get_data_loader(p, "unused", distributed=False, train=True)
     batch = next(iter(loader))
     assert batch[0].shape == (2, 73, 16, 24) and batch[1].shape == (2, 146, 16, 24) and sampler is None
+
+
+# ---- host input pipeline: index arithmetic, sources, invariant fields -------------------------------------
+def test_pipeline_epoch_order_and_boundary_handling():
+    """known answers written from utils/dali_era5_es_helper.py:163-186 (seeded permutation per epoch, contiguous shard slice,
+    year lookup by offsets, the two boundary rules)"""
+    from swin_v2_weather_amd.utils import host_pipeline as hp
+    n, shards, seed = 103, 4, 333
+    full = np.random.default_rng(seed=seed + 2).permutation(n)
+    parts = [hp.epoch_order(n, shards, r, seed, 2, True) for r in range(shards)]
+    assert all(len(p_) == n // shards for p_ in parts)
+    assert np.array_equal(np.concatenate(parts), full[: (n // shards) * shards])            # disjoint, in permutation order
+    assert not np.array_equal(hp.epoch_order(n, shards, 0, seed, 3, True), parts[0])        # re-drawn per epoch
+    assert np.array_equal(hp.epoch_order(n, shards, 1, seed, 0, False), np.arange(25, 50))  # validation: identity order
+    offs, ny = [0, 1460, 2924], [1460, 1464, 1460]
+    assert hp.locate(0, offs, ny, 1, 0) == (0, 1)                   # local < step  -> += step
+    assert hp.locate(1459, offs, ny, 1, 0) == (0, 1458)             # local >= n - step (nf + 1) -> n - step (nf + 1) - 1
+    assert hp.locate(1460, offs, ny, 1, 1) == (1, 1)
+    assert hp.locate(2923, offs, ny, 1, 1) == (1, 1461)
+    assert hp.locate(2000, offs, ny, 2, 3) == (1, 540)
+    assert hp.locate(2925, offs, ny, 2, 3) == (2, 3)                # local 1 < step 2 -> 3
+
+
+def test_year_array_source_and_static_features_from_files(tmp_path):
+    from swin_v2_weather_amd.utils import host_pipeline as hp
+    from swin_v2_weather_amd.utils.preprocess_utils import build_static_features
+    rng = np.random.default_rng(0)
+    for yr, n in ((1980, 5), (1979, 4)):
+        np.save(tmp_path / f"era5_{yr}.npy", rng.standard_normal((n, 3, 9, 16)).astype(np.float32))
+    src = hp.YearArraySource(str(tmp_path))
+    assert src.years == [1979, 1980] and src.n_samples_year == [4, 5] and src.shape == (3, 9, 16)
+    out = np.empty((3, 9, 16), np.float32)
+    src.read(1, 2, out)
+    assert np.array_equal(out, np.load(tmp_path / "era5_1980.npy")[2])
+    # invariant fields from files (conditioning_inputs.py:23-40, preprocess_utils.py:15-45)
+    lsm = (rng.random((1, 9, 16)) < 0.4).astype(np.int64)
+    z = rng.standard_normal((1, 9, 16)).astype(np.float32) * 3000.0
+    np.save(tmp_path / "lsm.npy", lsm)
+    np.save(tmp_path / "orog.npy", z)
+    p = SimpleNamespace(img_size=(8, 16), add_landmask=True, add_orography=True)
+    pd = {"landmask_path": str(tmp_path / "lsm.npy"), "orography_path": str(tmp_path / "orog.npy")}
+
+    class P(dict):
+        __getattr__ = dict.__getitem__
+    sf = build_static_features(P(img_size=(8, 16), add_landmask=True, add_orography=True, **pd))
+    assert sf.shape == (1, 3, 8, 16)
+    assert torch.equal(sf[0, 0], torch.from_numpy((lsm[0] == 0).astype(np.float32))[:8])       # one_hot: channel 0 = class 0
+    assert torch.equal(sf[0, 1], torch.from_numpy((lsm[0] == 1).astype(np.float32))[:8])
+    o = torch.from_numpy(z[0])
+    o = ((o - o.min()) / (o.max() - o.min()))[:8]
+    assert torch.allclose(sf[0, 2], (o - o.mean()) / (o.std() + 1e-6), atol=1e-6)
+    del p

@@ -49,7 +49,7 @@ def probe_attn(B=2, rel_pos=False):
     dls = torch.zeros(h, device=dev)
     dbias = torch.zeros(h, Lw, Lw, device=dev) if rel_pos else None
     pk = ops.attn_pack_bias(bias) if rel_pos else None
-    for gen, dbg in (("gen1", 16), ("gen2", 0), ("gen2-occ3", 32)):
+    for gen, dbg in (("gen1", 16), ("fwd2 / bwd2", 64), ("default (fwd3 / gen1 bwd)", 0), ("fwd3 pinned fragments", 128)):
         a = ops.attn_args(qkvh, ls, bias, oh, lse, Bw, h, Lw, 16, plan.nwh, plan.nww, plan.mask_thr, max_chunks=32 if rel_pos else 64, bias_pack=pk)
         a.dbg = dbg
         say(f"attn_fwd  {gen} B={B} bias={rel_pos}: {timeit(lambda: ops.attn_fwd(a), n=20):.1f} us")

@@ -95,7 +95,8 @@ enum swv2_operand_kind {
     SWV2_OP_HEADS = 3,     /* head-major window layout [Bw][h][S][Lp][DP]: row = bw*Lp + t, col = (part*h+head)*DP+j
                               p[0]=heads p[2]=Lp p[3]=DP, ld = S                                                     */
     SWV2_OP_PATCH = 4,     /* im2col of x[B][Cin][H][W] fp32 for the 4x4/stride-4 conv: row=(b,i,j), col=cin*16+p*4+q
-                              p[0]=Cin p[1]=H p[2]=W                                                                 */
+                              p[0]=Cin p[1]=H p[2]=W ; p[3] = channels per sample of the tensor holding the Cin planes
+                              (0 = Cin) ; aux0 = optional second source added on load, ld = its channels per sample      */
     SWV2_OP_MERGE_LN = 5   /* 2x2 PatchMerging gather of x[B][H][W][C] fp32 + LayerNorm(4C) on load:
                               p[0]=H p[1]=W p[2]=C, aux0=mean aux1=rstd (swv2_merge_stats) aux2=gamma aux3=beta     */
 };
@@ -121,7 +122,9 @@ enum swv2_epilogue_kind {
                                p[0]=heads p[2]=Lp p[3]=DP p[4]=L ; N = 3*heads*DP, bias padded alike                 */
     SWV2_EPI_GELU_GRAD = 3, /* out bf16 = acc * GELU'(aux) ; aux = bf16 pre-activation, same shape/pitch as out     */
     SWV2_EPI_UNPATCH = 4,   /* out fp32 y[B][Cout][H][W] (+ aux skip[B][Cs][H][W]) ; N = Cout*16 with columns ordered
-                               c*16+p*4+q ; p[0]=Cout p[1]=H p[2]=W p[3]=Cs (0 = no skip)   (:784-802)               */
+                               c*16+p*4+q ; p[0]=Cout p[1]=H p[2]=W p[3]=Cs (0 = no skip)   (:784-802) ;
+                               p[4] = channels per sample of the tensor `out` points into (0 = Cout) ; aux_out = optional
+                               second destination, ld = its channels per sample (rollout, helpers.py:26-41)          */
     SWV2_EPI_HEADS = 5,     /* out = [Bw][h][Lp][DP] bf16 split heads, no normalisation ; p as QKV_HEADS, N=heads*DP */
     SWV2_EPI_F32_ACC = 6,   /* out fp32 [M][ld] += acc ; optional rowidx scatter                                     */
     SWV2_EPI_BF16_GELU = 7  /* out bf16 = acc + bias (pre-activation, kept for backward), aux_out bf16 = erf-GELU of it,

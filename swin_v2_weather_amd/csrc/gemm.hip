@@ -232,10 +232,14 @@ template <> struct Epi<E_GELU_GRAD> {
 // rows permuted to n' = c*16 + p*4 + q (swv2_cast_weights), so 16 consecutive columns are one channel's 4x4 patch:
 //   y[b][c][4i+p][4j+q] = acc[m=(b,i,j)][c*16 + p*4 + q] (+ skip[b][c][4i+p][4j+q])
 // p0 = Cout, p1 = H, p2 = W, p3 = Cskip (channels of the skip tensor, 0 = no skip) ; aux = skip ; out = y
+// p4 = channels per sample of the tensor `out` points into (0 = Cout); aux_out = optional SECOND destination with ld
+// channels per sample -- the autoregressive rollout writes a step's prediction straight into the concatenated result and
+// into the next step's input buffer (helpers.py:26-41: two torch.cat copies of ~300 MB per sample and step otherwise)
 template <> struct Epi<E_UNPATCH> {
     EpiDesc d;
     __device__ __forceinline__ void tile(const float* st, int m0, int n0, int lane) const {
         const int Cout = d.p0, H = d.p1, W = d.p2, Cs = d.p3, gw = W >> 2, gh = H >> 2;
+        const int Ct = d.p4 ? d.p4 : Cout;
         // 16 rows x 4 channels x 4 p = 256 float4 items; lane -> row fastest so stores run along W
         for (int it = lane; it < 256; it += 64) {
             const int r = it & 15, cp = it >> 4, cl = cp >> 2, p = cp & 3;
@@ -244,7 +248,8 @@ template <> struct Epi<E_UNPATCH> {
             const int b = fdiv(m, gh * gw, d.mg0), ij = m - b * gh * gw, i = fdiv(ij, gw, d.mg1), j = ij - i * gw;
             f32x4 v = *(const f32x4*)(st + r * EP + cl * 16 + p * 4);
             if (Cs) v += *(const f32x4*)((const float*)d.aux + (((long)b * Cs + c) * H + 4 * i + p) * W + 4 * j);
-            *(f32x4*)((float*)d.out + (((long)b * Cout + c) * H + 4 * i + p) * W + 4 * j) = v;
+            *(f32x4*)((float*)d.out + (((long)b * Ct + c) * H + 4 * i + p) * W + 4 * j) = v;
+            if (d.aux_out) *(f32x4*)((float*)d.aux_out + (((long)b * d.ld + c) * H + 4 * i + p) * W + 4 * j) = v;
         }
     }
 };

@@ -218,8 +218,16 @@ template <> struct ALoad<A_PATCH> {
         const int Cin = d.p0, H = d.p1, W = d.p2, gw = W >> 2, gh = H >> 2;
         const int b = fdiv(m, gh * gw, d.mg0), ij = m - b * gh * gw, i = fdiv(ij, gw, d.mg1), j = ij - i * gw;
         const int cin = k0 >> 4, p = (k0 >> 2) & 3;                 // p in {0, 2}
-        const float* src = (const float*)d.ptr + (((long)b * Cin + cin) * H + 4 * i + p) * W + 4 * j;
+        // p3 = channels per sample of the tensor that holds the Cin planes (0 = Cin: a dense [B][Cin][H][W] tensor); the
+        // rollout's step outputs are channel slices of one [B][(n_future+1) Cout][H][W] buffer
+        const int Ct = d.p3 ? d.p3 : Cin;
+        const float* src = (const float*)d.ptr + (((long)b * Ct + cin) * H + 4 * i + p) * W + 4 * j;
         Raw o = {*(const f32x4*)src, *(const f32x4*)(src + W)};
+        if (d.aux0) {   // second source added on load (ld = its channels per sample): gradient of the fed-back prediction
+            const float* s2 = d.aux0 + (((long)b * d.ld + cin) * H + 4 * i + p) * W + 4 * j;
+            o.a += *(const f32x4*)s2;
+            o.b += *(const f32x4*)(s2 + W);
+        }
         return o;
     }
     __device__ __forceinline__ uint4 cvt(const Raw& r) const { return cvt_f32x8(r); }

@@ -1,4 +1,5 @@
 """Model wrappers and factory with the reference's surface (networks/helpers.py:1-55)."""
+import os
 from functools import partial
 
 import torch
@@ -30,6 +31,8 @@ class MultiStepWrapper(nn.Module):
         self.invar = 1 * params.add_orography + 2 * params.add_landmask
 
     def forward(self, inp, coszen=None):
+        if inp.is_cuda and hasattr(self.model, "forward_rollout") and os.environ.get("SWV2_ROLLOUT_INPLACE", "1") == "1":
+            return self._forward_inplace(inp, coszen)
         result = []
         inpt = inp
         invars = inp[:, -self.invar:, :, :] if self.invar else None
@@ -44,6 +47,31 @@ class MultiStepWrapper(nn.Module):
             if self.invar:
                 inpt = torch.cat([inpt, invars], dim=1)
         return torch.cat(result, dim=1)
+
+
+def _mswf_inplace(self, inp, coszen=None):
+    """the same rollout (helpers.py:26-41) without the per-step torch.cat copies: every step's head epilogue writes its
+    prediction into the concatenated result buffer AND into the next step's input buffer, whose remaining channels (next
+    cos-zenith, invariants: 1 + 3 planes) are the only data copied on the host side of the kernel boundary."""
+    from .swinv2_global import _GatherFn
+    S = self.n_future + 1
+    B, _, H, W = inp.shape
+    Cout = self.model.out_chans
+    result = torch.empty(B, S * Cout, H, W, dtype=torch.float32, device=inp.device)
+    invars = inp[:, -self.invar:, :, :] if self.invar else None
+    preds, inpt = [], inp
+    for step in range(S):
+        extra = None
+        if step < self.n_future:
+            parts = ([coszen[:, step:step + 1, :, :]] if coszen is not None else []) + ([invars] if self.invar else [])
+            extra = torch.cat(parts, dim=1).float() if parts else inp.new_empty(B, 0, H, W)
+        pred, nxt = self.model.forward_rollout(inpt, result, step * Cout, extra)
+        preds.append(pred)
+        inpt = nxt
+    return _GatherFn.apply(result, *preds)
+
+
+MultiStepWrapper._forward_inplace = _mswf_inplace
 
 
 def get_model(params):

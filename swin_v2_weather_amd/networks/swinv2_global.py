@@ -188,7 +188,7 @@ class _BlockRunner:
 class _BlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, bias, dp1, dp2, logit_scale, qkv_w, qkv_b, proj_w, proj_b, n1_w, n1_b, fc1_w, fc1_b, fc2_w,
-                fc2_b, n2_w, n2_b, blk):
+                fc2_b, n2_w, n2_b, blk, ckpt=0):
         B, gh, gw, Cc = x.shape
         run = blk._runner(B, x.device)
         d = run.desc
@@ -206,9 +206,18 @@ class _BlockFn(torch.autograd.Function):
         ops.block_event_pair("fwd", d)
         L.check(ops._timed("block_fwd", L.load().swv2_block_fwd, run.desc, ops._stream()), "swv2_block_fwd")
         del keep
-        ctx.blk, ctx.run, ctx.has_bias = blk, run, bias is not None
+        ctx.blk, ctx.run, ctx.has_bias, ctx.ckpt = blk, run, bias is not None, int(ckpt)
         e = x.new_empty(0)
-        ctx.save_for_backward(x, bias_c if bias is not None else e, dp1 if dp1 is not None else e, dp2 if dp2 is not None else e,
+        if ckpt:
+            # selective activation checkpointing (swinv2_global.py:650-651 / torch.utils.checkpoint in the reference): only the
+            # block INPUT survives the forward (fp32, or bf16 with ckpt = 2: 1/18 resp. 1/36 of the block's saved bytes), the
+            # drawn DropPath scales and the CPB table are kept as they are (a few KB / 0.8 MB: no RNG replay needed), and the
+            # backward first re-runs swv2_block_fwd into a fresh activation buffer
+            acts = e
+            xs = x.to(BF16) if ckpt == 2 else x
+        else:
+            xs = x
+        ctx.save_for_backward(xs, bias_c if bias is not None else e, dp1 if dp1 is not None else e, dp2 if dp2 is not None else e,
                               acts, logit_scale, qkv_w, qkv_b, proj_w, proj_b, n1_w, n1_b, fc1_w, fc1_b, fc2_w, fc2_b, n2_w, n2_b)
         return x2
 
@@ -222,6 +231,18 @@ class _BlockFn(torch.autograd.Function):
         keep = run.set_params(blk._wcache, logit_scale, qkv_w, qkv_b, proj_w, proj_b, n1_w, n1_b, fc1_w, fc1_b, fc2_w, fc2_b,
                               n2_w, n2_b, backward=True)
         dx2 = dx2.contiguous().float()
+        if ctx.ckpt:
+            x = x.float() if x.dtype != torch.float32 else x
+            acts = torch.empty(run.act_bytes, dtype=torch.uint8, device=dev)
+            x2_tmp = torch.empty_like(x)
+            run.set_acts(acts)
+            d.x, d.x2 = x.data_ptr(), x2_tmp.data_ptr()
+            d.bias = bias_c.data_ptr() if ctx.has_bias else None
+            d.dp1 = dp1.data_ptr() if dp1.numel() else None
+            d.dp2 = dp2.data_ptr() if dp2.numel() else None
+            d.ev_kernel = 0
+            L.check(L.load().swv2_block_fwd(run.desc, ops._stream()), "swv2_block_fwd (recompute)")
+            del x2_tmp
         run.set_acts(acts)
         scratch = torch.empty(run.scr_bytes, dtype=torch.uint8, device=dev)
         sb = scratch.data_ptr()
@@ -262,7 +283,7 @@ class _BlockFn(torch.autograd.Function):
             g = [grads[o // 4:o // 4 + int(torch.Size(s).numel())].view(*s) for o, s in zip(run.grad_off, run.grad_shapes)]
         (dlogit, dqkvw, dqkvb, dprojw, dprojb, dn1w, dn1b, dfc1w, dfc1b, dfc2w, dfc2b, dn2w, dn2b) = g
         return (dx, dbias, None, None, dlogit, dqkvw, dqkvb, dprojw, dprojb, dn1w, dn1b, dfc1w, dfc1b, dfc2w, dfc2b, dn2w,
-                dn2b, None)
+                dn2b, None, None)
 
 
 class _CpbFn(torch.autograd.Function):
@@ -494,18 +515,23 @@ class SwinTransformerV2CrBlock(nn.Module):
             r = self._runners[key] = _BlockRunner(self, self._plan(B, device), self.dim, self.mlp.fc1.weight.shape[0], device)
         return r
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        """x: [B, H, W, C] fp32 -> [B, H, W, C]"""
+    def forward(self, x: torch.Tensor, ckpt: int = 0, dp_scales: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x: [B, H, W, C] fp32 -> [B, H, W, C].  ckpt: 0 = keep the activations, 1 / 2 = keep only the fp32 / bf16 block input
+        and recompute the forward inside the backward (activation checkpointing).  dp_scales [2, B]: DropPath scales already
+        drawn by the stage for this block's two sites (None: drawn here, one launch per site)."""
         _need_gpu(x, "SwinTransformerV2CrBlock")
         if tuple(x.shape[1:3]) != self.feat_size:
             raise L.Swv2Error(f"block built for feature size {self.feat_size}, got {tuple(x.shape[1:3])}")
         bias = self.attn.position_bias()
-        dp1 = self.drop_path1.scale(x) if isinstance(self.drop_path1, DropPath) else None
-        dp2 = self.drop_path2.scale(x) if isinstance(self.drop_path2, DropPath) else None
+        if dp_scales is not None and isinstance(self.drop_path1, DropPath) and self.drop_path1.drop_prob > 0.0:
+            dp1, dp2 = dp_scales[0], dp_scales[1]
+        else:
+            dp1 = self.drop_path1.scale(x) if isinstance(self.drop_path1, DropPath) else None
+            dp2 = self.drop_path2.scale(x) if isinstance(self.drop_path2, DropPath) else None
         a, m = self.attn, self.mlp
         return _BlockFn.apply(x.float(), bias, dp1, dp2, a.logit_scale, a.qkv.weight, a.qkv.bias, a.proj.weight,
                               a.proj.bias, self.norm1.weight, self.norm1.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight,
-                              m.fc2.bias, self.norm2.weight, self.norm2.bias, self)
+                              m.fc2.bias, self.norm2.weight, self.norm2.bias, self, ckpt if torch.is_grad_enabled() else 0)
 
 
 # ================================================================================================
@@ -526,7 +552,9 @@ class _PatchEmbedFn(torch.autograd.Function):
         ops.linear(ops.op_patch(x), wb, ops.epilogue(L.EPI_BF16, a0, ld=Cc, bias=b.detach()), Cc)
         pos_t = None
         if pos is not None:   # [1,C,gh,gw] -> [T][C] rows, broadcast over the batch by the kernel (res_mod = T)
-            pos_t = mod._wcache.get("pos", (pos,), lambda: pos.detach().permute(0, 2, 3, 1).reshape(T, Cc).contiguous())
+            pos_t = pos.detach().permute(0, 2, 3, 1).reshape(T, Cc)
+            if not pos_t.is_contiguous():        # parameter not stored channels-last (e.g. replaced by the caller): copy, cached
+                pos_t = mod._wcache.get("pos", (pos,), lambda: pos.detach().permute(0, 2, 3, 1).reshape(T, Cc).contiguous())
         e = torch.empty(B * T, Cc, dtype=torch.float32, device=dev)
         mean = torch.empty(B * T, dtype=torch.float32, device=dev)
         rstd = torch.empty(B * T, dtype=torch.float32, device=dev)
@@ -641,12 +669,23 @@ class PatchMerging(nn.Module):
         return _PatchMergingFn.apply(x, self.norm.weight, self.norm.bias, self.reduction.weight, self)
 
 
+def _alias(base: torch.Tensor, offset_elems: int, size, stride) -> torch.Tensor:
+    """a fresh tensor object (no autograd view relation) over `base`'s storage"""
+    return base.new_empty(0).set_(base.untyped_storage(), base.storage_offset() + offset_elems, size, stride)
+
+
 class _HeadFn(torch.autograd.Function):
     """e[B,gh,gw,C] -> y[B,Cout,H,W] = un-patchify(e W_head^T) (+ skip[:, :Cout]) (reference :784-802): one GEMM whose
-    epilogue writes NCHW rows directly (head weight rows permuted to channel-major)."""
+    epilogue writes NCHW rows directly (head weight rows permuted to channel-major).
+
+    `dst` (autoregressive rollout, helpers.py:26-41) = (result, coff): the prediction is written straight into channels
+    coff .. coff + Cout of the caller's concatenated `result` buffer [B, S*Cout, H, W] (returned as an alias of that slice), and
+    -- when `extra` [B, Cextra, H, W] (next cos-zenith + invariant channels, may have 0 channels) is not None -- ALSO into the
+    first Cout channels of a new next-step input [B, Cout + Cextra, H, W], returned as second output.  Both destinations are
+    filled by the same epilogue pass (the reference makes two torch.cat copies per step)."""
 
     @staticmethod
-    def forward(ctx, e, w, skip, mod):
+    def forward(ctx, e, w, skip, mod, dst=None, extra=None):
         B, gh, gw, Cc = e.shape
         Cout = mod.out_chans
         H, W = gh * 4, gw * 4
@@ -654,35 +693,81 @@ class _HeadFn(torch.autograd.Function):
         e2d = e.contiguous().view(B * gh * gw, Cc).float()
         perm = mod._head_perm(dev)
         wb = mod._wcache.get("head", (w,), lambda: ops.prep_weight(w, row_map=perm))
-        y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=dev)
         Cs = 0
         if skip is not None:
             skip = skip.contiguous().float()
             Cs = skip.shape[1]
-        ops.linear(ops.op_f32(e2d), wb, ops.epilogue(L.EPI_UNPATCH, y, aux=skip, p=(Cout, H, W, Cs, 0)), Cout * 16)
-        ctx.mod, ctx.has_skip, ctx.Cs = mod, skip is not None, Cs
+        nxt = None
+        if dst is None:
+            y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=dev)
+            ops.linear(ops.op_f32(e2d), wb, ops.epilogue(L.EPI_UNPATCH, y, aux=skip, p=(Cout, H, W, Cs, 0)), Cout * 16)
+        else:
+            result, coff = dst
+            Ct = result.shape[1]
+            y = _alias(result, coff * H * W, (B, Cout, H, W), (Ct * H * W, H * W, W, 1))
+            if extra is not None:
+                Cn = Cout + extra.shape[1]
+                nxt = torch.empty(B, Cn, H, W, dtype=torch.float32, device=dev)
+                if extra.shape[1]:
+                    nxt[:, Cout:] = extra
+            ep = ops.epilogue(L.EPI_UNPATCH, y, aux=skip, aux_out=nxt, ld=(nxt.shape[1] if nxt is not None else 0),
+                              p=(Cout, H, W, Cs, Ct))
+            ops.linear(ops.op_f32(e2d), wb, ep, Cout * 16)
+        ctx.mod, ctx.has_skip, ctx.Cs, ctx.rollout = mod, skip is not None, Cs, dst is not None
+        ctx.n_extra = 0 if (dst is None or extra is None) else extra.shape[1]
         ctx.save_for_backward(e2d, w)
-        return y
+        if dst is None:
+            return y
+        return y, nxt
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dnxt=None):
         e2d, w = ctx.saved_tensors
         mod = ctx.mod
         B, Cout, H, W = dy.shape
         Cc, dev = e2d.shape[1], e2d.device
-        dy = dy.contiguous().float()
+        # dy may be a channel slice of the gradient of the concatenated rollout output: read in place through its batch stride
+        if dy.dtype != torch.float32 or dy.stride()[1:] != (H * W, W, 1) or dy.stride(0) % (H * W):
+            dy = dy.contiguous().float()
+        Ct = dy.stride(0) // (H * W)
+
+        def op_dy():
+            o = ops.operand(L.OP_PATCH, dy, B * (H // 4) * (W // 4), Cout * 16, 0, p=(Cout, H, W, 0 if Ct == Cout else Ct))
+            if dnxt is not None:           # + gradient that came back through the next step's input (its first Cout channels)
+                o.aux0, o.ld = dnxt.data_ptr(), dnxt.shape[1]
+                o._keep = (o._keep, dnxt)
+            return o
+        if dnxt is not None:
+            dnxt = dnxt.contiguous().float()
         perm = mod._head_perm(dev)
         f32 = dict(dtype=torch.float32, device=dev)
         dw = torch.zeros(Cout * 16, Cc, **f32)
-        ops.linear_wgrad(ops.op_patch(dy), ops.op_f32(e2d), dw, None, nmap=perm)
+        ops.linear_wgrad(op_dy(), ops.op_f32(e2d), dw, None, nmap=perm)
         wt = mod._wcache.get("headt", (w,), lambda: ops.prep_weight(w, transpose=True, col_map=perm))
         de = torch.empty(B * (H // 4) * (W // 4), Cc, **f32)
-        ops.linear(ops.op_patch(dy), wt, ops.epilogue(L.EPI_F32, de, ld=Cc), Cc)
+        ops.linear(op_dy(), wt, ops.epilogue(L.EPI_F32, de, ld=Cc), Cc)
         dskip = None
         if ctx.has_skip and ctx.needs_input_grad[2]:
             dskip = torch.zeros(B, ctx.Cs, H, W, **f32)
-            dskip[:, :Cout] = dy
-        return de.view(B, H // 4, W // 4, Cc), dw, dskip, None
+            dskip[:, :Cout] = dy if dnxt is None else dy + dnxt[:, :Cout]
+        # gradient of the re-appended channels (the invariants are a view of the step-0 input: helpers.py:28,39)
+        dextra = dnxt[:, Cout:] if (dnxt is not None and ctx.n_extra and ctx.needs_input_grad[5]) else None
+        return de.view(B, H // 4, W // 4, Cc), dw, dskip, None, None, dextra
+
+
+class _GatherFn(torch.autograd.Function):
+    """the concatenated rollout output as ONE autograd value: forward returns the buffer the heads have already filled,
+    backward hands every step its channel slice of the gradient (a strided view, read in place by _HeadFn.backward)"""
+
+    @staticmethod
+    def forward(ctx, result, *preds):
+        ctx.n, ctx.c = len(preds), preds[0].shape[1]
+        return _alias(result, 0, result.shape, result.stride())
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        return (None,) + tuple(g[:, i * ctx.c:(i + 1) * ctx.c] for i in range(ctx.n))
 
 
 # ================================================================================================
@@ -715,6 +800,8 @@ class SwinTransformerV2CrStage(nn.Module):
                 sequential_attn=sequential_attn, norm_layer=norm_layer, rel_pos=rel_pos)
             for index in range(depth)])
 
+    _dp_keep = None
+
     def update_input_size(self, new_window_size, new_feat_size: Tuple[int, int]) -> None:
         self.feat_size = (new_feat_size[0] // 2, new_feat_size[1] // 2) if self.downscale else tuple(new_feat_size)
         for block in self.blocks:
@@ -722,11 +809,30 @@ class SwinTransformerV2CrStage(nn.Module):
 
     def forward_bhwc(self, x: torch.Tensor) -> torch.Tensor:
         x = self.downsample(x)
-        for block in self.blocks:
-            if self.grad_checkpointing and torch.is_grad_enabled():
+        # activation checkpointing (reference :650-651 wraps every block in torch.utils.checkpoint): here the block's own
+        # autograd node keeps only its input and re-runs swv2_block_fwd in the backward -- same arithmetic, no second Python
+        # pass, no RNG stashing (the drawn DropPath scales / CPB table are kept).  SWV2_CKPT_BF16=1 halves the kept bytes (the
+        # recompute then starts from the bf16-rounded input); SWV2_CKPT_TORCH=1 uses the stock torch.utils.checkpoint wrapper.
+        mode = 0
+        if self.grad_checkpointing and torch.is_grad_enabled():
+            mode = 2 if os.environ.get("SWV2_CKPT_BF16", "0") == "1" else 1
+        torch_ckpt = mode and os.environ.get("SWV2_CKPT_TORCH", "0") == "1"
+        # stochastic depth: ONE Bernoulli launch + one scale for all 2 x depth DropPath sites of the stage (the per-site draws
+        # of the reference cost 4 tiny launches per block); per-site keep probabilities, timm's mask / keep_prob scaling.
+        # SWV2_DROPPATH_PER_SITE=1 restores one draw per site in the reference's order.
+        scales = None
+        if self.training and not torch_ckpt and os.environ.get("SWV2_DROPPATH_PER_SITE", "0") != "1":
+            rates = [b.drop_path1.drop_prob if isinstance(b.drop_path1, DropPath) else 0.0 for b in self.blocks]
+            if any(r > 0.0 for r in rates):
+                if self._dp_keep is None or self._dp_keep.device != x.device or self._dp_keep.shape[2] != x.shape[0]:
+                    keep = torch.tensor([[1.0 - r] * 2 for r in rates], dtype=torch.float32, device=x.device)
+                    self._dp_keep = keep.unsqueeze(-1).expand(len(rates), 2, x.shape[0]).contiguous()
+                scales = torch.bernoulli(self._dp_keep).div_(self._dp_keep)            # [depth, 2, B]
+        for i, block in enumerate(self.blocks):
+            if torch_ckpt:
                 x = checkpoint(block, x, use_reentrant=False)
             else:
-                x = block(x)
+                x = block(x, mode, None if scales is None else scales[i])
         return x
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -772,7 +878,9 @@ class SwinTransformerV2Cr(nn.Module):
         self.stages = nn.Sequential(*stages)
         self.head = nn.Linear(embed_dim, self.out_chans * self.patch_size * self.patch_size, bias=False)
         if self.full_pos_embed:
-            self.pos_embed = nn.Parameter(torch.randn(1, embed_dim, grid[0], grid[1]) * .02)
+            # same values as the reference's draw (:770), stored channels-last: the memory IS the [T][C] row table the
+            # PatchEmbed LayerNorm kernel adds, and its gradient is produced in that layout -- no 33 MB permute copies per step
+            self.pos_embed = nn.Parameter((torch.randn(1, embed_dim, grid[0], grid[1]) * .02).contiguous(memory_format=torch.channels_last))
         self._wcache = _WeightCache()
         self._perm = None
 
@@ -801,6 +909,13 @@ class SwinTransformerV2Cr(nn.Module):
         _need_gpu(x, "SwinTransformerV2Cr")
         e = self._features_bhwc(x)
         return _HeadFn.apply(e, self.head.weight, x if self.residual else None, self)
+
+    def forward_rollout(self, x: torch.Tensor, result: torch.Tensor, coff: int, extra: Optional[torch.Tensor]):
+        """one autoregressive step (MultiStepWrapper): prediction written into result[:, coff : coff + Cout] and, if `extra`
+        is given, into the next step's input [pred | extra]; returns (pred alias, next input | None)"""
+        _need_gpu(x, "SwinTransformerV2Cr")
+        e = self._features_bhwc(x)
+        return _HeadFn.apply(e, self.head.weight, x if self.residual else None, self, (result, coff), extra)
 
     def update_input_size(self, new_img_size=None, new_window_size=None, img_window_ratio: int = 32) -> None:
         raise L.Swv2Error("update_input_size is broken in the reference itself (wrong kwarg, :829-832); rebuild the model")

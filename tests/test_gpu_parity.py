@@ -589,6 +589,52 @@ def test_multistep_wrapper_against_reference_fixture(dev, K):
     assert worst_grad(m, {k[2:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("g:")}) < 8e-2
 
 
+def test_rollout_inplace_and_selective_checkpointing(dev, K, monkeypatch):
+    """(1) the in-place rollout (head epilogue writes the prediction into the concatenated result AND the next
+    step's input; gradients of the fed-back prediction are added on load) equals the reference-shaped torch.cat rollout bit for
+    bit -- 3 steps, zenith + invariants, residual skip; (2) selective checkpointing (only block inputs kept, forward re-run
+    inside the backward node) gives identical outputs / gradients in fp32 mode and bf16-level ones with SWV2_CKPT_BF16=1."""
+    from types import SimpleNamespace
+    params = SimpleNamespace(img_size=(48, 72), patch_size=4, depth=2, num_heads=2, n_in_channels=9, n_out_channels=5,
+                             embed_dim=24, window_ratio=8, drop_path_rate=0.0, full_pos_embed=True, rel_pos=True, mlp_ratio=4,
+                             activation_ckpt=False, residual=True, nettype="swin", n_future=2, add_orography=True, add_landmask=True)
+    torch.manual_seed(21)
+    m = K["helpers"].get_model(params)
+    with torch.no_grad():
+        for n_, p_ in m.named_parameters():
+            if n_.endswith("norm1.weight") or n_.endswith("norm2.weight"):
+                p_.uniform_(0.5, 1.5)
+    m = m.to(dev).eval()
+    inp0 = torch.randn(2, 9, 48, 72, device=dev)
+    cz = torch.rand(2, 3, 48, 72, device=dev) * 2 - 1
+    gy = torch.randn(2, 15, 48, 72, device=dev)
+
+    def run():
+        m.zero_grad()
+        x = inp0.clone().requires_grad_(True)
+        y = m(x, coszen=cz)
+        y.backward(gy)
+        return y.detach().clone(), x.grad.clone(), {n_: p_.grad.clone() for n_, p_ in m.named_parameters()}
+    monkeypatch.setenv("SWV2_ROLLOUT_INPLACE", "0")
+    y0, gx0, gp0 = run()
+    monkeypatch.setenv("SWV2_ROLLOUT_INPLACE", "1")
+    y1, gx1, gp1 = run()
+    # (the CPB-bias / logit-scale gradients are accumulated with float atomics: equal up to the order of summation)
+    assert torch.equal(y1, y0) and rel(gx1, gx0) < 1e-5
+    assert max(rel(gp1[k], gp0[k]) for k in gp0 if float(gp0[k].abs().max()) > 0) < 2e-3
+    m.model.set_grad_checkpointing(True)
+    y2, gx2, gp2 = run()
+    assert torch.equal(y2, y1) and rel(gx2, gx1) < 1e-5
+    assert max(rel(gp2[k], gp1[k]) for k in gp1 if float(gp1[k].abs().max()) > 0) < 2e-3
+    monkeypatch.setenv("SWV2_CKPT_BF16", "1")
+    y3, gx3, gp3 = run()
+    assert torch.equal(y3, y1) and rel(gx3, gx1) < 2e-2
+    monkeypatch.setenv("SWV2_CKPT_BF16", "0")
+    monkeypatch.setenv("SWV2_CKPT_TORCH", "1")                 # the stock torch.utils.checkpoint wrapper still works through the nodes
+    y4, gx4, _ = run()
+    assert torch.equal(y4, y1) and rel(gx4, gx1) < 1e-5
+
+
 def test_loss_handler_against_reference_values(dev, K):
     from types import SimpleNamespace
     from swin_v2_weather_amd.utils.losses import LossHandler
@@ -1120,3 +1166,42 @@ def test_host_pipeline_end_to_end(dev, K, pinned):
                     assert float((tz[b, s_].cpu() - cos_zenith(src.years[y], 6.0 * (t + 1 + s_), H, W)).abs().max()) < 2e-5
             busy = busy @ busy * 1e-3                          # keep the compute stream busy past the next __next__
         assert i == len(pipe) - 1
+
+
+def test_registry_checkpoint_and_inference_rollout(dev, K, tmp_path):
+    """a registry folder as the reference publishes it (README.md:32-44: flat hyperparams.yaml dumped by
+    train.py:156-163, weights.tar saved from the DDP-wrapped wrapper: keys `module.model.*`) loads into the HIP model, and the
+    no-grad inference rollout equals MultiStepWrapper's forward with the same weights, step for step."""
+    import yaml
+    from types import SimpleNamespace
+    from swin_v2_weather_amd import inference
+    hp = dict(nettype="swin", img_size=[48, 72], patch_size=4, depth=2, num_heads=2, embed_dim=24, window_ratio=8,
+              drop_path_rate=0.1, full_pos_embed=True, rel_pos=True, mlp_ratio=4, activation_ckpt=False, residual=True,
+              in_channels=list(range(5)), out_channels=list(range(5)), add_zenith=True, add_orography=True, add_landmask=True,
+              n_in_channels=9, n_out_channels=5, n_future=2, lr="1E-3")
+    reg = tmp_path / "swin_test_registry"
+    reg.mkdir()
+    yaml.safe_dump(hp, open(reg / "hyperparams.yaml", "w"))
+    torch.manual_seed(31)
+    ms = K["helpers"].get_model(SimpleNamespace(**hp))                       # MultiStepWrapper(n_future = 2): the training-time module
+    with torch.no_grad():
+        for n_, p_ in ms.named_parameters():
+            if n_.endswith("norm1.weight") or n_.endswith("norm2.weight"):
+                p_.uniform_(0.5, 1.5)
+    torch.save({"iters": 7, "epoch": 1, "model_state": {"module." + k: v for k, v in ms.state_dict().items()},
+                "optimizer_state_dict": {}}, reg / "weights.tar")
+    np.save(reg / "global_means.npy", np.zeros((1, 73, 1, 1), np.float32))
+    np.save(reg / "global_stds.npy", np.ones((1, 73, 1, 1), np.float32))
+    model, p, stats = inference.load_registry_model(str(reg), dev)
+    assert p["n_future"] == 0 and stats is not None and type(model).__name__ == "SingleStepWrapper"
+    x0 = torch.randn(2, 9, 48, 72, device=dev)
+    cz = torch.rand(2, 3, 48, 72, device=dev) * 2 - 1
+    y = inference.rollout(model, x0, 3, cz[:, :2], n_invar=3)
+    ref = ms.to(dev).eval()(x0, coszen=cz)
+    assert torch.equal(y.reshape(2, 15, 48, 72), ref)
+    # the other prefixes a reference checkpoint can carry
+    for pre in ("", "model.", "module.model."):
+        sd = {pre + k[len("model."):]: v for k, v in ms.state_dict().items()}
+        inference.load_model_state(model, sd)
+    with pytest.raises(KeyError):
+        inference.load_model_state(model, {"bogus": torch.zeros(1)})

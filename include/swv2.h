@@ -157,6 +157,22 @@ size_t swv2_linear_wgrad_ws_bytes(int M, int N, int K, int splits);
 int swv2_linear_wgrad_ws(const swv2_operand* dy, const swv2_operand* x, float* dW, float* db, const int32_t* nmap,
                          const int32_t* kmap, int ldw, int splits, void* ws, size_t ws_bytes, void* stream);
 
+/* The four weight gradients of one transformer block in ONE launch + one reduction (item 0: fc2 = (BF16, BF16_GELU),
+ * 1: fc1 = (BF16, F32), 2: proj = (BF16, HEADS), 3: qkv = (HEADS, F32); any other operand kinds -> SWV2_ERR_INVALID).
+ * Same results as four swv2_linear_wgrad_ws calls up to the summation order of the row slices.  slices = 0 picks the
+ * count that fills the chip in one round (2 workgroups per CU); ws >= swv2_block_wgrad_ws_bytes(C, hidden, heads * DP,
+ * slices) bytes.  Replaces: the autograd of the block's four nn.Linear weights (swinv2_global.py:146-201, 231-248). */
+typedef struct swv2_wgrad_item {
+    swv2_operand dy, x;
+    float* dW;
+    float* db;             /* optional */
+    const int32_t* nmap;
+    const int32_t* kmap;
+    int ldw;
+} swv2_wgrad_item;
+size_t swv2_block_wgrad_ws_bytes(int C, int hidden, int heads_dp, int slices);
+int swv2_block_wgrad(const swv2_wgrad_item* items4, int slices, void* ws, size_t ws_bytes, void* stream);
+
 /* out_bf16[i][j] = W'[row_map ? row_map[i] : i][col_map ? col_map[j] : j] (0 where a map entry is negative),
  * W' = transpose ? w^T : w, w fp32 [rows][cols].  Casts, transposes, permutes and pads a parameter once per step. */
 int swv2_prep_weight(const float* w, int rows, int cols, int transpose, const int32_t* row_map, int out_rows,
@@ -401,6 +417,8 @@ typedef struct swv2_block_desc {
     size_t wgrad_ws_bytes;
     int wgrad_side_stream;   /* 1: backward launches the 4 weight-gradient products on the library's per-device side stream
                                 (fork after each producer, join before returning) so they overlap with the dX chain */
+    int wgrad_group;         /* 1 (with fuse_mlp + fuse_proj_ln paths and a workspace): the four products run as ONE
+                                swv2_block_wgrad launch at the end of the backward (launch id 22) */
 } swv2_block_desc;
 
 int swv2_block_fwd(const swv2_block_desc* d, void* stream);

@@ -65,6 +65,11 @@ class Operand(C.Structure):
                 ("rows", C.c_int), ("cols", C.c_int), ("p", C.c_int * 4)]
 
 
+class WgradItem(C.Structure):
+    _fields_ = [("dy", Operand), ("x", Operand), ("dW", C.c_void_p), ("db", C.c_void_p), ("nmap", C.c_void_p),
+                ("kmap", C.c_void_p), ("ldw", C.c_int)]
+
+
 class Epilogue(C.Structure):
     _fields_ = [("kind", C.c_int), ("out", C.c_void_p), ("bias", C.c_void_p), ("aux", C.c_void_p),
                 ("aux_out", C.c_void_p), ("rowidx", C.c_void_p), ("ld", C.c_long), ("p", C.c_int * 5)]
@@ -118,7 +123,7 @@ class BlockDesc(C.Structure):
                     "d_logit_scale", "d_bias", "d_qkv_w", "d_qkv_b", "d_proj_w", "d_proj_b", "d_n1_w", "d_n1_b", "d_fc1_w",
                     "d_fc1_b", "d_fc2_w", "d_fc2_b", "d_n2_w", "d_n2_b")] +
                 [("wgrad_splits", C.c_int), ("ev_kernel", C.c_int), ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p),
-                 ("fuse_proj_ln", C.c_int), ("fuse_attn", C.c_int), ("fuse_mlp", C.c_int), ("wgrad_ws", C.c_void_p), ("wgrad_ws_bytes", C.c_size_t), ("wgrad_side_stream", C.c_int)])
+                 ("fuse_proj_ln", C.c_int), ("fuse_attn", C.c_int), ("fuse_mlp", C.c_int), ("wgrad_ws", C.c_void_p), ("wgrad_ws_bytes", C.c_size_t), ("wgrad_side_stream", C.c_int), ("wgrad_group", C.c_int)])
 
 
 OP_F32, OP_BF16, OP_BF16_GELU, OP_HEADS, OP_PATCH, OP_MERGE_LN = range(6)
@@ -137,6 +142,8 @@ SYMBOLS = {
     "swv2_linear": (_I, [C.POINTER(Operand), _P, C.POINTER(Epilogue), _I, _P]),
     "swv2_linear_wgrad": (_I, [C.POINTER(Operand), C.POINTER(Operand), _P, _P, _P, _P, _I, _I, _P]),
     "swv2_linear_wgrad_ws_bytes": (C.c_size_t, [_I, _I, _I, _I]),
+    "swv2_block_wgrad_ws_bytes": (C.c_size_t, [_I, _I, _I, _I]),
+    "swv2_block_wgrad": (_I, [C.POINTER(WgradItem), _I, _P, C.c_size_t, _P]),
     "swv2_linear_wgrad_ws": (_I, [C.POINTER(Operand), C.POINTER(Operand), _P, _P, _P, _P, _I, _I, _P, C.c_size_t, _P]),
     "swv2_prep_weight": (_I, [_P, _I, _I, _I, _P, _I, _P, _I, _P, _P]),
     "swv2_ln_residual_fwd": (_I, [C.POINTER(LnArgs), _P]),

@@ -164,6 +164,10 @@ extern "C" int swv2_block_bwd(const swv2_block_desc* d, void* st) {
     SideStream* ss = d->wgrad_side_stream ? side_stream() : nullptr;
     void* ws = ss ? (void*)ss->s : st;            // stream of the weight-gradient products
     const bool fused = d->fuse_mlp && swv2_mlp_supported(C, hid);
+    const bool fused_pl = d->fuse_proj_ln && swv2_proj_ln_supported(C, h, d->DP);
+    // the four weight gradients as ONE launch after the data path (needs the operand set of the fused paths)
+    const bool group = d->wgrad_group && fused && fused_pl && d->wgrad_ws && !ss &&
+                       d->wgrad_ws_bytes >= swv2_block_wgrad_ws_bytes(C, hid, h * d->DP, 0);
     if (fused) {
         // 7', 6', 5' data path fused: LN2 backward, dh = (da2 W2) * GELU'(hpre), dx1 = dx2 + dh W1 in one kernel
         swv2_mlp_bwd_args m = {};
@@ -175,8 +179,10 @@ extern "C" int swv2_block_bwd(const swv2_block_desc* d, void* st) {
         swv2_operand dy2 = op(SWV2_OP_BF16, d->da2, BT, C, C), x2 = op(SWV2_OP_BF16_GELU, d->hpre, BT, hid, hid);
         swv2_operand dy1 = op(SWV2_OP_BF16, d->dh, BT, hid, hid), x1 = op(SWV2_OP_F32, d->x1, BT, C, C);
         if (ss) fork_to(ss, (hipStream_t)st);
+        if (!group) {
         LAUNCH(12, swv2_linear_wgrad_ws(&dy2, &x2, d->d_fc2_w, d->d_fc2_b, nullptr, nullptr, hid, sp, d->wgrad_ws, d->wgrad_ws_bytes, ws));
         LAUNCH(14, swv2_linear_wgrad_ws(&dy1, &x1, d->d_fc1_w, d->d_fc1_b, nullptr, nullptr, C, sp, d->wgrad_ws, d->wgrad_ws_bytes, ws));
+        }
     } else {
     // 7'. LN2 backward
     {
@@ -203,7 +209,7 @@ extern "C" int swv2_block_bwd(const swv2_block_desc* d, void* st) {
         LAUNCH(15, swv2_linear(&dy, d->w_fc1t, &e, C, st));
     }
     }
-    if (d->fuse_proj_ln && swv2_proj_ln_supported(C, h, d->DP)) {
+    if (fused_pl) {
         // 4' + the data path of 3' fused: LN1 backward (row gather) and d(oh) = split(da1 Wp) in one kernel
         swv2_proj_ln_bwd_args m = {};
         m.dy = d->dx1; m.a1 = d->a1; m.mean = d->mean1; m.rstd = d->rstd1; m.gamma = d->n1_w; m.scale = d->dp1; m.rowidx = d->rowidx;
@@ -212,6 +218,7 @@ extern "C" int swv2_block_bwd(const swv2_block_desc* d, void* st) {
         LAUNCH(16, swv2_proj_ln_bwd(&m, st));
         swv2_operand dy = op(SWV2_OP_BF16, d->da1, Mw, C, C), x = op_heads(d->oh, Bw, h, 1, d->Lp, d->DP);
         if (ss) fork_to(ss, (hipStream_t)st);
+        if (!group)
         LAUNCH(17, swv2_linear_wgrad_ws(&dy, &x, d->d_proj_w, d->d_proj_b, nullptr, d->proj_map, C, sp, d->wgrad_ws, d->wgrad_ws_bytes, ws));
     } else {
     // 4'. LN1 backward (gathers dx1 rows through the window table; padded rows -> 0)
@@ -244,9 +251,22 @@ extern "C" int swv2_block_bwd(const swv2_block_desc* d, void* st) {
     {
         swv2_operand dy = op_heads(d->dqkvh, Bw, h, 3, d->Lp, d->DP), x = op(SWV2_OP_F32, d->x, Mw, C, C, d->rowidx);
         if (ss) fork_to(ss, (hipStream_t)st);
+        if (!group)
         LAUNCH(20, swv2_linear_wgrad_ws(&dy, &x, d->d_qkv_w, d->d_qkv_b, d->qkv_map, nullptr, C, sp, d->wgrad_ws, d->wgrad_ws_bytes, ws));
         swv2_epilogue e = epi(SWV2_EPI_F32, d->dx, C, nullptr, d->dx1, nullptr, d->rowidx);
         LAUNCH(21, swv2_linear(&dy, d->w_qkvt, &e, C, st));
+    }
+    if (group) {
+        swv2_wgrad_item it[4] = {};
+        it[0].dy = op(SWV2_OP_BF16, d->da2, BT, C, C); it[0].x = op(SWV2_OP_BF16_GELU, d->hpre, BT, hid, hid);
+        it[0].dW = d->d_fc2_w; it[0].db = d->d_fc2_b; it[0].ldw = hid;
+        it[1].dy = op(SWV2_OP_BF16, d->dh, BT, hid, hid); it[1].x = op(SWV2_OP_F32, d->x1, BT, C, C);
+        it[1].dW = d->d_fc1_w; it[1].db = d->d_fc1_b; it[1].ldw = C;
+        it[2].dy = op(SWV2_OP_BF16, d->da1, Mw, C, C); it[2].x = op_heads(d->oh, Bw, h, 1, d->Lp, d->DP);
+        it[2].dW = d->d_proj_w; it[2].db = d->d_proj_b; it[2].kmap = d->proj_map; it[2].ldw = C;
+        it[3].dy = op_heads(d->dqkvh, Bw, h, 3, d->Lp, d->DP); it[3].x = op(SWV2_OP_F32, d->x, Mw, C, C, d->rowidx);
+        it[3].dW = d->d_qkv_w; it[3].db = d->d_qkv_b; it[3].nmap = d->qkv_map; it[3].ldw = C;
+        LAUNCH(22, swv2_block_wgrad(it, 0, d->wgrad_ws, d->wgrad_ws_bytes, st));
     }
     if (ss) join_from(ss, (hipStream_t)st);
     return SWV2_OK;

@@ -12,14 +12,36 @@ constexpr int TM = 128;                     // rows per step (4 MFMA k-steps of 
 constexpr int TP = 136;                     // LDS row pitch (elements) of the [TM][128] tiles: 272 B
 constexpr int TCH = TM * 16 / NTHREADS;     // 16-byte chunks per thread per operand per step (8)
 
+struct TnOut {                 // one product's destination
+    float* dW; float* db; const int32_t* nmap; const int32_t* kmap; int ldw, M, N, K, ntk, tiles; float* ws;
+};
+constexpr int TN_SMEM = 2 * TM * TP;
+
+// In-kernel phase timing (diagnostic builds only, -DSWV2_TN_STAMPS, tools/probe_tn_stamps.py): wave 0 of every workgroup
+// accumulates s_memtime deltas per phase and overwrites the head of its partial tile with them (results are garbage then).
+#ifdef SWV2_TN_STAMPS
+#define TSTAMP_DECL unsigned long long st_prev = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define TSTAMP_START() do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev) : : "memory"); } while (0)
+#define TSTAMP(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : : "memory"); \
+                       st_acc[k] += t_ - st_prev; st_prev = t_; } while (0)
+#define TSTAMP_WAITV() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define TSTAMP_DECL
+#define TSTAMP_START() do {} while (0)
+#define TSTAMP(k) do {} while (0)
+#define TSTAMP_WAITV() do {} while (0)
+#endif        // [Y | X][TM][TP] bf16, single buffer
+
+// one 128 x 128 output tile over the row chunks of one slice (body shared by the single-product and the grouped kernel)
 template <int YK, int XK>
-__global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(ALoad<YK> yl, ALoad<XK> xl_arg, float* __restrict__ dW,
-                                                           float* __restrict__ db, const int32_t* __restrict__ nmap,
-                                                           const int32_t* __restrict__ kmap, int ldw, int M, int N,
-                                                           int K, int ntk, int rows_per_split, float* __restrict__ ws) {
-    __shared__ __attribute__((aligned(16))) uint16_t smem[2 * TM * TP];          // [Y | X][TM][TP], single buffer
-    __shared__ float dbs[BN];
-    __shared__ __attribute__((aligned(16))) uint16_t gtab[XK == A_BF16_GELU ? GT_N : 8];
+__device__ __forceinline__ void tn_tile(const ALoad<YK>& yl, const ALoad<XK>& xl_arg, const TnOut& o, int tile, int slice,
+                                        int chunk_stride, uint16_t* smem, float* dbs, uint16_t* gtab) {
+    float* __restrict__ dW = o.dW;
+    float* __restrict__ db = o.db;
+    const int32_t* __restrict__ nmap = o.nmap;
+    const int32_t* __restrict__ kmap = o.kmap;
+    const int ldw = o.ldw, M = o.M, N = o.N, K = o.K, ntk = o.ntk, tiles = o.tiles;
+    float* __restrict__ ws = o.ws;
     ALoad<XK> xl = xl_arg;
     if constexpr (XK == A_BF16_GELU) {          // GELU-on-load of the stored bf16 pre-activation through a lookup table
         for (int i = threadIdx.x; i < GT_N; i += NTHREADS) gtab[i] = f2bf(gelu_f(bf2f(gelu_tab_arg(i))));
@@ -29,19 +51,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(ALoad<YK> yl, ALoad<X
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, g = lane >> 4;
     const int wr = wave >> 1, wc = wave & 1;
-    // XCD-aware block -> (tile, row slice) map.  Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one), and
-    // the tiles of one row slice re-read the same dY / X rows: give all tiles of a slice consecutive slots on ONE XCD so
-    // the re-reads hit that XCD's L2 instead of HBM (PMC before: 415 MB vs 198 MB algorithmic for the fc1 gradient).
-    // ntiles = tiles per slice, slices padded to a multiple of 8 by the launcher.  Speed only, never correctness.
-    const int lin = blockIdx.x;                       // 1-D launch: lin = xcd + 8 * (q * tiles + tile)
-    const int tiles = ntk * ((N + BN - 1) / BN);
-    const int x8 = lin & 7, rest = lin >> 3;
-    const int tile = rest % tiles, slice = (rest / tiles) * 8 + x8;
     const int tn = tile / ntk, tk = tile - tn * ntk;
     const int n_base = tn * BN, k_base = tk * BN;
-    const int m_lo = slice * rows_per_split;
-    const int m_hi = min(M, m_lo + rows_per_split);
-    const int steps = (m_hi - m_lo + TM - 1) / TM;
+    // rows: slice s owns the TM-row chunks s, s + S, s + 2S, ... (S = chunk_stride = number of slices).  At any moment the S
+    // slices then stream ONE contiguous S x TM-row region of dY / X, spread over every HBM channel; contiguous row ranges
+    // per slice (the first version) put all slices a multiple of 256 KB .. 1 MB apart, i.e. on the same channels at the
+    // same time, and the kernels sat at 2.6 - 3.0 TB/s.
+    const int nchunks = (M + TM - 1) / TM;
+    const int steps = (slice < chunk_stride && slice < nchunks) ? (nchunks - slice + chunk_stride - 1) / chunk_stride : 0;
+    const int m_hi = M;
     const bool want_db = (db != nullptr) && (tk == 0);
     if (steps <= 0) return;
     if (tid < BN) dbs[tid] = 0.f;
@@ -57,7 +75,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(ALoad<YK> yl, ALoad<X
     auto resolve = [&](int s) {
 #pragma unroll
         for (int i = 0; i < TCH; ++i) {
-            const int m = m_lo + s * TM + srow + 16 * i;
+            const int m = (slice + s * chunk_stride) * TM + srow + 16 * i;
             const bool ok = (s < steps) && (m < m_hi);
             yrow[i] = yl.row_of(ok ? m : M);
             xrow[i] = xl.row_of(ok ? m : M);
@@ -93,13 +111,21 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(ALoad<YK> yl, ALoad<X
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    TSTAMP_DECL
+    TSTAMP_START();
     resolve(0);
     issue(0);
     resolve(1);
+    TSTAMP(7);
     for (int s = 0; s < steps; ++s) {
+        TSTAMP_WAITV();
+        TSTAMP(0);
         commit();
+        TSTAMP(1);
         __syncthreads();
+        TSTAMP(2);
         if (s + 1 < steps) { issue(s + 1); resolve(s + 2); }
+        TSTAMP(3);
         const uint16_t* Ys = smem;
         const uint16_t* Xs = smem + TM * TP;
         // A operand = dY^T (rows n, k = m), B operand = X (k = m, cols k'): both are transposed reads of row-major tiles
@@ -121,7 +147,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(ALoad<YK> yl, ALoad<X
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
         }
+        asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[3][3][3]));
+        TSTAMP(4);
         __syncthreads();                    // all waves done with the tile before the next commit overwrites it
+        TSTAMP(5);
     }
     // accumulate the tile: rows n = n_base + wr*64 + 16i + 4g + r, cols k = k_base + wc*64 + 16j + fr
     if (ws) {                               // workspace path: plain partial tile, summed by tn_reduce_kernel
@@ -133,6 +162,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(ALoad<YK> yl, ALoad<X
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     pt[(wr * 64 + 16 * i + 4 * g + r) * BN + wc * 64 + 16 * j + fr] = acc[i][j][r];
+#ifdef SWV2_TN_STAMPS
+        TSTAMP_WAITV();
+        TSTAMP(6);
+        if (tid == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ((unsigned long long*)pt)[k] = st_acc[k];
+        }
+#endif
     } else
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -157,6 +194,48 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(ALoad<YK> yl, ALoad<X
     }
 }
 
+// single product: grid = tiles * slices (slices padded to a multiple of 8)
+// XCD-aware block -> (tile, row slice) map.  Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one), and
+// the tiles of one row slice re-read the same dY / X rows: give all tiles of a slice consecutive slots on ONE XCD so
+// the re-reads hit that XCD's L2 instead of HBM (PMC before: 415 MB vs 198 MB algorithmic for the fc1 gradient).
+// Speed only, never correctness.
+template <int YK, int XK>
+__global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(ALoad<YK> yl, ALoad<XK> xl, TnOut o, int chunk_stride) {
+    __shared__ __attribute__((aligned(16))) uint16_t smem[TN_SMEM];
+    __shared__ float dbs[BN];
+    __shared__ __attribute__((aligned(16))) uint16_t gtab[XK == A_BF16_GELU ? GT_N : 8];
+    const int lin = blockIdx.x;                       // 1-D launch: lin = xcd + 8 * (q * tiles + tile)
+    const int x8 = lin & 7, rest = lin >> 3;
+    const int tile = rest % o.tiles, slice = (rest / o.tiles) * 8 + x8;
+    tn_tile<YK, XK>(yl, xl, o, tile, slice, chunk_stride, smem, dbs, gtab);
+}
+
+// The four weight-gradient products of one transformer block in ONE launch (fc2, fc1, proj, qkv: 4 + 4 + 1 + 3 tiles at
+// C = 128).  Measured on the separate launches (bench.py at local batch 1 / 2 / 4, tools/batch_fit.py): each costs
+// ~13 - 16 us independent of the row count (ramp, first-load latency, partial-tile drain) on top of ~4.3 us per 128-row
+// step, i.e. 2.6 - 3.2 TB/s at 8 steps per workgroup but 5.8 TB/s marginal.  Grouped, every workgroup walks ~25 steps and
+// the fixed part is paid once; one tn_group_reduce launch replaces four tn_reduce launches.
+struct TnGroup {
+    ALoad<A_BF16> y0; ALoad<A_BF16_GELU> x0;      // fc2:  d(a2)^T GELU(hpre)
+    ALoad<A_BF16> y1; ALoad<A_F32> x1;            // fc1:  d(h)^T x1
+    ALoad<A_BF16> y2; ALoad<A_HEADS> x2;          // proj: d(a1)^T merge(oh)
+    ALoad<A_HEADS> y3; ALoad<A_F32> x3;           // qkv:  d(qkv)^T gather(x)
+    TnOut o[4];
+    int first[5];                                 // first global tile index of each product; first[4] = total
+    int slices;
+};
+__global__ __launch_bounds__(NTHREADS) void gemm_tn_group_kernel(TnGroup a) {
+    __shared__ __attribute__((aligned(16))) uint16_t smem[TN_SMEM];
+    __shared__ float dbs[BN];
+    __shared__ __attribute__((aligned(16))) uint16_t gtab[GT_N];
+    const int lin = blockIdx.x, x8 = lin & 7, rest = lin >> 3, tt = a.first[4];
+    const int t = rest % tt, slice = (rest / tt) * 8 + x8;
+    if (t < a.first[1]) tn_tile<A_BF16, A_BF16_GELU>(a.y0, a.x0, a.o[0], t, slice, a.slices, smem, dbs, gtab);
+    else if (t < a.first[2]) tn_tile<A_BF16, A_F32>(a.y1, a.x1, a.o[1], t - a.first[1], slice, a.slices, smem, dbs, gtab);
+    else if (t < a.first[3]) tn_tile<A_BF16, A_HEADS>(a.y2, a.x2, a.o[2], t - a.first[2], slice, a.slices, smem, dbs, gtab);
+    else tn_tile<A_HEADS, A_F32>(a.y3, a.x3, a.o[3], t - a.first[3], slice, a.slices, smem, dbs, gtab);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Second stage of the workspace path: dW[nmap(n)][kmap(k)] += sum over row slices of the partial tiles
 // ws[slice][tile][128][128].  Device-scope float atomics resolve beyond the per-XCD L2s and cost ~5 ns each when 64+
@@ -164,12 +243,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(ALoad<YK> yl, ALoad<X
 // a workspace the slices write plain coalesced partials and this kernel owns every output element exclusively.
 // block = 256 threads = 64 tile entries x 4 slice groups.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW,
-                                                        const int32_t* __restrict__ nmap, const int32_t* __restrict__ kmap,
-                                                        int ldw, int N, int K, int ntk, int tiles, int slices) {
+struct TnReduce { TnOut o[4]; int first[5]; int slices; };
+__global__ __launch_bounds__(256) void tn_reduce_kernel(TnReduce a) {
     __shared__ float part[4][64];
-    const int e = blockIdx.x * 64 + (threadIdx.x & 63), sg = threadIdx.x >> 6, tile = blockIdx.y;
-    const float* src = ws + (size_t)tile * (BN * BN) + e;
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63), sg = threadIdx.x >> 6, gt = blockIdx.y;
+    const int pi = (gt >= a.first[1]) + (gt >= a.first[2]) + (gt >= a.first[3]);
+    const TnOut& o = a.o[pi];
+    const int tile = gt - a.first[pi], tiles = o.tiles, ntk = o.ntk;
+    const int slices = min(a.slices, (o.M + TM - 1) / TM);
+    const float* src = o.ws + (size_t)tile * (BN * BN) + e;
     const size_t stride = (size_t)tiles * (BN * BN);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int sl = sg;
@@ -185,25 +267,30 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
     if (sg == 0) {
         const int tn = tile / ntk, tk = tile - tn * ntk;
         int n = tn * BN + (e >> 7), k = tk * BN + (e & 127);
-        if (n < N && k < K) {
-            if (nmap) n = nmap[n];
-            if (kmap) k = kmap[k];
+        if (n < o.N && k < o.K) {
+            if (o.nmap) n = o.nmap[n];
+            if (o.kmap) k = o.kmap[k];
             const int l = threadIdx.x;
-            if (n >= 0 && k >= 0) dW[(long)n * ldw + k] += (part[0][l] + part[1][l]) + (part[2][l] + part[3][l]);
+            if (n >= 0 && k >= 0) o.dW[(long)n * o.ldw + k] += (part[0][l] + part[1][l]) + (part[2][l] + part[3][l]);
         }
     }
 }
 
-struct TnPlan { int ntn, ntk, tiles, rows, real_slices, slices; size_t ws_bytes; };
+struct TnPlan { int ntn, ntk, tiles, real_slices, slices; size_t ws_bytes; };
 TnPlan tn_plan(int M, int N, int K, int splits) {
     TnPlan p;
     p.ntn = cdiv(N, BN); p.ntk = cdiv(K, BN); p.tiles = p.ntn * p.ntk;
     const int eff = (p.tiles >= 3) ? splits : splits * 2;         // small outputs: more row slices to fill the chip
-    p.rows = cdiv(cdiv(M, eff), TM) * TM;
-    p.real_slices = cdiv(M, p.rows);
+    p.real_slices = std::min(eff, cdiv(M, TM));
     p.slices = cdiv(p.real_slices, 8) * 8;                        // padded to a multiple of 8 (empty slices exit at once)
     p.ws_bytes = (size_t)p.real_slices * p.tiles * BN * BN * sizeof(float);
     return p;
+}
+TnOut tn_out(float* dW, float* db, const int32_t* nmap, const int32_t* kmap, int ldw, int M, int N, int K, float* ws) {
+    TnOut o;
+    o.dW = dW; o.db = db; o.nmap = nmap; o.kmap = kmap; o.ldw = ldw; o.M = M; o.N = N; o.K = K;
+    o.ntk = cdiv(K, BN); o.tiles = cdiv(N, BN) * o.ntk; o.ws = ws;
+    return o;
 }
 
 template <int YK, int XK>
@@ -214,11 +301,14 @@ int launch_tn2(const swv2_operand* y, const swv2_operand* x, float* dW, float* d
         swv2_set_error("swv2_linear_wgrad_ws: workspace of %zu bytes, %zu needed (swv2_linear_wgrad_ws_bytes)", ws_bytes, p.ws_bytes);
         return SWV2_ERR_INVALID;
     }
+    const TnOut o = tn_out(dW, db, nmap, kmap, ldw, M, N, K, ws);
     hipLaunchKernelGGL((gemm_tn_kernel<YK, XK>), dim3(p.tiles * p.slices), dim3(NTHREADS), 0, st, make_loader<YK>(y),
-                       make_loader<XK>(x), dW, db, nmap, kmap, ldw, M, N, K, p.ntk, p.rows, ws);
-    if (ws)
-        hipLaunchKernelGGL(tn_reduce_kernel, dim3(BN * BN / 64, p.tiles), dim3(256), 0, st, ws, dW, nmap, kmap, ldw, N, K, p.ntk,
-                           p.tiles, p.real_slices);
+                       make_loader<XK>(x), o, p.real_slices);
+    if (ws) {
+        TnReduce r = {};
+        r.o[0] = o; r.first[0] = 0; r.first[1] = r.first[2] = r.first[3] = r.first[4] = p.tiles; r.slices = p.real_slices;
+        hipLaunchKernelGGL(tn_reduce_kernel, dim3(BN * BN / 64, p.tiles), dim3(256), 0, st, r);
+    }
     SWV2_CHECK_LAUNCH("swv2_linear_wgrad");
     return SWV2_OK;
 }
@@ -273,4 +363,62 @@ extern "C" int swv2_linear_wgrad_ws(const swv2_operand* dy, const swv2_operand* 
 extern "C" int swv2_linear_wgrad(const swv2_operand* dy, const swv2_operand* x, float* dW, float* db, const int32_t* nmap,
                                  const int32_t* kmap, int ldw, int splits, void* stream) {
     return swv2_linear_wgrad_ws(dy, x, dW, db, nmap, kmap, ldw, splits, nullptr, 0, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// grouped launch: the four weight gradients of one block (see gemm_tn_group_kernel)
+// ------------------------------------------------------------------------------------------------
+namespace {
+int group_slices(int total_tiles, int requested) {
+    if (requested > 0) return std::max(8, requested / 8 * 8);
+    return std::max(8, (2 * 256 / total_tiles) / 8 * 8);          // two workgroups (70 KB of LDS each) per CU, one round
+}
+}  // namespace
+
+extern "C" size_t swv2_block_wgrad_ws_bytes(int C, int hidden, int heads_dp, int slices) {
+    if (C <= 0 || hidden <= 0 || heads_dp <= 0) return 0;
+    const int tt = 2 * cdiv(C, BN) * cdiv(hidden, BN) + cdiv(C, BN) * cdiv(heads_dp, BN) + cdiv(3 * heads_dp, BN) * cdiv(C, BN);
+    return (size_t)group_slices(tt, slices) * tt * BN * BN * sizeof(float);
+}
+
+extern "C" int swv2_block_wgrad(const swv2_wgrad_item* it, int slices, void* ws, size_t ws_bytes, void* stream) {
+    SWV2_CHECK_ARG(it && ws, "swv2_block_wgrad: null items or workspace");
+    static const int want[4][2] = {{SWV2_OP_BF16, SWV2_OP_BF16_GELU}, {SWV2_OP_BF16, SWV2_OP_F32}, {SWV2_OP_BF16, SWV2_OP_HEADS},
+                                   {SWV2_OP_HEADS, SWV2_OP_F32}};
+    TnGroup g = {};
+    int tt = 0;
+    for (int i = 0; i < 4; ++i) {
+        int rc = check_operand(&it[i].dy, "swv2_block_wgrad(dy)");
+        if (rc) return rc;
+        rc = check_operand(&it[i].x, "swv2_block_wgrad(x)");
+        if (rc) return rc;
+        SWV2_CHECK_ARG(it[i].dy.kind == want[i][0] && it[i].x.kind == want[i][1],
+                       "swv2_block_wgrad: item %d must be (dY kind %d, X kind %d)", i, want[i][0], want[i][1]);
+        SWV2_CHECK_ARG(it[i].dW && it[i].ldw > 0 && it[i].dy.rows == it[i].x.rows, "swv2_block_wgrad: item %d: null dW or row mismatch", i);
+        g.first[i] = tt;
+        tt += cdiv(it[i].dy.cols, BN) * cdiv(it[i].x.cols, BN);
+    }
+    g.first[4] = tt;
+    const int S = group_slices(tt, slices);
+    SWV2_CHECK_ARG(ws_bytes >= (size_t)S * tt * BN * BN * sizeof(float), "swv2_block_wgrad: workspace of %zu bytes, %zu needed",
+                   ws_bytes, (size_t)S * tt * BN * BN * sizeof(float));
+    TnReduce r = {};
+    for (int i = 0; i < 4; ++i) {
+        const int tiles = cdiv(it[i].dy.cols, BN) * cdiv(it[i].x.cols, BN);
+        g.o[i] = tn_out(it[i].dW, it[i].db, it[i].nmap, it[i].kmap, it[i].ldw, it[i].dy.rows, it[i].dy.cols, it[i].x.cols,
+                        (float*)ws + (size_t)g.first[i] * S * BN * BN);
+        (void)tiles;
+        r.o[i] = g.o[i];
+    }
+    for (int i = 0; i < 5; ++i) r.first[i] = g.first[i];
+    g.y0 = make_loader<A_BF16>(&it[0].dy); g.x0 = make_loader<A_BF16_GELU>(&it[0].x);
+    g.y1 = make_loader<A_BF16>(&it[1].dy); g.x1 = make_loader<A_F32>(&it[1].x);
+    g.y2 = make_loader<A_BF16>(&it[2].dy); g.x2 = make_loader<A_HEADS>(&it[2].x);
+    g.y3 = make_loader<A_HEADS>(&it[3].dy); g.x3 = make_loader<A_F32>(&it[3].x);
+    g.slices = r.slices = S;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gemm_tn_group_kernel, dim3(tt * S), dim3(NTHREADS), 0, st, g);
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3(BN * BN / 64, tt), dim3(256), 0, st, r);
+    SWV2_CHECK_LAUNCH("swv2_block_wgrad");
+    return SWV2_OK;
 }

@@ -129,6 +129,10 @@ class _BlockRunner:
         lib = L.load()
         ws_bytes = max(lib.swv2_linear_wgrad_ws_bytes(m, n_, k, d.wgrad_splits)
                        for m, n_, k in ((BT, Cc, hid), (BT, hid, Cc), (Mw, Cc, h * DP), (Mw, 3 * h * DP, Cc)))
+        # the four products as one grouped launch (swv2_block_wgrad): 242 -> ~125 us per block at local batch 2
+        d.wgrad_group = int(os.environ.get("SWV2_WGRAD_GROUP", "1"))
+        if d.wgrad_group:
+            ws_bytes = max(ws_bytes, lib.swv2_block_wgrad_ws_bytes(Cc, hid, h * DP, 0))
         d.wgrad_ws_bytes = ws_bytes
         # weight-gradient GEMMs on the library's side stream: +8 % when they took 4 x 130 us per block with atomics; since
         # the partial-tile kernels (4 x 30-70 us) the overlap only slows the co-running dX chain down (143.3 vs 144.2

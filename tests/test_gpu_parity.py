@@ -950,7 +950,7 @@ def test_fused_mlp_backward_matches_autograd(dev, K, M, Cc, hid, T):
 
 
 @pytest.mark.parametrize("knob,value", [("SWV2_FUSE_MLP", "0"), ("SWV2_FUSE_MLP", "1"), ("SWV2_FUSE_PROJ_LN", "0"),
-                                        ("SWV2_FUSE_PROJ_LN", "1")])
+                                        ("SWV2_FUSE_PROJ_LN", "1"), ("SWV2_WGRAD_GROUP", "0"), ("SWV2_WGRAD_GROUP", "1")])
 def test_block_fused_and_unfused_paths(dev, K, monkeypatch, knob, value):
     """Both variants of the MLP branch (SWV2_FUSE_MLP: swv2_mlp_fwd / _bwd vs. LN + GEMM launches) and of proj + LN1
     (SWV2_FUSE_PROJ_LN: swv2_proj_ln_fwd / _bwd) against the bf16-emulating oracle on a reference block fixture whose
@@ -968,7 +968,7 @@ def test_block_fused_and_unfused_paths(dev, K, monkeypatch, knob, value):
     y = blk(x)
     y.backward(torch.from_numpy(fx["gy"]).to(dev))
     desc = blk._runner(B, x.device).desc
-    assert {"SWV2_FUSE_MLP": desc.fuse_mlp, "SWV2_FUSE_PROJ_LN": desc.fuse_proj_ln}[knob] == int(value)
+    assert {"SWV2_FUSE_MLP": desc.fuse_mlp, "SWV2_FUSE_PROJ_LN": desc.fuse_proj_ln, "SWV2_WGRAD_GROUP": desc.wgrad_group}[knob] == int(value)
     p = {"b." + k[2:]: torch.from_numpy(fx[k]).clone().requires_grad_(True) for k in fx.files if k.startswith("p:")}
     xo = torch.from_numpy(fx["x"]).clone().requires_grad_(True)
     O.set_rounding(O.bf16_round)
@@ -979,6 +979,34 @@ def test_block_fused_and_unfused_paths(dev, K, monkeypatch, knob, value):
         O.set_rounding(None)
     assert rel(y, yo) < 1e-3 and rel(x.grad, xo.grad) < 1.5e-2
     assert worst_grad(blk, {k[2:]: v.grad for k, v in p.items()}) < 3e-2
+
+
+@pytest.mark.parametrize("gh,gw,wh,ww,sh,sw,Cc,h", [(36, 72, 9, 18, 4, 9, 128, 8), (12, 27, 6, 9, 3, 4, 64, 4), (12, 18, 6, 9, 0, 0, 96, 8)])
+def test_grouped_weight_gradients_match_separate_launches(dev, K, monkeypatch, gh, gw, wh, ww, sh, sw, Cc, h):
+    """swv2_block_wgrad (the block's four weight gradients + bias gradients as one launch over 12 output tiles at C = 128)
+    against the four swv2_linear_wgrad_ws launches on the same block backward: same products, only the order in which the
+    row slices are summed differs (fp32) -> 2e-5 of each gradient's largest element."""
+    N = K["N"]
+    B = 3
+    x0 = torch.randn(B, gh, gw, Cc, generator=torch.Generator().manual_seed(5))
+    gy0 = torch.randn(B, gh, gw, Cc, generator=torch.Generator().manual_seed(6))
+    grads = {}
+    for grp in ("0", "1"):
+        monkeypatch.setenv("SWV2_WGRAD_GROUP", grp)
+        torch.manual_seed(11)
+        blk = N.SwinTransformerV2CrBlock(dim=Cc, num_heads=h, feat_size=(gh, gw), window_size=(wh, ww), shift_size=(sh, sw),
+                                         rel_pos=False, drop_path=0.0)
+        with torch.no_grad():
+            blk.norm1.weight.uniform_(0.5, 1.0)
+            blk.norm2.weight.uniform_(0.5, 1.0)
+        blk = blk.to(dev).train()
+        x = x0.to(dev).requires_grad_(True)
+        blk(x).backward(gy0.to(dev))
+        assert blk._runner(B, x.device).desc.wgrad_group == int(grp)
+        grads[grp] = {n_: p_.grad.detach().cpu() for n_, p_ in blk.named_parameters()} | {"x": x.grad.cpu()}
+    for n_, g1 in grads["1"].items():
+        g0 = grads["0"][n_]
+        assert float((g1 - g0).abs().max()) <= 2e-5 * float(g0.abs().max()) + 1e-12, n_
 
 
 @pytest.mark.parametrize("gh,gw,wh,ww,sh,sw,Cc,h,fixture", [
@@ -1062,7 +1090,10 @@ def _ddp_close(a, b, tol=2e-3):
     floored at the size of an update) must agree"""
     worst = max(float((x - y).abs().max() / max(float(y.abs().max()), 1e-2)) for x, y in zip(a["params"], b["params"]))
     assert worst < tol, worst
-    assert all(abs(x - y) < 1e-4 * abs(y) + 1e-6 for x, y in zip(a["losses"], b["losses"])), (a["losses"], b["losses"])
+    # first loss: same parameters, same batch -> 1e-6; later ones sit behind 1 - 2 SGD steps at lr 0.02, which amplify the
+    # run-to-run rounding of the atomically accumulated gradients (measured: up to 1.2e-4 between two identical runs)
+    assert abs(a["losses"][0] - b["losses"][0]) < 2e-6 * abs(b["losses"][0]), (a["losses"], b["losses"])
+    assert all(abs(x - y) < 5e-4 * abs(y) for x, y in zip(a["losses"], b["losses"])), (a["losses"], b["losses"])
 
 
 def test_ddp_bucket_view_gradients(dev, K, tmp_path):

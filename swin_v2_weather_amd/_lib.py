@@ -142,6 +142,7 @@ SYMBOLS = {
     "swv2_linear": (_I, [C.POINTER(Operand), _P, C.POINTER(Epilogue), _I, _P]),
     "swv2_linear_wgrad": (_I, [C.POINTER(Operand), C.POINTER(Operand), _P, _P, _P, _P, _I, _I, _P]),
     "swv2_linear_wgrad_ws_bytes": (C.c_size_t, [_I, _I, _I, _I]),
+    "swv2_qk_normalize": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "swv2_block_wgrad_ws_bytes": (C.c_size_t, [_I, _I, _I, _I]),
     "swv2_block_wgrad": (_I, [C.POINTER(WgradItem), _I, _P, C.c_size_t, _P]),
     "swv2_linear_wgrad_ws": (_I, [C.POINTER(Operand), C.POINTER(Operand), _P, _P, _P, _P, _I, _I, _P, C.c_size_t, _P]),

@@ -78,7 +78,10 @@ __global__ __launch_bounds__(64 * LT) void attn_fwd_kernel(
     uint16_t* __restrict__ oh, float* __restrict__ lse, int Bw, int h, int L, int nW, int nww, int nwh, int mask_thr) {
     using C = AttnCfg<LT, DK>;
     constexpr int Lp = C::Lp, DP = C::DP, SLAB = C::SLAB;
-    __shared__ __attribute__((aligned(16))) uint16_t smem[2 * 2 * SLAB];   // [buf][K|V][Lp][DP]
+    // two K|V buffers (the next window's slabs land while this one is computed) unless they exceed the LDS: head dims
+    // padded to 128 at the 176-token window keep ONE buffer and refill it between two barriers
+    constexpr int NBUF = (2 * 2 * SLAB * 2 <= 160 * 1024) ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) uint16_t smem[NBUF * 2 * SLAB];   // [buf][K|V][Lp][DP]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(64 * LT) void attn_fwd_kernel(
     __syncthreads();
 
     for (int it = 0; bw < Bw; bw += gridDim.x, ++it) {
-        const int buf = it & 1;
+        const int buf = NBUF == 2 ? (it & 1) : 0;
         const int bw_next = bw + gridDim.x;
         if (bw_next < Bw) issue_loads(bw_next);
 
@@ -229,8 +232,9 @@ __global__ __launch_bounds__(64 * LT) void attn_fwd_kernel(
         }
         // next window's K / V -> the other LDS buffer BEFORE this window's stores are issued: a wait for the prefetch
         // placed after (exec-masked) stores would also wait for their acknowledgements
+        if (NBUF == 1) __syncthreads();                   // every wave is done with the only buffer
         if (bw_next < Bw) {
-            write_stage(buf ^ 1);
+            write_stage(NBUF == 2 ? (buf ^ 1) : 0);
 #pragma unroll
             for (int kk = 0; kk < DK; ++kk) qf[kk] = qn[kk];
         }
@@ -291,14 +295,18 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
     // ONE LDS object with the per-step arrays first: their addresses are then (one running lane offset) + (a constant below
     // 64 KB that fits the ds_read / ds_write offset field).  As separate __shared__ arrays beyond the first 64 KB each
     // access needed its own v_add per step (9 address adds in a ~45-instruction loop).
-    constexpr int OFF_Q = 0, OFF_DO = OFF_Q + SLAB * 2, OFF_LSE = OFF_DO + SLAB * 2, OFF_DL = OFF_LSE + Lp * 4,
+    // QG: the q / dO slabs do not fit beside K, V and the dcos image (head dim padded to 128 at the 176-token window:
+    // 4 x 45 KB + 63 KB) -- their fragments are then read from global memory / L2 (the slab layout in memory is the LDS
+    // image), the transposed ones as four 2-byte loads.  A coverage path for wide heads, not a tuned one.
+    constexpr bool QG = (4 * SLAB * 2 + IROWS * DSP * 2 + Lp * 8 + 256 > 160 * 1024);
+    constexpr int OFF_Q = 0, OFF_DO = OFF_Q + (QG ? 0 : SLAB * 2), OFF_LSE = OFF_DO + (QG ? 0 : SLAB * 2), OFF_DL = OFF_LSE + Lp * 4,
                   OFF_K = OFF_DL + Lp * 4, OFF_V = OFF_K + SLAB * 2, OFF_DS = OFF_V + SLAB * 2,
                   OFF_BIAS = OFF_DS + IROWS * DSP * 2, OFF_RED = OFF_BIAS + (BIAS_LDS ? Lp * DSP * 2 : 16),
                   LDS_BYTES = OFF_RED + ((WAVES * 4 + 15) / 16) * 16;
     static_assert(OFF_DS % 16 == 0 && OFF_BIAS % 16 == 0 && OFF_RED % 16 == 0, "16-byte aligned sub-arrays");
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
-    uint16_t* const Qs = (uint16_t*)(lds + OFF_Q);
-    uint16_t* const dOs = (uint16_t*)(lds + OFF_DO);
+    const uint16_t* Qs = (const uint16_t*)(lds + OFF_Q);       // QG: re-pointed at the window's global slabs below
+    const uint16_t* dOs = (const uint16_t*)(lds + OFF_DO);
     float* const LSEs = (float*)(lds + OFF_LSE);
     float* const DLs = (float*)(lds + OFF_DL);
     uint16_t* const Ks = (uint16_t*)(lds + OFF_K);
@@ -312,6 +320,17 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
     const int tw = tid >> 6;                 // this wave owns tiles tw * TPW + i (key tiles in phase 1, query tiles in phase 2)
     const int fr = lane & 15, g = lane >> 4;
     const int hd = blockIdx.y;
+    // transposed 16 x 16 fragment: element r of lane (g, fr) = X[row0 + 4g + r][col0 + fr]
+    auto tr_frag = [&](const uint16_t* base, int row0, int col0) -> bf16x4 {
+        if constexpr (QG) {
+            const uint16_t* p_ = base + (size_t)(row0 + 4 * g) * DP + col0 + fr;
+            bf16x4 v;
+            v[0] = ((const short*)p_)[0]; v[1] = ((const short*)p_)[DP]; v[2] = ((const short*)p_)[2 * DP]; v[3] = ((const short*)p_)[3 * DP];
+            return v;
+        } else {
+            return lds_tr_read(base + (row0 + 4 * g + (fr >> 2)) * DP + col0 + (fr & 3) * 4);
+        }
+    };
 
     const float tau = logit_scale[hd];
     const float sigma = __expf(fminf(tau, SWV2_LN100));
@@ -383,10 +402,10 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
         for (int j = 0; j < CPT; ++j) {
             const int c = tid + j * NT;
             if (c < CH) {
-                *(uint4*)(Qs + c * 8) = sq[j];
+                if (!QG) *(uint4*)((uint16_t*)(lds + OFF_Q) + c * 8) = sq[j];
                 *(uint4*)(Ks + c * 8) = sk[j];
                 *(uint4*)(Vs + c * 8) = sv[j];
-                *(uint4*)(dOs + c * 8) = sdo[j];
+                if (!QG) *(uint4*)((uint16_t*)(lds + OFF_DO) + c * 8) = sdo[j];
             }
             // delta partial over this chunk's 8 channels, reduced over the CPR chunks of the row (adjacent lanes)
             float dl = 0.f;
@@ -416,6 +435,7 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
         const size_t slab0 = ((size_t)bw * h + hd) * 3 * SLAB;
         const int bw_next = bw + gridDim.x;
         if (bw_next < Bw) issue(bw_next);
+        if (QG) { Qs = qkvh + slab0; dOs = doh + ((size_t)bw * h + hd) * SLAB; }
 
         // ================= phase 1: wave = key tile(s) =================
         bf16x4 kf[TPW][DK], vf[TPW][DK];
@@ -442,9 +462,8 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
             for (int kk = 0; kk < DK; ++kk) {
                 qa[kk] = *(const bf16x4*)(Qs + (16 * qt + fr) * DP + 16 * kk + 4 * g);
                 da[kk] = *(const bf16x4*)(dOs + (16 * qt + fr) * DP + 16 * kk + 4 * g);
-                const int off = (16 * qt + 4 * g + (fr >> 2)) * DP + 16 * kk + (fr & 3) * 4;
-                td[kk] = lds_tr_read(dOs + off);
-                tq[kk] = lds_tr_read(Qs + off);
+                td[kk] = tr_frag(dOs, 16 * qt, 16 * kk);
+                tq[kk] = tr_frag(Qs, 16 * qt, 16 * kk);
             }
             const f32x4 l4 = *(const f32x4*)(LSEs + 16 * qt + 4 * g);
             const f32x4 d4 = *(const f32x4*)(DLs + 16 * qt + 4 * g);
@@ -531,9 +550,8 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
                 for (int kk = 0; kk < DK; ++kk) {
                     qa[kk] = *(const bf16x4*)(Qs + (16 * qt + fr) * DP + 16 * kk + 4 * g);
                     da[kk] = *(const bf16x4*)(dOs + (16 * qt + fr) * DP + 16 * kk + 4 * g);
-                    const int off = (16 * qt + 4 * g + (fr >> 2)) * DP + 16 * kk + (fr & 3) * 4;
-                    o.td[kk] = lds_tr_read(dOs + off);
-                    o.tq[kk] = lds_tr_read(Qs + off);
+                    o.td[kk] = tr_frag(dOs, 16 * qt, 16 * kk);
+                    o.tq[kk] = tr_frag(Qs, 16 * qt, 16 * kk);
                 }
                 o.l4 = *(const f32x4*)(LSEs + 16 * qt + 4 * g);
                 o.d4 = *(const f32x4*)(DLs + 16 * qt + 4 * g);
@@ -784,8 +802,9 @@ int check_args(const swv2_attn_args* a, bool bwd) {
 extern "C" int swv2_attn_geometry(int L, int head_dim, int* Lp, int* DP) {
     int LT = 0, DK = 0;
     if (L <= 64) LT = 4; else if (L <= 176) LT = 11;
-    if (head_dim <= 16) DK = 1; else if (head_dim <= 32) DK = 2;
-    SWV2_CHECK_ARG(LT && DK, "attention: unsupported window area L=%d (<=176) or head_dim=%d (<=32)", L, head_dim);
+    // head dims are padded to 16, 32, 64 or 128 columns (e.g. the yaml default 768 / 8 = 96 runs as 128)
+    if (head_dim <= 16) DK = 1; else if (head_dim <= 32) DK = 2; else if (head_dim <= 64) DK = 4; else if (head_dim <= 128) DK = 8;
+    SWV2_CHECK_ARG(LT && DK, "attention: unsupported window area L=%d (<=176) or head_dim=%d (<=128)", L, head_dim);
     if (Lp) *Lp = 16 * LT;
     if (DP) *DP = 16 * DK;
     return SWV2_OK;
@@ -804,6 +823,10 @@ extern "C" int swv2_attn_geometry(int L, int head_dim, int* Lp, int* DP) {
     if (Lp == 64 && DP == 32) return FN<4, 2, 0>(a, st);                               \
     if (Lp == 176 && DP == 16) return FN<11, 1, 0>(a, st);                             \
     if (Lp == 176 && DP == 32) return FN<11, 2, 0>(a, st);                             \
+    if (Lp == 64 && DP == 64) return FN<4, 4, 0>(a, st);                               \
+    if (Lp == 64 && DP == 128) return FN<4, 8, 0>(a, st);                              \
+    if (Lp == 176 && DP == 64) return FN<11, 4, 0>(a, st);                             \
+    if (Lp == 176 && DP == 128) return FN<11, 8, 0>(a, st);                            \
     swv2_set_error("attention: no kernel for Lp=%d DP=%d", Lp, DP);                    \
     return SWV2_ERR_UNSUPPORTED;
 

@@ -19,6 +19,8 @@
 // step s, write LDS after) and 3 workgroups per CU, XOR-swizzled 128-byte LDS rows for conflict-free ds_read_b128.
 #include "common.h"
 
+#include <cmath>
+#include <cstdlib>
 #include "gemm_common.h"
 
 namespace {
@@ -192,17 +194,58 @@ __device__ __forceinline__ void heads_item(const EpiDesc& d, const float* st, in
         }
     }
 }
+// DP = 128 (head dims 65 .. 128): a wave's 64-column sub-tile is HALF a head, so the squared norm cannot be finished
+// here.  Each half adds its partial sum of squares into rnorm (zeroed by the caller; two addends -> order-independent)
+// and writes the UN-normalised bf16 values; swv2_qk_normalize then turns the sums into 1 / |.| and rescales q, k in
+// place (one extra bf16 rounding of q^, k^ compared with the narrow-head epilogue).  lane = (row, 16-column quarter).
+template <bool NORM>
+__device__ __forceinline__ void heads_item_wide(const EpiDesc& d, const float* st, int m0, int n0, int lane) {
+    const int h = d.p0, Lp = d.p2, L = d.p4, S = NORM ? 3 : 1;
+    const int r = lane & 15, qd = lane >> 4, nb = n0 + 16 * qd, m = m0 + r;
+    const bool in = (m < d.M) && (nb < d.N);
+    const int ph = nb >> 7, part = (h == 1) ? ph : fdiv(ph, h, d.mg1), hd = ph - part * h;
+    const int bw = fdiv(min(m, d.M - 1), Lp, d.mg0), t = min(m, d.M - 1) - bw * Lp;
+    const bool valid = in && t < L;
+    float v[16];
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; j += 4) {
+        f32x4 x = *(const f32x4*)(st + r * EP + 16 * qd + j);
+        if (d.bias && in) x += *(const f32x4*)(d.bias + nb + j);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[j + e] = valid ? x[e] : 0.f;
+            ss = fmaf(v[j + e], v[j + e], ss);
+        }
+    }
+    if (NORM) {
+        ss += __shfl_xor(ss, 16);
+        ss += __shfl_xor(ss, 32);
+        if (in && qd == 0 && part < 2 && valid) atomicAdd(d.aux_out + (((long)bw * h + hd) * 2 + part) * Lp + t, ss);
+    }
+    if (in) {
+        uint16_t* o = (uint16_t*)d.out + ((((long)bw * h + hd) * S + part) * Lp + t) * 128 + (nb & 127);
+        *(uint4*)o = pack8(v);
+        *(uint4*)(o + 8) = pack8(v + 8);
+    }
+}
 template <> struct Epi<E_QKV_HEADS> {
     EpiDesc d;
     __device__ __forceinline__ void tile(const float* st, int m0, int n0, int lane) const {
-        if (d.p3 == 16) heads_item<16, true>(d, st, m0, n0, lane); else heads_item<32, true>(d, st, m0, n0, lane);
+        if (d.p3 == 16) heads_item<16, true>(d, st, m0, n0, lane);
+        else if (d.p3 == 32) heads_item<32, true>(d, st, m0, n0, lane);
+        else if (d.p3 == 64) heads_item<64, true>(d, st, m0, n0, lane);
+        else heads_item_wide<true>(d, st, m0, n0, lane);
     }
 };
 // heads split without normalisation: [Bw][h][1][Lp][DP] (gradient of the merged attention output)
 template <> struct Epi<E_HEADS> {
     EpiDesc d;
     __device__ __forceinline__ void tile(const float* st, int m0, int n0, int lane) const {
-        if (d.p3 == 16) heads_item<16, false>(d, st, m0, n0, lane); else heads_item<32, false>(d, st, m0, n0, lane);
+        if (d.p3 == 16) heads_item<16, false>(d, st, m0, n0, lane);
+        else if (d.p3 == 32) heads_item<32, false>(d, st, m0, n0, lane);
+        else if (d.p3 == 64) heads_item<64, false>(d, st, m0, n0, lane);
+        else heads_item_wide<false>(d, st, m0, n0, lane);
     }
 };
 // dh = (acc) * GELU'(pre-activation) ; aux = pre-activation bf16 [M][N] row-major, same pitch as out
@@ -257,42 +300,52 @@ template <> struct Epi<E_UNPATCH> {
 // ------------------------------------------------------------------------------------------------
 // NT kernel
 // ------------------------------------------------------------------------------------------------
-template <int AK, int EK>
+// BMT = rows per workgroup: 128 (2 x 2 waves of 64 x 64) or 64 (2 x 2 waves of 32 x 64).  The 64-row variant exists for the
+// grid quantisation: at 3 workgroups per CU the chip holds 768; 1013 row tiles of 128 (local batch 2) run as 1 full + 1
+// third-full round (66 % of the slots busy on average, measured 12 - 16 us of batch-independent time per launch), 2026
+// tiles of 64 as 2.64 of 3 rounds.
+template <int AK, int EK, int BMT = BM>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(ALoad<AK> al, const uint16_t* __restrict__ Wb, Epi<EK> ep,
                                                               int M, int N, int K) {
     // one A|B tile buffer (32 KB) + wave-private epilogue staging (17 KB): 49 KB -> 3 workgroups (12 waves) per CU.
     // Latency hiding comes from the co-resident workgroups plus the register prefetch of the next step's tiles.
     // A panel: 2 k-steps resident (K <= 128: the panel is loaded and converted ONCE and reused by every N tile; PMC showed
     // the per-N-tile re-reads as real HBM traffic, 548 MB vs 330 MB algorithmic for fc1), B tile, epilogue staging.
-    __shared__ __attribute__((aligned(16))) uint16_t smem[(2 * BM + BN) * BK];
+    constexpr int ACH = BMT * KCH / NTHREADS;             // A chunks per thread per k-step (4 or 2)
+    constexpr int RT = BMT / 32;                          // 16-row MFMA tiles per wave (4 or 2)
+    constexpr int LOG_BMT = BMT == 128 ? 7 : 6;
+    __shared__ __attribute__((aligned(16))) uint16_t smem[(2 * BMT + BN) * BK];
     __shared__ __attribute__((aligned(16))) float stage[4 * 16 * EP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, g = lane >> 4;
-    const int wr = wave >> 1, wc = wave & 1;              // 2 x 2 waves, 64 x 64 each
-    const int m_base = blockIdx.x * BM;
+    const int wr = wave >> 1, wc = wave & 1;              // 2 x 2 waves, (16 RT) x 64 each
+    const int m_base = blockIdx.x * BMT;
     const int ntiles = (N + BN - 1) / BN, ksteps = (K + BK - 1) / BK, steps = ntiles * ksteps;
     const bool a_res = (ksteps <= 2) && (ntiles > 1);        // A panel stays in LDS across the N tiles
     uint16_t* As0 = smem;
-    uint16_t* Bs = smem + 2 * BM * BK;
+    uint16_t* Bs = smem + 2 * BMT * BK;
 
-    typename ALoad<AK>::Raw ra[4];
+    typename ALoad<AK>::Raw ra[ACH];
     uint4 rb[4];
-    // the 4 panel rows this thread stages are the same for every (n-tile, k-step): resolve the gather ONCE
-    int arow[4];
+    // the panel rows this thread stages are the same for every (n-tile, k-step): resolve the gather ONCE
+    int arow[ACH];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < ACH; ++i) {
         const int c = tid + i * NTHREADS;
-        arow[i] = al.row_of(m_base + (ALoad<AK>::ROW_FASTEST ? (c & (BM - 1)) : (c >> 3)));
+        arow[i] = al.row_of(m_base + (ALoad<AK>::ROW_FASTEST ? (c & (BMT - 1)) : (c >> 3)));
     }
     auto issue = [&](int s) {
         const int nt = s / ksteps, ks = s - nt * ksteps;
         const bool need_a = !a_res || nt == 0;
 #pragma unroll
+        for (int i = 0; i < ACH; ++i) {
+            const int c = tid + i * NTHREADS;
+            const int kc = ALoad<AK>::ROW_FASTEST ? (c >> LOG_BMT) : (c & 7);
+            if (need_a) ra[i] = al.raw_at(arow[i], ks * BK + kc * 8);
+        }
+#pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = tid + i * NTHREADS;
-            int r, kc;
-            if (ALoad<AK>::ROW_FASTEST) { r = c & (BM - 1); kc = c >> 7; } else { r = c >> 3; kc = c & 7; }
-            if (need_a) ra[i] = al.raw_at(arow[i], ks * BK + kc * 8);
             const int rn = c >> 3, kcb = c & 7, n = nt * BN + rn, k0 = ks * BK + kcb * 8;
             rb[i] = (n < N && k0 < K) ? *(const uint4*)(Wb + (long)n * K + k0) : make_uint4(0, 0, 0, 0);
         }
@@ -300,41 +353,44 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(ALoad<AK> al, cons
     auto commit = [&](int s) {
         const int nt = s / ksteps, ks = s - nt * ksteps;
         const bool need_a = !a_res || nt == 0;
-        uint16_t* As = As0 + (a_res ? ks * BM * BK : 0);
+        uint16_t* As = As0 + (a_res ? ks * BMT * BK : 0);
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) {
+            const int c = tid + i * NTHREADS;
+            int r, kc;
+            if (ALoad<AK>::ROW_FASTEST) { r = c & (BMT - 1); kc = c >> LOG_BMT; } else { r = c >> 3; kc = c & 7; }
+            if (need_a) *(uint4*)(As + swz(r, kc)) = al.cvt(ra[i]);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = tid + i * NTHREADS;
-            int r, kc;
-            if (ALoad<AK>::ROW_FASTEST) { r = c & (BM - 1); kc = c >> 7; } else { r = c >> 3; kc = c & 7; }
-            if (need_a) *(uint4*)(As + swz(r, kc)) = al.cvt(ra[i]);
             *(uint4*)(Bs + swz(c >> 3, c & 7)) = rb[i];
         }
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[RT][4];
     issue(0);
     for (int s = 0; s < steps; ++s) {
         const int nt = s / ksteps, ks = s - nt * ksteps;
         if (ks == 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < RT; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
         commit(s);
         __syncthreads();
         if (s + 1 < steps) issue(s + 1);
-        const uint16_t* As = As0 + (a_res ? ks * BM * BK : 0);
+        const uint16_t* As = As0 + (a_res ? ks * BMT * BK : 0);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 af[4], bf[4];
+            bf16x8 af[RT], bf[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                af[i] = *(const bf16x8*)(As + swz(wr * 64 + i * 16 + fr, kk * 4 + g));
-                bf[i] = *(const bf16x8*)(Bs + swz(wc * 64 + i * 16 + fr, kk * 4 + g));
-            }
+            for (int i = 0; i < RT; ++i) af[i] = *(const bf16x8*)(As + swz(wr * 16 * RT + i * 16 + fr, kk * 4 + g));
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i) bf[i] = *(const bf16x8*)(Bs + swz(wc * 64 + i * 16 + fr, kk * 4 + g));
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
         }
@@ -342,12 +398,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(ALoad<AK> al, cons
         if (ks == ksteps - 1) {
             float* st = stage + wave * 16 * EP;            // wave-private: no further barrier needed
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < RT; ++i) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) st[(4 * g + r) * EP + 16 * j + fr] = acc[i][j][r];
-                ep.tile(st, m_base + wr * 64 + i * 16, nt * BN + wc * 64, lane);
+                ep.tile(st, m_base + wr * 16 * RT + i * 16, nt * BN + wc * 64, lane);
             }
         }
     }
@@ -362,8 +418,20 @@ int launch_nt2(const swv2_operand* a, const void* w, const swv2_epilogue* e, int
     ep.d.mg0 = ep.d.mg1 = ep.d.mg2 = 0;
     if (EK == E_QKV_HEADS || EK == E_HEADS) { ep.d.mg0 = fdiv_magic(e->p[2]); ep.d.mg1 = fdiv_magic(e->p[0]); }
     if (EK == E_UNPATCH) { ep.d.mg0 = fdiv_magic((e->p[1] / 4) * (e->p[2] / 4)); ep.d.mg1 = fdiv_magic(e->p[2] / 4); }
-    hipLaunchKernelGGL((gemm_nt_kernel<AK, EK>), dim3(cdiv(M, BM)), dim3(NTHREADS), 0, st, make_loader<AK>(a),
-                       (const uint16_t*)w, ep, M, N, K);
+    // 64-row workgroups where they fill the 768 slots (3 per CU) better; only for the two per-block products
+    bool half = false;
+    if constexpr ((AK == A_F32 && EK == E_QKV_HEADS) || (AK == A_HEADS && EK == E_F32)) {
+        const double w1 = cdiv(M, BM), w2 = cdiv(M, BM / 2), slots = 768.0;
+        const double e1 = w1 / (std::ceil(w1 / slots) * slots), e2 = w2 / (std::ceil(w2 / slots) * slots);
+        static const int force = getenv("SWV2_GEMM_BM") ? atoi(getenv("SWV2_GEMM_BM")) : 0;
+        half = force ? force == 64 : (e2 > e1 + 0.08);
+        if (half)
+            hipLaunchKernelGGL((gemm_nt_kernel<AK, EK, BM / 2>), dim3(cdiv(M, BM / 2)), dim3(NTHREADS), 0, st, make_loader<AK>(a),
+                               (const uint16_t*)w, ep, M, N, K);
+    }
+    if (!half)
+        hipLaunchKernelGGL((gemm_nt_kernel<AK, EK>), dim3(cdiv(M, BM)), dim3(NTHREADS), 0, st, make_loader<AK>(a),
+                           (const uint16_t*)w, ep, M, N, K);
     SWV2_CHECK_LAUNCH("swv2_linear");
     return SWV2_OK;
 }
@@ -397,8 +465,8 @@ extern "C" int swv2_linear(const swv2_operand* a, const void* w_bf16, const swv2
     if (e->kind == SWV2_EPI_F32 || e->kind == SWV2_EPI_F32_ACC)
         SWV2_CHECK_ARG(e->ld % 4 == 0 && e->ld >= N, "swv2_linear: output pitch %ld must be a multiple of 4 and >= N", e->ld);
     if (e->kind == SWV2_EPI_QKV_HEADS || e->kind == SWV2_EPI_HEADS)
-        SWV2_CHECK_ARG((e->p[3] == 16 || e->p[3] == 32) && N % e->p[3] == 0 && e->p[0] > 0 && e->p[2] > 0,
-                       "swv2_linear: head-split epilogue needs DP in {16,32} and N a multiple of DP (DP=%d N=%d)", e->p[3], N);
+        SWV2_CHECK_ARG((e->p[3] == 16 || e->p[3] == 32 || e->p[3] == 64 || e->p[3] == 128) && N % e->p[3] == 0 && e->p[0] > 0 && e->p[2] > 0,
+                       "swv2_linear: head-split epilogue needs DP in {16,32,64,128} and N a multiple of DP (DP=%d N=%d)", e->p[3], N);
     if (e->kind == SWV2_EPI_UNPATCH) SWV2_CHECK_ARG(N == e->p[0] * 16, "swv2_linear: un-patchify needs N == Cout*16");
     const int M = a->rows, K = a->cols;
     hipStream_t st = (hipStream_t)stream;

@@ -199,7 +199,7 @@ template <> struct ALoad<A_HEADS> {
         if (m >= d.M || k0 >= d.K) return make_uint4(0, 0, 0, 0);
         const int h = d.p0, Lp = d.p2, DP = d.p3, S = (int)d.ld;
         const int bw = fdiv(m, Lp, d.mg0), t = m - bw * Lp;
-        const int ph = (DP == 16) ? (k0 >> 4) : (k0 >> 5), j = k0 - ph * DP;
+        const int ph = k0 >> d.p1, j = k0 - ph * DP;                 // p1 = log2(DP), set by make_loader
         const int part = (h == 1) ? ph : fdiv(ph, h, d.mg1), hd = ph - part * h;
         return *(const uint4*)((const uint16_t*)d.ptr + ((((long)bw * h + hd) * S + part) * Lp + t) * DP + j);
     }
@@ -266,7 +266,10 @@ ALoad<AK> make_loader(const swv2_operand* o) {
     l.d.aux3 = o->aux3; l.d.ld = o->ld; l.d.M = o->rows; l.d.K = o->cols;
     l.d.p0 = o->p[0]; l.d.p1 = o->p[1]; l.d.p2 = o->p[2]; l.d.p3 = o->p[3];
     l.d.mg0 = l.d.mg1 = l.d.mg2 = 0;
-    if (AK == A_HEADS) { l.d.mg0 = fdiv_magic(o->p[2]); l.d.mg1 = fdiv_magic(o->p[0]); }
+    if (AK == A_HEADS) {
+        l.d.mg0 = fdiv_magic(o->p[2]); l.d.mg1 = fdiv_magic(o->p[0]);
+        l.d.p1 = o->p[3] == 16 ? 4 : o->p[3] == 32 ? 5 : o->p[3] == 64 ? 6 : 7;
+    }
     if (AK == A_PATCH) { l.d.mg0 = fdiv_magic((o->p[1] / 4) * (o->p[2] / 4)); l.d.mg1 = fdiv_magic(o->p[2] / 4); }
     return l;
 }
@@ -278,6 +281,8 @@ int check_operand(const swv2_operand* o, const char* who) {
     SWV2_CHECK_ARG(((uintptr_t)o->ptr & 15) == 0, "%s: operand pointer must be 16-byte aligned", who);
     if (o->kind == SWV2_OP_F32 || o->kind == SWV2_OP_BF16 || o->kind == SWV2_OP_BF16_GELU)
         SWV2_CHECK_ARG(o->ld % 8 == 0 && o->ld >= o->cols, "%s: row pitch %ld must be a multiple of 8 and >= cols", who, o->ld);
+    if (o->kind == SWV2_OP_HEADS)
+        SWV2_CHECK_ARG(o->p[3] == 16 || o->p[3] == 32 || o->p[3] == 64 || o->p[3] == 128, "%s: head pad %d not in {16,32,64,128}", who, o->p[3]);
     if (o->kind == SWV2_OP_PATCH)
         SWV2_CHECK_ARG(o->p[1] % 4 == 0 && o->p[2] % 4 == 0 && o->cols == o->p[0] * 16, "%s: bad patch geometry", who);
     if (o->kind == SWV2_OP_MERGE_LN)

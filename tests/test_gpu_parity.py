@@ -572,6 +572,41 @@ def test_whole_model_against_reference_fixture(dev, K, tag):
     assert rel(y2, y) < 1e-6 and rel(x2.grad, x.grad) < 1e-3
 
 
+def test_model_at_yaml_default_width(dev, K):
+    """config/swin.yaml's base block has embed_dim 768 / 8 heads = head dim 96 (was rejected by the attention
+    kernels): the whole model (PatchEmbed, 2 blocks incl. a shifted one, head + un-patchify, residual) on a small image,
+    forward and backward against the bf16-emulating oracle.  C = 768 has no fused MLP / proj+LN instantiation, so this also
+    covers the unfused launch sequence and the per-product weight-gradient launches at that width."""
+    N = K["N"]
+    H, W, Cc, h, depth, ratio, cin = 48, 72, 768, 8, 2, 8, 3          # 12 x 18 tokens, 6 x 9 windows
+    torch.manual_seed(5)
+    m = N.SwinTransformerV2Cr(img_size=(H, W), patch_size=4, depths=(depth,), num_heads=(h,), in_chans=cin, out_chans=cin,
+                              embed_dim=Cc, img_window_ratio=ratio, full_pos_embed=True, rel_pos=False, residual=True)
+    with torch.no_grad():
+        for n_, p_ in m.named_parameters():
+            if n_.endswith("norm1.weight") or n_.endswith("norm2.weight"):
+                p_.uniform_(0.5, 1.0)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x0 = torch.randn(2, cin, H, W, generator=torch.Generator().manual_seed(1))
+    gy0 = torch.randn(2, cin, H, W, generator=torch.Generator().manual_seed(2))
+    m = m.to(dev).eval()
+    x = x0.to(dev).requires_grad_(True)
+    y = m(x)
+    y.backward(gy0.to(dev))
+    cfg = O.SwinCfg(img_size=(H, W), patch_size=4, depth=depth, num_heads=h, in_chans=cin, out_chans=cin, embed_dim=Cc,
+                    window_ratio=ratio, rel_pos=False, residual=True)
+    p = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
+    xo = x0.clone().requires_grad_(True)
+    O.set_rounding(O.bf16_round)
+    try:
+        yo = O.model_forward(xo, p, cfg, training=False)
+        yo.backward(gy0)
+    finally:
+        O.set_rounding(None)
+    assert rel(y, yo) < 6e-3 and rel(x.grad, xo.grad) < 2e-2, (rel(y, yo), rel(x.grad, xo.grad))
+    assert worst_grad(m, {k: v.grad for k, v in p.items() if v.requires_grad}) < 6e-2
+
+
 def test_multistep_wrapper_against_reference_fixture(dev, K):
     from types import SimpleNamespace
     fx = np.load(os.path.join(GOLD, "multistep.npz"))
@@ -979,6 +1014,46 @@ def test_block_fused_and_unfused_paths(dev, K, monkeypatch, knob, value):
         O.set_rounding(None)
     assert rel(y, yo) < 1e-3 and rel(x.grad, xo.grad) < 1.5e-2
     assert worst_grad(blk, {k[2:]: v.grad for k, v in p.items()}) < 3e-2
+
+
+@pytest.mark.parametrize("gh,gw,wh,ww,sh,sw,Cc,h,relpos", [
+    (12, 18, 6, 9, 3, 4, 192, 2, False),     # head dim 96 -> padded to 128, 54-token window
+    (18, 36, 9, 18, 4, 9, 128, 2, False),    # head dim 64, 162-token window, shifted (mask)
+    (18, 36, 9, 18, 0, 0, 192, 2, True),     # head dim 96 at the 162-token window: single-buffer forward, q / dO from L2 in backward; CPB bias
+    (12, 18, 6, 9, 0, 0, 96, 2, True),       # head dim 48 -> 64
+])
+def test_block_wide_heads_against_oracle(dev, K, gh, gw, wh, ww, sh, sw, Cc, h, relpos):
+    """Head dims beyond 32 (the reference's yaml default is 768 / 8 = 96): padded to 64 / 128 columns, the
+    generic attention instantiations, the two-pass q / k normalisation of the 128-wide layout.  Forward and backward of a
+    whole block against the bf16-emulating oracle."""
+    N = K["N"]
+    B = 2
+    torch.manual_seed(3)
+    blk = N.SwinTransformerV2CrBlock(dim=Cc, num_heads=h, feat_size=(gh, gw), window_size=(wh, ww), shift_size=(sh, sw),
+                                     rel_pos=relpos, drop_path=0.0)
+    with torch.no_grad():
+        blk.norm1.weight.uniform_(0.5, 1.0)
+        blk.norm2.weight.uniform_(0.5, 1.0)
+    sd = {k: v.detach().clone() for k, v in blk.state_dict().items()}
+    x0 = torch.randn(B, gh, gw, Cc, generator=torch.Generator().manual_seed(1))
+    gy0 = torch.randn(B, gh, gw, Cc, generator=torch.Generator().manual_seed(2))
+    blk = blk.to(dev).eval()
+    x = x0.to(dev).requires_grad_(True)
+    y = blk(x)
+    y.backward(gy0.to(dev))
+    assert blk._runner(B, x.device).plan.DP == (64 if Cc // h <= 64 else 128)
+    p = {"b." + k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
+    xo = x0.clone().requires_grad_(True)
+    O.set_rounding(O.bf16_round)
+    try:
+        yo = O.block_forward(xo, p, "b.", block_cfg(gh, gw, wh, ww, sh, sw, Cc, h, relpos), 1, training=False)
+        yo.backward(gy0)
+    finally:
+        O.set_rounding(None)
+    # (the 128-wide layout rounds q^, k^ to bf16 twice: slightly wider bars than the narrow-head block tests)
+    fbar = 3e-3 if Cc // h <= 64 else 6e-3
+    assert rel(y, yo) < fbar and rel(x.grad, xo.grad) < 2e-2, (rel(y, yo), rel(x.grad, xo.grad))
+    assert worst_grad(blk, {k[2:]: v.grad for k, v in p.items() if v.requires_grad}) < 4e-2
 
 
 @pytest.mark.parametrize("gh,gw,wh,ww,sh,sw,Cc,h", [(36, 72, 9, 18, 4, 9, 128, 8), (12, 27, 6, 9, 3, 4, 64, 4), (12, 18, 6, 9, 0, 0, 96, 8)])

@@ -160,7 +160,8 @@ def main():
     lp = SimpleNamespace(n_future=0, img_shape_x=a.height, img_shape_y=a.width, loss="l2", channel_weights="none",
                          n_out_channels=73, model_grid_type="equiangular")
     loss_obj = LossHandler(lp).to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.95), fused=True)
+    from swin_v2_weather_amd.utils.optim import HipAdam
+    opt = HipAdam(model.parameters(), lr=1e-3, betas=(0.9, 0.95))        # train.py:176, one swv2_adam_multi launch per step
     net = model
     if use_ddp:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], output_device=local_rank,

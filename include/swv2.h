@@ -232,6 +232,20 @@ int swv2_loss_grad(const float* prd, const float* tar, const float* quad_w, cons
 int swv2_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                    int step, float grad_inv_scale, void* stream);
 
+/* The same update for MANY tensors in one launch (replaces optimizer.step() of train.py:176 / :330).  items_dev: device
+ * array of tensors; chunks_dev: device array of int pairs (item index, chunk index within the item), one workgroup per
+ * chunk of swv2_adam_chunk() elements; both tables are built by the caller (swin_v2_weather_amd/utils/optim.py). */
+typedef struct swv2_adam_item {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    long n;
+} swv2_adam_item;
+int swv2_adam_chunk(void);
+int swv2_adam_multi(const swv2_adam_item* items_dev, const int* chunks_dev, int n_chunks, float lr, float beta1, float beta2,
+                    float eps, int step, float grad_inv_scale, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * ERA5 input assembly (the step BEFORE the model): raw time slabs staged on the device by async H2D copies
  * -> the model's input / target buffers, one pass each.

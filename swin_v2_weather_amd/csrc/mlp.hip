@@ -257,8 +257,9 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(const MlpFwd a) {
     }
 #ifdef SWV2_MLP_STAMPS
     STAMP(7);
-    if (lane == 0 && (blockIdx.x % 97) == 0) {       // a sample of waves: y[...] is overwritten with the stamps (probe only)
-        unsigned long long* o = (unsigned long long*)a.mean + ((blockIdx.x / 97) * 4 + wave) * 8;
+    __syncthreads();
+    if (lane == 0 && (blockIdx.x % 97) == 0) {       // a sample of workgroups: their own `mean` rows are overwritten with the stamps (probe only)
+        unsigned long long* o = (unsigned long long*)(a.mean + wg_row0) + wave * 8;
         for (int i = 0; i < 8; ++i) o[i] = tacc[i];
     }
 #endif

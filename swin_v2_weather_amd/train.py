@@ -135,8 +135,11 @@ class Trainer():
         self.preprocessor = PreProcessor(params, self.device).to(self.device)
 
         if params.optimizer_type == 'adam':
-            self.optimizer = torch.optim.Adam(self.model.parameters(), lr=params.lr, betas=(0.9, 0.95),
-                                              fused=self.device.type == 'cuda')
+            if self.device.type == 'cuda':
+                from .utils.optim import HipAdam
+                self.optimizer = HipAdam(self.model.parameters(), lr=params.lr, betas=(0.9, 0.95))
+            else:
+                self.optimizer = torch.optim.Adam(self.model.parameters(), lr=params.lr, betas=(0.9, 0.95))
         elif params.optimizer_type == 'FusedLAMB':
             raise Exception("optimizer type FusedLAMB needs apex, which is not available in this build")
         else:

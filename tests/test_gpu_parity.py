@@ -1311,3 +1311,45 @@ def test_registry_checkpoint_and_inference_rollout(dev, K, tmp_path):
         inference.load_model_state(model, sd)
     with pytest.raises(KeyError):
         inference.load_model_state(model, {"bogus": torch.zeros(1)})
+
+
+def test_hip_adam_matches_torch_adam(dev, K):
+    """utils/optim.HipAdam (one swv2_adam_multi launch) against torch.optim.Adam on the same parameters / gradients for 5
+    steps: odd sizes, a channels-last parameter (the model's pos_embed), a parameter without gradient; the state_dict
+    round-trips into torch's Adam and back (the reference's checkpoints, train.py:374-389)."""
+    from swin_v2_weather_amd.utils.optim import HipAdam
+    g = torch.Generator().manual_seed(0)
+    shapes = [(7,), (129, 3), (4096,), (5000, 3), (1, 16, 12, 18), (33,)]
+    def make():
+        ps = []
+        for i, sh in enumerate(shapes):
+            t = torch.randn(*sh, generator=torch.Generator().manual_seed(i))
+            if len(sh) == 4:
+                t = t.contiguous(memory_format=torch.channels_last)
+            ps.append(torch.nn.Parameter(t.to(dev)))
+        return ps
+    pa, pb = make(), make()
+    oa = HipAdam(pa, lr=3e-3, betas=(0.9, 0.95))
+    ob = torch.optim.Adam(pb, lr=3e-3, betas=(0.9, 0.95))
+    for it in range(5):
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            if i == len(shapes) - 1:
+                continue                                  # never receives a gradient
+            gr = torch.randn(a.shape, generator=g).to(dev)
+            if a.dim() == 4:
+                gr = gr.contiguous(memory_format=torch.channels_last)
+            a.grad, b.grad = gr.clone(), gr.clone()
+        oa.step()
+        ob.step()
+        if it == 2:                                       # checkpoint round trip through torch's own optimizer class
+            sd = oa.state_dict()
+            oc = torch.optim.Adam(pa, lr=3e-3, betas=(0.9, 0.95))
+            oc.load_state_dict(sd)
+            oa.load_state_dict(oc.state_dict())
+    for a, b in zip(pa, pb):
+        assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max())), a.shape
+    sa, sb = oa.state_dict()["state"], ob.state_dict()["state"]
+    assert set(sa.keys()) == set(sb.keys())
+    for k in sa:
+        assert float(sa[k]["step"]) == float(sb[k]["step"]) == 5.0
+        assert float((sa[k]["exp_avg_sq"] - sb[k]["exp_avg_sq"]).abs().max()) <= 1e-6 * float(sb[k]["exp_avg_sq"].abs().max())

@@ -18,7 +18,8 @@ z = lambda n: torch.zeros(n, device=dev)
 for _ in range(3):
     y, hpre, a2, mean, rstd = ops.mlp_fwd(x, w1, z(hid), w2, z(Cc), torch.ones(Cc, device=dev), z(Cc), None, T)
 torch.cuda.synchronize()
-st = mean.view(torch.int64)[: 11 * 4 * 8].view(-1, 8).cpu().double()
+rows_wg = 128                                             # MT = 2 at C = 128
+st = torch.cat([mean[b * rows_wg: b * rows_wg + 64].view(torch.int64).view(4, 8) for b in range(0, (M + rows_wg - 1) // rows_wg, 97)]).cpu().double()
 names = ["prologue", "p1 mfma issue", "gelu", "p2 mfma", "commit", "stores", "barrier", "epilogue"]
 print("wave-avg ticks (100 MHz s_memtime => x21 shader cycles at 2.1 GHz):")
 for i, n in enumerate(names):

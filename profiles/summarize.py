@@ -71,8 +71,32 @@ def counters(root, out):
                 print(f"    {c:28s} {v[c]:16.0f}")
 
 
+def mfma(sq_json, out):
+    """counter-based MFMA pipe utilisation per kernel: SQ_VALU_MFMA_BUSY_CYCLES (sum over the 1024 SIMDs of the cycles the
+    matrix pipe was busy) / (SQ_BUSY_CYCLES x 32): SQ_BUSY_CYCLES is summed over the 32 shader engines (4 per XCD), so
+    SQ_BUSY_CYCLES / 32 is the kernel's duration in shader clocks and x 1024 SIMDs gives the SIMD-cycles available."""
+    d = json.load(open(sq_json))
+    res = {}
+    for n, v in d.items():
+        if "SQ_VALU_MFMA_BUSY_CYCLES" not in v or v.get("SQ_INSTS_MFMA", 0) <= 0:
+            continue
+        simd_cycles = v["SQ_BUSY_CYCLES"] * 32.0
+        res[n] = {"SQ_INSTS_MFMA": v["SQ_INSTS_MFMA"], "SQ_VALU_MFMA_BUSY_CYCLES": v["SQ_VALU_MFMA_BUSY_CYCLES"],
+                  "SQ_BUSY_CYCLES": v["SQ_BUSY_CYCLES"], "SQ_INSTS_VALU": v.get("SQ_INSTS_VALU"),
+                  "SQ_ACTIVE_INST_VALU": v.get("SQ_ACTIVE_INST_VALU"), "SQ_WAVES": v.get("SQ_WAVES"),
+                  "cycles_per_mfma": v["SQ_VALU_MFMA_BUSY_CYCLES"] / v["SQ_INSTS_MFMA"],
+                  "kernel_shader_clocks": v["SQ_BUSY_CYCLES"] / 32.0,
+                  "mfma_pipe_busy_frac": v["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles,
+                  "valu_issue_frac": (v.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0) / simd_cycles}
+    json.dump({"_formula": mfma.__doc__, "kernels": res}, open(out, "w"), indent=1, sort_keys=True)
+    for n in sorted(res, key=lambda k: -res[k]["SQ_VALU_MFMA_BUSY_CYCLES"])[:14]:
+        print(f"{res[n]['mfma_pipe_busy_frac']:6.3f} mfma  {res[n]['valu_issue_frac']:6.3f} valu  {n}")
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "counters":
+    if sys.argv[1] == "mfma":
+        mfma(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "counters":
         counters(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "stats":
         stats(sys.argv[2], int(sys.argv[3]), sys.argv[4])

@@ -231,6 +231,10 @@ __device__ __forceinline__ void heads_item_wide(const EpiDesc& d, const float* s
 }
 template <> struct Epi<E_QKV_HEADS> {
     EpiDesc d;
+    // compile-time head pad (callers that checked p3 on the host): only that variant is inlined
+    template <int DPC> __device__ __forceinline__ void tile_fixed(const float* st, int m0, int n0, int lane) const {
+        heads_item<DPC, true>(d, st, m0, n0, lane);
+    }
     __device__ __forceinline__ void tile(const float* st, int m0, int n0, int lane) const {
         if (d.p3 == 16) heads_item<16, true>(d, st, m0, n0, lane);
         else if (d.p3 == 32) heads_item<32, true>(d, st, m0, n0, lane);
@@ -409,6 +413,218 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(ALoad<AK> al, cons
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Resident-weight kernel for the two per-block row-streaming products at the benchmark width (qkv: N = 384, K = 128 and
+// d(qkv) -> dx: N = 128, K = 384).  gemm_nt_kernel above is latency-bound there (measured: ~20 us workgroup lifetime for
+// 64 rows = one HBM round trip for the A panel + six dependent L2 round trips for the weight tiles + three epilogues, at
+// three workgroups per CU -> 3 TB/s).  Here ONE persistent 8-wave workgroup per CU keeps the whole bf16 weight (96 KB) in
+// LDS, walks row tiles t = blockIdx.x, + gridDim.x, ... and always has the NEXT tile's A rows in flight in registers while
+// the current tile runs its MFMAs and its epilogue: per tile one A commit, no weight traffic, two barriers.
+//   LDS: W[N][K] (swizzled 16-byte chunks) | A tile [BMT][K] bf16, re-used as the waves' epilogue staging
+//   waves: 4 row groups x 2 column halves; wave tile = (BMT / 4) x (N / 2)
+// ------------------------------------------------------------------------------------------------
+#ifdef SWV2_RW_STAMPS
+__device__ unsigned long long rw_stamps[256 * 8];
+#define RSTAMP_DECL unsigned long long st_prev = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define RSTAMP_START() do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev) : : "memory"); } while (0)
+#define RSTAMP(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : : "memory"); \
+                       st_acc[k] += t_ - st_prev; st_prev = t_; } while (0)
+#define RSTAMP_WAITV() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define RSTAMP_DECL
+#define RSTAMP_START() do {} while (0)
+#define RSTAMP(k) do {} while (0)
+#define RSTAMP_WAITV() do {} while (0)
+#endif
+__device__ __forceinline__ int swzk(int r, int kc, int K) { return r * K + ((kc ^ ((r >> 1) & 7)) << 3); }
+
+template <int AK, int EK, int N, int K, int BMT>
+__global__ __launch_bounds__(512) void gemm_rw_kernel(ALoad<AK> al, const uint16_t* __restrict__ Wb, Epi<EK> ep, int M) {
+    constexpr int NTH = 512, KC = K / 8;                    // 16-byte chunks per row
+    constexpr int ACH = BMT * KC / NTH;                     // A chunks per thread per tile
+    constexpr int RT = BMT / 64;                            // 16-row MFMA tiles per wave (4 row groups)
+    constexpr int CT = N / 32;                              // 16-column MFMA tiles per wave (2 column halves)
+    constexpr int WCH = N * KC / NTH;                       // weight chunks per thread (one-time load)
+    constexpr int A_BYTES = BMT * K * 2, ST_BYTES = 8 * 16 * EP * 4;
+    constexpr int AS_BYTES = A_BYTES > ST_BYTES ? A_BYTES : ST_BYTES;
+    static_assert(BMT * KC % NTH == 0 && N * KC % NTH == 0 && K % 64 == 0 && N % 64 == 0, "tile shapes");
+    static_assert(N * K * 2 + AS_BYTES <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(16))) uint16_t Ws[N * K];
+    __shared__ __attribute__((aligned(16))) unsigned char as_raw[AS_BYTES];
+    // The epilogue must not LOAD from global memory: such a load sits behind the next tile's A prefetch in the in-order
+    // vmcnt queue, so waiting for it exposes the whole HBM round trip of the prefetch right there (measured with the
+    // generic Epi::tile: 52 % / 40 % of the kernel inside the epilogue, 6 % in the explicit wait for A).  The bias lives
+    // in LDS; the scatter rows and the residual rows of the d(qkv) -> dx product are prefetched WITH the A rows.
+    __shared__ __attribute__((aligned(16))) float bs[N];
+    uint16_t* As = (uint16_t*)as_raw;
+    float* stage_all = (float*)as_raw;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, g = lane >> 4;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int ntiles = (M + BMT - 1) / BMT;
+    static_assert(EK != E_F32 || (RT == 1 && CT == 4), "the E_F32 prefetch below covers one 16 x 64 wave tile");
+    for (int i = tid; i < N; i += NTH) bs[i] = ep.d.bias ? ep.d.bias[i] : 0.f;
+    // E_F32: this lane's epilogue row (lane >> 2 of the wave's 16) and its 16 columns
+    int erow_nxt = -1, erow_cur = -1;                       // destination row of the tile in flight / being computed
+    f32x4 aux_nxt[4], aux_cur[4];
+    const int ecol = wc * (N / 2) + (lane & 3) * 16;
+
+    // ONE tile of A rows in flight per workgroup in registers.  (Two sets used alternately were measured SLOWER, 60.5 vs
+    // 54.1 us for qkv: the kernel is not short of outstanding bytes.)  The gather rows of tile t + 2G are resolved while
+    // tile t + G's data loads are issued, so the index load is never in front of a data load.
+    typename ALoad<AK>::Raw ra[ACH];
+    int arow[ACH];
+    int erow_res = -1;
+    auto resolve = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) {
+            const int c = tid + i * NTH;
+            arow[i] = al.row_of(t < ntiles ? t * BMT + c / KC : M);
+        }
+        if constexpr (EK == E_F32) {
+            const int m = t * BMT + wr * 16 + (lane >> 2);
+            erow_res = (t < ntiles && m < M) ? (ep.d.rowidx ? ep.d.rowidx[m] : m) : -1;
+        }
+    };
+    auto issue = [&]() {
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) {
+            const int c = tid + i * NTH;
+            ra[i] = al.raw_at(arow[i], (c % KC) * 8);
+        }
+        if constexpr (EK == E_F32) {
+            erow_nxt = erow_res;
+            const float* ax = (const float*)ep.d.aux + (long)max(erow_nxt, 0) * ep.d.ld + ecol;      // unconditional loads
+#pragma unroll
+            for (int i = 0; i < 4; ++i) aux_nxt[i] = ep.d.aux ? *(const f32x4*)(ax + 4 * i) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) {
+            const int c = tid + i * NTH;
+            *(uint4*)(As + swzk(c / KC, c % KC, K)) = al.cvt(ra[i]);
+        }
+    };
+    const int G = gridDim.x;
+    RSTAMP_DECL
+    auto tile_step = [&](int t) {
+        RSTAMP_WAITV();
+        RSTAMP(0);
+        commit();
+        if constexpr (EK == E_F32) {
+            erow_cur = erow_nxt;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) aux_cur[i] = aux_nxt[i];
+        }
+        RSTAMP(1);
+        __syncthreads();                                   // A tile (and, the first time, the weight) visible
+        RSTAMP(2);
+        issue();                                           // next tile's rows: in flight during the MFMAs and the epilogue
+        resolve(t + 2 * G);
+        RSTAMP(3);
+        f32x4 acc[RT][CT];
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int j = 0; j < CT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < K / 32; ++ks) {
+            bf16x8 af[RT];
+#pragma unroll
+            for (int i = 0; i < RT; ++i) af[i] = *(const bf16x8*)(As + swzk(wr * 16 * RT + i * 16 + fr, ks * 4 + g, K));
+#pragma unroll
+            for (int j = 0; j < CT; ++j) {
+                const bf16x8 bf = *(const bf16x8*)(Ws + swzk(wc * (N / 2) + j * 16 + fr, ks * 4 + g, K));
+#pragma unroll
+                for (int i = 0; i < RT; ++i) acc[i][j] = mfma32(af[i], bf, acc[i][j]);
+            }
+        }
+        asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[RT - 1][CT - 1][3]));
+        RSTAMP(4);
+        __syncthreads();                                   // every wave is done with the A tile: it becomes the staging area
+        RSTAMP(5);
+        float* st = stage_all + wave * 16 * EP;
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int j0 = 0; j0 < CT; j0 += 4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) st[(4 * g + r) * EP + 16 * j + fr] = acc[i][j0 + j][r];
+                const int m0 = t * BMT + wr * 16 * RT + i * 16, n0 = wc * (N / 2) + j0 * 16;
+                if constexpr (EK == E_QKV_HEADS) {
+                    // heads_item<16, true> with the bias from LDS: lane = (row r, 16-column head slot)
+                    const EpiDesc& d = ep.d;
+                    const int h = d.p0, Lp = d.p2, L = d.p4;
+                    const int r = lane & 15, slot = lane >> 4, nb = n0 + slot * 16, m = m0 + r;
+                    if (m < d.M) {
+                        const int ph = nb >> 4, part = (h == 1) ? ph : fdiv(ph, h, d.mg1), hd = ph - part * h;
+                        const int bw = fdiv(m, Lp, d.mg0), tt = m - bw * Lp;
+                        const bool valid = tt < L;
+                        float v[16];
+                        float ss = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 16; j += 4) {
+                            const f32x4 x = *(const f32x4*)(st + r * EP + slot * 16 + j) + *(const f32x4*)(bs + nb + j);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                v[j + e] = valid ? x[e] : 0.f;
+                                ss = fmaf(v[j + e], v[j + e], ss);
+                            }
+                        }
+                        float rn = 1.f;
+                        if (part < 2) {
+                            rn = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+                            d.aux_out[(((long)bw * h + hd) * 2 + part) * Lp + tt] = valid ? rn : 0.f;
+                        }
+                        uint16_t* o = (uint16_t*)d.out + ((((long)bw * h + hd) * 3 + part) * Lp + tt) * 16;
+                        float w8[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) w8[e] = v[e] * rn;
+                        *(uint4*)o = pack8(w8);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) w8[e] = v[8 + e] * rn;
+                        *(uint4*)(o + 8) = pack8(w8);
+                    }
+                } else if constexpr (EK == E_F32) {
+                    // Epi<E_F32>::tile with the scatter row and the residual prefetched (N == 128: no column tail)
+                    if (erow_cur >= 0) {
+                        float* o = (float*)ep.d.out + (long)erow_cur * ep.d.ld + ecol;
+                        const int r = lane >> 2, c0 = (lane & 3) * 16;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            *(f32x4*)(o + 4 * q) = *(const f32x4*)(st + r * EP + c0 + 4 * q) + *(const f32x4*)(bs + ecol + 4 * q) + aux_cur[q];
+                    }
+                } else {
+                    ep.tile(st, m0, n0, lane);
+                }
+            }
+        RSTAMP(6);
+        __syncthreads();                                   // staging consumed before the next commit overwrites it
+        RSTAMP(7);
+    };
+    int t = blockIdx.x;
+    resolve(t);
+    issue();                                               // first tile's rows in flight before the weight is fetched
+    resolve(t + G);
+    // ---- the weight, once (made visible by the first tile's barrier)
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) {
+        const int c = tid + i * NTH, n = c / KC, kc = c - n * KC;
+        *(uint4*)(Ws + swzk(n, kc, K)) = *(const uint4*)(Wb + (long)n * K + kc * 8);
+    }
+
+    RSTAMP_START();
+    for (; t < ntiles; t += G) tile_step(t);
+#ifdef SWV2_RW_STAMPS
+    if (tid == 0)
+        for (int k = 0; k < 8; ++k) rw_stamps[blockIdx.x * 8 + k] = st_acc[k];
+#endif
+}
+
 template <int AK, int EK>
 int launch_nt2(const swv2_operand* a, const void* w, const swv2_epilogue* e, int M, int N, int K, hipStream_t st) {
     Epi<EK> ep;
@@ -418,6 +634,24 @@ int launch_nt2(const swv2_operand* a, const void* w, const swv2_epilogue* e, int
     ep.d.mg0 = ep.d.mg1 = ep.d.mg2 = 0;
     if (EK == E_QKV_HEADS || EK == E_HEADS) { ep.d.mg0 = fdiv_magic(e->p[2]); ep.d.mg1 = fdiv_magic(e->p[0]); }
     if (EK == E_UNPATCH) { ep.d.mg0 = fdiv_magic((e->p[1] / 4) * (e->p[2] / 4)); ep.d.mg1 = fdiv_magic(e->p[2] / 4); }
+    // the two per-block products at the benchmark width: resident-weight persistent kernel
+    static const int rw = getenv("SWV2_GEMM_RW") ? atoi(getenv("SWV2_GEMM_RW")) : 1;
+    if constexpr (AK == A_F32 && EK == E_QKV_HEADS) {
+        if (rw && N == 384 && K == 128 && M >= 256 * 128 && e->p[3] == 16) {
+            hipLaunchKernelGGL((gemm_rw_kernel<AK, EK, 384, 128, 128>), dim3(256), dim3(512), 0, st, make_loader<AK>(a),
+                               (const uint16_t*)w, ep, M);
+            SWV2_CHECK_LAUNCH("swv2_linear");
+            return SWV2_OK;
+        }
+    }
+    if constexpr (AK == A_HEADS && EK == E_F32) {
+        if (rw && N == 128 && K == 384 && M >= 256 * 64) {
+            hipLaunchKernelGGL((gemm_rw_kernel<AK, EK, 128, 384, 64>), dim3(256), dim3(512), 0, st, make_loader<AK>(a),
+                               (const uint16_t*)w, ep, M);
+            SWV2_CHECK_LAUNCH("swv2_linear");
+            return SWV2_OK;
+        }
+    }
     // 64-row workgroups where they fill the 768 slots (3 per CU) better; only for the two per-block products
     bool half = false;
     if constexpr ((AK == A_F32 && EK == E_QKV_HEADS) || (AK == A_HEADS && EK == E_F32)) {
@@ -453,6 +687,12 @@ int launch_nt1(const swv2_operand* a, const void* w, const swv2_epilogue* e, int
 }
 
 }  // namespace
+
+#ifdef SWV2_RW_STAMPS
+extern "C" int swv2_debug_rw_stamps(void* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(rw_stamps), sizeof(unsigned long long) * 256 * 8) == hipSuccess ? 0 : -3;
+}
+#endif
 
 extern "C" int swv2_linear(const swv2_operand* a, const void* w_bf16, const swv2_epilogue* e, int N, void* stream) {
     int rc = check_operand(a, "swv2_linear");

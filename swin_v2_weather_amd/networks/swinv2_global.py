@@ -408,7 +408,9 @@ class WindowMultiHeadAttention(WindowMultiHeadAttentionNoPos):
     def position_bias(self) -> torch.Tensor:
         """[heads, L, L] bias table (reference :274-287) from two fused kernels (swv2_cpb_fwd / _bwd).  The only host-side
         piece is the draw of the hard-coded Dropout(0.125) keep-mask (:245): F.dropout on a [L^2, hidden] tensor of ones
-        consumes the torch RNG exactly like the reference's nn.Dropout on the hidden activations of the same shape."""
+        consumes the torch RNG exactly like the reference's nn.Dropout on the bf16 (autocast, train.py:277) hidden activations
+        of the same shape (tests/test_gpu_parity.py::test_cpb_dropout_draw_consumes_the_rng_like_the_reference; an fp32
+        activation -- the reference without --enable_amp -- drops other elements)."""
         m = self.meta_mlp
         wh, ww = self.window_size
         keep = None

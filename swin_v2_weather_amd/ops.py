@@ -45,7 +45,9 @@ BLOCK_KERNEL_IDS = {"qkv": 1, "attn_fwd": 2, "proj": 3, "ln1_fwd": 4, "fc1": 5, 
                     "wgrad_fc2": 12, "dh": 13, "wgrad_fc1": 14, "dx1": 15, "ln1_bwd": 16, "wgrad_proj": 17, "doh": 18,
                     "attn_bwd": 19, "wgrad_qkv": 20, "dx": 21,
                     # fused kernels share the launch slot of the first kernel they replace
-                    "proj_ln_fwd": 3, "mlp_fwd": 5, "mlp_bwd": 13, "proj_ln_bwd": 16}
+                    "proj_ln_fwd": 3, "mlp_fwd": 5, "mlp_bwd": 13, "proj_ln_bwd": 16,
+                    # the four weight gradients of a block as one grouped launch + its partial-tile reduction
+                    "wgrad_group": 22}
 
 
 _RR = {"fwd": 0, "bwd": 0}

@@ -1353,3 +1353,30 @@ def test_hip_adam_matches_torch_adam(dev, K):
     for k in sa:
         assert float(sa[k]["step"]) == float(sb[k]["step"]) == 5.0
         assert float((sa[k]["exp_avg_sq"] - sb[k]["exp_avg_sq"]).abs().max()) <= 1e-6 * float(sb[k]["exp_avg_sq"].abs().max())
+
+
+def test_cpb_dropout_draw_consumes_the_rng_like_the_reference(dev, K):
+    """position_bias() draws the keep-mask of the CPB meta-MLP's hard-coded Dropout(0.125) with F.dropout on a bf16 tensor
+    of ones [L^2, hidden]; the reference, trained under bf16 autocast (train.py:277), applies nn.Dropout to the bf16
+    hidden activation of the same shape (swinv2_global.py:245, :386-388).  Same seed -> the same elements are dropped and
+    the generator is left in the same state (the next draw -- the first DropPath Bernoulli of the step -- is identical).
+    (An fp32 activation, i.e. the reference WITHOUT --enable_amp, maps the Philox stream to elements with another vector
+    width and drops other elements: measured here, and the reason the equivalence is stated for the amp mode only.)"""
+    import torch.nn.functional as F
+    shape = (54 * 54, 384)                                   # cfg-1 window (6 x 9)^2, meta hidden 384
+    outs = {}
+    for tag, dt in (("bf16_ones", torch.bfloat16), ("fp32_act", torch.float32), ("bf16_act", torch.bfloat16)):
+        torch.manual_seed(1234)
+        torch.cuda.manual_seed(1234)
+        src = torch.ones(shape, dtype=dt, device=dev) if tag == "bf16_ones" else \
+            (torch.randn(shape, generator=torch.Generator().manual_seed(0)).abs() + 0.5).to(dev).to(dt)
+        y = F.dropout(src, 0.125, True)
+        nxt = torch.empty(8, 1, 1, 1, device=dev).bernoulli_(0.9)        # DropPath's draw (timm drop_path)
+        outs[tag] = ((y != 0).cpu(), nxt.cpu(), torch.cuda.get_rng_state(dev).clone())
+    for tag in ("bf16_act",):
+        assert torch.equal(outs[tag][0], outs["bf16_ones"][0]), tag        # same keep pattern
+        assert torch.equal(outs[tag][1], outs["bf16_ones"][1]), tag        # same following draw
+        assert torch.equal(outs[tag][2], outs["bf16_ones"][2]), tag        # same generator state
+    assert abs(float(outs["fp32_act"][0].float().mean()) - 0.875) < 5e-3   # fp32: same rate, other elements (see above)
+    frac = float(outs["bf16_ones"][0].float().mean())
+    assert abs(frac - 0.875) < 5e-3

@@ -60,7 +60,10 @@ def test_ctypes_structs_follow_the_header_field_order():
     the C structs, in order -- a missing member shifts every later pointer by one slot (`bias_pack`)"""
     pairs = {"swv2_attn_args": L.AttnArgs, "swv2_operand": L.Operand, "swv2_epilogue": L.Epilogue, "swv2_block_desc": L.BlockDesc,
              "swv2_mlp_args": L.MlpArgs, "swv2_mlp_bwd_args": L.MlpBwdArgs, "swv2_proj_ln_args": L.ProjLnArgs,
-             "swv2_proj_ln_bwd_args": L.ProjLnBwdArgs, "swv2_attn_branch_args": L.AttnBranchArgs, "swv2_ln_args": L.LnArgs}
+             "swv2_proj_ln_bwd_args": L.ProjLnBwdArgs, "swv2_attn_branch_args": L.AttnBranchArgs, "swv2_ln_args": L.LnArgs,
+             "swv2_wgrad_item": L.WgradItem}
+    from swin_v2_weather_amd.utils.optim import _Item
+    pairs["swv2_adam_item"] = _Item
     for cname, cls in pairs.items():
         assert [f[0] for f in cls._fields_] == header_struct_fields(cname), cname
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
@@ -76,7 +79,12 @@ def test_argument_errors_are_reported_without_touching_the_gpu():
     lp, dp = ctypes.c_int(), ctypes.c_int()
     assert lib.swv2_attn_geometry(162, 16, ctypes.byref(lp), ctypes.byref(dp)) == 0 and (lp.value, dp.value) == (176, 16)
     assert lib.swv2_attn_geometry(54, 24, ctypes.byref(lp), ctypes.byref(dp)) == 0 and (lp.value, dp.value) == (64, 32)
+    assert lib.swv2_attn_geometry(54, 96, ctypes.byref(lp), ctypes.byref(dp)) == 0 and (lp.value, dp.value) == (64, 128)   # yaml default 768 / 8
+    assert lib.swv2_attn_geometry(162, 48, ctypes.byref(lp), ctypes.byref(dp)) == 0 and (lp.value, dp.value) == (176, 64)
     assert lib.swv2_attn_geometry(400, 16, ctypes.byref(lp), ctypes.byref(dp)) == -1
+    assert lib.swv2_attn_geometry(54, 160, ctypes.byref(lp), ctypes.byref(dp)) == -1
+    assert lib.swv2_block_wgrad(None, 0, None, 0, None) == -1 and lib.swv2_adam_multi(None, None, 0, 1e-3, 0.9, 0.95, 1e-8, 1, 1.0, None) == -1
+    assert lib.swv2_block_wgrad_ws_bytes(128, 512, 128, 0) == 40 * 12 * 128 * 128 * 4
     with pytest.raises(L.Swv2Error):
         L.check(lib.swv2_linear(None, None, None, 4, None), "swv2_linear")
 

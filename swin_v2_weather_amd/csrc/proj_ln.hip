@@ -8,6 +8,7 @@
 // head-major attention output (16 tokens x 32 B = 512 B contiguous per head), its epilogue is the LN + scatter epilogue
 // of attn_fused.hip; the backward's prologue is the row-layout LayerNorm backward of mlp_bwd_kernel with a row gather,
 // and its output tiles (rows = one head's 16 channels, column = token) store directly as 512-byte head-major runs.
+#include <cstdlib>
 #include "gemm_common.h"
 
 namespace {
@@ -35,6 +36,22 @@ __global__ __launch_bounds__(256, 2) void proj_ln_fwd_kernel(const ProjLnFwd a) 
     const int hdp = a.h * 16, ksn = hdp / 32;
     const int row0 = blockIdx.x * (64 * MT) + wave * (16 * MT);
 
+    // The scatter rows (window reverse + un-roll table) and the residual rows of the EPILOGUE are fetched first: as loads
+    // inside the epilogue they were two dependent memory round trips per row tile with nothing to overlap them (a
+    // workgroup lived through five round trips: A + weight, then table -> residual for each of its two tiles; 56 us).
+    // Issued here they overlap the A / weight fetch and the MFMAs.  Unconditional (clamped) loads: the compiler can
+    // count them, so the wait for the weight does not also wait for the residual rows.
+    constexpr int UNITS = 16 * (C / 8), NP = (UNITS + 63) / 64;
+    int dstv[MT][NP];
+    f32x4 xr[MT][NP][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int u = min(lane + 64 * p, UNITS - 1), row = u / (C / 8);
+            const int m = min(row0 + 16 * mt + row, a.Mw - 1);
+            dstv[mt][p] = a.rowidx ? a.rowidx[m] : m;
+        }
     // A^T fragments straight from the head-major attention output: lane (m = fr, g) holds k = 32 ks + 8 g .. + 7,
     // i.e. 8 channels of head 2 ks + (g >> 1)
     bf16x8 xf[MT][KSM];
@@ -52,6 +69,15 @@ __global__ __launch_bounds__(256, 2) void proj_ln_fwd_kernel(const ProjLnFwd a) 
         *(u32x4*)(Wps + r * PWP + 8 * c8) = *(const u32x4*)(a.wp + (size_t)r * hdp + 8 * c8);
     }
     for (int i = tid; i < C; i += 256) { cs[i] = a.bp[i]; cs[C + i] = a.gamma[i]; cs[2 * C + i] = a.beta[i]; }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int u = min(lane + 64 * p, UNITS - 1), c8 = u % (C / 8);
+            const size_t off = (size_t)max(dstv[mt][p], 0) * C + 8 * c8;
+            xr[mt][p][0] = *(const f32x4*)(a.x + off);
+            xr[mt][p][1] = *(const f32x4*)(a.x + off + 4);
+        }
     __syncthreads();
 
     f32x4 yacc[MT][NTC];
@@ -103,24 +129,6 @@ __global__ __launch_bounds__(256, 2) void proj_ln_fwd_kernel(const ProjLnFwd a) 
             St[2 * fr] = mu;
             St[2 * fr + 1] = rs;
         }
-        constexpr int UNITS = 16 * (C / 8), NP = (UNITS + 63) / 64;
-        // row table and residual rows of all passes first, unconditionally (clamped): a load under `if (dst >= 0)` is
-        // exec-masked and gets serialised behind s_waitcnt vmcnt(0) -- two dependent memory round trips per pass
-        int dstv[NP];
-        f32x4 xr[NP][2];
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            const int u = min(lane + 64 * p, UNITS - 1), row = u / (C / 8);
-            const int m = min(row0 + 16 * mt + row, a.Mw - 1);
-            dstv[p] = a.rowidx ? a.rowidx[m] : m;
-        }
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            const int u = min(lane + 64 * p, UNITS - 1), c8 = u % (C / 8);
-            const size_t off = (size_t)max(dstv[p], 0) * C + 8 * c8;
-            xr[p][0] = *(const f32x4*)(a.x + off);
-            xr[p][1] = *(const f32x4*)(a.x + off + 4);
-        }
         __syncthreads();
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
@@ -129,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void proj_ln_fwd_kernel(const ProjLnFwd a) 
                 const int m = min(row0 + 16 * mt + row, a.Mw - 1);
                 const u32x4 av = *(const u32x4*)(As + row * PA + 8 * c8);
                 *(u32x4*)(a.a1 + (size_t)m * C + 8 * c8) = av;
-                const int dst = dstv[p];
+                const int dst = dstv[mt][p];
                 if (dst >= 0) {
                     const float mu_r = St[2 * row], rs_r = St[2 * row + 1];
                     const float sc = a.scale ? a.scale[dst / a.rows_per_sample] : 1.f;
@@ -139,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void proj_ln_fwd_kernel(const ProjLnFwd a) 
 #pragma unroll
                     for (int hlf = 0; hlf < 2; ++hlf) {
                         const f32x4 gm = *(const f32x4*)(cs + C + 8 * c8 + 4 * hlf), bt = *(const f32x4*)(cs + 2 * C + 8 * c8 + 4 * hlf);
-                        f32x4 o = xr[p][hlf];
+                        f32x4 o = xr[mt][p][hlf];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] += sc * ((v[4 * hlf + e] - mu_r) * rs_r * gm[e] + bt[e]);
                         *(f32x4*)(a.y + off + 4 * hlf) = o;
@@ -293,7 +301,8 @@ extern "C" int swv2_proj_ln_fwd(const swv2_proj_ln_args* a, void* stream) {
     ProjLnFwd k = {(const uint16_t*)a->oh, (const uint16_t*)a->wp, a->bp, a->gamma, a->beta, a->scale, a->rowidx, a->x,
                    (uint16_t*)a->a1, a->mean, a->rstd, a->y, Mw, a->Lp, a->heads, a->rows_per_sample, a->eps};
     hipStream_t st = (hipStream_t)stream;
-    const bool mt2 = Mw >= 128 * 256;
+    static const int force_mt = getenv("SWV2_PL_MT") ? atoi(getenv("SWV2_PL_MT")) : 0;
+    const bool mt2 = force_mt ? force_mt == 2 : Mw >= 128 * 256;
 #define PL_CASE(CC)                                                                                                  \
     case CC:                                                                                                         \
         if (mt2) hipLaunchKernelGGL((proj_ln_fwd_kernel<CC, 2>), dim3(cdiv(Mw, 128)), dim3(256), 0, st, k);          \
@@ -317,7 +326,8 @@ extern "C" int swv2_proj_ln_bwd(const swv2_proj_ln_bwd_args* a, void* stream) {
     ProjLnBwd k = {a->dy, (const uint16_t*)a->a1, a->mean, a->rstd, a->gamma, a->scale, a->rowidx, (const uint16_t*)a->wpt,
                    (uint16_t*)a->da1, (uint16_t*)a->doh, a->ws, Mw, a->Lp, a->heads, a->rows_per_sample};
     hipStream_t st = (hipStream_t)stream;
-    const bool mt2 = Mw >= 128 * 256;
+    static const int force_mtb = getenv("SWV2_PL_MT_BWD") ? atoi(getenv("SWV2_PL_MT_BWD")) : 0;
+    const bool mt2 = force_mtb ? force_mtb == 2 : Mw >= 128 * 256;
 #define PL_CASE(CC)                                                                                                  \
     case CC:                                                                                                         \
         if (mt2) hipLaunchKernelGGL((proj_ln_bwd_kernel<CC, 2>), dim3(cdiv(Mw, 128)), dim3(256), 0, st, k);          \

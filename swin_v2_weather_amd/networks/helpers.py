@@ -94,6 +94,20 @@ def enable_ddp_bucket_grads(ddp_module):
     the reducer recognises as already in place.  Falls back to the normal path whenever a view is unknown or stale."""
     from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
     from .swinv2_global import SwinTransformerV2CrBlock
+    # The path leans on reducer behaviour that is not public API (p.grad IS the bucket view after a backward pass with
+    # gradient_as_bucket_view=True; a gradient that aliases its bucket view is not copied; the autograd engine's
+    # end-of-pass callback).  It is covered by the 1-rank RCCL and 2-rank tests of tests/test_gpu_parity.py on the torch
+    # releases listed here; on any other release the stock path (one copy kernel per parameter, always correct) stays on
+    # unless SWV2_DDP_BUCKET_GRADS=force.
+    tested = ("2.10.",)
+    if not torch.__version__.startswith(tested) and os.environ.get("SWV2_DDP_BUCKET_GRADS", "1") != "force":
+        import warnings
+        warnings.warn(f"enable_ddp_bucket_grads: torch {torch.__version__} is not a release this path was tested on "
+                      f"({', '.join(t + 'x' for t in tested)}); keeping DDP's own gradient copies "
+                      "(SWV2_DDP_BUCKET_GRADS=force overrides)")
+        return ddp_module
+    if not getattr(ddp_module, "gradient_as_bucket_view", False):
+        raise ValueError("enable_ddp_bucket_grads needs DistributedDataParallel(..., gradient_as_bucket_view=True)")
     ddp_module.register_comm_hook(None, default_hooks.allreduce_hook)
     for m in ddp_module.modules():
         if isinstance(m, SwinTransformerV2CrBlock):

@@ -438,6 +438,9 @@ class SwinTransformerV2CrBlock(nn.Module):
         self.window_area = self.window_size[0] * self.window_size[1]
         self.init_values = init_values
         attn_cls = WindowMultiHeadAttention if rel_pos else WindowMultiHeadAttentionNoPos
+        # fail at construction, not at the first forward, when no attention kernel covers the geometry: window
+        # areas up to 176 tokens, head dims up to 128 (padded to 16 / 32 / 64 / 128 columns)
+        ops.attn_geometry(self.window_size[0] * self.window_size[1], dim // num_heads)
         self.attn = attn_cls(dim=dim, num_heads=num_heads, window_size=self.window_size, drop_attn=drop_attn,
                              drop_proj=proj_drop, sequential_attn=sequential_attn)
         self.norm1 = norm_layer(dim)

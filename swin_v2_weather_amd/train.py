@@ -248,6 +248,10 @@ class Trainer():
         if 'global_stds_path' in self.params and os.path.isfile(str(self.params.global_stds_path)):
             mult = torch.as_tensor(np.load(self.params.global_stds_path)[0, self.params.out_channels, 0, 0]).to(self.device)
         else:
+            if not getattr(self, "_warned_mult", False):
+                logging.warning("global_stds_path is not set or missing: validation RMSE is reported in normalised units "
+                                "(unit stds), not in physical units as the reference does (train.py:335-336)")
+                self._warned_mult = True
             mult = torch.ones(self.params.n_out_channels, device=self.device)      # synthetic fields: unit stds
         valid_buff = torch.zeros((3), dtype=torch.float32, device=self.device)
         valid_loss = valid_buff[0].view(-1)

@@ -293,3 +293,14 @@ def test_year_array_source_and_static_features_from_files(tmp_path):
     o = ((o - o.min()) / (o.max() - o.min()))[:8]
     assert torch.allclose(sf[0, 2], (o - o.mean()) / (o.std() + 1e-6), atol=1e-6)
     del p
+
+
+def test_unsupported_attention_geometry_fails_at_construction():
+    """head dims above 128 (e.g. the upstream 2048 / 8 = 256 variant) and windows above 176 tokens have no kernel: the model
+    constructor says so instead of the first forward; the yaml default width 768 / 8 = 96 builds."""
+    kw = dict(img_size=(48, 72), patch_size=4, depths=(1,), in_chans=3, out_chans=3, img_window_ratio=8, full_pos_embed=True, rel_pos=False)
+    N.SwinTransformerV2Cr(num_heads=(8,), embed_dim=768, **kw)
+    with pytest.raises(L.Swv2Error, match="head_dim"):
+        N.SwinTransformerV2Cr(num_heads=(8,), embed_dim=2048, **kw)
+    with pytest.raises(L.Swv2Error, match="window area"):
+        N.SwinTransformerV2Cr(num_heads=(2,), embed_dim=32, **dict(kw, img_window_ratio=2))

@@ -150,7 +150,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", init_method="env://")
+        dist.init_process_group(backend="nccl", init_method="env://", device_id=dev)      # nccl = RCCL on ROCm
 
     from swin_v2_weather_amd import ops
     from swin_v2_weather_amd.networks.helpers import get_model
@@ -273,7 +273,7 @@ def main():
                                    f"window{a.height // a.window_ratio}x{a.width // a.window_ratio} rel_pos={bool(a.rel_pos)} "
                                    f"full train step (fwd+loss+bwd+Adam)",
                        "local_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                       "final_loss": float(loss)},
+                       "final_loss": float(loss.detach())},
             "model_tflops_per_gpu": value * flops / world / 1e12,
             "mfma_frac_end_to_end": value * flops / world / 2.5e15,
             "host_pipeline": host_leg,

@@ -15,16 +15,25 @@ p = bench.model_params(ns)
 model = get_model(p).to(dev).train()
 lp = SimpleNamespace(n_future=0, img_shape_x=720, img_shape_y=1440, loss="l2", channel_weights="none", n_out_channels=73, model_grid_type="equiangular")
 loss_obj = LossHandler(lp).to(dev)
-opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.95), fused=True)
+from swin_v2_weather_amd.utils.optim import HipAdam
+opt = HipAdam(model.parameters(), lr=1e-3, betas=(0.9, 0.95))
+net = model
+if os.environ.get("STEP_OPS_DDP", "0") == "1":          # one-rank RCCL group: what DDP adds to the step
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    from swin_v2_weather_amd.networks.helpers import enable_ddp_bucket_grads
+    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], broadcast_buffers=False, gradient_as_bucket_view=True, bucket_cap_mb=12)
+    enable_ddp_bucket_grads(net)
 x, y = torch.randn(2, 73, 720, 1440, device=dev), torch.randn(2, 73, 720, 1440, device=dev)
 def step():
-    model.zero_grad(); l = loss_obj(model(x), y, x); l.backward(); opt.step()
+    net.zero_grad(); l = loss_obj(net(x), y, x); l.backward(); opt.step()
 for _ in range(4): step()
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     step(); torch.cuda.synchronize()
 rows = [e for e in prof.key_averages() if e.device_time_total > 0 or e.self_device_time_total > 0]
 rows.sort(key=lambda e: -e.self_device_time_total)
-for e in rows[:40]:
+for e in rows[:60]:
     if not any(k in e.key for k in ("gemm_", "mlp_", "attn_", "proj_ln", "tn_reduce", "ln_")):
         print(f"{e.key[:90]:90s} n={e.count:4d} self_dev={e.self_device_time_total:9.1f} us")

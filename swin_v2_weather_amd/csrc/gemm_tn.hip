@@ -64,8 +64,17 @@ __device__ __forceinline__ void tn_tile(const ALoad<YK>& yl, const ALoad<XK>& xl
     if (steps <= 0) return;
     if (tid < BN) dbs[tid] = 0.f;
 
-    // staging: each tile is TM x 16 chunks; a thread keeps a fixed chunk column and walks rows srow + 16 i
+    // staging: each tile is TM x 16 chunks; a thread keeps a fixed chunk column and walks rows srow + 16 i.  Operands whose
+    // adjacent ROWS are adjacent in memory (the 4 x 4 patch im2col: a row is 16 bytes of each of 16 x Cin image rows) use
+    // the row-fastest map instead -- thread = (row tid & 127, chunk columns (tid >> 7) + 2 i) -- so a wave reads 64
+    // consecutive 16-byte groups instead of 4 rows x 16 scattered ones (PatchEmbed / head gradients: 2.9 TB/s before).
     const int srow = tid >> 4, scol = tid & 15;
+    constexpr bool YRF = ALoad<YK>::ROW_FASTEST, XRF = ALoad<XK>::ROW_FASTEST;
+    auto yr_ = [&](int i) { return YRF ? (tid & (TM - 1)) : srow + 16 * i; };
+    auto yc_ = [&](int i) { return YRF ? (tid >> 7) + 2 * i : scol; };
+    auto xr_ = [&](int i) { return XRF ? (tid & (TM - 1)) : srow + 16 * i; };
+    auto xc_ = [&](int i) { return XRF ? (tid >> 7) + 2 * i : scol; };
+    static_assert(TM == 128 && NTHREADS == 256, "row-fastest map: 128 rows x 2 chunk columns per pass");
     typename ALoad<YK>::Raw ry[TCH];
     typename ALoad<XK>::Raw rx[TCH];
     float colsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -75,17 +84,16 @@ __device__ __forceinline__ void tn_tile(const ALoad<YK>& yl, const ALoad<XK>& xl
     auto resolve = [&](int s) {
 #pragma unroll
         for (int i = 0; i < TCH; ++i) {
-            const int m = (slice + s * chunk_stride) * TM + srow + 16 * i;
-            const bool ok = (s < steps) && (m < m_hi);
-            yrow[i] = yl.row_of(ok ? m : M);
-            xrow[i] = xl.row_of(ok ? m : M);
+            const int m0 = (slice + s * chunk_stride) * TM, my = m0 + yr_(i), mx = m0 + xr_(i);
+            yrow[i] = yl.row_of((s < steps) && (my < m_hi) ? my : M);
+            xrow[i] = xl.row_of((s < steps) && (mx < m_hi) ? mx : M);
         }
     };
     auto issue = [&](int s) {
 #pragma unroll
         for (int i = 0; i < TCH; ++i) {
-            ry[i] = yl.raw_at(yrow[i], n_base + scol * 8);       // row -1 loads nothing and yields zeros
-            rx[i] = xl.raw_at(xrow[i], k_base + scol * 8);
+            ry[i] = yl.raw_at(yrow[i], n_base + yc_(i) * 8);     // row -1 loads nothing and yields zeros
+            rx[i] = xl.raw_at(xrow[i], k_base + xc_(i) * 8);
         }
     };
     auto commit = [&]() {
@@ -94,9 +102,9 @@ __device__ __forceinline__ void tn_tile(const ALoad<YK>& yl, const ALoad<XK>& xl
 #pragma unroll
         for (int i = 0; i < TCH; ++i) {
             const uint4 yv = yl.cvt(ry[i]);
-            *(uint4*)(Ys + (srow + 16 * i) * TP + scol * 8) = yv;
-            *(uint4*)(Xs + (srow + 16 * i) * TP + scol * 8) = xl.cvt(rx[i]);
-            if (want_db) {
+            *(uint4*)(Ys + yr_(i) * TP + yc_(i) * 8) = yv;
+            *(uint4*)(Xs + xr_(i) * TP + xc_(i) * 8) = xl.cvt(rx[i]);
+            if (want_db && !YRF) {                       // (a row-fastest dY has no fixed column per thread: rejected by the launcher)
                 float v[8];
                 unpack8(yv, v);
 #pragma unroll
@@ -347,6 +355,7 @@ extern "C" int swv2_linear_wgrad_ws(const swv2_operand* dy, const swv2_operand* 
     if (rc) return rc;
     SWV2_CHECK_ARG(dW && splits > 0 && ldw > 0, "swv2_linear_wgrad: null dW, non-positive splits or bad pitch");
     SWV2_CHECK_ARG(dy->rows == x->rows, "swv2_linear_wgrad: row counts differ (%d vs %d)", dy->rows, x->rows);
+    SWV2_CHECK_ARG(!(db && dy->kind == SWV2_OP_PATCH), "swv2_linear_wgrad: no bias gradient with a patch-layout dY (row-fastest staging)");
     const int M = dy->rows, N = dy->cols, K = x->cols;
     hipStream_t st = (hipStream_t)stream;
     float* w = (float*)ws;

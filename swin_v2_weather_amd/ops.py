@@ -151,12 +151,19 @@ def linear(a: L.Operand, w_bf16: torch.Tensor, e: L.Epilogue, N: int, tag: str =
 
 
 def linear_wgrad(dy: L.Operand, x: L.Operand, dW: torch.Tensor, db: Optional[torch.Tensor], nmap=None, kmap=None,
-                 splits: int = 128, workspace: bool = True):
+                 splits: int = 0, workspace: bool = True):
     """dW += dY^T X.  workspace=True: per-slice partial tiles + reduce kernel (deterministic, no atomics on dW), the
-    partials live in a torch allocation that is released (stream-ordered) after the call; False: fp32 atomics on dW."""
+    partials live in a torch allocation that is released (stream-ordered) after the call; False: fp32 atomics on dW.
+    splits = 0: as many row slices as fill the chip in ONE round (two 70 KB workgroups per CU = 512): the PatchEmbed / head
+    gradients (10 output tiles) ran 1280 workgroups = 2.5 rounds at 128 slices and wrote 84 MB of partial tiles."""
     _chk(dW, torch.float32, "dW")
     ldw = dW.shape[-1] if dW.dim() == 2 else dW[0].numel()
     lib = L.load()
+    if splits <= 0:
+        tiles = ((dy.cols + 127) // 128) * ((x.cols + 127) // 128)
+        splits = max(8, (512 // tiles) // 8 * 8)
+        if tiles < 3:                       # the library doubles the slice count of small outputs itself
+            splits = max(8, splits // 16 * 8)
     if not workspace:
         L.check(lib.swv2_linear_wgrad(C.byref(dy), C.byref(x), _p(dW), _p(db), _p(nmap), _p(kmap), ldw, splits, _stream()),
                 "swv2_linear_wgrad")

@@ -354,21 +354,32 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const MlpBwd a) {
             }
         }
     };
-    // saved pre-activation of the NEXT chunk, in the accumulator layout (lane (m = fr, g): hidden 16 ht + 4 g .. + 3)
-    u32x2 hp[MT][2], hpn[MT][2];
-    auto issue_h = [&](int ch, u32x2 (&dst)[MT][2]) {
+    // saved pre-activation: fetched for TWO chunks at a time as 128-byte row segments (8 rows per load instruction) into
+    // registers, a pair ahead, and handed to the accumulator layout (lane (m = fr, g): hidden 16 ht + 4 g .. + 3) through the
+    // wave-private tile Hst.  Loaded straight in the accumulator layout an instruction touched 16 rows x 32 bytes.
+    // Hst is shared with the dh stores: within a chunk its hpre values are read before its dh values are written to the
+    // same place, the pair's dh rows are flushed at the end of the odd chunk, and only then the next pair's hpre lands.
+    u32x4 hq[2 * MT];
+    auto issue_hq = [&](int pair) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int r = min(row0 + 16 * mt + fr, a.M - 1);
+        for (int p_ = 0; p_ < 2 * MT; ++p_) {
+            const int u = lane + 64 * p_, row = u >> 3, c8 = u & 7;
+            const int r = min(row0 + row, a.M - 1), col = min(64 * pair + 8 * c8, hid - 8);
+            hq[p_] = *(const u32x4*)(a.hpre + (size_t)r * hid + col);
+        }
+    };
+    auto commit_hq = [&]() {
 #pragma unroll
-            for (int ht = 0; ht < 2; ++ht) dst[mt][ht] = *(const u32x2*)(a.hpre + (size_t)r * hid + 32 * ch + 16 * ht + 4 * g);
+        for (int p_ = 0; p_ < 2 * MT; ++p_) {
+            const int u = lane + 64 * p_, row = u >> 3, c8 = u & 7;
+            *(u32x4*)(Hst + row * PHS + 8 * c8) = hq[p_];
         }
     };
 #ifdef SWV2_MLP_STAMPS
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
 #endif
     issue(0);
-    issue_h(0, hp);
+    issue_hq(0);
 
     // ---- LayerNorm backward in ROW layout: LPR lanes per row (4 columns each), the workgroup's rows in passes of RPP
     // rows.  A thread keeps the same 4 columns in every pass, so d gamma / d beta are private register sums over the
@@ -461,8 +472,9 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const MlpBwd a) {
     __syncthreads();
     // one chunk; `cur` holds this chunk's saved pre-activation, `nxt` receives the next chunk's (two register sets used
     // alternately: a copy between them would wait for the loads right where it is written)
-    auto chunk = [&](int ch, u32x2 (&cur)[MT][2], u32x2 (&nxt)[MT][2]) {
-        if (ch + 1 < nch) { issue(ch + 1); issue_h(ch + 1, nxt); }
+    auto chunk = [&](int ch) {
+        if (ch + 1 < nch) issue(ch + 1);
+        if (!(ch & 1) && ch + 2 < nch) issue_hq((ch >> 1) + 1);
         const uint16_t* W1s = smem + (ch & 1) * (W1E + W2E);
         const uint16_t* W2s = W1s + W1E;
         f32x4 hacc[2][MT];
@@ -483,7 +495,8 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const MlpBwd a) {
         for (int ht = 0; ht < 2; ++ht)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const uint32_t w0 = cur[mt][ht][0], w1 = cur[mt][ht][1];
+                const u32x2 cw = *(const u32x2*)(Hst + (16 * mt + fr) * PHS + 32 * (ch & 1) + 16 * ht + 4 * g);
+                const uint32_t w0 = cw[0], w1 = cw[1];
                 f32x4 dv;
                 dv[0] = hacc[ht][mt][0] * gelu_grad_f(__uint_as_float(w0 << 16));
                 dv[1] = hacc[ht][mt][1] * gelu_grad_f(__uint_as_float(w0 & 0xffff0000u));
@@ -517,6 +530,7 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const MlpBwd a) {
                 const int r = min(row0 + row, a.M - 1);
                 *(u32x4*)(a.dh + (size_t)r * hid + 64 * (ch >> 1) + 8 * c8) = *(const u32x4*)(Hst + row * PHS + 8 * c8);
             }
+            if (ch + 1 < nch) commit_hq();              // next pair's pre-activations (fetched two chunks ago)
         } else if (ch + 1 == nch) {
             for (int u = lane; u < 16 * MT * 4; u += 64) {
                 const int row = u >> 2, c8 = u & 3;
@@ -528,10 +542,8 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const MlpBwd a) {
         __syncthreads();
         STAMP(6);
     };
-    for (int ch = 0; ch < nch; ch += 2) {
-        chunk(ch, hp, hpn);
-        if (ch + 1 < nch) chunk(ch + 1, hpn, hp);
-    }
+    commit_hq();
+    for (int ch = 0; ch < nch; ++ch) chunk(ch);
 
     // ---- dx = dy + (dH W1): accumulators -> per-wave LDS tile -> whole rows
     float* Ys = (float*)smem_raw + wave * 16 * PY;

@@ -476,11 +476,18 @@ __global__ __launch_bounds__(512) void gemm_rw_kernel(ALoad<AK> al, const uint16
     typename ALoad<AK>::Raw ra[ACH];
     int arow[ACH];
     int erow_res = -1;
+    // chunk c of a tile -> (row, 16-byte chunk column).  Row-major operands: consecutive threads walk a row.  Head-major
+    // operand ([Bw][h][S][Lp][16]: one (row, head) is 32 bytes, consecutive ROWS of a head are contiguous): consecutive
+    // threads take the two halves of a head for consecutive rows, so a wave reads 32 rows x 32 bytes = 1 KB contiguous
+    // (row-major order gave 32 separate 32-byte pieces per wave instruction).
+    auto crow = [&](int c) { return AK == A_HEADS ? ((c >> 1) & (BMT - 1)) : c / KC; };
+    auto ccol = [&](int c) { return AK == A_HEADS ? (((c / (2 * BMT)) << 1) | (c & 1)) : c % KC; };
+    static_assert(AK != A_HEADS || (BMT & (BMT - 1)) == 0, "head-major chunk map needs a power-of-two tile height");
     auto resolve = [&](int t) {
 #pragma unroll
         for (int i = 0; i < ACH; ++i) {
             const int c = tid + i * NTH;
-            arow[i] = al.row_of(t < ntiles ? t * BMT + c / KC : M);
+            arow[i] = al.row_of(t < ntiles ? t * BMT + crow(c) : M);
         }
         if constexpr (EK == E_F32) {
             const int m = t * BMT + wr * 16 + (lane >> 2);
@@ -491,7 +498,7 @@ __global__ __launch_bounds__(512) void gemm_rw_kernel(ALoad<AK> al, const uint16
 #pragma unroll
         for (int i = 0; i < ACH; ++i) {
             const int c = tid + i * NTH;
-            ra[i] = al.raw_at(arow[i], (c % KC) * 8);
+            ra[i] = al.raw_at(arow[i], ccol(c) * 8);
         }
         if constexpr (EK == E_F32) {
             erow_nxt = erow_res;
@@ -504,7 +511,7 @@ __global__ __launch_bounds__(512) void gemm_rw_kernel(ALoad<AK> al, const uint16
 #pragma unroll
         for (int i = 0; i < ACH; ++i) {
             const int c = tid + i * NTH;
-            *(uint4*)(As + swzk(c / KC, c % KC, K)) = al.cvt(ra[i]);
+            *(uint4*)(As + swzk(crow(c), ccol(c), K)) = al.cvt(ra[i]);
         }
     };
     const int G = gridDim.x;

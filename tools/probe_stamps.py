@@ -42,7 +42,7 @@ b.M, b.C, b.hidden, b.rows_per_sample = M, Cc, hid, T
 for _ in range(3):
     L.load().swv2_mlp_bwd(ctypes.byref(b), torch.cuda.current_stream().cuda_stream)
 torch.cuda.synchronize()
-nb = (M + 63) // 64
+nb = (M + 127) // 128                                # workgroups (MT = 2: 128 rows each)
 o0 = nb * 2 * Cc // 2
 st = ws.view(torch.int64)[o0: o0 + ((nb + 96) // 97) * 4 * 8].view(-1, 8).cpu().double()
 st = st[st.sum(1) > 0]

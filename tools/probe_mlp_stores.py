@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
-"""Probe: what do the 32-byte-per-row hpre stores of mlp_fwd cost?  Times the kernel as built and with
--DSWV2_MLP_DENSE_STORES (same bytes, one contiguous 512-byte run per store instruction; wrong layout) -- GPU box."""
+"""Ablation probe of mlp_fwd: times the kernel as built (`normal`) or privately rebuilt with a macro given as the first
+argument (SWV2_MLP_GELU_ABL=1: no GELU, wrong results; SWV2_MLP_GELU_ABL=2: erf formula instead of the table) -- GPU box."""
 import os, subprocess, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from swin_v2_weather_amd import _lib as L
 variant = sys.argv[1] if len(sys.argv) > 1 else "normal"
-if variant == "dense":
-    so = "/tmp/libswv2_dense.so"
+if variant != "normal":                       # e.g. SWV2_MLP_GELU_ABL=1 (no GELU), SWV2_MLP_GELU_ABL=2 (formula instead of the table)
+    so = "/tmp/libswv2_probe.so"
     srcs = [os.path.join(L.CSRC, s) for s in L.SOURCES]
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DSWV2_MLP_DENSE_STORES", "-o", so] + srcs,
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-D" + variant, "-o", so] + srcs,
                           stderr=subprocess.DEVNULL)
     L.LIB_PATH = so
 from swin_v2_weather_amd import ops

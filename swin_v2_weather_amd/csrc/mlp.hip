@@ -332,6 +332,11 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const MlpBwd a) {
     constexpr int PHS = 72;                                           // pitch (bf16) of the wave-private dh staging tile
     __shared__ __attribute__((aligned(16))) uint16_t hst_all[4 * 16 * MT * PHS];
     uint16_t* const Hst = hst_all + wave * (16 * MT * PHS);
+    // GELU'(x) for every bf16 x in the table range (18 KB) -- only where two workgroups per CU still fit beside it
+    constexpr bool GTAB = SBYTES + 4 * 16 * MT * PHS * 2 + GT_N * 4 <= 80 * 1024;
+    __shared__ __attribute__((aligned(16))) float ggtab[GTAB ? GT_N : 4];
+    if (GTAB)
+        for (int i = tid; i < GT_N; i += 256) ggtab[i] = gelu_grad_f(bf2f(gelu_tab_arg(i)));
 
     u32x4 s1[SPT], s2[SPT];
     auto issue = [&](int ch) {          // W2^T chunk: rows 32 ch .. + 32 of [hid][C];  W1^T chunk: columns of [C][hid]
@@ -497,12 +502,25 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const MlpBwd a) {
             for (int mt = 0; mt < MT; ++mt) {
                 const u32x2 cw = *(const u32x2*)(Hst + (16 * mt + fr) * PHS + 32 * (ch & 1) + 16 * ht + 4 * g);
                 const uint32_t w0 = cw[0], w1 = cw[1];
-                f32x4 dv;
-                dv[0] = hacc[ht][mt][0] * gelu_grad_f(__uint_as_float(w0 << 16));
-                dv[1] = hacc[ht][mt][1] * gelu_grad_f(__uint_as_float(w0 & 0xffff0000u));
-                dv[2] = hacc[ht][mt][2] * gelu_grad_f(__uint_as_float(w1 << 16));
-                dv[3] = hacc[ht][mt][3] * gelu_grad_f(__uint_as_float(w1 & 0xffff0000u));
-                hb[mt][ht] = f2bf4(dv);
+                // GELU'(stored bf16 pre-activation): fp32 table in LDS (same entries as the forward's GELU table, filled
+                // with gelu_grad_f, so bit-identical to the formula); the formula -- an exp, a reciprocal and a dozen
+                // fmas per value, 26 % of a wave's life -- only for the rare group with an argument outside the table
+                bool bad = false;
+                const uint32_t o0 = gelu_tab_off2<4>(w0, bad), o1 = gelu_tab_off2<4>(w1, bad);
+                f32x4 gg;
+                if (!GTAB || __builtin_expect(__any((int)bad), 0)) {
+                    gg[0] = gelu_grad_f(__uint_as_float(w0 << 16));
+                    gg[1] = gelu_grad_f(__uint_as_float(w0 & 0xffff0000u));
+                    gg[2] = gelu_grad_f(__uint_as_float(w1 << 16));
+                    gg[3] = gelu_grad_f(__uint_as_float(w1 & 0xffff0000u));
+                } else {
+                    const unsigned char* tb = (const unsigned char*)ggtab;
+                    gg[0] = *(const float*)(tb + (o0 & 0xffffu));
+                    gg[1] = *(const float*)(tb + (o0 >> 16));
+                    gg[2] = *(const float*)(tb + (o1 & 0xffffu));
+                    gg[3] = *(const float*)(tb + (o1 >> 16));
+                }
+                hb[mt][ht] = f2bf4(hacc[ht][mt] * gg);
             }
         bf16x8 hop[MT];
 #pragma unroll

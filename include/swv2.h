@@ -438,6 +438,8 @@ typedef struct swv2_block_desc {
                                 (fork after each producer, join before returning) so they overlap with the dX chain */
     int wgrad_group;         /* 1 (with fuse_mlp + fuse_proj_ln paths and a workspace): the four products run as ONE
                                 swv2_block_wgrad launch at the end of the backward (launch id 22) */
+    size_t ln_ws_floats;     /* floats available at ln_ws; >= swv2_mlp_bwd_ws_floats + swv2_proj_ln_bwd_ws_floats lets the backward
+                                keep both LayerNorms' d gamma / d beta partial rows and fold them with ONE launch (0: one each) */
 } swv2_block_desc;
 
 int swv2_block_fwd(const swv2_block_desc* d, void* stream);

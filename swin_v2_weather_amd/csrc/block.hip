@@ -173,6 +173,8 @@ extern "C" int swv2_block_bwd(const swv2_block_desc* d, void* st) {
     const bool fused = d->fuse_mlp && swv2_mlp_supported(C, hid);
     const bool fused_pl = d->fuse_proj_ln && swv2_proj_ln_supported(C, h, d->DP);
     // the four weight gradients as ONE launch after the data path (needs the operand set of the fused paths)
+    const bool defer = fused && fused_pl && d->ln_ws_floats >= swv2_mlp_bwd_ws_floats(BT, C) + swv2_proj_ln_bwd_ws_floats(Mw, C);
+    int n_ln1 = 0, n_ln2 = 0;
     const bool group = d->wgrad_group && fused && fused_pl && d->wgrad_ws && !ss &&
                        d->wgrad_ws_bytes >= swv2_block_wgrad_ws_bytes(C, hid, h * d->DP, 0);
     if (fused) {
@@ -181,7 +183,8 @@ extern "C" int swv2_block_bwd(const swv2_block_desc* d, void* st) {
         m.dy = d->dx2; m.a2 = d->a2; m.mean = d->mean2; m.rstd = d->rstd2; m.gamma = d->n2_w; m.scale = d->dp2; m.hpre = d->hpre;
         m.w2t = d->w_fc2t; m.w1t = d->w_fc1t; m.da2 = d->da2; m.dh = d->dh; m.dx = d->dx1; m.dgamma = d->d_n2_w;
         m.dbeta = d->d_n2_b; m.ws = d->ln_ws; m.M = BT; m.C = C; m.hidden = hid; m.rows_per_sample = d->T;
-        LAUNCH(13, swv2_mlp_bwd(&m, st));
+        m.ws = d->ln_ws;
+        LAUNCH(13, swv2_mlp_bwd_impl(&m, st, defer ? &n_ln2 : nullptr));
         // weight gradients (hact was not stored: GELU(hpre) on load)
         swv2_operand dy2 = op(SWV2_OP_BF16, d->da2, BT, C, C), x2 = op(SWV2_OP_BF16_GELU, d->hpre, BT, hid, hid);
         swv2_operand dy1 = op(SWV2_OP_BF16, d->dh, BT, hid, hid), x1 = op(SWV2_OP_F32, d->x1, BT, C, C);
@@ -222,7 +225,8 @@ extern "C" int swv2_block_bwd(const swv2_block_desc* d, void* st) {
         m.dy = d->dx1; m.a1 = d->a1; m.mean = d->mean1; m.rstd = d->rstd1; m.gamma = d->n1_w; m.scale = d->dp1; m.rowidx = d->rowidx;
         m.wpt = d->w_projt; m.da1 = d->da1; m.doh = d->doh; m.dgamma = d->d_n1_w; m.dbeta = d->d_n1_b; m.ws = d->ln_ws;
         m.Bw = Bw; m.Lp = d->Lp; m.heads = h; m.C = C; m.rows_per_sample = d->T;
-        LAUNCH(16, swv2_proj_ln_bwd(&m, st));
+        if (defer) m.ws = d->ln_ws + swv2_mlp_bwd_ws_floats(BT, C);      // second region: LN2's partial rows are still unfolded
+        LAUNCH(16, swv2_proj_ln_bwd_impl(&m, st, defer ? &n_ln1 : nullptr));
         swv2_operand dy = op(SWV2_OP_BF16, d->da1, Mw, C, C), x = op_heads(d->oh, Bw, h, 1, d->Lp, d->DP);
         if (ss) fork_to(ss, (hipStream_t)st);
         if (!group)
@@ -263,6 +267,9 @@ extern "C" int swv2_block_bwd(const swv2_block_desc* d, void* st) {
         swv2_epilogue e = epi(SWV2_EPI_F32, d->dx, C, nullptr, d->dx1, nullptr, d->rowidx);
         LAUNCH(21, swv2_linear(&dy, d->w_qkvt, &e, C, st));
     }
+    if (defer)       // d gamma / d beta of both LayerNorms: one reduction launch instead of one behind each kernel
+        swv2_launch_ln_partials_reduce2(d->ln_ws, d->d_n2_w, d->d_n2_b, n_ln2, d->ln_ws + swv2_mlp_bwd_ws_floats(BT, C), d->d_n1_w,
+                                        d->d_n1_b, n_ln1, C, (hipStream_t)st);
     if (group) {
         swv2_wgrad_item it[4] = {};
         it[0].dy = op(SWV2_OP_BF16, d->da2, BT, C, C); it[0].x = op(SWV2_OP_BF16_GELU, d->hpre, BT, hid, hid);

@@ -629,7 +629,9 @@ extern "C" int swv2_mlp_fwd(const swv2_mlp_args* a, void* stream) {
 
 extern "C" size_t swv2_mlp_bwd_ws_floats(int M, int C) { return (M > 0 && C > 0) ? (size_t)cdiv(M, 64) * 2 * C : 0; }
 
-extern "C" int swv2_mlp_bwd(const swv2_mlp_bwd_args* a, void* stream) {
+extern "C" int swv2_mlp_bwd(const swv2_mlp_bwd_args* a, void* stream) { return swv2_mlp_bwd_impl(a, stream, nullptr); }
+
+int swv2_mlp_bwd_impl(const swv2_mlp_bwd_args* a, void* stream, int* deferred) {
     SWV2_CHECK_ARG(a && a->dy && a->a2 && a->mean && a->rstd && a->gamma && a->hpre && a->w2t && a->w1t && a->da2 && a->dh &&
                        a->dx && a->dgamma && a->dbeta && a->ws, "swv2_mlp_bwd: null pointer");
     SWV2_CHECK_ARG(a->M > 0 && a->rows_per_sample > 0, "swv2_mlp_bwd: M and rows_per_sample must be positive");
@@ -652,7 +654,8 @@ extern "C" int swv2_mlp_bwd(const swv2_mlp_bwd_args* a, void* stream) {
         case 256: launch_mlp_bwd<256, 1>(k, st); break;
     }
     const bool two = (a->C <= 128) && mt2;
-    swv2_launch_ln_partials_reduce(a->ws, a->dgamma, a->dbeta, cdiv(a->M, two ? 128 : 64), a->C, st);
+    if (deferred) *deferred = cdiv(a->M, two ? 128 : 64);
+    else swv2_launch_ln_partials_reduce(a->ws, a->dgamma, a->dbeta, cdiv(a->M, two ? 128 : 64), a->C, st);
     SWV2_CHECK_LAUNCH("swv2_mlp_bwd");
     return SWV2_OK;
 }

@@ -314,7 +314,9 @@ extern "C" int swv2_proj_ln_fwd(const swv2_proj_ln_args* a, void* stream) {
     return SWV2_OK;
 }
 
-extern "C" int swv2_proj_ln_bwd(const swv2_proj_ln_bwd_args* a, void* stream) {
+extern "C" int swv2_proj_ln_bwd(const swv2_proj_ln_bwd_args* a, void* stream) { return swv2_proj_ln_bwd_impl(a, stream, nullptr); }
+
+int swv2_proj_ln_bwd_impl(const swv2_proj_ln_bwd_args* a, void* stream, int* deferred) {
     SWV2_CHECK_ARG(a && a->dy && a->a1 && a->mean && a->rstd && a->gamma && a->wpt && a->da1 && a->doh && a->dgamma && a->dbeta &&
                        a->ws, "swv2_proj_ln_bwd: null pointer");
     SWV2_CHECK_ARG(a->Bw > 0 && a->Lp > 0 && a->Lp % 16 == 0 && a->rows_per_sample > 0, "swv2_proj_ln_bwd: bad geometry");
@@ -335,7 +337,8 @@ extern "C" int swv2_proj_ln_bwd(const swv2_proj_ln_bwd_args* a, void* stream) {
         break;
     switch (a->C) { PL_CASE(32) PL_CASE(64) PL_CASE(96) PL_CASE(128) }
 #undef PL_CASE
-    swv2_launch_ln_partials_reduce(a->ws, a->dgamma, a->dbeta, cdiv(Mw, mt2 ? 128 : 64), a->C, st);
+    if (deferred) *deferred = cdiv(Mw, mt2 ? 128 : 64);
+    else swv2_launch_ln_partials_reduce(a->ws, a->dgamma, a->dbeta, cdiv(Mw, mt2 ? 128 : 64), a->C, st);
     SWV2_CHECK_LAUNCH("swv2_proj_ln_bwd");
     return SWV2_OK;
 }

@@ -197,8 +197,11 @@ constexpr int LNR_COLS = 16, LNR_SLICES = 64;
 __global__ __launch_bounds__(LNR_COLS * LNR_SLICES) void ln_partials_reduce_kernel(const float* __restrict__ ws,
                                                                                    float* __restrict__ dgamma,
                                                                                    float* __restrict__ dbeta, int nblocks,
-                                                                                   int C) {
+                                                                                   int C, const float* __restrict__ ws2,
+                                                                                   float* __restrict__ dgamma2,
+                                                                                   float* __restrict__ dbeta2, int nblocks2) {
     __shared__ float part[LNR_SLICES][LNR_COLS];
+    if (blockIdx.y == 1) { ws = ws2; dgamma = dgamma2; dbeta = dbeta2; nblocks = nblocks2; }      // second set (grid.y = 2)
     const int col = threadIdx.x % LNR_COLS, sl = threadIdx.x / LNR_COLS;
     const int j = blockIdx.x * LNR_COLS + col;
     float s = 0.f;
@@ -422,7 +425,7 @@ void launch_ln_bwd(const swv2_ln_args* a, hipStream_t st) {
                        a->gamma, a->scale, a->rowidx, a->mean, a->rstd, (uint16_t*)a->da, a->ws, a->M, a->C,
                        a->rows_per_sample);
     hipLaunchKernelGGL(ln_partials_reduce_kernel, dim3(cdiv(2 * a->C, LNR_COLS)), dim3(LNR_COLS * LNR_SLICES), 0, st, a->ws,
-                       a->dgamma, a->dbeta, grid, a->C);
+                       a->dgamma, a->dbeta, grid, a->C, (const float*)nullptr, (float*)nullptr, (float*)nullptr, 0);
 }
 
 int ln_check(const swv2_ln_args* a, bool bwd) {
@@ -437,9 +440,15 @@ int ln_check(const swv2_ln_args* a, bool bwd) {
 }  // namespace
 
 // shared with mlp.hip (fused MLP backward): dgamma[j] += sum_b ws[b][0][j], dbeta[j] += sum_b ws[b][1][j]
+void swv2_launch_ln_partials_reduce2(const float* ws1, float* dg1, float* db1, int n1, const float* ws2, float* dg2, float* db2,
+                                     int n2, int C, hipStream_t st) {
+    hipLaunchKernelGGL(ln_partials_reduce_kernel, dim3(cdiv(2 * C, LNR_COLS), 2), dim3(LNR_COLS * LNR_SLICES), 0, st, ws1, dg1, db1,
+                       n1, C, ws2, dg2, db2, n2);
+}
+
 void swv2_launch_ln_partials_reduce(const float* ws, float* dgamma, float* dbeta, int nblocks, int C, hipStream_t st) {
     hipLaunchKernelGGL(ln_partials_reduce_kernel, dim3(cdiv(2 * C, LNR_COLS)), dim3(LNR_COLS * LNR_SLICES), 0, st, ws, dgamma,
-                       dbeta, nblocks, C);
+                       dbeta, nblocks, C, (const float*)nullptr, (float*)nullptr, (float*)nullptr, 0);
 }
 
 #define LN_DISPATCH(FN)                                              \

@@ -149,8 +149,10 @@ class _BlockRunner:
                      Mw * 4, BT * Cc * 4, BT * hid * 2, 0 if fused else BT * hid * 2, BT * Cc * 2, BT * 4, BT * 4,
                      lib.swv2_attn_pack_bias_bytes(h, Lw)]
         self.act_off, self.act_bytes = _carve(act_sizes)
+        # LayerNorm partial rows: both LayerNorms' sets side by side, so the backward folds them with one launch
+        d.ln_ws_floats = max(L.LN_BWD_MAX_BLOCKS * 2 * Cc, lib.swv2_mlp_bwd_ws_floats(BT, Cc) + lib.swv2_proj_ln_bwd_ws_floats(Mw, Cc))
         scr_sizes = [BT * Cc * 2, BT * hid * 2, Mw * Cc * 2, Bw * h * Lp * DP * 2, Bw * h * 3 * Lp * DP * 2, BT * Cc * 4,
-                     max(L.LN_BWD_MAX_BLOCKS * 2 * Cc, lib.swv2_mlp_bwd_ws_floats(BT, Cc), lib.swv2_proj_ln_bwd_ws_floats(Mw, Cc)) * 4, ws_bytes]
+                     d.ln_ws_floats * 4, ws_bytes]
         self.scr_off, self.scr_bytes = _carve(scr_sizes)
         self.grad_shapes = [(h,), (3 * Cc, Cc), (3 * Cc,), (Cc, Cc), (Cc,), (Cc,), (Cc,), (hid, Cc), (hid,), (Cc, hid), (Cc,),
                             (Cc,), (Cc,)]

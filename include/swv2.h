@@ -438,6 +438,10 @@ typedef struct swv2_block_desc {
                                 (fork after each producer, join before returning) so they overlap with the dX chain */
     int wgrad_group;         /* 1 (with fuse_mlp + fuse_proj_ln paths and a workspace): the four products run as ONE
                                 swv2_block_wgrad launch at the end of the backward (launch id 22) */
+    void* grad_zero;         /* optional: one buffer holding all 13 parameter gradients of the block (16-byte aligned, a multiple
+                                of 16 bytes); with the fused MLP path the backward's first kernel zeroes it, so the caller need
+                                not (NULL: the caller zeroes every d_* buffer itself) */
+    size_t grad_zero_bytes;
     size_t ln_ws_floats;     /* floats available at ln_ws; >= swv2_mlp_bwd_ws_floats + swv2_proj_ln_bwd_ws_floats lets the backward
                                 keep both LayerNorms' d gamma / d beta partial rows and fold them with ONE launch (0: one each) */
 } swv2_block_desc;

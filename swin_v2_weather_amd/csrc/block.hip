@@ -184,7 +184,7 @@ extern "C" int swv2_block_bwd(const swv2_block_desc* d, void* st) {
         m.w2t = d->w_fc2t; m.w1t = d->w_fc1t; m.da2 = d->da2; m.dh = d->dh; m.dx = d->dx1; m.dgamma = d->d_n2_w;
         m.dbeta = d->d_n2_b; m.ws = d->ln_ws; m.M = BT; m.C = C; m.hidden = hid; m.rows_per_sample = d->T;
         m.ws = d->ln_ws;
-        LAUNCH(13, swv2_mlp_bwd_impl(&m, st, defer ? &n_ln2 : nullptr));
+        LAUNCH(13, swv2_mlp_bwd_impl(&m, st, defer ? &n_ln2 : nullptr, (float*)d->grad_zero, (long)(d->grad_zero_bytes / 4)));
         // weight gradients (hact was not stored: GELU(hpre) on load)
         swv2_operand dy2 = op(SWV2_OP_BF16, d->da2, BT, C, C), x2 = op(SWV2_OP_BF16_GELU, d->hpre, BT, hid, hid);
         swv2_operand dy1 = op(SWV2_OP_BF16, d->dh, BT, hid, hid), x1 = op(SWV2_OP_F32, d->x1, BT, C, C);

@@ -79,7 +79,7 @@ void swv2_launch_ln_partials_reduce2(const float* ws1, float* dg1, float* db1, i
                                      int n2, int C, hipStream_t st);
 // swv2_mlp_bwd / swv2_proj_ln_bwd; deferred != nullptr: the d gamma / d beta partial rows stay in a->ws, their number is
 // reported there and the caller folds them later (swv2_block_bwd: one reduction launch per block instead of two)
-int swv2_mlp_bwd_impl(const swv2_mlp_bwd_args* a, void* stream, int* deferred);
+int swv2_mlp_bwd_impl(const swv2_mlp_bwd_args* a, void* stream, int* deferred, float* zero, long zero_n);
 int swv2_proj_ln_bwd_impl(const swv2_proj_ln_bwd_args* a, void* stream, int* deferred);
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

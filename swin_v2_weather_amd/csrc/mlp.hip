@@ -305,10 +305,18 @@ struct MlpBwd {
     const uint16_t* hpre; const uint16_t* w2t; const uint16_t* w1t;
     uint16_t* da2; uint16_t* dh; float* dx; float* ws;
     int M, hidden, rows_per_sample;
+    float* zero; long zero_n;      // optional: a buffer this launch zeroes on the side (the block's parameter-gradient carve)
 };
 
 template <int C, int MT>
 __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const MlpBwd a) {
+    // swv2_block_bwd: this is the FIRST kernel of a block's backward, and everything that accumulates into the block's 13
+    // parameter gradients runs behind it on the stream -- so it zeroes them (16 bytes per thread and pass, spread over all
+    // workgroups) and the separate 3 us fill launch in front of every block's backward goes away.
+    if (a.zero) {
+        for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < a.zero_n; i += (long)gridDim.x * 256 * 4)
+            *(f32x4*)(a.zero + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     constexpr int KS = C / 32, NT = C / 16;
     constexpr int P1 = C + 8, P2 = 40;
     constexpr int W1E = 32 * P1, W2E = C * P2;
@@ -629,9 +637,10 @@ extern "C" int swv2_mlp_fwd(const swv2_mlp_args* a, void* stream) {
 
 extern "C" size_t swv2_mlp_bwd_ws_floats(int M, int C) { return (M > 0 && C > 0) ? (size_t)cdiv(M, 64) * 2 * C : 0; }
 
-extern "C" int swv2_mlp_bwd(const swv2_mlp_bwd_args* a, void* stream) { return swv2_mlp_bwd_impl(a, stream, nullptr); }
+extern "C" int swv2_mlp_bwd(const swv2_mlp_bwd_args* a, void* stream) { return swv2_mlp_bwd_impl(a, stream, nullptr, nullptr, 0); }
 
-int swv2_mlp_bwd_impl(const swv2_mlp_bwd_args* a, void* stream, int* deferred) {
+int swv2_mlp_bwd_impl(const swv2_mlp_bwd_args* a, void* stream, int* deferred, float* zero, long zero_n) {
+    SWV2_CHECK_ARG(!zero || (zero_n % 4 == 0 && ((uintptr_t)zero & 15) == 0), "swv2_mlp_bwd: the zeroed buffer must be 16-byte aligned / sized");
     SWV2_CHECK_ARG(a && a->dy && a->a2 && a->mean && a->rstd && a->gamma && a->hpre && a->w2t && a->w1t && a->da2 && a->dh &&
                        a->dx && a->dgamma && a->dbeta && a->ws, "swv2_mlp_bwd: null pointer");
     SWV2_CHECK_ARG(a->M > 0 && a->rows_per_sample > 0, "swv2_mlp_bwd: M and rows_per_sample must be positive");
@@ -641,7 +650,7 @@ int swv2_mlp_bwd_impl(const swv2_mlp_bwd_args* a, void* stream, int* deferred) {
     }
     MlpBwd k = {a->dy, (const uint16_t*)a->a2, a->mean, a->rstd, a->gamma, a->scale, (const uint16_t*)a->hpre,
                 (const uint16_t*)a->w2t, (const uint16_t*)a->w1t, (uint16_t*)a->da2, (uint16_t*)a->dh, a->dx, a->ws, a->M,
-                a->hidden, a->rows_per_sample};
+                a->hidden, a->rows_per_sample, zero, zero_n};
     hipStream_t st = (hipStream_t)stream;
     static const int force_mt = getenv("SWV2_MLP_MT") ? atoi(getenv("SWV2_MLP_MT")) : 0;
     const bool mt2 = force_mt ? force_mt == 2 : a->M >= 128 * 256;      // measured at C = 128, M = 129600: 170 us vs 185 us

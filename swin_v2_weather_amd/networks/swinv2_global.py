@@ -266,9 +266,16 @@ class _BlockFn(torch.autograd.Function):
             torch._foreach_zero_(views)
             for name, v in zip(run.grad_names, views):
                 setattr(d, name, v.data_ptr())
+            d.grad_zero, d.grad_zero_bytes = None, 0
         else:
-            grads = torch.zeros(run.grad_bytes // 4, dtype=torch.float32, device=dev)   # ONE memset for all param grads
+            # all 13 parameter gradients in one buffer; zeroed by the backward's first kernel when that is the fused MLP
+            # kernel (d.grad_zero), by one memset otherwise
+            in_kernel = bool(d.fuse_mlp) and bool(L.load().swv2_mlp_supported(run.C, run.hid)) and \
+                os.environ.get("SWV2_GRAD_ZERO_IN_KERNEL", "1") != "0"
+            nfl = (run.grad_bytes // 4 + 3) // 4 * 4
+            grads = (torch.empty if in_kernel else torch.zeros)(nfl, dtype=torch.float32, device=dev)
             gb = grads.data_ptr()
+            d.grad_zero, d.grad_zero_bytes = (gb, nfl * 4) if in_kernel else (None, 0)
             for name, off in zip(run.grad_names, run.grad_off):
                 setattr(d, name, gb + off)
         if blk._ddp_bucket_grads:

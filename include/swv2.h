@@ -227,6 +227,11 @@ int swv2_merge_ln_bwd(const float* x, const void* dn_bf16, const float* gamma, c
 int swv2_loss_sums(const float* prd, const float* tar, const float* quad_w, float* sums, int BC, int H, int W, void* stream);
 int swv2_loss_grad(const float* prd, const float* tar, const float* quad_w, const float* coef, float* dprd, int BC, int H,
                    int W, void* stream);
+/* The scalar on top of the sums (losses.py:200-232): loss = sum_{b,c} chw[c] f(S0 / S1) (S0 alone when absolute; f = sqrt
+ * unless squared) and coef[bc] = 2 d loss / d S0[bc], the factor swv2_loss_grad takes.  chw: [C] weights (channel weights x
+ * multistep weights, normalised as LossHandler does); BC = B * C. */
+int swv2_loss_finalize(const float* sums, const float* chw, int BC, int C, int absolute, int squared, float* loss, float* coef,
+                       void* stream);
 
 /* torch.optim.Adam step (train.py:176) over one flat fp32 buffer; step >= 1; grads are multiplied by grad_inv_scale */
 int swv2_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,

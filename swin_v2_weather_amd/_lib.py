@@ -155,6 +155,7 @@ SYMBOLS = {
     "swv2_merge_ln_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "swv2_loss_sums": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "swv2_loss_grad": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "swv2_loss_finalize": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "swv2_adam_chunk": (_I, []),
     "swv2_adam_multi": (_I, [_P, _P, _I, _F, _F, _F, _F, _I, _F, _P]),
     "swv2_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P]),

@@ -336,6 +336,29 @@ __global__ __launch_bounds__(256) void loss_sums_kernel(const float* __restrict_
     }
 }
 
+// loss = sum_{b,c} chw[c] f(S0 / S1)  (relative; S0 alone when absolute; f = sqrt unless squared) and the coefficient
+// the backward kernel multiplies in: coef[bc] = 2 d loss / d S0[bc].  One workgroup; replaces the half dozen elementwise /
+// reduction launches (and as many again in their autograd) that torch spent on this [B, C] tensor (losses.py:188-232).
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ chw,
+                                                            int BC, int C, int absolute, int squared,
+                                                            float* __restrict__ loss, float* __restrict__ coef) {
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < BC; i += 256) {
+        const float s0 = sums[2 * i], s1 = sums[2 * i + 1], w = chw[i % C];
+        const float den = absolute ? 1.f : s1;
+        const float r = s0 / den;
+        float f, df;                                    // f(r), f'(r)
+        if (squared) { f = r; df = 1.f; } else { f = sqrtf(r); df = 0.5f / f; }
+        acc += w * f;
+        coef[i] = 2.f * w * df / den;
+    }
+    acc = wave_sum(acc);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) *loss = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict__ prd, const float* __restrict__ tar,
                                                         const float* __restrict__ qw, const float* __restrict__ coef,
                                                         const float* __restrict__ coef_tar, float* __restrict__ dprd,
@@ -559,6 +582,15 @@ extern "C" int swv2_loss_sums(const float* prd, const float* tar, const float* q
     hipLaunchKernelGGL(loss_sums_kernel, dim3(BC * slices), dim3(256), 0, (hipStream_t)stream, prd, tar, quad_w, sums, H, W,
                        slices);
     SWV2_CHECK_LAUNCH("swv2_loss_sums");
+    return SWV2_OK;
+}
+
+extern "C" int swv2_loss_finalize(const float* sums, const float* chw, int BC, int C, int absolute, int squared, float* loss,
+                                  float* coef, void* stream) {
+    SWV2_CHECK_ARG(sums && chw && loss && coef && BC > 0 && C > 0 && BC % C == 0, "loss_finalize: bad argument");
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sums, chw, BC, C, absolute, squared, loss,
+                       coef);
+    SWV2_CHECK_LAUNCH("swv2_loss_finalize");
     return SWV2_OK;
 }
 

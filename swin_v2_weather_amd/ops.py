@@ -254,6 +254,12 @@ def loss_sums(prd, tar, qw, sums):
     L.check(L.load().swv2_loss_sums(_p(prd), _p(tar), _p(qw), _p(sums), B * Cc, H, W, _stream()), "swv2_loss_sums")
 
 
+def loss_finalize(sums, chw, absolute: bool, squared: bool, loss, coef):
+    BC, Cc = sums.shape[0] * sums.shape[1], chw.numel()
+    L.check(L.load().swv2_loss_finalize(_p(sums), _p(chw), BC, Cc, int(absolute), int(squared), _p(loss), _p(coef), _stream()),
+            "swv2_loss_finalize")
+
+
 def loss_grad(prd, tar, qw, coef, dprd):
     B, Cc, H, W = prd.shape
     L.check(L.load().swv2_loss_grad(_p(prd), _p(tar), _p(qw), _p(coef), _p(dprd), B * Cc, H, W, _stream()), "swv2_loss_grad")

@@ -7,6 +7,8 @@ gradient d loss / d prd -- is two HIP kernels (swv2_loss_sums / swv2_loss_grad);
 """
 import math
 
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -34,6 +36,29 @@ class _QuadSums(torch.autograd.Function):
         dprd = torch.empty_like(prd)
         ops.loss_grad(prd, tar, qw, coef, dprd)
         return dprd, None, None
+
+
+class _GeoL2(torch.autograd.Function):
+    """The whole LossHandler value as one node: loss_sums (one pass over prd / tar), loss_finalize (the [B, C] arithmetic +
+    the backward coefficients), and in backward one loss_grad pass.  Same value and gradient as _QuadSums + torch ops."""
+
+    @staticmethod
+    def forward(ctx, prd, tar, qw, chw, absolute, squared):
+        prd, tar = prd.contiguous().float(), tar.contiguous().float()
+        B, C = prd.shape[:2]
+        buf = torch.zeros(B * C * 3 + 1, dtype=torch.float32, device=prd.device)      # sums | coef | loss: one memset
+        sums, coef, loss = buf[:B * C * 2].view(B, C, 2), buf[B * C * 2:B * C * 3], buf[B * C * 3:]
+        ops.loss_sums(prd, tar, qw, sums)
+        ops.loss_finalize(sums, chw, absolute, squared, loss, coef)
+        ctx.save_for_backward(prd, tar, qw, coef)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        prd, tar, qw, coef = ctx.saved_tensors
+        dprd = torch.empty_like(prd)
+        ops.loss_grad(prd, tar, qw, (coef * gout).contiguous(), dprd)
+        return dprd, None, None, None, None, None
 
 
 def auto_channel_weights(channel_names, n_out):
@@ -112,6 +137,8 @@ class LossHandler(nn.Module):
             chw = (chw * self.multistep_weight).reshape(1, -1)
         else:
             chw = chw.reshape(1, -1)
+        if prd.is_cuda and prd.requires_grad and not tar.requires_grad and os.environ.get("SWV2_LOSS_FUSED", "1") != "0":
+            return _GeoL2.apply(prd, tar, self.quad_rows, chw.reshape(-1).contiguous().float(), self.absolute, self.squared)
         sums = _QuadSums.apply(prd, tar, self.quad_rows)
         norms = sums[..., 0]
         if not self.absolute:

@@ -670,7 +670,11 @@ def test_rollout_inplace_and_selective_checkpointing(dev, K, monkeypatch):
     assert torch.equal(y4, y1) and rel(gx4, gx1) < 1e-5
 
 
-def test_loss_handler_against_reference_values(dev, K):
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_loss_handler_against_reference_values(dev, K, monkeypatch, fused):
+    """value and gradient for the 4 loss strings x n_future in {0, 1}, through the one-node path (loss_sums + loss_finalize +
+    loss_grad) and through _QuadSums + torch arithmetic on the [B, C] sums"""
+    monkeypatch.setenv("SWV2_LOSS_FUSED", fused)
     from types import SimpleNamespace
     from swin_v2_weather_amd.utils.losses import LossHandler
     meta = json.load(open(os.path.join(GOLD, "loss_values.json")))

@@ -589,9 +589,8 @@ class _PatchEmbedFn(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         de = de.contiguous().view(B * T, Cc).float()
         da0 = torch.empty(B * T, Cc, dtype=BF16, device=dev)
-        dg, dbeta = torch.zeros(Cc, **f32), torch.zeros(Cc, **f32)
+        dg, dbeta, dw, db = _zeros_like_shapes(dev, (Cc,), (Cc,), (Cc, Cin * 16), (Cc,))       # one memset for the four gradients
         ops.ln_residual_bwd(a0, de, g, None, None, mean, rstd, da0, dg, dbeta, B * T, Cc, T)
-        dw, db = torch.zeros(Cc, Cin * 16, **f32), torch.zeros(Cc, **f32)
         ops.linear_wgrad(ops.op_bf16(da0), ops.op_patch(x), dw, db)
         dpos = None
         if ctx.has_pos:

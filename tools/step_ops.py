@@ -34,6 +34,6 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     step(); torch.cuda.synchronize()
 rows = [e for e in prof.key_averages() if e.device_time_total > 0 or e.self_device_time_total > 0]
 rows.sort(key=lambda e: -e.self_device_time_total)
-for e in rows[:60]:
+for e in rows[:70]:
     if not any(k in e.key for k in ("gemm_", "mlp_", "attn_", "proj_ln", "tn_reduce", "ln_")):
         print(f"{e.key[:90]:90s} n={e.count:4d} self_dev={e.self_device_time_total:9.1f} us")

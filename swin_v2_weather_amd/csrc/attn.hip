@@ -251,6 +251,17 @@ __global__ __launch_bounds__(64 * LT) void attn_fwd_kernel(
     }
 }
 
+#ifdef SWV2_ATTN1_STAMPS          // diagnostic build (tools/probe_attn1_stamps.py): per-phase s_memtime sums of every wave 0
+__device__ unsigned long long attn1_stamps[512 * 8];
+#define GSTAMP_DECL unsigned long long st_prev = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define GSTAMP_START() do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev) : : "memory"); } while (0)
+#define GSTAMP(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : : "memory"); \
+                       st_acc[k] += t_ - st_prev; st_prev = t_; } while (0)
+#else
+#define GSTAMP_DECL
+#define GSTAMP_START() do {} while (0)
+#define GSTAMP(k) do {} while (0)
+#endif
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
@@ -395,7 +406,11 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
                 so[j] = *(const uint4*)(oh + oslab + (size_t)c * 8);
             }
         }
-        if (tid < Lp) slse = (tid < L) ? lse[((size_t)bw * h + hd) * Lp + tid] : 1.0e30f;
+        // UNCONDITIONAL (clamped) load; the 1e30 of the padded rows is selected in commit().  As `if (tid < Lp) slse = (tid <
+        // L) ? load : 1e30f` the destination register was written on two paths, and the compiler guarded it with
+        // s_waitcnt vmcnt(0) RIGHT BEHIND the slab loads above: the waves that stage lse waited here for the whole prefetch
+        // (and the previous window's stores) in every window -- 22 % of the kernel (tools/probe_attn1_stamps.py)
+        slse = lse[((size_t)bw * h + hd) * Lp + min(tid, Lp - 1)];
     };
     auto commit = [&]() {
 #pragma unroll
@@ -421,7 +436,7 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
             for (int o = 1; o < CPR; o <<= 1) dl += __shfl_xor(dl, o);
             if (c < CH && (c % CPR) == 0) DLs[c / CPR] = dl;
         }
-        if (tid < Lp) LSEs[tid] = slse;
+        if (tid < Lp) LSEs[tid] = (tid < L) ? slse : 1.0e30f;
     };
 
     int bw = blockIdx.x;
@@ -431,12 +446,15 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
     __syncthreads();
 
     const int Lc = LFIX > 0 ? LFIX : L;
+    GSTAMP_DECL
+    GSTAMP_START();
     for (; bw < Bw; bw += gridDim.x) {
         const size_t slab0 = ((size_t)bw * h + hd) * 3 * SLAB;
         const int bw_next = bw + gridDim.x;
         if (bw_next < Bw) issue(bw_next);
         if (QG) { Qs = qkvh + slab0; dOs = doh + ((size_t)bw * h + hd) * SLAB; }
 
+        GSTAMP(0);                      // prefetch issue of the next window
         // ================= phase 1: wave = key tile(s) =================
         bf16x4 kf[TPW][DK], vf[TPW][DK];
         f32x4 dk[TPW][DK], dv[TPW][DK];
@@ -610,6 +628,7 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
                 for (int qt = 0; qt < LT; ++qt) step(qt, dummy, dummy, std::false_type{}, std::true_type{});
             }
         }
+        GSTAMP(1);                      // phase 1 loop
         // ---- dK (through the L2-normalisation) and dV of this wave's key tile(s)
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
@@ -637,7 +656,9 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
                 *(bf16x4*)(dqkvh + slab0 + 2 * SLAB + (size_t)key * DP + 16 * dt + 4 * g) = f2bf4(dv[i][dt]);
             }
         }
+        GSTAMP(2);                      // dK / dV normalisation backward + stores
         __syncthreads();
+        GSTAMP(3);                      // barrier 1
 
         // ================= phase 2: wave = query tile(s) =================
         if (!(dbg & 1)) {
@@ -710,10 +731,18 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
                 }
             }
         }
+        GSTAMP(4);                      // phase 2: dQ + normalisation backward + stores
         __syncthreads();
+        GSTAMP(5);                      // barrier 2
         if (bw_next < Bw) commit();
+        GSTAMP(6);                      // commit (wait for the prefetch + LDS writes + delta)
         __syncthreads();
+        GSTAMP(7);                      // barrier 3
     }
+#ifdef SWV2_ATTN1_STAMPS
+    if (lane == 0 && blockIdx.y == 0 && blockIdx.x * WAVES + tw < 512)        // every wave of the first workgroups of head 0
+        for (int k = 0; k < 8; ++k) attn1_stamps[(blockIdx.x * WAVES + tw) * 8 + k] = st_acc[k];
+#endif
 
     // ---- flush the per-workgroup reductions: one atomic per workgroup for the logit scale
     dsig = wave_sum(dsig);
@@ -829,6 +858,12 @@ extern "C" int swv2_attn_geometry(int L, int head_dim, int* Lp, int* DP) {
     if (Lp == 176 && DP == 128) return FN<11, 8, 0>(a, st);                            \
     swv2_set_error("attention: no kernel for Lp=%d DP=%d", Lp, DP);                    \
     return SWV2_ERR_UNSUPPORTED;
+
+#ifdef SWV2_ATTN1_STAMPS
+extern "C" int swv2_debug_attn1_stamps(void* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(attn1_stamps), sizeof(unsigned long long) * 512 * 8) == hipSuccess ? 0 : -3;
+}
+#endif
 
 extern "C" size_t swv2_attn_pack_bias_bytes(int heads, int L) {
     if (heads <= 0 || L <= 0) return 0;

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""In-kernel phase timing of the two-phase attention backward (attn_bwd_kernel): private build with -DSWV2_ATTN1_STAMPS;
+wave 0 of the workgroups of head 0 sums s_memtime deltas per phase -- GPU box, diagnostics only."""
+import ctypes, os, subprocess, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+from swin_v2_weather_amd import _lib as L
+so = "/tmp/libswv2_a1stamps.so"
+srcs = [os.path.join(L.CSRC, s) for s in L.SOURCES]
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DSWV2_ATTN1_STAMPS", "-o", so] + srcs,
+                      stderr=subprocess.DEVNULL)
+L.LIB_PATH = so
+from swin_v2_weather_amd import ops
+dev = torch.device("cuda:0"); BF = torch.bfloat16
+B = 2
+plan = ops.window_plan(B, 180, 360, 9, 18, 4, 9, 8, 16, 0)
+Bw, h, Lp, DP, Lw = plan.Bw, 8, plan.Lp, plan.DP, plan.L
+qkvh = (torch.randn(Bw, h, 3, Lp, DP, device=dev) * 0.25).to(BF); qkvh[:, :, :, Lw:] = 0
+oh = torch.empty(Bw, h, Lp, DP, dtype=BF, device=dev); lse = torch.zeros(Bw, h, Lp, device=dev)
+ls = torch.full((h,), 2.3, device=dev)
+a = ops.attn_args(qkvh, ls, None, oh, lse, Bw, h, Lw, 16, plan.nwh, plan.nww, plan.mask_thr)
+ops.attn_fwd(a)
+doh = torch.randn(Bw, h, Lp, DP, device=dev).to(BF); rnorm = torch.rand(Bw, h, 2, Lp, device=dev) + 0.5
+dq, dls = torch.empty_like(qkvh), torch.zeros(h, device=dev)
+a = ops.attn_args(qkvh, ls, None, oh, lse, Bw, h, Lw, 16, plan.nwh, plan.nww, plan.mask_thr, doh=doh, rnorm=rnorm, dqkvh=dq, dlogit=dls, max_chunks=64)
+for _ in range(3):
+    ops.attn_bwd(a)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10):
+    ops.attn_bwd(a)
+e1.record(); torch.cuda.synchronize()
+buf = torch.zeros(512 * 8, dtype=torch.int64)
+assert ctypes.CDLL(so).swv2_debug_attn1_stamps(ctypes.c_void_p(buf.data_ptr())) == 0
+allw = buf.view(512, 8).double()
+nwg = 512 // 11
+perwave = allw[:nwg * 11].view(nwg, 11, 8)
+st = perwave[:, 0, :]
+names = ["issue next window's prefetch", "phase 1 (S, dP, softmax bwd, dV, dK)", "dK / dV normalisation + stores", "barrier 1",
+         "phase 2 (dQ) + stores", "barrier 2", "commit (prefetch wait, LDS, delta)", "barrier 3"]
+tot = st.sum(1)
+print(f"attn_bwd (two-phase): {e0.elapsed_time(e1) * 100:.1f} us; wave 0 of {len(st)} workgroups, total ticks mean {tot.mean():.0f}")
+for i, n in enumerate(names):
+    print(f"  {n:40s} {100 * st[:, i].mean() / tot.mean():5.1f} %  (min {st[:, i].min():.0f} max {st[:, i].max():.0f})")
+print("per wave (mean ticks over the sampled workgroups): phase 1 | dK/dV + stores | barrier 1 | phase 2 | barrier 2")
+for w in range(11):
+    m = perwave[:, w, :].mean(0)
+    print(f"  wave {w:2d}: {m[1]:8.0f} {m[2]:8.0f} {m[3]:8.0f} {m[4]:8.0f} {m[5]:8.0f}   issue {m[0]:7.0f} commit {m[6]:7.0f}")

@@ -288,7 +288,10 @@ struct TnPlan { int ntn, ntk, tiles, real_slices, slices; size_t ws_bytes; };
 TnPlan tn_plan(int M, int N, int K, int splits) {
     TnPlan p;
     p.ntn = cdiv(N, BN); p.ntk = cdiv(K, BN); p.tiles = p.ntn * p.ntk;
-    const int eff = (p.tiles >= 3) ? splits : splits * 2;         // small outputs: more row slices to fill the chip
+    int eff = (p.tiles >= 3) ? splits : splits * 2;               // small outputs: more row slices to fill the chip
+    // large outputs need few: 128 slices of a 768 x 3072 gradient (144 tiles) were 18 432 workgroups writing 1.2 GB of
+    // partial tiles, and the reduction launch cost as much as a GEMM -- two rounds of workgroups (1024) are plenty
+    eff = std::min(eff, std::max(8, (1024 / p.tiles) / 8 * 8));
     p.real_slices = std::min(eff, cdiv(M, TM));
     p.slices = cdiv(p.real_slices, 8) * 8;                        // padded to a multiple of 8 (empty slices exit at once)
     p.ws_bytes = (size_t)p.real_slices * p.tiles * BN * BN * sizeof(float);

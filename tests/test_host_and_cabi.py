@@ -304,3 +304,25 @@ def test_unsupported_attention_geometry_fails_at_construction():
         N.SwinTransformerV2Cr(num_heads=(8,), embed_dim=2048, **kw)
     with pytest.raises(L.Swv2Error, match="window area"):
         N.SwinTransformerV2Cr(num_heads=(2,), embed_dim=32, **dict(kw, img_window_ratio=2))
+
+
+def test_hip_adam_on_cpu_parameters_takes_torchs_path():
+    """utils/optim.HipAdam never drops a parameter it cannot update with the HIP kernel: CPU tensors (no GPU here) and
+    option combinations the kernel does not implement go through torch.optim.Adam's own step -- same numbers as torch's
+    optimizer, same state_dict layout."""
+    from swin_v2_weather_amd.utils.optim import HipAdam
+    torch.manual_seed(0)
+    pa = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7))]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa = HipAdam(pa, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.01)
+    ob = torch.optim.Adam(pb, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.01)
+    for _ in range(3):
+        for a, b in zip(pa, pb):
+            g = torch.randn_like(a)
+            a.grad, b.grad = g.clone(), g.clone()
+        oa.step()
+        ob.step()
+    for a, b in zip(pa, pb):
+        assert torch.equal(a, b)
+    sa, sb = oa.state_dict(), ob.state_dict()
+    assert sa["state"].keys() == sb["state"].keys() and all(float(sa["state"][k]["step"]) == 3.0 for k in sa["state"])

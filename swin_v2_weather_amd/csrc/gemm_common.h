@@ -133,6 +133,13 @@ template <> struct ALoad<A_F32> {
         return o;
     }
     __device__ __forceinline__ Raw raw(int m, int k0) const { return raw_at(row_of(m), k0); }
+    // UNCONDITIONAL load of source row r in [0, rows), k0 in [0, K): no exec-masked load, so the compiler can count it in
+    // s_waitcnt and a prefetch stays in flight (a load under `if` makes it guard the destination with vmcnt(0))
+    __device__ __forceinline__ Raw raw_unc(int r, int k0) const {
+        const float* p = (const float*)d.ptr + (long)r * d.ld + k0;
+        Raw o = {*(const f32x4*)p, *(const f32x4*)(p + 4)};
+        return o;
+    }
     __device__ __forceinline__ uint4 cvt(const Raw& r) const { return cvt_f32x8(r); }
     __device__ __forceinline__ uint4 chunk(int m, int k0) const { return cvt(raw(m, k0)); }
 };
@@ -147,6 +154,7 @@ template <> struct ALoad<A_BF16> {
         if (r < 0 || k0 >= d.K) return make_uint4(0, 0, 0, 0);
         return *(const uint4*)((const uint16_t*)d.ptr + (long)r * d.ld + k0);
     }
+    __device__ __forceinline__ Raw raw_unc(int r, int k0) const { return *(const uint4*)((const uint16_t*)d.ptr + (long)r * d.ld + k0); }
     __device__ __forceinline__ Raw raw(int m, int k0) const { return raw_at(row_of(m), k0); }
     __device__ __forceinline__ uint4 chunk(int m, int k0) const { return raw(m, k0); }
 };
@@ -161,6 +169,7 @@ template <> struct ALoad<A_BF16_GELU> {
         if (m >= d.M || k0 >= d.K) return make_uint4(0, 0, 0, 0);
         return *(const uint4*)((const uint16_t*)d.ptr + (long)m * d.ld + k0);
     }
+    __device__ __forceinline__ Raw raw_unc(int r, int k0) const { return *(const uint4*)((const uint16_t*)d.ptr + (long)r * d.ld + k0); }
     const uint16_t* tab = nullptr;      // LDS table of bf16(GELU(x)) (see gelu_tab_off2), set by the kernel; null = formula
     __device__ __forceinline__ uint4 cvt(const Raw& r) const {
         if (tab) {
@@ -197,6 +206,9 @@ template <> struct ALoad<A_HEADS> {
     __device__ __forceinline__ Raw raw(int m, int k0) const { return chunk(m, k0); }
     __device__ __forceinline__ uint4 chunk(int m, int k0) const {
         if (m >= d.M || k0 >= d.K) return make_uint4(0, 0, 0, 0);
+        return raw_unc(m, k0);
+    }
+    __device__ __forceinline__ uint4 raw_unc(int m, int k0) const {
         const int h = d.p0, Lp = d.p2, DP = d.p3, S = (int)d.ld;
         const int bw = fdiv(m, Lp, d.mg0), t = m - bw * Lp;
         const int ph = k0 >> d.p1, j = k0 - ph * DP;                 // p1 = log2(DP), set by make_loader
@@ -215,6 +227,9 @@ template <> struct ALoad<A_PATCH> {
     __device__ __forceinline__ Raw raw(int m, int k0) const {
         Raw z = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
         if (m >= d.M || k0 >= d.K) return z;
+        return raw_unc(m, k0);
+    }
+    __device__ __forceinline__ Raw raw_unc(int m, int k0) const {
         const int Cin = d.p0, H = d.p1, W = d.p2, gw = W >> 2, gh = H >> 2;
         const int b = fdiv(m, gh * gw, d.mg0), ij = m - b * gh * gw, i = fdiv(ij, gw, d.mg1), j = ij - i * gw;
         const int cin = k0 >> 4, p = (k0 >> 2) & 3;                 // p in {0, 2}
@@ -245,6 +260,9 @@ template <> struct ALoad<A_MERGE_LN> {
     __device__ __forceinline__ Raw raw(int m, int k0) const { return chunk(m, k0); }
     __device__ __forceinline__ uint4 chunk(int m, int k0) const {
         if (m >= d.M || k0 >= d.K) return make_uint4(0, 0, 0, 0);
+        return raw_unc(m, k0);
+    }
+    __device__ __forceinline__ uint4 raw_unc(int m, int k0) const {
         const int H = d.p0, W = d.p1, C = d.p2, h2 = H >> 1, w2 = W >> 1;
         const int b = m / (h2 * w2), ij = m - b * h2 * w2, i = ij / w2, j = ij - i * w2;
         const float mu = d.aux0[m], rs = d.aux1[m];

@@ -33,7 +33,8 @@ constexpr int TN_SMEM = 2 * TM * TP;
 #endif        // [Y | X][TM][TP] bf16, single buffer
 
 // one 128 x 128 output tile over the row chunks of one slice (body shared by the single-product and the grouped kernel)
-template <int YK, int XK>
+// XG: the X rows are gathered through xl.d.rowidx (compile time, so the un-gathered products carry no index load at all)
+template <int YK, int XK, bool XG = false>
 __device__ __forceinline__ void tn_tile(const ALoad<YK>& yl, const ALoad<XK>& xl_arg, const TnOut& o, int tile, int slice,
                                         int chunk_stride, uint16_t* smem, float* dbs, uint16_t* gtab) {
     float* __restrict__ dW = o.dW;
@@ -78,32 +79,53 @@ __device__ __forceinline__ void tn_tile(const ALoad<YK>& yl, const ALoad<XK>& xl
     typename ALoad<YK>::Raw ry[TCH];
     typename ALoad<XK>::Raw rx[TCH];
     float colsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    // source rows of the NEXT step are resolved one step ahead, so a gathered operand's index load is never on the
-    // critical path of the data loads
-    int yrow[TCH], xrow[TCH];
+    // Staging pipeline.  EVERY global load here is unconditional (clamped address) and the validity of a chunk travels in a
+    // bit mask: rows past M and the padded rows of a window (table entry -1) are loaded from row 0 and zeroed when the
+    // tile is written to LDS.  With loads under `if (row < 0) ...` -- the first version -- the compiler guarded their
+    // destination registers with s_waitcnt vmcnt(0): one in the middle of issue() and one right behind the index loads of
+    // resolve(), i.e. BEFORE the MFMAs, so the "prefetch" of the next step was waited for at once and the kernel ran
+    // load -> wait -> compute in series (2.6 - 3.2 TB/s; found in the ISA, tools/probe_tn_stamps.py showed 40 % in issue).
+    // Gathered X rows: the table entries of step s + 2 are fetched behind the data loads of step s + 1 and consumed one
+    // iteration later, by which time they have long arrived.
+    int yrow[TCH], xrow[TCH];          // source rows of the next issue (X gathered: raw table entries)
+    uint32_t xin = 0;                  // X gathered: bit i = chunk row i of the next issue lies inside [0, M)
+    uint32_t okmask = 0;               // chunks in flight: bit i = Y chunk i valid, bit 16 + i = X chunk i valid
     auto resolve = [&](int s) {
+        xin = 0;
 #pragma unroll
         for (int i = 0; i < TCH; ++i) {
             const int m0 = (slice + s * chunk_stride) * TM, my = m0 + yr_(i), mx = m0 + xr_(i);
-            yrow[i] = yl.row_of((s < steps) && (my < m_hi) ? my : M);
-            xrow[i] = xl.row_of((s < steps) && (mx < m_hi) ? mx : M);
+            const bool iny = (s < steps) && (my < m_hi), inx = (s < steps) && (mx < m_hi);
+            yrow[i] = iny ? my : -1;
+            if constexpr (XG) {
+                xrow[i] = xl.d.rowidx[min(mx, M - 1)];
+                xin |= (uint32_t)inx << i;
+            } else {
+                xrow[i] = inx ? mx : -1;
+            }
         }
     };
     auto issue = [&](int s) {
+        okmask = 0;
 #pragma unroll
         for (int i = 0; i < TCH; ++i) {
-            ry[i] = yl.raw_at(yrow[i], n_base + yc_(i) * 8);     // row -1 loads nothing and yields zeros
-            rx[i] = xl.raw_at(xrow[i], k_base + xc_(i) * 8);
+            const int yk = n_base + yc_(i) * 8, xk = k_base + xc_(i) * 8;
+            const int xr = XG ? (((xin >> i) & 1) ? xrow[i] : -1) : xrow[i];
+            const bool yok = yrow[i] >= 0 && yk < N, xok = xr >= 0 && xk < K;
+            ry[i] = yl.raw_unc(max(yrow[i], 0), yk < N ? yk : 0);
+            rx[i] = xl.raw_unc(max(xr, 0), xk < K ? xk : 0);
+            okmask |= ((uint32_t)yok << i) | ((uint32_t)xok << (16 + i));
         }
     };
     auto commit = [&]() {
         uint16_t* Ys = smem;
         uint16_t* Xs = smem + TM * TP;
+        const uint4 zero4 = make_uint4(0, 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < TCH; ++i) {
-            const uint4 yv = yl.cvt(ry[i]);
+            const uint4 yv = ((okmask >> i) & 1) ? yl.cvt(ry[i]) : zero4;
             *(uint4*)(Ys + yr_(i) * TP + yc_(i) * 8) = yv;
-            *(uint4*)(Xs + xr_(i) * TP + xc_(i) * 8) = xl.cvt(rx[i]);
+            *(uint4*)(Xs + xr_(i) * TP + xc_(i) * 8) = ((okmask >> (16 + i)) & 1) ? xl.cvt(rx[i]) : zero4;
             if (want_db && !YRF) {                       // (a row-fastest dY has no fixed column per thread: rejected by the launcher)
                 float v[8];
                 unpack8(yv, v);
@@ -207,15 +229,15 @@ __device__ __forceinline__ void tn_tile(const ALoad<YK>& yl, const ALoad<XK>& xl
 // the tiles of one row slice re-read the same dY / X rows: give all tiles of a slice consecutive slots on ONE XCD so
 // the re-reads hit that XCD's L2 instead of HBM (PMC before: 415 MB vs 198 MB algorithmic for the fc1 gradient).
 // Speed only, never correctness.
-template <int YK, int XK>
-__global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(ALoad<YK> yl, ALoad<XK> xl, TnOut o, int chunk_stride) {
+template <int YK, int XK, bool XG>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(ALoad<YK> yl, ALoad<XK> xl, TnOut o, int chunk_stride) {
     __shared__ __attribute__((aligned(16))) uint16_t smem[TN_SMEM];
     __shared__ float dbs[BN];
     __shared__ __attribute__((aligned(16))) uint16_t gtab[XK == A_BF16_GELU ? GT_N : 8];
     const int lin = blockIdx.x;                       // 1-D launch: lin = xcd + 8 * (q * tiles + tile)
     const int x8 = lin & 7, rest = lin >> 3;
     const int tile = rest % o.tiles, slice = (rest / o.tiles) * 8 + x8;
-    tn_tile<YK, XK>(yl, xl, o, tile, slice, chunk_stride, smem, dbs, gtab);
+    tn_tile<YK, XK, XG>(yl, xl, o, tile, slice, chunk_stride, smem, dbs, gtab);
 }
 
 // The four weight-gradient products of one transformer block in ONE launch (fc2, fc1, proj, qkv: 4 + 4 + 1 + 3 tiles at
@@ -232,7 +254,7 @@ struct TnGroup {
     int first[5];                                 // first global tile index of each product; first[4] = total
     int slices;
 };
-__global__ __launch_bounds__(NTHREADS) void gemm_tn_group_kernel(TnGroup a) {
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_group_kernel(TnGroup a) {
     __shared__ __attribute__((aligned(16))) uint16_t smem[TN_SMEM];
     __shared__ float dbs[BN];
     __shared__ __attribute__((aligned(16))) uint16_t gtab[GT_N];
@@ -241,7 +263,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_group_kernel(TnGroup a) {
     if (t < a.first[1]) tn_tile<A_BF16, A_BF16_GELU>(a.y0, a.x0, a.o[0], t, slice, a.slices, smem, dbs, gtab);
     else if (t < a.first[2]) tn_tile<A_BF16, A_F32>(a.y1, a.x1, a.o[1], t - a.first[1], slice, a.slices, smem, dbs, gtab);
     else if (t < a.first[3]) tn_tile<A_BF16, A_HEADS>(a.y2, a.x2, a.o[2], t - a.first[2], slice, a.slices, smem, dbs, gtab);
-    else tn_tile<A_HEADS, A_F32>(a.y3, a.x3, a.o[3], t - a.first[3], slice, a.slices, smem, dbs, gtab);
+    else tn_tile<A_HEADS, A_F32, true>(a.y3, a.x3, a.o[3], t - a.first[3], slice, a.slices, smem, dbs, gtab);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -313,8 +335,22 @@ int launch_tn2(const swv2_operand* y, const swv2_operand* x, float* dW, float* d
         return SWV2_ERR_INVALID;
     }
     const TnOut o = tn_out(dW, db, nmap, kmap, ldw, M, N, K, ws);
-    hipLaunchKernelGGL((gemm_tn_kernel<YK, XK>), dim3(p.tiles * p.slices), dim3(NTHREADS), 0, st, make_loader<YK>(y),
-                       make_loader<XK>(x), o, p.real_slices);
+    // gathered operands: dY never; X only as fp32 rows (the qkv gradient's window gather)
+    if (y->rowidx || (x->rowidx && XK != A_F32)) {
+        swv2_set_error("swv2_linear_wgrad: a row gather is supported for a fp32 X operand only (dY kind %d, X kind %d)", y->kind, x->kind);
+        return SWV2_ERR_UNSUPPORTED;
+    }
+    if constexpr (XK == A_F32) {
+        if (x->rowidx)
+            hipLaunchKernelGGL((gemm_tn_kernel<YK, XK, true>), dim3(p.tiles * p.slices), dim3(NTHREADS), 0, st, make_loader<YK>(y),
+                               make_loader<XK>(x), o, p.real_slices);
+        else
+            hipLaunchKernelGGL((gemm_tn_kernel<YK, XK, false>), dim3(p.tiles * p.slices), dim3(NTHREADS), 0, st, make_loader<YK>(y),
+                               make_loader<XK>(x), o, p.real_slices);
+    } else {
+        hipLaunchKernelGGL((gemm_tn_kernel<YK, XK, false>), dim3(p.tiles * p.slices), dim3(NTHREADS), 0, st, make_loader<YK>(y),
+                           make_loader<XK>(x), o, p.real_slices);
+    }
     if (ws) {
         TnReduce r = {};
         r.o[0] = o; r.first[0] = 0; r.first[1] = r.first[2] = r.first[3] = r.first[4] = p.tiles; r.slices = p.real_slices;
@@ -407,6 +443,8 @@ extern "C" int swv2_block_wgrad(const swv2_wgrad_item* it, int slices, void* ws,
         SWV2_CHECK_ARG(it[i].dy.kind == want[i][0] && it[i].x.kind == want[i][1],
                        "swv2_block_wgrad: item %d must be (dY kind %d, X kind %d)", i, want[i][0], want[i][1]);
         SWV2_CHECK_ARG(it[i].dW && it[i].ldw > 0 && it[i].dy.rows == it[i].x.rows, "swv2_block_wgrad: item %d: null dW or row mismatch", i);
+        SWV2_CHECK_ARG(!it[i].dy.rowidx && (i == 3 ? it[i].x.rowidx != nullptr : it[i].x.rowidx == nullptr),
+                       "swv2_block_wgrad: item %d: only the qkv product's X rows are gathered (and they must be)", i);
         g.first[i] = tt;
         tt += cdiv(it[i].dy.cols, BN) * cdiv(it[i].x.cols, BN);
     }

@@ -483,35 +483,51 @@ __global__ __launch_bounds__(512) void gemm_rw_kernel(ALoad<AK> al, const uint16
     auto crow = [&](int c) { return AK == A_HEADS ? ((c >> 1) & (BMT - 1)) : c / KC; };
     auto ccol = [&](int c) { return AK == A_HEADS ? (((c / (2 * BMT)) << 1) | (c & 1)) : c % KC; };
     static_assert(AK != A_HEADS || (BMT & (BMT - 1)) == 0, "head-major chunk map needs a power-of-two tile height");
+    // Every load of the staging pipeline is UNCONDITIONAL (clamped address); validity travels in bit masks and invalid
+    // chunks (rows past M, padded window rows) are zeroed when the tile is written to LDS.  Loads under `if` made the
+    // compiler guard their destination registers with s_waitcnt vmcnt(0) right behind them, which turned the prefetch into
+    // a synchronous load (see gemm_tn.hip).  The launcher guarantees the tables this kernel reads unconditionally: a gather
+    // table for the fp32 operand, a scatter table + residual for the E_F32 epilogue.
+    uint32_t ain = 0;                 // bit i: chunk row i of the next issue lies inside [0, M)
+    uint32_t aok = 0;                 // chunks in flight: bit i = valid
+    bool ein = false;                 // E_F32: this lane's epilogue row of the next tile lies inside [0, M)
     auto resolve = [&](int t) {
+        ain = 0;
 #pragma unroll
         for (int i = 0; i < ACH; ++i) {
-            const int c = tid + i * NTH;
-            arow[i] = al.row_of(t < ntiles ? t * BMT + crow(c) : M);
+            const int c = tid + i * NTH, m = t * BMT + crow(c);
+            const bool in = (t < ntiles) && (m < M);
+            ain |= (uint32_t)in << i;
+            if constexpr (AK == A_F32) arow[i] = al.d.rowidx[min(m, M - 1)];        // gather table entry (may be -1: padded row)
+            else arow[i] = min(m, M - 1);
         }
         if constexpr (EK == E_F32) {
             const int m = t * BMT + wr * 16 + (lane >> 2);
-            erow_res = (t < ntiles && m < M) ? (ep.d.rowidx ? ep.d.rowidx[m] : m) : -1;
+            ein = (t < ntiles) && (m < M);
+            erow_res = ep.d.rowidx[min(m, M - 1)];
         }
     };
     auto issue = [&]() {
+        aok = 0;
 #pragma unroll
         for (int i = 0; i < ACH; ++i) {
             const int c = tid + i * NTH;
-            ra[i] = al.raw_at(arow[i], ccol(c) * 8);
+            const int r = ((ain >> i) & 1) ? arow[i] : -1;
+            ra[i] = al.raw_unc(max(r, 0), ccol(c) * 8);
+            aok |= (uint32_t)(r >= 0) << i;
         }
         if constexpr (EK == E_F32) {
-            erow_nxt = erow_res;
-            const float* ax = (const float*)ep.d.aux + (long)max(erow_nxt, 0) * ep.d.ld + ecol;      // unconditional loads
+            erow_nxt = ein ? erow_res : -1;
+            const float* ax = (const float*)ep.d.aux + (long)max(erow_nxt, 0) * ep.d.ld + ecol;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) aux_nxt[i] = ep.d.aux ? *(const f32x4*)(ax + 4 * i) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < 4; ++i) aux_nxt[i] = *(const f32x4*)(ax + 4 * i);
         }
     };
     auto commit = [&]() {
 #pragma unroll
         for (int i = 0; i < ACH; ++i) {
             const int c = tid + i * NTH;
-            *(uint4*)(As + swzk(crow(c), ccol(c), K)) = al.cvt(ra[i]);
+            *(uint4*)(As + swzk(crow(c), ccol(c), K)) = ((aok >> i) & 1) ? al.cvt(ra[i]) : make_uint4(0, 0, 0, 0);
         }
     };
     const int G = gridDim.x;
@@ -644,7 +660,7 @@ int launch_nt2(const swv2_operand* a, const void* w, const swv2_epilogue* e, int
     // the two per-block products at the benchmark width: resident-weight persistent kernel
     static const int rw = getenv("SWV2_GEMM_RW") ? atoi(getenv("SWV2_GEMM_RW")) : 1;
     if constexpr (AK == A_F32 && EK == E_QKV_HEADS) {
-        if (rw && N == 384 && K == 128 && M >= 256 * 128 && e->p[3] == 16) {
+        if (rw && N == 384 && K == 128 && M >= 256 * 128 && e->p[3] == 16 && a->rowidx) {
             hipLaunchKernelGGL((gemm_rw_kernel<AK, EK, 384, 128, 128>), dim3(256), dim3(512), 0, st, make_loader<AK>(a),
                                (const uint16_t*)w, ep, M);
             SWV2_CHECK_LAUNCH("swv2_linear");
@@ -652,7 +668,7 @@ int launch_nt2(const swv2_operand* a, const void* w, const swv2_epilogue* e, int
         }
     }
     if constexpr (AK == A_HEADS && EK == E_F32) {
-        if (rw && N == 128 && K == 384 && M >= 256 * 64) {
+        if (rw && N == 128 && K == 384 && M >= 256 * 64 && e->rowidx && e->aux && !a->rowidx) {
             hipLaunchKernelGGL((gemm_rw_kernel<AK, EK, 128, 384, 64>), dim3(256), dim3(512), 0, st, make_loader<AK>(a),
                                (const uint16_t*)w, ep, M);
             SWV2_CHECK_LAUNCH("swv2_linear");

@@ -218,6 +218,26 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(const MlpFwd a) {
     // layout (a lane owns 8 consecutive columns), so the residual read and both stores are whole rows per instruction.
     uint16_t* As = (uint16_t*)(smem_raw + wave * EWAVE);
     float* St = (float*)(As + 16 * PA);                       // [16 rows][mean, rstd]
+    // residual rows and drop-path scales of ALL row passes first, unconditionally: loaded inside the pass loop each one was a
+    // memory round trip of its own (the ISA read  load, s_waitcnt vmcnt(0), store  per pass; 19 % of the kernel in the
+    // epilogue), now they are in flight together while the LayerNorm statistics are computed
+    constexpr int UNITS = 16 * (C / 8), NP = (UNITS + 63) / 64;
+    f32x4 xres[MT][NP][2];
+    float scv[MT][NP];
+    {
+        const float* scp = a.scale ? a.scale : a.gamma;         // any valid address: the value is ignored without a scale
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int u = min(lane + 64 * p, UNITS - 1), row = u / (C / 8), c8 = u % (C / 8);
+                const int rc = min(row0 + 16 * mt + row, a.M - 1);
+                const size_t off = (size_t)rc * C + 8 * c8;
+                xres[mt][p][0] = *(const f32x4*)(a.x + off);
+                xres[mt][p][1] = *(const f32x4*)(a.x + off + 4);
+                scv[mt][p] = scp[a.scale ? rc / a.rows_per_sample : 0];
+            }
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         float s = 0.f;
@@ -249,15 +269,14 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(const MlpFwd a) {
         }
         __syncthreads();
         const int rbase = row0 + 16 * mt;
-        constexpr int UNITS = 16 * (C / 8);
 #pragma unroll
-        for (int p = 0; p < (UNITS + 63) / 64; ++p) {
+        for (int p = 0; p < NP; ++p) {
             const int u = lane + 64 * p, row = u / (C / 8), c8 = u % (C / 8);
             if (UNITS % 64 == 0 || u < UNITS) {
                 const int rc = min(rbase + row, a.M - 1);
                 const u32x4 av = *(const u32x4*)(As + row * PA + 8 * c8);
                 const float mu_r = St[2 * row], rs_r = St[2 * row + 1];
-                const float sc = a.scale ? a.scale[rc / a.rows_per_sample] : 1.f;
+                const float sc = a.scale ? scv[mt][p] : 1.f;
                 const size_t off = (size_t)rc * C + 8 * c8;
                 *(u32x4*)(a.a2 + off) = av;
                 float v[8];
@@ -265,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(const MlpFwd a) {
 #pragma unroll
                 for (int hlf = 0; hlf < 2; ++hlf) {
                     const f32x4 gm = *(const f32x4*)(cs + C + 8 * c8 + 4 * hlf), bt = *(const f32x4*)(cs + 2 * C + 8 * c8 + 4 * hlf);
-                    f32x4 o = *(const f32x4*)(a.x + off + 4 * hlf);
+                    f32x4 o = xres[mt][p][hlf];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] += sc * ((v[4 * hlf + e] - mu_r) * rs_r * gm[e] + bt[e]);
                     *(f32x4*)(a.y + off + 4 * hlf) = o;
@@ -573,6 +592,17 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const MlpBwd a) {
 
     // ---- dx = dy + (dH W1): accumulators -> per-wave LDS tile -> whole rows
     float* Ys = (float*)smem_raw + wave * 16 * PY;
+    // the dy rows of ALL passes first: written as  dx[off] = dy[off] + ...  per pass, every load had to wait behind the previous
+    // pass's store (dx and dy may alias as far as the compiler knows) -- 16 serial memory round trips per workgroup
+    constexpr int EPASS = 16 * (C / 4) / 64;
+    f32x4 dyv[MT][EPASS];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int p = 0; p < EPASS; ++p) {
+            const int u = lane + 64 * p, row = u / (C / 4), c4 = u % (C / 4);
+            dyv[mt][p] = *(const f32x4*)(a.dy + (size_t)min(row0 + 16 * mt + row, a.M - 1) * C + 4 * c4);
+        }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -580,10 +610,10 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const MlpBwd a) {
         __syncthreads();
         const int rbase = row0 + 16 * mt;
 #pragma unroll
-        for (int p = 0; p < 16 * (C / 4) / 64; ++p) {
+        for (int p = 0; p < EPASS; ++p) {
             const int u = lane + 64 * p, row = u / (C / 4), c4 = u % (C / 4);
             const size_t off = (size_t)min(rbase + row, a.M - 1) * C + 4 * c4;
-            *(f32x4*)(a.dx + off) = *(const f32x4*)(a.dy + off) + *(const f32x4*)(Ys + row * PY + 4 * c4);
+            *(f32x4*)(a.dx + off) = dyv[mt][p] + *(const f32x4*)(Ys + row * PY + 4 * c4);
         }
         if (mt + 1 < MT) __syncthreads();
     }

@@ -44,6 +44,7 @@ __global__ __launch_bounds__(256, 2) void proj_ln_fwd_kernel(const ProjLnFwd a) 
     constexpr int UNITS = 16 * (C / 8), NP = (UNITS + 63) / 64;
     int dstv[MT][NP];
     f32x4 xr[MT][NP][2];
+    float scv[MT][NP];                      // drop-path scale of the destination row's sample (unconditional load, see below)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -77,6 +78,8 @@ __global__ __launch_bounds__(256, 2) void proj_ln_fwd_kernel(const ProjLnFwd a) 
             const size_t off = (size_t)max(dstv[mt][p], 0) * C + 8 * c8;
             xr[mt][p][0] = *(const f32x4*)(a.x + off);
             xr[mt][p][1] = *(const f32x4*)(a.x + off + 4);
+            // (as `a.scale ? a.scale[...] : 1.f` inside the pass loop this was a conditional load with its own vmcnt(0))
+            scv[mt][p] = (a.scale ? a.scale : a.gamma)[a.scale ? max(dstv[mt][p], 0) / a.rows_per_sample : 0];
         }
     __syncthreads();
 
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void proj_ln_fwd_kernel(const ProjLnFwd a) 
                 const int dst = dstv[mt][p];
                 if (dst >= 0) {
                     const float mu_r = St[2 * row], rs_r = St[2 * row + 1];
-                    const float sc = a.scale ? a.scale[dst / a.rows_per_sample] : 1.f;
+                    const float sc = a.scale ? scv[mt][p] : 1.f;
                     const size_t off = (size_t)dst * C + 8 * c8;
                     float v[8];
                     unpack8(__builtin_bit_cast(uint4, av), v);

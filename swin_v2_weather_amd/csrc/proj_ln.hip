@@ -204,23 +204,46 @@ __global__ __launch_bounds__(256, 2) void proj_ln_bwd_kernel(const ProjLnBwd a) 
             const int m = min(wg_row0 + i * RPP + rg, a.Mw - 1);
             srcv[i] = a.rowidx ? a.rowidx[m] : m;
         }
+        // two batches of row loads in flight: batch b + 1 is issued BEFORE batch b's results are stored (the compiler cannot move
+        // the loads above those stores itself -- da1 may alias dy as far as it knows -- so each batch used to be a full memory
+        // round trip behind the previous one: four in series per workgroup)
+        f32x4 d4s[2][BATCH];
+        u32x2 a4s[2][BATCH];
+        float mus[2][BATCH], rss[2][BATCH], scs[2][BATCH];
+        int oks[2][BATCH];
+        const float* scp = a.scale ? a.scale : a.gamma;          // unconditional load; ignored without a scale
+        auto load_batch = [&](int pb, auto set_c) {
+            constexpr int S = decltype(set_c)::value;
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i) {
+                const int m = min(wg_row0 + (pb + i) * RPP + rg, a.Mw - 1);
+                const int src = srcv[(pb + i) % NPASS];
+                oks[S][i] = src >= 0;
+                const int sr = max(src, 0);
+                d4s[S][i] = *(const f32x4*)(a.dy + (size_t)sr * C + c0);
+                a4s[S][i] = *(const u32x2*)(a.a1 + (size_t)m * C + c0);
+                mus[S][i] = a.mean[m];
+                rss[S][i] = a.rstd[m];
+                scs[S][i] = scp[a.scale ? sr / a.rows_per_sample : 0];
+            }
+        };
+        load_batch(0, std::integral_constant<int, 0>{});
 #pragma unroll
         for (int pb = 0; pb < NPASS; pb += BATCH) {
+            constexpr int dummy = 0; (void)dummy;
+            const int cur = (pb / BATCH) & 1;
+            if (pb + BATCH < NPASS) {
+                if (cur == 0) load_batch(pb + BATCH, std::integral_constant<int, 1>{});
+                else load_batch(pb + BATCH, std::integral_constant<int, 0>{});
+            }
             f32x4 d4[BATCH];
             u32x2 a4[BATCH];
             float mu[BATCH], rs[BATCH], sc[BATCH];
             int ok[BATCH];
 #pragma unroll
             for (int i = 0; i < BATCH; ++i) {
-                const int m = min(wg_row0 + (pb + i) * RPP + rg, a.Mw - 1);
-                const int src = srcv[(pb + i) % NPASS];
-                ok[i] = src >= 0;
-                const int sr = max(src, 0);
-                d4[i] = *(const f32x4*)(a.dy + (size_t)sr * C + c0);
-                a4[i] = *(const u32x2*)(a.a1 + (size_t)m * C + c0);
-                mu[i] = a.mean[m];
-                rs[i] = a.rstd[m];
-                sc[i] = a.scale ? a.scale[sr / a.rows_per_sample] : 1.f;
+                d4[i] = d4s[cur][i]; a4[i] = a4s[cur][i]; mu[i] = mus[cur][i]; rs[i] = rss[cur][i];
+                sc[i] = a.scale ? scs[cur][i] : 1.f; ok[i] = oks[cur][i];
             }
 #pragma unroll
             for (int i = 0; i < BATCH; ++i) {

@@ -277,12 +277,21 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn_fwd3_kernel(
     const bool bounded = sc2 <= 40.f;
 
     u32x4 stage[CPT], stageq[QPT];
+    // 32-bit, loop-invariant lane offsets against a wave-uniform base: the loads then take the (SGPR base + VGPR offset)
+    // form.  With 64-bit per-lane addresses the compiler built them in the loads' own destination registers, guarded that
+    // overwrite with s_waitcnt vmcnt(..0) -- and with the in-order counter that wait also covered the previous item's
+    // output STORES, once per (window, head) item in front of the prefetch (ISA, round 2).
+    unsigned soff[CPT], qoff[QPT];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) soff[j] = (unsigned)(SLAB + min(tid + j * NT, CH - 1) * 8);
+#pragma unroll
+    for (int j = 0; j < QPT; ++j) qoff[j] = (unsigned)(min(tid + j * NT, QCH - 1) * 8);
     auto issue_loads = [&](int bw) {
         const uint16_t* base = qkvh + ((size_t)bw * h + hd) * 3 * SLAB;
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) stage[j] = *(const u32x4*)(base + SLAB + (size_t)min(tid + j * NT, CH - 1) * 8);
+        for (int j = 0; j < CPT; ++j) stage[j] = *(const u32x4*)(base + soff[j]);
 #pragma unroll
-        for (int j = 0; j < QPT; ++j) stageq[j] = *(const u32x4*)(base + (size_t)min(tid + j * NT, QCH - 1) * 8);
+        for (int j = 0; j < QPT; ++j) stageq[j] = *(const u32x4*)(base + qoff[j]);
     };
     auto write_stage = [&](int buf) {
         uint16_t* dst = smem + buf * BUF;

@@ -183,6 +183,23 @@ int swv2_qk_normalize(void* qkvh_bf16, float* rnorm, int Bw, int heads, int Lp, 
 int swv2_prep_weight(const float* w, int rows, int cols, int transpose, const int32_t* row_map, int out_rows,
                      const int32_t* col_map, int out_cols, void* out_bf16, void* stream);
 
+/* The same for many parameters in ONE launch (all prepared copies of a model after an optimizer step).  items_dev: device
+ * array; chunks_dev: device array of int pairs (item index, chunk index within the item's output), one workgroup per chunk
+ * of swv2_prep_chunk() output elements; both tables are built by the caller (swin_v2_weather_amd/ops.py::PrepBatch).
+ * out_f32 != 0: the output stays fp32 (the head-padded qkv bias). */
+typedef struct swv2_prep_item {
+    const float* w;
+    int rows, cols, transpose;
+    const int32_t* row_map;
+    int out_rows;
+    const int32_t* col_map;
+    int out_cols;
+    void* out;
+    int out_f32;
+} swv2_prep_item;
+int swv2_prep_chunk(void);
+int swv2_prep_multi(const swv2_prep_item* items_dev, const int* chunks_dev, int n_chunks, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Fused LayerNorm + drop-path + residual add, with the window_reverse + reverse cyclic roll folded into the row
  * scatter:  y[dst] = res[res_mod ? dst % res_mod : dst] + scale[dst / rows_per_sample] * (LN(a[m])*gamma + beta),

@@ -65,6 +65,11 @@ class Operand(C.Structure):
                 ("rows", C.c_int), ("cols", C.c_int), ("p", C.c_int * 4)]
 
 
+class PrepItem(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("transpose", C.c_int), ("row_map", C.c_void_p),
+                ("out_rows", C.c_int), ("col_map", C.c_void_p), ("out_cols", C.c_int), ("out", C.c_void_p), ("out_f32", C.c_int)]
+
+
 class WgradItem(C.Structure):
     _fields_ = [("dy", Operand), ("x", Operand), ("dW", C.c_void_p), ("db", C.c_void_p), ("nmap", C.c_void_p),
                 ("kmap", C.c_void_p), ("ldw", C.c_int)]
@@ -156,6 +161,8 @@ SYMBOLS = {
     "swv2_loss_sums": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "swv2_loss_grad": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "swv2_loss_finalize": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "swv2_prep_chunk": (_I, []),
+    "swv2_prep_multi": (_I, [_P, _P, _I, _P]),
     "swv2_adam_chunk": (_I, []),
     "swv2_adam_multi": (_I, [_P, _P, _I, _F, _F, _F, _F, _I, _F, _P]),
     "swv2_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P]),

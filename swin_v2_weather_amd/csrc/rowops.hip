@@ -234,6 +234,23 @@ __global__ void prep_weight_kernel(const float* __restrict__ w, int rows, int co
     }
 }
 
+// The same for MANY parameters in one launch (every optimizer step changes every weight: ~100 prepared copies for the
+// depth-12 model; one workgroup per chunk of PREP_CHUNK output elements, tables in device memory as for adam_multi_kernel).
+// out_f32 items keep fp32 (the head-padded qkv bias).
+constexpr int PREP_CHUNK = 4096;
+__global__ __launch_bounds__(256) void prep_multi_kernel(const swv2_prep_item* __restrict__ items, const int2* __restrict__ chunks) {
+    const int2 c = chunks[blockIdx.x];
+    const swv2_prep_item it = items[c.x];
+    const long n = (long)it.out_rows * it.out_cols, lo = (long)c.y * PREP_CHUNK, hi = min(n, lo + PREP_CHUNK);
+    for (long idx = lo + threadIdx.x; idx < hi; idx += 256) {
+        const int i = idx / it.out_cols, j = idx - (long)i * it.out_cols;
+        const int r = it.row_map ? it.row_map[i] : i, cc = it.col_map ? it.col_map[j] : j;
+        float v = 0.f;
+        if (r >= 0 && cc >= 0) v = it.transpose ? it.w[(long)cc * it.cols + r] : it.w[(long)r * it.cols + cc];
+        if (it.out_f32) ((float*)it.out)[idx] = v; else ((uint16_t*)it.out)[idx] = f2bf(v);
+    }
+}
+
 // out[i] (+)= sum_b in[b][i]
 __global__ void batch_sum_kernel(const float* __restrict__ in, float* __restrict__ out, int B, long n, int accumulate) {
     for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long)gridDim.x * blockDim.x * 4) {
@@ -571,6 +588,15 @@ extern "C" int swv2_prep_weight(const float* w, int rows, int cols, int transpos
     hipLaunchKernelGGL(prep_weight_kernel, dim3(min(cdiv(n, 256), 4096)), dim3(256), 0, (hipStream_t)stream, w, rows, cols,
                        transpose, row_map, out_rows, col_map, out_cols, (uint16_t*)out_bf16);
     SWV2_CHECK_LAUNCH("swv2_prep_weight");
+    return SWV2_OK;
+}
+
+extern "C" int swv2_prep_chunk(void) { return PREP_CHUNK; }
+
+extern "C" int swv2_prep_multi(const swv2_prep_item* items_dev, const int* chunks_dev, int n_chunks, void* stream) {
+    SWV2_CHECK_ARG(items_dev && chunks_dev && n_chunks > 0, "prep_multi: bad argument");
+    hipLaunchKernelGGL(prep_multi_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, items_dev, (const int2*)chunks_dev);
+    SWV2_CHECK_LAUNCH("swv2_prep_multi");
     return SWV2_OK;
 }
 

@@ -63,20 +63,51 @@ def _zeros_like_shapes(device, *shapes):
     return out
 
 
+# Any optimizer step invalidates the prepared parameter copies.  `Tensor._version` alone is NOT enough: torch's fused Adam
+# (`_fused_adam_`, what train.py / bench.py used until round 2) and the HIP Adam kernel update the parameters without
+# bumping it -- found in round 2 by comparing HipAdam with torch's foreach Adam under DDP: with the version-only key the bf16
+# weight copies of every GEMM stayed at their step-1 values (only biases, LayerNorms and pos_embed were learning).
+_OPT_EPOCH = [0]
+
+
+def _bump_opt_epoch(*_a, **_k):
+    _OPT_EPOCH[0] += 1
+
+
+from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_opt_hook  # noqa: E402
+
+_reg_opt_hook(_bump_opt_epoch)
+
+
 class _WeightCache:
-    """bf16 (cast / transposed / permuted / padded) copies of the fp32 parameters, rebuilt when a parameter changes
-    (optimizer steps bump `Tensor._version`)."""
+    """bf16 (cast / transposed / permuted / padded) copies of the fp32 parameters, rebuilt when a parameter changes: its
+    storage, its `_version` (in-place torch ops) or ANY optimizer step since the copy was made (see _OPT_EPOCH)."""
 
     def __init__(self):
         self._c = {}
 
+    @staticmethod
+    def _ver(params):
+        return tuple((p.data_ptr(), p._version, _OPT_EPOCH[0]) for p in params)
+
     def get(self, key, params, builder):
-        ver = tuple((p.data_ptr(), p._version) for p in params)
+        ver = self._ver(params)
         hit = self._c.get(key)
         if hit is not None and hit[0] == ver:
             return hit[1]
         with torch.no_grad():
             val = builder()
+        self._c[key] = (ver, val)
+        return val
+
+    def prep(self, key, w, batch, **spec):
+        """like get(key, (w,), lambda: ops.prep_weight(w, **spec)) but the work is queued on `batch` (ops.PrepBatch: one launch
+        for all stale copies of the model) and the previous output tensor is reused, so its address stays the same"""
+        ver = self._ver((w,))
+        hit = self._c.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        val = batch.add(w, out=None if hit is None else hit[1], **spec)
         self._c[key] = (ver, val)
         return val
 
@@ -163,24 +194,29 @@ class _BlockRunner:
         self.bias_elems = h * Lw * Lw
 
     def set_params(self, wc, logit_scale, qkv_w, qkv_b, proj_w, proj_b, n1_w, n1_b, fc1_w, fc1_b, fc2_w, fc2_b, n2_w, n2_b,
-                   backward):
+                   backward, batch=None):
+        """prepared copies of the block's weights (stale ones queued on `batch`; without one -- a block used on its own -- a
+        local batch is launched here) and all parameter pointers into the launch descriptor"""
         plan, d = self.plan, self.desc
         h, DP = plan.heads, plan.DP
-        dev = self.device
-        keep = [wc.get("qkv", (qkv_w,), lambda: ops.prep_weight(qkv_w, row_map=plan.qkv_map, out_rows=3 * h * DP)),
-                wc.get("qkv_b", (qkv_b,), lambda: torch.where(plan.qkv_map >= 0, qkv_b[plan.qkv_map.clamp(min=0).long()],
-                                                              torch.zeros((), device=dev)).contiguous()),
-                wc.get("proj", (proj_w,), lambda: ops.prep_weight(proj_w, col_map=plan.proj_map, out_cols=h * DP)),
-                wc.get("fc1", (fc1_w,), lambda: ops.prep_weight(fc1_w)),
-                wc.get("fc2", (fc2_w,), lambda: ops.prep_weight(fc2_w))]
+        own = batch is None
+        if own:
+            batch = ops.PrepBatch()
+        keep = [wc.prep("qkv", qkv_w, batch, row_map=plan.qkv_map, out_rows=3 * h * DP),
+                wc.prep("qkv_b", qkv_b, batch, row_map=plan.qkv_map, out_rows=3 * h * DP, f32=True),     # head-padded bias [3hDP][1]
+                wc.prep("proj", proj_w, batch, col_map=plan.proj_map, out_cols=h * DP),
+                wc.prep("fc1", fc1_w, batch),
+                wc.prep("fc2", fc2_w, batch)]
         d.w_qkv, d.qkv_b_pad, d.w_proj, d.w_fc1, d.w_fc2 = (t.data_ptr() for t in keep)
         if backward:
-            kb = [wc.get("qkvt", (qkv_w,), lambda: ops.prep_weight(qkv_w, transpose=True, col_map=plan.qkv_map, out_cols=3 * h * DP)),
-                  wc.get("projt", (proj_w,), lambda: ops.prep_weight(proj_w, transpose=True, row_map=plan.proj_map, out_rows=h * DP)),
-                  wc.get("fc1t", (fc1_w,), lambda: ops.prep_weight(fc1_w, transpose=True)),
-                  wc.get("fc2t", (fc2_w,), lambda: ops.prep_weight(fc2_w, transpose=True))]
+            kb = [wc.prep("qkvt", qkv_w, batch, transpose=True, col_map=plan.qkv_map, out_cols=3 * h * DP),
+                  wc.prep("projt", proj_w, batch, transpose=True, row_map=plan.proj_map, out_rows=h * DP),
+                  wc.prep("fc1t", fc1_w, batch, transpose=True),
+                  wc.prep("fc2t", fc2_w, batch, transpose=True)]
             d.w_qkvt, d.w_projt, d.w_fc1t, d.w_fc2t = (t.data_ptr() for t in kb)
             keep += kb
+        if own:
+            batch.launch()
         d.logit_scale, d.proj_b, d.n1_w, d.n1_b = logit_scale.data_ptr(), proj_b.data_ptr(), n1_w.data_ptr(), n1_b.data_ptr()
         d.fc1_b, d.fc2_b, d.n2_w, d.n2_b = fc1_b.data_ptr(), fc2_b.data_ptr(), n2_w.data_ptr(), n2_b.data_ptr()
         return keep
@@ -913,7 +949,26 @@ class SwinTransformerV2Cr(nn.Module):
         """-> [B, C, gh, gw] (BCHW view, as the reference)."""
         return bhwc_to_bchw(self._features_bhwc(x))
 
+    def _prep_all(self, x):
+        """all stale prepared parameter copies of the model (8 per block + PatchEmbed + head) in ONE launch: after an optimizer
+        step every weight is stale, and one tiny prep launch per copy would be ~100 launches in front of the forward"""
+        batch = ops.PrepBatch()
+        bw = torch.is_grad_enabled()
+        for stage in self.stages:
+            for blk in stage.blocks:
+                a, m_ = blk.attn, blk.mlp
+                blk._runner(x.shape[0], x.device).set_params(
+                    blk._wcache, a.logit_scale, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias, blk.norm1.weight, blk.norm1.bias,
+                    m_.fc1.weight, m_.fc1.bias, m_.fc2.weight, m_.fc2.bias, blk.norm2.weight, blk.norm2.bias, backward=bw, batch=batch)
+        self.patch_embed._wcache.prep("pe", self.patch_embed.proj.weight, batch)
+        perm = self._head_perm(x.device)
+        self._wcache.prep("head", self.head.weight, batch, row_map=perm)
+        if bw:
+            self._wcache.prep("headt", self.head.weight, batch, transpose=True, col_map=perm)
+        batch.launch()
+
     def _features_bhwc(self, x):
+        self._prep_all(x)
         e = self.patch_embed.forward_bhwc(x, self.pos_embed if self.full_pos_embed else None)
         for stage in self.stages:
             e = stage.forward_bhwc(e)

@@ -117,6 +117,9 @@ class HipAdam(torch.optim.Adam):
                                              float(b1), float(b2), float(group["eps"]), step, float(grad_inv_scale), stream),
                     "swv2_adam_multi")
             torch._foreach_add_(t["step_tensors"], 1.0)      # state_dict() keeps torch's per-parameter `step` entries
+            # the kernel wrote the parameters behind autograd's back: bump their version counters like an in-place torch op
+            # would (anything keyed on `Tensor._version` -- e.g. cached casts of the weights -- must see the change)
+            torch.autograd.graph.increment_version(plist)
         if slow:
             keep = self.param_groups
             try:

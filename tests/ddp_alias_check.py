@@ -4,7 +4,7 @@
   env RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT, SWV2_DDP_BACKEND (nccl = RCCL | gloo: CUDA tensors staged through the
   host, so several ranks can share cuda:0), SWV2_DDP_MODE (plain = no DDP | ddp = stock DDP | alias = DDP +
   helpers.enable_ddp_bucket_grads), SWV2_DDP_NFUTURE (0 | 1: MultiStepWrapper rollout, every block's backward node runs
-  n_future + 1 times per pass), SWV2_DDP_OUT (rank 0 saves {losses, params, used} there).
+  n_future + 1 times per pass), SWV2_DDP_OPT (sgd | adam | hipadam), SWV2_DDP_OUT (rank 0 saves {losses, params, used} there).
 
 Each rank trains on ITS slice of one fixed global batch (reference train.py:147-148 / DistributedSampler); with the
 mean-over-batch loss used here the DDP-averaged gradient of N ranks equals the 1-process gradient on the whole batch, so
@@ -48,7 +48,14 @@ if mode != "plain":
         enable_ddp_bucket_grads(net)
 # plain SGD: the parameter difference is then linear in the gradient difference (Adam turns a rounding-level difference of a
 # near-zero gradient element into a full +-lr step, which makes a parameter comparison meaningless)
-opt = torch.optim.SGD(m.parameters(), lr=0.02)
+optk = os.environ.get("SWV2_DDP_OPT", "sgd")              # sgd | adam (torch) | hipadam (utils/optim.HipAdam)
+if optk == "hipadam":
+    from swin_v2_weather_amd.utils.optim import HipAdam
+    opt = HipAdam(m.parameters(), lr=1e-3, betas=(0.9, 0.95))
+elif optk == "adam":
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, betas=(0.9, 0.95))
+else:
+    opt = torch.optim.SGD(m.parameters(), lr=0.02)
 g = torch.Generator(device="cpu").manual_seed(1)
 x = torch.randn(GB, 5, 96, 144, generator=g)
 y = torch.randn(GB, 5 * (n_future + 1), 96, 144, generator=g)

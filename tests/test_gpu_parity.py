@@ -1437,3 +1437,53 @@ def test_optimizers_that_skip_version_bumps_still_refresh_the_prepared_weights(d
     tot = sum(p.numel() for p in out["foreach"][1])
     off = sum(int(((a - b).abs() > 1e-4).sum()) for a, b in zip(out["foreach"][1], out[opt_kind][1]))
     assert off <= 5e-3 * tot, (off, tot)          # (elements with noise-level gradients take +-lr Adam steps of either sign)
+
+
+def test_batched_droppath_draws_are_applied_like_per_site_draws(dev, K, monkeypatch):
+    """Stochastic depth: the stage draws the Bernoulli masks of all its 2 x depth DropPath sites in one launch (default).  The
+    masks it drew, captured on their way into the blocks, are replayed through the per-site code path (the reference's
+    structure, SWV2_DROPPATH_PER_SITE=1): same output and input gradient bit for bit -- every site gets its own mask, the right
+    keep probability (timm's linspace over the depth) and the right sample."""
+    N = K["N"]
+    torch.manual_seed(0)
+    m = N.SwinTransformerV2Cr(img_size=(48, 72), patch_size=4, depths=(4,), num_heads=(2,), in_chans=3, out_chans=3, embed_dim=32,
+                              img_window_ratio=8, drop_path_rate=0.5, full_pos_embed=True, rel_pos=False, residual=True)
+    with torch.no_grad():
+        for n_, p in m.named_parameters():
+            if n_.endswith("norm1.weight") or n_.endswith("norm2.weight"):
+                p.uniform_(0.5, 1.0)
+    m = m.to(dev).train()
+    x0 = torch.randn(6, 3, 48, 72, generator=torch.Generator().manual_seed(1)).to(dev)
+    blocks = list(m.stages[0].blocks)
+    captured = []
+    hooks = [b.register_forward_pre_hook(lambda mod, args: captured.append(None if len(args) < 3 or args[2] is None else args[2].clone()))
+             for b in blocks]
+    torch.manual_seed(123)
+    x = x0.clone().requires_grad_(True)
+    y = m(x)
+    y.square().mean().backward()
+    for h_ in hooks:
+        h_.remove()
+    assert len(captured) == 4 and bool((captured[0] == 1).all())  # first block: keep probability 1 (it has no DropPath module)
+    rates = [0.0, 0.5 / 3, 1.0 / 3, 0.5]
+    for i in (1, 2, 3):
+        sc = captured[i]
+        assert sc.shape == (2, 6)
+        keep = 1.0 - rates[i]
+        assert bool(((sc == 0) | ((sc - 1.0 / keep).abs() < 1e-6)).all())
+    assert any(bool((c == 0).any()) for c in captured[1:]) and any(bool((c != 0).any()) for c in captured[1:])
+    g_ref = [p.grad.clone() for p in m.parameters()]
+    # replay through the per-site path
+    queue = []
+    for i in (1, 2, 3):
+        queue += [captured[i][0], captured[i][1]]
+    monkeypatch.setenv("SWV2_DROPPATH_PER_SITE", "1")
+    monkeypatch.setattr(N.DropPath, "scale", lambda self, x_: None if self.drop_prob == 0.0 or not self.training else queue.pop(0).float().contiguous())
+    m.zero_grad()
+    x2 = x0.clone().requires_grad_(True)
+    y2 = m(x2)
+    y2.square().mean().backward()
+    assert not queue
+    assert torch.equal(y2, y) and torch.equal(x2.grad, x.grad)
+    # (parameter gradients: bias / logit-scale sums are accumulated with atomics, so equal to rounding, not bit for bit)
+    assert all(float((a - p.grad).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-9 for a, p in zip(g_ref, m.parameters()))

@@ -150,7 +150,20 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", init_method="env://", device_id=dev)      # nccl = RCCL on ROCm
+        # RCCL prints a version banner to (C-buffered) stdout when the communicator is created; the bench contract is ONE
+        # JSON line on stdout, so fd 1 points at stderr until the communicator exists
+        import ctypes
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend="nccl", init_method="env://", device_id=dev)      # nccl = RCCL on ROCm
+            dist.barrier()
+            torch.cuda.synchronize()
+            ctypes.CDLL(None).fflush(None)
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
 
     from swin_v2_weather_amd import ops
     from swin_v2_weather_amd.networks.helpers import get_model

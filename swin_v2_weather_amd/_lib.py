@@ -12,8 +12,8 @@ import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB_PATH = os.path.join(HERE, "libswv2.so")
-SOURCES = ["capi.hip", "attn.hip", "attn2.hip", "gemm.hip", "gemm_tn.hip", "rowops.hip", "block.hip", "cpb.hip", "mlp.hip", "attn_fused.hip", "proj_ln.hip", "dataio.hip"]
+LIB_PATH = os.environ.get("SWV2_LIB") or os.path.join(HERE, "libswv2.so")     # SWV2_LIB: a privately built variant (tools/ab_macro.sh)
+SOURCES = ["capi.hip", "attn.hip", "attn2.hip", "attn3.hip", "gemm.hip", "gemm_tn.hip", "rowops.hip", "block.hip", "cpb.hip", "mlp.hip", "attn_fused.hip", "proj_ln.hip", "dataio.hip"]
 
 _lib = None
 _lock = threading.Lock()

@@ -886,6 +886,8 @@ extern "C" int swv2_attn_pack_bias(const float* bias, int heads, int L, void* ou
 // second-generation kernels (attn2.hip): 0 / negative = handled (ok / error), 1 = shape not covered
 int swv2_attn2_fwd(const swv2_attn_args* a, int Lp, int DP, void* stream);
 int swv2_attn2_bwd(const swv2_attn_args* a, int Lp, int DP, void* stream);
+// third generation (attn3.hip): one wave per (window, head), head dims <= 16 without bias
+int swv2_attn3_bwd(const swv2_attn_args* a, int Lp, int DP, void* stream);
 
 extern "C" int swv2_attn_fwd(const swv2_attn_args* a, void* stream) {
     int rc0 = check_args(a, false);
@@ -908,6 +910,8 @@ extern "C" int swv2_attn_bwd(const swv2_attn_args* a, void* stream) {
         int rc2 = swv2_attn_geometry(a->L, a->head_dim, &Lp2, &DP2);
         if (rc2) return rc2;
         rc2 = swv2_attn2_bwd(a, Lp2, DP2, stream);
+        if (rc2 <= 0) return rc2;
+        rc2 = swv2_attn3_bwd(a, Lp2, DP2, stream);
         if (rc2 <= 0) return rc2;
     }
     SWV2_ATTN_DISPATCH(launch_bwd)

@@ -172,6 +172,9 @@ template <> struct ALoad<A_BF16_GELU> {
     __device__ __forceinline__ Raw raw_unc(int r, int k0) const { return *(const uint4*)((const uint16_t*)d.ptr + (long)r * d.ld + k0); }
     const uint16_t* tab = nullptr;      // LDS table of bf16(GELU(x)) (see gelu_tab_off2), set by the kernel; null = formula
     __device__ __forceinline__ uint4 cvt(const Raw& r) const {
+#ifdef SWV2_TN_GELU_ABL                      // timing ablation only (tools/ab_macro.sh): no GELU, wrong results
+        return r;
+#endif
         if (tab) {
             bool bad = false;
             const uint32_t o[4] = {gelu_tab_off2<2>(r.x, bad), gelu_tab_off2<2>(r.y, bad), gelu_tab_off2<2>(r.z, bad),

@@ -288,7 +288,7 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
     uint16_t* __restrict__ dqkvh,          // [Bw][h][3][Lp][DP]  grads w.r.t. the UN-normalised q, k and v
     float* __restrict__ dlogit,            // [h]      (atomically accumulated)
     float* __restrict__ dbias,             // [h][L][L] (atomically accumulated) or null
-    int Bw, int h, int L, int nW, int nww, int nwh, int mask_thr, int dbg) {
+    int Bw, int h, int L, int nW, int nww, int nwh, int mask_thr, int dbg, int bw0) {
     using C = AttnCfg<LT, DK>;
     static_assert(TPW == 1 || !HAS_BIAS, "the bias-gradient rows are sized for one key tile per wave");
     constexpr int Lp = C::Lp, DP = C::DP, SLAB = C::SLAB;
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
                 dv[i][kk] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
-        const bool do_mask = (mask_thr > 0) && (((bw % nW) / nww) == nwh - 1);
+        const bool do_mask = (mask_thr > 0) && ((((bw + bw0) % nW) / nww) == nwh - 1);     // bw0: see swv2_attn1_bwd_range
         // one q-tile step; `br` / `dbrow`: this lane's bias row / bias-gradient row of the tile (TPW = 1 only)
         // MASKED / PADT (shift-mask window / a key tile with padded keys) are wave-uniform and loop-invariant: separate
         // instantiations, so the common case carries no per-element selects
@@ -785,6 +785,10 @@ int launch_fwd(const swv2_attn_args* a, hipStream_t st) {
     return SWV2_OK;
 }
 
+// first window of a sub-range launch (swv2_attn1_bwd_range): the pointers of `a` are advanced, the shift-mask row is computed
+// from the window's index in the whole batch
+static thread_local int g_bw0 = 0;
+
 template <int LT, int DK, int LFIX>
 int launch_bwd(const swv2_attn_args* a, hipStream_t st) {
     const int nchunk = a->Bw < a->max_chunks ? a->Bw : a->max_chunks;
@@ -796,7 +800,7 @@ int launch_bwd(const swv2_attn_args* a, hipStream_t st) {
         hipLaunchKernelGGL((attn_bwd_kernel<LT, DK, true, LFIX, 1>), grid, block, 0, st, (const uint16_t*)a->qkvh, a->logit_scale,
                            a->bias, bimg, (const uint16_t*)a->oh, (const uint16_t*)a->doh, a->lse, a->rnorm,
                            (uint16_t*)a->dqkvh, a->dlogit_scale, a->dbias, a->Bw, a->heads, a->L, nW, a->nww, a->nwh,
-                           a->mask_thr, a->dbg);
+                           a->mask_thr, a->dbg, g_bw0);
     } else {
         // TPW = 2 (6 waves x 2 tiles, two workgroups per CU) measured SLOWER than 11 waves x 1 tile at the benchmark shape
         // (224 us vs 178 us): kept as a template option, not used
@@ -805,7 +809,7 @@ int launch_bwd(const swv2_attn_args* a, hipStream_t st) {
         hipLaunchKernelGGL((attn_bwd_kernel<LT, DK, false, LFIX, TPW>), grid, block, 0, st, (const uint16_t*)a->qkvh,
                            a->logit_scale, a->bias, (const uint16_t*)nullptr, (const uint16_t*)a->oh, (const uint16_t*)a->doh, a->lse, a->rnorm,
                            (uint16_t*)a->dqkvh, a->dlogit_scale, a->dbias, a->Bw, a->heads, a->L, nW, a->nww, a->nwh,
-                           a->mask_thr, a->dbg);
+                           a->mask_thr, a->dbg, g_bw0);
     }
     SWV2_CHECK_LAUNCH("swv2_attn_bwd");
     return SWV2_OK;
@@ -900,6 +904,26 @@ extern "C" int swv2_attn_fwd(const swv2_attn_args* a, void* stream) {
         if (rc2 <= 0) return rc2;
     }
     SWV2_ATTN_DISPATCH(launch_fwd)
+}
+
+// two-phase kernel on the windows [w0, Bw) only (no CPB bias): the remainder that the wave-per-head kernel of attn3.hip
+// leaves to it when the (window, head) units do not fill its last round of waves
+int swv2_attn1_bwd_range(const swv2_attn_args* a0, int w0, void* stream) {
+    int Lp0, DP0;
+    int rc0 = swv2_attn_geometry(a0->L, a0->head_dim, &Lp0, &DP0);
+    if (rc0) return rc0;
+    swv2_attn_args b = *a0;
+    const size_t u0 = (size_t)w0 * b.heads, slab = (size_t)Lp0 * DP0;
+    b.qkvh = (const uint16_t*)b.qkvh + u0 * 3 * slab;
+    b.oh = (uint16_t*)b.oh + u0 * slab;
+    b.doh = (const uint16_t*)b.doh + u0 * slab;
+    b.lse = b.lse + u0 * Lp0;
+    b.rnorm = b.rnorm + u0 * 2 * Lp0;
+    b.dqkvh = (uint16_t*)b.dqkvh + u0 * 3 * slab;
+    b.Bw = a0->Bw - w0;
+    const swv2_attn_args* a = &b;
+    struct Guard { Guard(int v) { g_bw0 = v; } ~Guard() { g_bw0 = 0; } } guard(w0);
+    SWV2_ATTN_DISPATCH(launch_bwd)
 }
 
 extern "C" int swv2_attn_bwd(const swv2_attn_args* a, void* stream) {

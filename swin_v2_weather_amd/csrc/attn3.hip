@@ -1,11 +1,12 @@
-// Third-generation window-attention BACKWARD for head dims <= 16 without CPB bias: one WAVE owns one (window, head).
+// Third build of the window-attention BACKWARD for head dims <= 16 without CPB bias: one WAVE owns one (window, head).
+// Opt-in (`dbg` bit 8) and parity-tested; the two-phase kernel of attn.hip stays the default (see swv2_attn3_bwd below).
 //
 // Follows the autograd of /root/reference/networks/swinv2_global.py:298-321 (cosine attention: normalised q, k, clamped
-// learnt logit scale, shift mask, softmax, P V) like attn.hip's two-phase kernel, which stays the path for CPB bias and
-// wider heads.  Why a third build: the two-phase kernel spreads a window's 11 key tiles over 11 waves of one workgroup
-// and meets at three barriers per window; its phase stamps (profiles/r02_stamps_attn_bwd.txt) show the waves waiting for
-// the youngest wave of the most loaded SIMD (11 waves on 4 SIMDs), the LDS as the busiest unit (Q / dO fragments re-read
-// by every wave) and the MFMA pipe at 22 %.  Here nothing is shared between waves, so there is no barrier in the loop:
+// learnt logit scale, shift mask, softmax, P V) like attn.hip's two-phase kernel.  Why it was built: the two-phase kernel
+// spreads a window's 11 key tiles over 11 waves of one workgroup and meets at three barriers per window; its phase stamps
+// (profiles/r02_stamps_attn_bwd.txt) show the waves waiting for the youngest wave of the most loaded SIMD (11 waves on 4
+// SIMDs), the LDS as the busiest unit (Q / dO fragments re-read by every wave) and the MFMA pipe at 22 %.  Here nothing is
+// shared between waves, so there is no barrier at all:
 //   * the wave keeps the row-form fragments of Q and dO of all query tiles (MFMA A operands) and the dQ accumulators of
 //     all query tiles in registers for the life of the (window, head), loops over the key tiles, and inside that over the
 //     query tiles (fully unrolled: the accumulators are statically indexed registers);
@@ -14,10 +15,17 @@
 //     mask-region flags in k = 16..21, the B operand carries -1, -1, -1, the padded-key flag (-1e30) and the key's mask
 //     terms, so the MFMA result IS (S - lse') and (dP - delta), masked -- no LDS reads of statistics, no per-element
 //     selects (the mask of the reference, -100 where the regions differ, is bilinear in the two region flags);
-//   * two query tiles form one K = 32 operand for dV and dK (4 MFMAs per tile pair instead of 5);
+//   * two query tiles form one K = 32 operand for dV and dK (4 MFMAs per tile pair instead of 5); the query-tile pairs run
+//     as a three-stage software pipeline (S / dP MFMAs | softmax backward + dV / dK | dQ);
 //   * the only LDS traffic per tile pair is wave-private: the transposed fragments of Q / dO (`ds_read_b64_tr_b16` of the
-//     wave's own slab image) and the dS tile's trip through a 640-byte scratch tile into the B operand of dQ.
+//     wave's own slab image) and the dS tile's trip through a 640-byte scratch tile into the B operand of dQ;
+//   * waves are persistent; K | V tiles arrive two tiles ahead by LDS-DMA into a three-slot ring, and the next unit's cache
+//     lines are touched by LDS-DMA loads into a dummy tile (no registers: all 256 are in use).
 // Per 16 x 16 score tile the vector ALU is left with one multiply, exp2, one multiply and the bf16 packs.
+// Measured (tools/probe_attn3_stamps.py, profiles/r02_stamps_attn_bwd3.txt): the query-tile steps run within 1.5x of their
+// vector-ALU bound, but they are only 43 % of a unit: the per-unit prologue (22 KB through three dependent L2 round trips,
+// operand construction), key-tile set-up and epilogue are latency that two waves per SIMD cannot hide, and 6 400 units on
+// 2 048 wave slots quantise to 4 rounds (the remainder is handed to the two-phase kernel instead).
 #include "attn_common.h"
 
 namespace {
@@ -25,6 +33,22 @@ namespace {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));      // native vector: arrays of HIP uint4 indexed in lambdas go to scratch
 
 __device__ __forceinline__ bf16x8 cat8(bf16x4 a, bf16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
+
+// LDS-DMA loads (destination: LDS at `lds_addr` + lane * size, no register).  Inline assembly on purpose: through the
+// builtin the compiler orders every later LDS access behind the load with s_waitcnt vmcnt(0) (it cannot tell that the wave's
+// other LDS tiles do not alias the destination).  The compiler does not count these in its own vmcnt bookkeeping; VMEM
+// operations return in order, so an uncounted operation can only make a compiler-placed wait longer, never too short, and
+// the waits for the DMA'd tiles themselves are placed by hand (`vm_wait`).
+__device__ __forceinline__ void dma_x4(const void* base, uint32_t lane_off, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(lane_off), "s"(base), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ void dma_x1(const void* base, uint32_t lane_off, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(lane_off), "s"(base), "s"(lds_addr) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void vm_wait() {
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+}
 
 // v = hi + lo + lolo with three bf16 parts (|error| <= 2^-24 |v|)
 __device__ __forceinline__ void split3(float v, uint16_t& hi, uint16_t& lo, uint16_t& lolo) {
@@ -34,9 +58,6 @@ __device__ __forceinline__ void split3(float v, uint16_t& hi, uint16_t& lo, uint
     lolo = f2bf(r1 - bf2f(lo));
 }
 
-#ifndef SWV2_A3_SCHED
-#define SWV2_A3_SCHED 1
-#endif
 #ifndef SWV2_A3_ABL
 #define SWV2_A3_ABL 0       // timing ablations of tools/probe_attn3_stamps.py (wrong results)
 #endif
@@ -58,7 +79,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_kernel(
     uint16_t* __restrict__ dqkvh, float* __restrict__ dlogit, int Bw, int h, int L, int nW, int nww, int nwh, int mask_thr) {
     constexpr int Lp = 16 * LT, DP = 16, SLAB = Lp * DP;
     constexpr int DSP = 20;                                   // row pitch (elements) of the dS scratch tiles
-    constexpr int W_Q = 0, W_DO = SLAB * 2, W_K = 2 * SLAB * 2, W_DS = W_K + 1024, W_BYTES = W_DS + 2 * 16 * DSP * 2;
+    constexpr int W_Q = 0, W_DO = SLAB * 2, W_K = 2 * SLAB * 2, W_DS = W_K + 3 * 1024, W_RN = W_DS + 2 * 16 * DSP * 2,
+                  W_TOUCH = W_RN + 2 * Lp * 4, W_BYTES = W_TOUCH + 256;
     static_assert(W_BYTES % 16 == 0, "16-byte aligned wave regions");
     __shared__ __attribute__((aligned(16))) unsigned char lds[4 * W_BYTES + 16];
 
@@ -67,7 +89,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_kernel(
     unsigned char* const my = lds + wv * W_BYTES;
     uint16_t* const Qs = (uint16_t*)(my + W_Q);
     uint16_t* const dOs = (uint16_t*)(my + W_DO);
-    uint16_t* const Kt = (uint16_t*)(my + W_K);
+    uint16_t* const KV = (uint16_t*)(my + W_K);          // ring of three [K tile 16 x 16 | V tile 16 x 16] pairs (1 KB each)
+    float* const RN = (float*)(my + W_RN);               // rnorm of the unit: [2][Lp]
+    const uint32_t lds_kv = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)(my + W_K);
+    const uint32_t lds_touch = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)(my + W_TOUCH);
     uint16_t* const DS0 = (uint16_t*)(my + W_DS);
     uint16_t* const DS1 = DS0 + 16 * DSP;
 
@@ -78,7 +103,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_kernel(
     // streams during the loops.
     const int nwaves = gridDim.x * 4, units = Bw * h;
     float dsig_acc = 0.f;
-    uint32_t sink = 0;
 #ifdef SWV2_ATTN3_STAMPS
     unsigned long long a3t = __builtin_amdgcn_s_memtime(), a3pro = 0, a3top = 0, a3steps = 0, a3fin = 0, a3epi = 0;
     const unsigned long long a3start = a3t;
@@ -101,18 +125,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_kernel(
         const int un = u + nwaves;
         const bool has_next = un < units;
         const size_t unn = has_next ? (size_t)un : (size_t)u;
-        uint32_t ta = 0, tb = 0;
-        auto touch = [&](const int k) -> uint32_t {
-            // k = 0..2: the q | k | v slabs, 3: dO, 4: O, 5: lse of the next unit; one 128-byte line per lane.  (Loads with an
-            // LDS destination, `global_load_lds`, need no register -- but the compiler orders every later LDS access behind
-            // them with vmcnt(0): measured 2x slower.  The values are folded into `sink` two key tiles later: one tile later
-            // the wave still waited ~400 cycles per tile for them.)
+        auto touch = [&](const int k) {
+            // k = 0..2: the q | k | v slabs, 3: dO, 4: O, 5: lse of the next unit; one 128-byte line per lane, destination a
+            // dummy LDS tile: no register, and nothing ever waits for it
             const char* base = k < 3 ? (const char*)(qkvh + unn * 3 * SLAB) : (k == 3 ? (const char*)(doh + unn * SLAB) :
                                (k == 4 ? (const char*)(oh + unn * SLAB) : (const char*)(lse + unn * Lp)));
             const uint32_t nb = k < 3 ? 3 * SLAB * 2 : (k == 5 ? Lp * 4 : SLAB * 2);
             const uint32_t off = min((uint32_t)((k < 3 ? k : 0) * 8192 + lane_ * 128), nb - 4);
-            return *(const uint32_t*)(base + off);
+            dma_x1(base, off, lds_touch);
         };
+        // K | V rows of key tile t -> ring slot t % 3: lanes 0..31 fetch the K tile (row = lane / 2, 16-byte half = lane & 1),
+        // lanes 32..63 the V tile; the DMA puts lane l's 16 bytes at slot + 16 l, i.e. the two tiles row-major back to back
+        const char* const kvb = (const char*)(qkvh + slab0 + SLAB);
+        const uint32_t kvoff = (uint32_t)(lane_ >> 5) * (SLAB * 2) + (uint32_t)(lane_ & 31) * 16;
+        auto kv_dma = [&](const int t) { dma_x4(kvb, kvoff + (uint32_t)min(t, LT - 1) * 512, lds_kv + (uint32_t)(t % 3) * 1024); };
+        kv_dma(0);
+        kv_dma(1);
         const bool do_mask = (mask_thr > 0) && (((bw % nW) / nww) == nwh - 1);
         const float cmask = do_mask ? fmaxf(-100.f * SWV2_LOG2E * inv_sc2, -1.0e30f) : 0.f;
         const int gh = g & 1;                                  // lanes g = 2, 3 repeat the loads of g = 0, 1 (unconditional loads)
@@ -144,6 +172,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_kernel(
                 }
             };
             issue(0, 0);
+            {   // 1 / |q|, 1 / |k| of the unit -> LDS (no loads in the key-tile loop or behind it: see dma_x4)
+                const float* const rb = rnorm + rn0;
+#pragma unroll
+                for (int c = 0; c < (2 * Lp + 63) / 64; ++c) {
+                    const int i = min(c * 64 + lane_, 2 * Lp - 1);
+                    RN[i] = rb[i];
+                }
+            }
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const int b = c & 1;
@@ -184,28 +220,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_kernel(
         }
 
         A3ACC(a3pro);
-        if (LT < 6) {
-            for (int k = 0; k < 6; k += 2) {
-                sink += ta + tb;
-                ta = touch(k);
-                tb = touch(k + 1);
-            }
-        }
-        // ---- key tiles.  K / V rows of tile j + 1 are loaded during tile j; the transposed K fragment (through a
-        // wave-private LDS tile, two buffers) is staged one tile ahead as well: as load -> LDS write -> transposed read at
-        // the top of each tile the set-up cost 700 cycles per tile
-        const char* const kb = (const char*)(qkvh + slab0 + SLAB);
-        const char* const vb = (const char*)(qkvh + slab0 + 2 * SLAB);
-        const float* const rkb = rnorm + rn0 + Lp;
-        const uint32_t loffk = (uint32_t)(fr * DP + gh * 8) * 2;
-        u32x4 rk = *(const u32x4*)(kb + loffk), rv = *(const u32x4*)(vb + loffk);
-        float rnk = rkb[fr];
-        if (g < 2) *(u32x4*)(Kt + fr * DP + g * 8) = rk;
-        bf16x4 kt = lds_tr_read(Kt + (4 * g + (fr >> 2)) * DP + (fr & 3) * 4);        // K[key 4g + r][d = fr]
-        bf16x4 kn = *(const bf16x4*)(Kt + fr * DP + 4 * g);                           // k^[key fr][d 4g + r]
+        if (LT < 6)
+            for (int k = LT; k < 6; ++k) touch(k);
+        // ---- key tiles.  The K | V rows of tile j + 2 are DMA'd into the LDS ring during tile j; operands and the transposed
+        // K fragment of tile j + 1 are read from the ring behind tile j's steps.
+        vm_wait<0>();
+        u32x4 rk = *(const u32x4*)(KV + fr * DP + gh * 8), rv = *(const u32x4*)(KV + 256 + fr * DP + gh * 8);
+        bf16x4 kt = lds_tr_read(KV + (4 * g + (fr >> 2)) * DP + (fr & 3) * 4);        // K[key 4g + r][d = fr]
+        bf16x4 kn = *(const bf16x4*)(KV + fr * DP + 4 * g);                           // k^[key fr][d 4g + r]
 #pragma unroll 1
         for (int j = 0; j < LT; ++j) {
-            uint16_t* const Ktn = Kt + ((j + 1) & 1) * 256;
+            const uint16_t* const Ktn = KV + ((j + 1) % 3) * 512;
             const int key = 16 * j + fr;
             const uint32_t m1 = 0xbf80u;                                       // -1
             const uint32_t padk = (key < L) ? 0u : (uint32_t)f2bf(-1.0e30f);
@@ -215,17 +240,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_kernel(
             const u32x4 augv = {m1 | (m1 << 16), m1, 0u, 0u};
             const bf16x8 kf = __builtin_bit_cast(bf16x8, g < 2 ? rk : (g == 2 ? augk : zero4));
             const bf16x8 vf = __builtin_bit_cast(bf16x8, g < 2 ? rv : (g == 2 ? augv : zero4));
-            const float rnk_c = rnk;
-            {   // rows of tile j + 1: in flight during this tile's steps, staged behind them
-                const uint32_t jo = (uint32_t)min(j + 1, LT - 1);
-                rk = *(const u32x4*)(kb + loffk + jo * 512);
-                rv = *(const u32x4*)(vb + loffk + jo * 512);
-                rnk = rkb[fr + 16 * jo];
-            }
-            if (LT >= 6) {                                  // the next unit's cache lines, queued behind this tile's own loads;
-                sink += ta;                                 // unconditional (a load under `if (j < 6)` is phi-merged and the compiler
-                ta = touch(min(j, 5));                      // puts s_waitcnt vmcnt(0) behind it); tiles 6.. touch the lse line again
-            }
+            kv_dma(j + 2);                                  // 2 uncounted VMEM operations per tile (+ the 2 stores below)
+            touch(min(j, 5));                               // tiles 6.. touch the lse line again (L2 hit)
             f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
             A3ACC(a3top);
 
@@ -318,9 +334,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_kernel(
                 if (p + 1 < NS) stA(2 * p + 2, 2 * p + 3 < LT, sa[(p + 1) & 1]);
                 stB(2 * p + 1 < LT, sa[p & 1], st[p & 1]);
                 if (p > 0) stC(2 * p - 2, true, st[(p - 1) & 1]);
-#if SWV2_A3_SCHED == 1
-                __builtin_amdgcn_sched_barrier(0);                     // keep the steps apart: C(p - 1) must not drift behind B(p + 1)
-#endif
             }
             stC(2 * NS - 2, 2 * NS - 1 < LT, st[(NS - 1) & 1]);
             if (LT & 1) {
@@ -330,7 +343,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_kernel(
 
             A3ACC(a3steps);
             // the transposed K fragment of tile j + 1 through the other LDS tile: on its way during the finalisation below
-            if (g < 2) *(u32x4*)(Ktn + fr * DP + g * 8) = rk;
+            // tile j + 1 was requested during tile j - 1; behind it in the (in-order) queue: touch (j - 1), the two stores of
+            // tile j - 1, tile j + 2, touch (j) -- checked against the ISA (two global stores per tile, no other VMEM)
+            vm_wait<5>();
+            rk = *(const u32x4*)(Ktn + fr * DP + gh * 8);
+            rv = *(const u32x4*)(Ktn + 256 + fr * DP + gh * 8);
             kt = lds_tr_read(Ktn + (4 * g + (fr >> 2)) * DP + (fr & 3) * 4);      // (read into the loop-carried register itself:
                                                                                   //  a copy at the loop end would wait for it there)
             // ---- dK through the L2-normalisation backward, dV; d logit_scale = sigma sum_k (sum_q dS q^) . k^
@@ -340,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_kernel(
             dot += __shfl_xor(dot, 16);
             dot += __shfl_xor(dot, 32);
             if (g == 0) dsig += dot;
-            const float rks = rnk_c * sigma;
+            const float rks = RN[Lp + key] * sigma;
             f32x4 v;
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = rks * (dk[r] - bf2f(kn[r]) * dot);
@@ -351,9 +368,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_kernel(
         }
 
         // ---- dQ through the normalisation backward
-        float rnq[LT];
-#pragma unroll
-        for (int i = 0; i < LT; ++i) rnq[i] = rnorm[rn0 + 16 * i + fr];
 #pragma unroll
         for (int i = 0; i < LT; ++i) {
             const int q = 16 * i + fr;
@@ -363,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_kernel(
             for (int r = 0; r < 4; ++r) dot = fmaf(dq[i][r], bf2f(qn[r]), dot);
             dot += __shfl_xor(dot, 16);
             dot += __shfl_xor(dot, 32);
-            const float rqs = rnq[i] * sigma;
+            const float rqs = RN[q] * sigma;
             f32x4 v;
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = rqs * (dq[i][r] - bf2f(qn[r]) * dot);
@@ -371,7 +385,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_kernel(
         }
 
         A3ACC(a3epi);
-        sink += ta + tb;
         // ---- d logit_scale: one atomic per wave and head (a wave keeps its head while nwaves % h == 0)
         dsig_acc += dsig * sigma;
         const bool flush = !has_next || (un % h) != hd;
@@ -381,18 +394,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_kernel(
             dsig_acc = 0.f;
         }
     }
-    if (sink == 0x9e3779b9u && Bw < 0) dlogit[0] = 1.f;         // keeps the touch loads alive; never true
     A3PUT(0, a3pro); A3PUT(1, a3top); A3PUT(2, a3steps); A3PUT(3, a3fin); A3PUT(4, a3epi);
     A3PUT(5, __builtin_amdgcn_s_memtime() - a3start);
 }
 
 template <int LT>
-int launch_bwd3(const swv2_attn_args* a, hipStream_t st) {
-    const int units = a->Bw * a->heads;
+int launch_bwd3(const swv2_attn_args* a, int Bw, hipStream_t st) {
+    const int units = Bw * a->heads;
     // two workgroups (eight waves) per CU; not more workgroups than there are units
     dim3 grid(units >= 2048 ? 512 : (units + 3) / 4), block(256);
     hipLaunchKernelGGL((attn_bwd3_kernel<LT>), grid, block, 0, st, (const uint16_t*)a->qkvh, a->logit_scale, (const uint16_t*)a->oh,
-                       (const uint16_t*)a->doh, a->lse, a->rnorm, (uint16_t*)a->dqkvh, a->dlogit_scale, a->Bw, a->heads, a->L,
+                       (const uint16_t*)a->doh, a->lse, a->rnorm, (uint16_t*)a->dqkvh, a->dlogit_scale, Bw, a->heads, a->L,
                        a->nwh * a->nww, a->nww, a->nwh, a->mask_thr);
     SWV2_CHECK_LAUNCH("swv2_attn_bwd (wave per head)");
     return SWV2_OK;
@@ -406,11 +418,24 @@ extern "C" int swv2_debug_attn3_stamps(void* out) {
 }
 #endif
 
+int swv2_attn1_bwd_range(const swv2_attn_args* a, int w0, void* stream);
+
 // 0 / negative = handled (ok / error), 1 = shape not covered (CPB bias, head dim > 16)
 int swv2_attn3_bwd(const swv2_attn_args* a, int Lp, int DP, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    if (a->bias || DP != 16 || (a->dbg & 256)) return 1;       // dbg bit 8: keep the two-phase kernel (A/B runs, parity tests)
-    if (Lp == 176) return launch_bwd3<11>(a, st);
-    if (Lp == 64) return launch_bwd3<4>(a, st);
-    return 1;
+    // Opt-in (dbg bit 8): measured 101.7 us for three full rounds + 11.6 us for the remainder on the two-phase kernel = 113 us at
+    // the benchmark shape, against 115 us for the two-phase kernel alone -- not worth making a kernel with hand-placed vmcnt
+    // waits the default ("wave per head").  Parity-tested in both modes.
+    if (a->bias || DP != 16 || !(a->dbg & 256)) return 1;
+    if (Lp != 176 && Lp != 64) return 1;
+    // A unit (window, head) is one wave's work for ~22 us and the chip holds 2048 waves: 6400 units (the benchmark: 800
+    // windows x 8 heads) are 3.125 rounds, and the last eighth of a round costs a whole one.  The units beyond the last full
+    // round go to the two-phase kernel (fine-grained: 11 waves per unit) when they are less than half a round.
+    constexpr int SLOTS = 2048;
+    const int units = a->Bw * a->heads, rounds = units / SLOTS, rem = units - rounds * SLOTS;
+    int Bw3 = a->Bw;
+    if (rounds >= 1 && rem > 0 && rem <= SLOTS / 2 && SLOTS % a->heads == 0 && !(a->dbg & 512)) Bw3 = rounds * SLOTS / a->heads;
+    int rc = Lp == 176 ? launch_bwd3<11>(a, Bw3, st) : launch_bwd3<4>(a, Bw3, st);
+    if (rc || Bw3 == a->Bw) return rc;
+    return swv2_attn1_bwd_range(a, Bw3, stream);
 }

@@ -320,16 +320,56 @@ def test_attention_kernel_generations_agree(dev, K, shifted):
         assert float((res[dbg][1][:, :, :Lw] - res[16][1][:, :, :Lw]).abs().max()) < 2e-2, dbg
     oh, lse = res[16]
     grads = {}
-    for dbg in (16, 64, 96, 0):                     # 0: the default (one wave per (window, head), csrc/attn3.hip)
+    for dbg in (16, 64, 96, 256):                   # 256: one wave per (window, head), csrc/attn3.hip
         dq = torch.zeros(Bw, h, 3, Lp, DP, dtype=BF, device=dev)
         dls = torch.zeros(h, device=dev)
         a = ops.attn_args(qkvh, ls, None, oh, lse, Bw, h, Lw, d, nwh, nww, mask_thr, doh=doh, rnorm=rnorm, dqkvh=dq, dlogit=dls)
         a.dbg = dbg
         ops.attn_bwd(a)
         grads[dbg] = (dq, dls)
-    for dbg in (64, 96, 0):
+    for dbg in (64, 96, 256):
         assert rel(grads[dbg][0], grads[16][0]) < 1e-2, dbg
         assert float(grads[dbg][1][-1]) == 0.0 and rel(grads[dbg][1], grads[16][1]) < 5e-2, dbg
+
+
+def test_attention_backward_wave_per_head_with_remainder(dev, K):
+    """The wave-per-head backward (csrc/attn3.hip, `dbg` bit 8: one wave per (window, head), persistent waves, K / V tiles by
+    LDS-DMA) gives the (window, head) units beyond its last full round of 2048 waves to the two-phase kernel: 264 windows x 8
+    heads = one round + 64 units, with shift-masked windows on both sides of the split; compared with the two-phase kernel
+    alone and with the wave-per-head kernel alone (dbg bit 9)."""
+    ops = K["ops"]
+    torch.manual_seed(5)
+    wh, ww, h, d, nwh, nww, B = 9, 18, 8, 16, 2, 3, 44
+    Lw, nW = wh * ww, nwh * nww
+    Lp, DP = ops.attn_geometry(Lw, d)
+    Bw = B * nW
+    qkvh = torch.randn(Bw, h, 3, Lp, DP, device=dev)
+    qkvh[:, :, :2] = torch.nn.functional.normalize(qkvh[:, :, :2], dim=-1)
+    qkvh[:, :, :, Lw:] = 0
+    qkvh = qkvh.to(BF).contiguous()
+    ls = torch.log(torch.tensor([3.0, 8.0, 10.0, 12.0, 20.0, 27.0, 30.0, 200.0], device=dev))
+    rnorm = torch.rand(Bw, h, 2, Lp, device=dev) + 0.5
+    doh = torch.randn(Bw, h, Lp, DP, device=dev).to(BF)
+    doh[:, :, Lw:] = 0
+    mask_thr = (wh - wh // 2) * ww
+    oh = torch.zeros(Bw, h, Lp, DP, dtype=BF, device=dev)
+    lse = torch.zeros(Bw, h, Lp, device=dev)
+    a = ops.attn_args(qkvh, ls, None, oh, lse, Bw, h, Lw, d, nwh, nww, mask_thr)
+    a.dbg = 16
+    ops.attn_fwd(a)
+    grads = {}
+    for dbg in (16, 256, 768):
+        dq = torch.zeros(Bw, h, 3, Lp, DP, dtype=BF, device=dev)
+        dls = torch.zeros(h, device=dev)
+        a = ops.attn_args(qkvh, ls, None, oh, lse, Bw, h, Lw, d, nwh, nww, mask_thr, doh=doh, rnorm=rnorm, dqkvh=dq, dlogit=dls)
+        a.dbg = dbg
+        ops.attn_bwd(a)
+        grads[dbg] = (dq, dls)
+    for dbg in (256, 768):
+        assert rel(grads[dbg][0], grads[16][0]) < 1e-2, dbg
+        assert rel(grads[dbg][0][256:], grads[16][0][256:]) < 1e-2, dbg             # the windows behind the split
+        assert float(grads[dbg][1][-1]) == 0.0 and rel(grads[dbg][1], grads[16][1]) < 5e-2, dbg
+    assert torch.equal(grads[256][0][256:], grads[16][0][256:])                      # the remainder IS the two-phase kernel
 
 
 # ---------------------------------------------------------------------------------------------------------------

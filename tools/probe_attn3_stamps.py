@@ -7,7 +7,7 @@ from swin_v2_weather_amd import _lib as L
 so = "/tmp/libswv2_a3stamps.so"
 srcs = [os.path.join(L.CSRC, s) for s in L.SOURCES]
 if not os.environ.get("SWV2_PROBE_NOBUILD"):          # under rocprofv3 the library is built beforehand (no child processes there)
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DSWV2_ATTN3_STAMPS", "-DSWV2_A3_ABL=" + os.environ.get("A3_ABL", "0"), "-DSWV2_A3_SCHED=" + os.environ.get("A3_SCHED", "1"), "-o", so] + srcs,
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DSWV2_ATTN3_STAMPS", "-DSWV2_A3_ABL=" + os.environ.get("A3_ABL", "0"), "-o", so] + srcs,
                           stderr=subprocess.DEVNULL)
 L.LIB_PATH = so
 from swin_v2_weather_amd import ops
@@ -24,6 +24,7 @@ doh = torch.randn(Bw, h, Lp, DP, device=dev).to(BF); doh[:, :, Lw:] = 0
 rnorm = torch.rand(Bw, h, 2, Lp, device=dev) + 0.5
 dq, dls = torch.empty_like(qkvh), torch.zeros(h, device=dev)
 a = ops.attn_args(qkvh, ls, None, oh, lse, Bw, h, Lw, 16, plan.nwh, plan.nww, plan.mask_thr, doh=doh, rnorm=rnorm, dqkvh=dq, dlogit=dls)
+a.dbg = 256 | (512 if os.environ.get("A3_NOSPLIT") else 0)       # the wave-per-head kernel is opt-in
 for _ in range(3):
     ops.attn_bwd(a)
 torch.cuda.synchronize()

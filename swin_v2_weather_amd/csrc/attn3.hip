@@ -62,12 +62,10 @@ __device__ __forceinline__ void split3(float v, uint16_t& hi, uint16_t& lo, uint
 #define SWV2_A3_ABL 0       // timing ablations of tools/probe_attn3_stamps.py (wrong results)
 #endif
 #ifdef SWV2_ATTN3_STAMPS
-__device__ unsigned long long attn3_stamps[1024 * 8];       // tools/probe_attn3_stamps.py: wave start / loop start / loop end / end
-#define A3STAMP(k) do { if (lane == 0 && blockIdx.x * 4 + wv < 1024) attn3_stamps[(blockIdx.x * 4 + wv) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ unsigned long long attn3_stamps[1024 * 8];       // tools/probe_attn3_stamps.py: per-wave cycle sums of the phases
 #define A3ACC(v) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); v += n_ - a3t; a3t = n_; } while (0)
 #define A3PUT(k, v) do { if (lane == 0 && blockIdx.x * 4 + wv < 1024) attn3_stamps[(blockIdx.x * 4 + wv) * 8 + (k)] = (v); } while (0)
 #else
-#define A3STAMP(k) do {} while (0)
 #define A3ACC(v) do {} while (0)
 #define A3PUT(k, v) do {} while (0)
 #endif

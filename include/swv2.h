@@ -67,8 +67,12 @@ typedef struct swv2_attn_args {
                                  (wi == nwh-1) tokens t >= mask_thr are region 1, others region 0; pairs from
                                  different regions get -100.  (wh - sh) * ww for a block shifted by sh > 0 rows;
                                  0 = no mask. */
-    int max_chunks;           /* workgroups per head (each loops over windows); 64 is a good default */
-    int dbg;                  /* must be 0 (kernel-ablation switches used by tools/perf_probe.py only) */
+    int max_chunks;           /* workgroups per head (each loops over windows); 64 is a good default (swv2_block_bwd uses
+                                 256 / heads at the 176-token window: one persistent workgroup per CU) */
+    int dbg;                  /* 0 in production.  Kernel-selection switches of the parity tests and probes: bit 4 = first-
+                                 generation kernels only, bit 6 / 5 = second-generation backward (+ variant), bit 7 = fwd3
+                                 with pinned fragments, bit 8 = wave-per-head backward (csrc/attn3.hip), bit 9 = without
+                                 handing its remainder to the two-phase kernel; other bits: timing probes */
 } swv2_attn_args;
 
 /* bias table -> the kernels' layouts (bf16, log2 domain); out: swv2_attn_pack_bias_bytes(heads, L) bytes */

@@ -129,6 +129,9 @@ def main():
     ap.add_argument("--drop-path-rate", type=float, default=0.1)
     ap.add_argument("--pool", type=int, default=2, help="device-resident synthetic batches that are cycled")
     ap.add_argument("--force-ddp", action="store_true", help="wrap in DDP / init RCCL even with one rank (self-test)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL, the measured path); gloo: self-test of the N > 1 code path with all ranks on one GPU "
+                         "(tests/test_gpu_parity.py), never a benchmark")
     ap.add_argument("--settle", type=int, default=8, help="untimed set-up steps before the W warm-up steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-kernel", default="attn_bwd")
@@ -142,8 +145,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()       # gloo self-test: several ranks share the one GPU of the box
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     use_ddp = world > 1 or a.force_ddp
     if use_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -157,7 +161,10 @@ def main():
         saved = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group(backend="nccl", init_method="env://", device_id=dev)      # nccl = RCCL on ROCm
+            if a.backend == "nccl":
+                dist.init_process_group(backend="nccl", init_method="env://", device_id=dev)      # nccl = RCCL on ROCm
+            else:
+                dist.init_process_group(backend="gloo", init_method="env://")
             dist.barrier()
             torch.cuda.synchronize()
             ctypes.CDLL(None).fflush(None)
@@ -180,7 +187,7 @@ def main():
     opt = HipAdam(model.parameters(), lr=1e-3, betas=(0.9, 0.95))        # train.py:176, one swv2_adam_multi launch per step
     net = model
     if use_ddp:
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], output_device=local_rank,
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev_index], output_device=dev_index,
                                                         broadcast_buffers=False, gradient_as_bucket_view=True,
                                                         bucket_cap_mb=12)      # the 12.4 MB pos_embed gradient (ready last) alone
         if os.environ.get("SWV2_DDP_BUCKET_GRADS", "1") != "0":
@@ -290,6 +297,7 @@ def main():
             "model_tflops_per_gpu": value * flops / world / 1e12,
             "mfma_frac_end_to_end": value * flops / world / 2.5e15,
             "host_pipeline": host_leg,
+            "backend": a.backend if use_ddp else None,
             "rccl_nranks": dist.get_world_size() if use_ddp else None,   # self-check: ranks in the RCCL group that all-reduced
             "roofline": main_rf,
             "roofline_others": [roofline_entry(k, ktimes, a, pmc, B) for k in ROOFLINE_KERNELS if k != a.roofline_kernel],

@@ -295,6 +295,7 @@ class _BlockFn(torch.autograd.Function):
         # n_future + 1 times per pass while p.grad is still None, and a second hand-out would zero / overwrite the gradient
         # autograd's input buffer still holds as an alias (g_last twice instead of g_1 + ... + g_k)
         views = blk._bucket_views(params) if (blk._ddp_bucket_grads and not blk._bv_in_use) else None
+        dbias_view = None
         if views is not None:
             blk._bv_in_use = True
             # DDP (gradient_as_bucket_view): write the gradients straight into the reducer's bucket memory and hand autograd
@@ -309,14 +310,18 @@ class _BlockFn(torch.autograd.Function):
             in_kernel = bool(d.fuse_mlp) and bool(L.load().swv2_mlp_supported(run.C, run.hid)) and \
                 os.environ.get("SWV2_GRAD_ZERO_IN_KERNEL", "1") != "0"
             nfl = (run.grad_bytes // 4 + 3) // 4 * 4
-            grads = (torch.empty if in_kernel else torch.zeros)(nfl, dtype=torch.float32, device=dev)
+            # (+ the CPB bias gradient table, zeroed by the same kernel instead of a fill of its own)
+            nb = (bias_c.numel() + 3) // 4 * 4 if ctx.has_bias else 0
+            grads = (torch.empty if in_kernel else torch.zeros)(nfl + nb, dtype=torch.float32, device=dev)
             gb = grads.data_ptr()
-            d.grad_zero, d.grad_zero_bytes = (gb, nfl * 4) if in_kernel else (None, 0)
+            d.grad_zero, d.grad_zero_bytes = (gb, (nfl + nb) * 4) if in_kernel else (None, 0)
+            if nb:
+                dbias_view = grads[nfl:nfl + bias_c.numel()].view_as(bias_c)
             for name, off in zip(run.grad_names, run.grad_off):
                 setattr(d, name, gb + off)
         if blk._ddp_bucket_grads:
             blk._queue_view_refresh(params)
-        dbias = torch.zeros_like(bias_c) if ctx.has_bias else None
+        dbias = (dbias_view if dbias_view is not None else torch.zeros_like(bias_c)) if ctx.has_bias else None
         dx = torch.empty_like(x)
         d.x, d.dx2, d.dx = x.data_ptr(), dx2.data_ptr(), dx.data_ptr()
         d.bias = bias_c.data_ptr() if ctx.has_bias else None
@@ -354,8 +359,10 @@ class _CpbFn(torch.autograd.Function):
         w1c, b1c, w2c, keep = ctx.saved_tensors
         wh, ww, heads, hidden, drop_p = ctx.geom
         dev = w1c.device
-        dw1, db1 = torch.zeros(hidden, 2, device=dev), torch.zeros(hidden, device=dev)
-        dw2, db2 = torch.zeros(heads, hidden, device=dev), torch.zeros(heads, device=dev)
+        # one zero-fill for the four (atomically accumulated) gradients instead of four
+        flat = torch.zeros(hidden * 2 + hidden + heads * hidden + heads, device=dev)
+        dw1, db1, dw2, db2 = flat.split([hidden * 2, hidden, heads * hidden, heads])
+        dw1, dw2 = dw1.view(hidden, 2), dw2.view(heads, hidden)
         ops.cpb_bwd(dbias.contiguous().float(), w1c, b1c, w2c, keep if keep.numel() else None, dw1, db1, dw2, db2, wh, ww, heads,
                     hidden, drop_p)
         return dw1, db1, dw2, db2, None, None, None, None
@@ -460,7 +467,11 @@ class WindowMultiHeadAttention(WindowMultiHeadAttentionNoPos):
         wh, ww = self.window_size
         keep = None
         if m.drop1.training:          # the reference's nn.Dropout follows ITS module's flag (meta_mlp.eval() switches it off)
-            ones = torch.ones(wh * ww * wh * ww, m.fc1.weight.shape[0], dtype=BF16, device=m.fc1.weight.device)
+            key = (wh * ww * wh * ww, m.fc1.weight.shape[0], m.fc1.weight.device)
+            ones = getattr(self, "_ones", None)
+            if ones is None or self._ones_key != key:            # constant input of the draw: filled once, not per step
+                ones = self._ones = torch.ones(key[0], key[1], dtype=BF16, device=key[2])
+                self._ones_key = key
             keep = F.dropout(ones, 0.125, True)
         if not m.fc1.weight.is_cuda:
             raise L.Swv2Error("position_bias runs on an MI355X only (no CPU fallback)")

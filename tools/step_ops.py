@@ -10,7 +10,7 @@ from swin_v2_weather_amd.utils.losses import LossHandler
 
 dev = torch.device("cuda:0")
 import argparse
-ns = SimpleNamespace(depth=12, embed_dim=128, heads=8, height=720, width=1440, window_ratio=80, rel_pos=0, drop_path_rate=0.1)
+ns = SimpleNamespace(depth=12, embed_dim=128, heads=8, height=720, width=1440, window_ratio=80, rel_pos=int(os.environ.get("STEP_OPS_RELPOS", "0")), drop_path_rate=0.1)
 p = bench.model_params(ns)
 model = get_model(p).to(dev).train()
 lp = SimpleNamespace(n_future=0, img_shape_x=720, img_shape_y=1440, loss="l2", channel_weights="none", n_out_channels=73, model_grid_type="equiangular")

@@ -1192,14 +1192,21 @@ def _ddp_run(tmp_path, tag, world, backend, mode, n_future, port, opt="sgd"):
     """spawn `world` worker processes (tests/ddp_alias_check.py), all on cuda:0; returns rank 0's record"""
     import subprocess
     out = os.path.join(str(tmp_path), f"{tag}.pt")
-    procs = []
-    for r in range(world):
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0",
-                   HSA_ENABLE_IPC_MODE_LEGACY="0", SWV2_DDP_BACKEND=backend, SWV2_DDP_MODE=mode, SWV2_DDP_NFUTURE=str(n_future),
-                   SWV2_DDP_STEPS="3", SWV2_DDP_OUT=out, SWV2_DDP_OPT=opt)
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ddp_alias_check.py")], env=env,
-                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
-    logs = [p_.communicate(timeout=900)[0].decode() for p_ in procs]
+    # A worker that dies before it has produced anything (rendezvous on a port still in TIME_WAIT, a communicator that fails
+    # to come up: seen once in ~15 runs of the whole suite, never in isolation) is test infrastructure, not the product:
+    # one more attempt on another port.  Numerical checks are made by the callers on the returned record, never retried.
+    for attempt in (0, 1):
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port + 100 * attempt), RANK=str(r), WORLD_SIZE=str(world),
+                       LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0", SWV2_DDP_BACKEND=backend, SWV2_DDP_MODE=mode,
+                       SWV2_DDP_NFUTURE=str(n_future), SWV2_DDP_STEPS="3", SWV2_DDP_OUT=out, SWV2_DDP_OPT=opt)
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ddp_alias_check.py")], env=env,
+                                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        logs = [p_.communicate(timeout=900)[0].decode() for p_ in procs]
+        if all(p_.returncode == 0 for p_ in procs):
+            break
+        print(f"_ddp_run {tag}: attempt {attempt} failed:\n" + "\n".join(l[-1500:] for l in logs))
     assert all(p_.returncode == 0 for p_ in procs), "\n".join(l[-1500:] for l in logs)
     return torch.load(out)
 
@@ -1220,7 +1227,7 @@ def test_ddp_bucket_view_gradients(dev, K, tmp_path):
     DDP reducer's bucket views.  Same losses / parameters as no DDP at all -- also through a 2-step MultiStepWrapper rollout,
     where every block's backward node runs twice per pass and the views may be handed out only once."""
     for nf in (0, 1):
-        ref = _ddp_run(tmp_path, f"plain{nf}", 1, "nccl", "plain", nf, 29531)
+        ref = _ddp_run(tmp_path, f"plain{nf}", 1, "nccl", "plain", nf, 29531 + 4 * nf)
         al = _ddp_run(tmp_path, f"alias{nf}", 1, "nccl", "alias", nf, 29533 + nf)
         assert al["used"] == 4 and al["stuck"] == 0 and al["nranks"] == 1, (al["used"], al["stuck"])
         _ddp_close(al, ref)
@@ -1232,7 +1239,7 @@ def test_ddp_two_ranks_hip_model(dev, K, tmp_path):
     bucket rebuild after the first step and the mark-ready logic with > 1 rank.  Invariant (tests/test_ddp_gloo.py): after 3
     Adam steps the parameters equal the 1-process run on the whole batch."""
     for nf in (0, 1):
-        ref = _ddp_run(tmp_path, f"plain{nf}", 1, "gloo", "plain", nf, 29541)
+        ref = _ddp_run(tmp_path, f"plain{nf}", 1, "gloo", "plain", nf, 29541 + nf)
         two = _ddp_run(tmp_path, f"two{nf}", 2, "gloo", "alias", nf, 29543 + nf)
         assert two["nranks"] == 2 and two["stuck"] == 0
         # (two ranks sum the weight-gradient partial tiles in another order than one process on the whole batch: rounding level)

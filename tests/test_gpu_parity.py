@@ -1211,7 +1211,7 @@ def _ddp_run(tmp_path, tag, world, backend, mode, n_future, port, opt="sgd"):
     return torch.load(out)
 
 
-def _ddp_close(a, b, tol=2e-3):
+def _ddp_close(a, b, tol=5e-3):
     """parameters after 3 SGD steps: the UPDATE (p - p0 is not available, so: difference relative to the parameter's scale,
     floored at the size of an update) must agree"""
     worst = max(float((x - y).abs().max() / max(float(y.abs().max()), 1e-2)) for x, y in zip(a["params"], b["params"]))
@@ -1219,7 +1219,8 @@ def _ddp_close(a, b, tol=2e-3):
     # first loss: same parameters, same batch -> 1e-6; later ones sit behind 1 - 2 SGD steps at lr 0.02, which amplify the
     # run-to-run rounding of the atomically accumulated gradients (measured: up to 1.2e-4 between two identical runs)
     assert abs(a["losses"][0] - b["losses"][0]) < 2e-6 * abs(b["losses"][0]), (a["losses"], b["losses"])
-    assert all(abs(x - y) < 5e-4 * abs(y) for x, y in zip(a["losses"], b["losses"])), (a["losses"], b["losses"])
+    # (the whole suite failed here once in ~15 runs at 5e-4 / 2e-3; a wrong or missing gradient moves the losses by percents)
+    assert all(abs(x - y) < 2e-3 * abs(y) for x, y in zip(a["losses"], b["losses"])), (a["losses"], b["losses"])
 
 
 def test_ddp_bucket_view_gradients(dev, K, tmp_path):
@@ -1256,7 +1257,7 @@ def test_ddp_two_ranks_hip_model(dev, K, tmp_path):
     tot = sum(x.numel() for x in ha["params"])
     off = sum(int(((x - y).abs() > 2e-5).sum()) for x, y in zip(ha["params"], ta["params"]))
     assert off <= 5e-3 * tot, (off, tot)
-    assert all(abs(x - y) < 5e-4 * abs(y) for x, y in zip(ha["losses"], ta["losses"]))
+    assert all(abs(x - y) < 2e-3 * abs(y) for x, y in zip(ha["losses"], ta["losses"]))
 
 
 def test_bench_two_rank_code_path(dev):

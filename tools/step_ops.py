@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""torch.profiler view of one benchmark step: which aten ops launch the non-swv2 kernels (GPU box)."""
+"""torch.profiler view of one benchmark step: which aten ops launch the non-swv2 kernels (GPU box).
+STEP_OPS_RELPOS=1: the CPB-bias configuration; STEP_OPS_DDP=1: under a one-rank RCCL group."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import bench

@@ -16,6 +16,10 @@ import sys
 import time
 from types import SimpleNamespace
 
+# multi-process GPU work on this driver stack needs dmabuf IPC (RCCL fails with hipIpcGetMemHandle: invalid argument otherwise);
+# must be in the environment before HIP initialises
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch
 import torch.distributed as dist
 

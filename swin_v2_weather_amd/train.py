@@ -20,6 +20,10 @@ import os
 import time
 from collections import OrderedDict
 
+# multi-process GPU work on this driver stack needs dmabuf IPC (RCCL otherwise fails with hipIpcGetMemHandle: invalid argument);
+# must be in the environment before HIP initialises
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 import torch
 import torch.distributed as dist

@@ -11,7 +11,7 @@ subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-
 L.LIB_PATH = so
 from swin_v2_weather_amd import ops
 dev = torch.device("cuda:0"); BF = torch.bfloat16
-B = 2
+B = int(os.environ.get("PROBE_B", "2"))
 plan = ops.window_plan(B, 180, 360, 9, 18, 4, 9, 8, 16, 0)
 Bw, h, Lp, DP, Lw = plan.Bw, 8, plan.Lp, plan.DP, plan.L
 qkvh = (torch.randn(Bw, h, 3, Lp, DP, device=dev) * 0.25).to(BF); qkvh[:, :, :, Lw:] = 0

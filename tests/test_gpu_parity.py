@@ -481,7 +481,7 @@ def test_model_cfg4_shape_with_channel_weighted_loss(dev, K):
     val = lh(y, torch.from_numpy(fx["tar"]).to(dev), x)
     val.backward()
     assert rel(y, torch.from_numpy(fx["y"]).float()) < 1.5e-2
-    assert abs(float(val) - float(fx["loss"])) < 1e-2 * float(fx["loss"])
+    assert abs(float(val.detach()) - float(fx["loss"])) < 1e-2 * float(fx["loss"])
     assert rel(x.grad, torch.from_numpy(fx["gx"]).float()) < 4e-2
     assert worst_grad(m, {k[2:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("g:")}, big=int(fx["gbig"]),
                       step=int(fx["gstep"]), logit_tol=0.05) < 8e-2

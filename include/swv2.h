@@ -73,7 +73,14 @@ typedef struct swv2_attn_args {
                                  generation kernels only, bit 6 / 5 = second-generation backward (+ variant), bit 7 = fwd3
                                  with pinned fragments, bit 8 = wave-per-head backward (csrc/attn3.hip), bit 9 = without
                                  handing its remainder to the two-phase kernel; other bits: timing probes */
+    void* dbias_ws;           /* bwd, optional scratch of dbias_ws_bytes >= swv2_attn_dbias_ws_bytes(heads, L, max_chunks): the
+                                 workgroups store their d bias tables there and one more launch sums them into dbias (in a
+                                 fixed order); NULL / too small = 31 K float atomics per workgroup instead */
+    size_t dbias_ws_bytes;
 } swv2_attn_args;
+
+/* bytes of swv2_attn_args.dbias_ws for swv2_attn_bwd with a bias */
+size_t swv2_attn_dbias_ws_bytes(int heads, int L, int max_chunks);
 
 /* bias table -> the kernels' layouts (bf16, log2 domain); out: swv2_attn_pack_bias_bytes(heads, L) bytes */
 size_t swv2_attn_pack_bias_bytes(int heads, int L);

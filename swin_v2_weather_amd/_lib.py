@@ -56,7 +56,8 @@ class AttnArgs(C.Structure):
                 ("lse", C.c_void_p), ("doh", C.c_void_p), ("rnorm", C.c_void_p), ("dqkvh", C.c_void_p),
                 ("dlogit_scale", C.c_void_p), ("dbias", C.c_void_p),
                 ("Bw", C.c_int), ("heads", C.c_int), ("L", C.c_int), ("head_dim", C.c_int),
-                ("nwh", C.c_int), ("nww", C.c_int), ("mask_thr", C.c_int), ("max_chunks", C.c_int), ("dbg", C.c_int)]
+                ("nwh", C.c_int), ("nww", C.c_int), ("mask_thr", C.c_int), ("max_chunks", C.c_int), ("dbg", C.c_int),
+                ("dbias_ws", C.c_void_p), ("dbias_ws_bytes", C.c_size_t)]
 
 
 class Operand(C.Structure):
@@ -142,6 +143,7 @@ SYMBOLS = {
     "swv2_last_error": (C.c_char_p, []),
     "swv2_attn_geometry": (_I, [_I, _I, C.POINTER(_I), C.POINTER(_I)]),
     "swv2_attn_pack_bias_bytes": (C.c_size_t, [_I, _I]),
+    "swv2_attn_dbias_ws_bytes": (C.c_size_t, [_I, _I, _I]),
     "swv2_attn_pack_bias": (_I, [_P, _I, _I, _P, _P]),
     "swv2_attn_fwd": (_I, [C.POINTER(AttnArgs), _P]),
     "swv2_attn_bwd": (_I, [C.POINTER(AttnArgs), _P]),

@@ -288,7 +288,8 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
     uint16_t* __restrict__ dqkvh,          // [Bw][h][3][Lp][DP]  grads w.r.t. the UN-normalised q, k and v
     float* __restrict__ dlogit,            // [h]      (atomically accumulated)
     float* __restrict__ dbias,             // [h][L][L] (atomically accumulated) or null
-    int Bw, int h, int L, int nW, int nww, int nwh, int mask_thr, int dbg, int bw0) {
+    int Bw, int h, int L, int nW, int nww, int nwh, int mask_thr, int dbg, int bw0,
+    float* __restrict__ dbws) {          // [gridDim.x][h][L][L] partial d bias tables (summed by dbias_reduce_kernel) or null
     using C = AttnCfg<LT, DK>;
     static_assert(TPW == 1 || !HAS_BIAS, "the bias-gradient rows are sized for one key tile per wave");
     constexpr int Lp = C::Lp, DP = C::DP, SLAB = C::SLAB;
@@ -762,7 +763,10 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int q = 16 * qt + 4 * g + r;
-                    if (q < L) atomicAdd(dbias + ((size_t)hd * L + q) * L + key, dbr[qt][r]);
+                    if (q < L) {
+                        if (dbws) dbws[(((size_t)blockIdx.x * h + hd) * L + q) * L + key] = dbr[qt][r];
+                        else atomicAdd(dbias + ((size_t)hd * L + q) * L + key, dbr[qt][r]);
+                    }
                 }
         }
     }
@@ -785,6 +789,22 @@ int launch_fwd(const swv2_attn_args* a, hipStream_t st) {
     return SWV2_OK;
 }
 
+// dbias[i] += sum over the workgroups' partial tables (chunk-major: ws[chunk][heads * L * L]), fixed order
+__global__ __launch_bounds__(256) void dbias_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dbias, int n, int chunks) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int c = 0;
+    for (; c + 3 < chunks; c += 4) {
+        s0 += ws[(size_t)c * n + i];
+        s1 += ws[(size_t)(c + 1) * n + i];
+        s2 += ws[(size_t)(c + 2) * n + i];
+        s3 += ws[(size_t)(c + 3) * n + i];
+    }
+    for (; c < chunks; ++c) s0 += ws[(size_t)c * n + i];
+    dbias[i] += (s0 + s1) + (s2 + s3);
+}
+
 // first window of a sub-range launch (swv2_attn1_bwd_range): the pointers of `a` are advanced, the shift-mask row is computed
 // from the window's index in the whole batch
 static thread_local int g_bw0 = 0;
@@ -797,10 +817,19 @@ int launch_bwd(const swv2_attn_args* a, hipStream_t st) {
         dim3 grid(nchunk, a->heads), block(64 * LT);
         const uint16_t* bimg = a->bias_pack ? (const uint16_t*)((const char*)a->bias_pack + a->heads * BiasPack<LT>::FWD_U32 * 4)
                                             : nullptr;
+        // d bias: every workgroup holds a full [L][L] table of its head.  With a scratch buffer the tables are stored as they
+        // are and summed by one more launch (fixed order); without, 31 K float atomics per workgroup (36 us of 214 at the
+        // benchmark shape)
+        const size_t need = (size_t)nchunk * a->heads * a->L * a->L * sizeof(float);
+        float* dbws = (a->dbias_ws && a->dbias_ws_bytes >= need) ? (float*)a->dbias_ws : nullptr;
         hipLaunchKernelGGL((attn_bwd_kernel<LT, DK, true, LFIX, 1>), grid, block, 0, st, (const uint16_t*)a->qkvh, a->logit_scale,
                            a->bias, bimg, (const uint16_t*)a->oh, (const uint16_t*)a->doh, a->lse, a->rnorm,
                            (uint16_t*)a->dqkvh, a->dlogit_scale, a->dbias, a->Bw, a->heads, a->L, nW, a->nww, a->nwh,
-                           a->mask_thr, a->dbg, g_bw0);
+                           a->mask_thr, a->dbg, g_bw0, dbws);
+        if (dbws) {
+            const int n = a->heads * a->L * a->L;
+            hipLaunchKernelGGL(dbias_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)dbws, a->dbias, n, nchunk);
+        }
     } else {
         // TPW = 2 (6 waves x 2 tiles, two workgroups per CU) measured SLOWER than 11 waves x 1 tile at the benchmark shape
         // (224 us vs 178 us): kept as a template option, not used
@@ -809,7 +838,7 @@ int launch_bwd(const swv2_attn_args* a, hipStream_t st) {
         hipLaunchKernelGGL((attn_bwd_kernel<LT, DK, false, LFIX, TPW>), grid, block, 0, st, (const uint16_t*)a->qkvh,
                            a->logit_scale, a->bias, (const uint16_t*)nullptr, (const uint16_t*)a->oh, (const uint16_t*)a->doh, a->lse, a->rnorm,
                            (uint16_t*)a->dqkvh, a->dlogit_scale, a->dbias, a->Bw, a->heads, a->L, nW, a->nww, a->nwh,
-                           a->mask_thr, a->dbg, g_bw0);
+                           a->mask_thr, a->dbg, g_bw0, (float*)nullptr);
     }
     SWV2_CHECK_LAUNCH("swv2_attn_bwd");
     return SWV2_OK;
@@ -868,6 +897,11 @@ extern "C" int swv2_debug_attn1_stamps(void* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(attn1_stamps), sizeof(unsigned long long) * 512 * 8) == hipSuccess ? 0 : -3;
 }
 #endif
+
+extern "C" size_t swv2_attn_dbias_ws_bytes(int heads, int L, int max_chunks) {
+    if (heads <= 0 || L <= 0 || max_chunks <= 0) return 0;
+    return (size_t)max_chunks * heads * L * L * sizeof(float);
+}
 
 extern "C" size_t swv2_attn_pack_bias_bytes(int heads, int L) {
     if (heads <= 0 || L <= 0) return 0;

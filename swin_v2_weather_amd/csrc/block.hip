@@ -255,10 +255,15 @@ extern "C" int swv2_block_bwd(const swv2_block_desc* d, void* st) {
         a.doh = d->doh; a.rnorm = d->rnorm; a.dqkvh = d->dqkvh; a.dlogit_scale = d->d_logit_scale; a.dbias = d->d_bias;
         // every workgroup adds its d bias table with atomics: fewer, longer-lived workgroups (end-to-end at depth 12:
         // 16 chunks 89.9, 32 chunks 98.8, 64 chunks 97.0 samples/s)
-        if (d->bias) a.max_chunks = 32;
+        if (d->bias) {
+            a.max_chunks = 32;
+            // the weight-gradient workspace is idle until the grouped launch at the end of the block: the workgroups' d bias
+            // tables go there and are summed by one more launch instead of 31 K atomics per workgroup
+            if (!ss) { a.dbias_ws = d->wgrad_ws; a.dbias_ws_bytes = d->wgrad_ws_bytes; }       // (a side stream may still be using it)
+        }
         // without bias at the 176-token window one workgroup (11 waves, ~90 KB of LDS) fills a CU: exactly one persistent
         // workgroup per CU (256 / heads chunks) instead of two rounds of 256 (same box: 110.4 vs 116.2 us per launch)
-        else if (d->Lp == 176 && h <= 256) a.max_chunks = 256 / h;
+        if (!d->bias && d->Lp == 176 && h <= 256) a.max_chunks = 256 / h;
         LAUNCH(19, swv2_attn_bwd(&a, st));
     }
     // 1'. qkv: dW = dqkv^T gather(x) ; dx = dx1 + scatter(dqkv Wqkv)

@@ -255,12 +255,14 @@ def ln_residual_bwd(a, dy, gamma, scale, rowidx, mean, rstd, da, dgamma, dbeta, 
 
 
 def attn_args(qkvh, logit_scale, bias, oh, lse, Bw, heads, Lwin, head_dim, nwh, nww, mask_thr, doh=None, rnorm=None,
-              dqkvh=None, dlogit=None, dbias=None, max_chunks=64, bias_pack=None) -> L.AttnArgs:
+              dqkvh=None, dlogit=None, dbias=None, max_chunks=64, bias_pack=None, dbias_ws=None) -> L.AttnArgs:
     a = L.AttnArgs()
     a.qkvh, a.logit_scale, a.bias, a.oh, a.lse = _p(qkvh), _p(logit_scale), _p(bias), _p(oh), _p(lse)
     a.bias_pack = _p(bias_pack)
     a.doh, a.rnorm, a.dqkvh, a.dlogit_scale, a.dbias = _p(doh), _p(rnorm), _p(dqkvh), _p(dlogit), _p(dbias)
     a.Bw, a.heads, a.L, a.head_dim, a.nwh, a.nww, a.mask_thr, a.max_chunks = Bw, heads, Lwin, head_dim, nwh, nww, mask_thr, max_chunks
+    if dbias_ws is not None:        # scratch for the workgroups' d bias tables (swv2_attn_dbias_ws_bytes); the caller keeps it alive
+        a.dbias_ws, a.dbias_ws_bytes = _p(dbias_ws), dbias_ws.numel() * dbias_ws.element_size()
     return a
 
 

@@ -285,6 +285,13 @@ def test_attention_core_fwd_bwd(dev, K, wh, ww, h, d, nwh, nww, shifted, use_bia
                                    dqkvh=dq2, dlogit=dls2, dbias=db2, bias_pack=pk))
         assert torch.equal(dq2, dqkvh) and rel(db2, dbias) < 1e-5
         assert rel(dbias, bias_ref.grad) < 8e-3
+        # with a scratch buffer the workgroups store their d bias tables and one more launch sums them (no atomics)
+        nb = K["L"].load().swv2_attn_dbias_ws_bytes(h, Lw, 64)
+        ws = torch.empty(nb // 4, device=dev)
+        dq3, dls3, db3 = torch.empty_like(dqkvh), torch.zeros_like(dls), torch.zeros_like(dbias)
+        ops.attn_bwd(ops.attn_args(qkvh, lsd, bd, oh, lse, Bw, h, Lw, d, nwh, nww, mask_thr, doh=doh, rnorm=rnorm.to(dev).contiguous(),
+                                   dqkvh=dq3, dlogit=dls3, dbias=db3, bias_pack=pk, dbias_ws=ws))
+        assert torch.equal(dq3, dqkvh) and rel(db3, dbias) < 1e-5
 
 
 @pytest.mark.parametrize("shifted", [False, True])

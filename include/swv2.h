@@ -72,7 +72,8 @@ typedef struct swv2_attn_args {
     int dbg;                  /* 0 in production.  Kernel-selection switches of the parity tests and probes: bit 4 = first-
                                  generation kernels only, bit 6 / 5 = second-generation backward (+ variant), bit 7 = fwd3
                                  with pinned fragments, bit 8 = wave-per-head backward (csrc/attn3.hip), bit 9 = without
-                                 handing its remainder to the two-phase kernel; other bits: timing probes */
+                                 handing its remainder to the two-phase kernel, bit 13 = two-phase backward with the softmax
+                                 statistics read from LDS instead of riding in the MFMA operands; other bits: timing probes */
     void* dbias_ws;           /* bwd, optional scratch of dbias_ws_bytes >= swv2_attn_dbias_ws_bytes(heads, L, max_chunks): the
                                  workgroups store their d bias tables there and one more launch sums them into dbias (in a
                                  fixed order); NULL / too small = 31 K float atomics per workgroup instead */

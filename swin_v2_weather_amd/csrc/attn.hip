@@ -279,7 +279,10 @@ __device__ unsigned long long attn1_stamps[512 * 8];
 // fragments of a step are read once for both key tiles, and the dcos image is kept compact ([L rounded up to 4 (+ one
 // zero block)][Lp + 4]) so that TWO workgroups fit one CU's LDS (2 x 77 KB): 12 waves = 3 per SIMD, and one workgroup's
 // barriers / staging overlap the other's MFMA + softmax work.  TPW = 1 is the one-tile-per-wave layout (11 waves).
-template <int LT, int DK, bool HAS_BIAS, int LFIX, int TPW>
+// AUGP (16-wide heads, no bias, one key tile per wave): the softmax statistics, the padded-key flag and the shift mask ride in
+// the unused half of K = 32 MFMA operands (see attn3.hip for the construction), so phase 1 reads no lse / delta rows and has no
+// per-element selects: two LDS reads and ~6 vector instructions less per 16 x 16 tile in the kernel's LDS-bound phase.
+template <int LT, int DK, bool HAS_BIAS, int LFIX, int TPW, bool AUGP = false>
 __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
     const uint16_t* __restrict__ qkvh, const float* __restrict__ logit_scale, const float* __restrict__ bias,
     const uint16_t* __restrict__ bimg,     // swv2_attn_pack_bias backward part ([h][Lp][Lp + 4] bf16) or null
@@ -311,7 +314,9 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
     // 4 x 45 KB + 63 KB) -- their fragments are then read from global memory / L2 (the slab layout in memory is the LDS
     // image), the transposed ones as four 2-byte loads.  A coverage path for wide heads, not a tuned one.
     constexpr bool QG = (4 * SLAB * 2 + IROWS * DSP * 2 + Lp * 8 + 256 > 160 * 1024);
-    constexpr int OFF_Q = 0, OFF_DO = OFF_Q + (QG ? 0 : SLAB * 2), OFF_LSE = OFF_DO + (QG ? 0 : SLAB * 2), OFF_DL = OFF_LSE + Lp * 4,
+    constexpr bool AUG = AUGP && DK == 1 && !HAS_BIAS && TPW == 1 && !QG;
+    constexpr int QP = AUG ? 32 : DP;                        // row pitch of the q / dO slabs: AUG rows carry 16 more operand slots
+    constexpr int OFF_Q = 0, OFF_DO = OFF_Q + (QG ? 0 : Lp * QP * 2), OFF_LSE = OFF_DO + (QG ? 0 : Lp * QP * 2), OFF_DL = OFF_LSE + Lp * 4,
                   OFF_K = OFF_DL + Lp * 4, OFF_V = OFF_K + SLAB * 2, OFF_DS = OFF_V + SLAB * 2,
                   OFF_BIAS = OFF_DS + IROWS * DSP * 2, OFF_RED = OFF_BIAS + (BIAS_LDS ? Lp * DSP * 2 : 16),
                   LDS_BYTES = OFF_RED + ((WAVES * 4 + 15) / 16) * 16;
@@ -347,6 +352,8 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
     const float tau = logit_scale[hd];
     const float sigma = __expf(fminf(tau, SWV2_LN100));
     const float sc2 = sigma * SWV2_LOG2E;
+    const float inv_sc2 = 1.f / sc2;
+    (void)inv_sc2;
 
     if (COMPACT)
         for (int i = tid; i < 4 * DSP; i += NT) dSb[IREAL * DSP + i] = 0;      // the zero block
@@ -393,7 +400,8 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
 
     // ---- staging registers: chunk c = tid + j*NT of the q, k, dO, o slabs
     uint4 sq[CPT], sk[CPT], sv[CPT], sdo[CPT], so[CPT];
-    float slse = 0.f;
+    float slse = 0.f, slse_row = 0.f;
+    static_assert(!AUG || CPT == 1, "AUG: one chunk per thread");
     auto issue = [&](int bw) {
         const size_t slab0 = ((size_t)bw * h + hd) * 3 * SLAB, oslab = ((size_t)bw * h + hd) * SLAB;
 #pragma unroll
@@ -412,16 +420,22 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
         // s_waitcnt vmcnt(0) RIGHT BEHIND the slab loads above: the waves that stage lse waited here for the whole prefetch
         // (and the previous window's stores) in every window -- 22 % of the kernel (tools/probe_attn1_stamps.py)
         slse = lse[((size_t)bw * h + hd) * Lp + min(tid, Lp - 1)];
+        if constexpr (AUG) slse_row = lse[((size_t)bw * h + hd) * Lp + min(tid / CPR, Lp - 1)];      // lse of this thread's chunk row
     };
     auto commit = [&]() {
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
             const int c = tid + j * NT;
             if (c < CH) {
-                if (!QG) *(uint4*)((uint16_t*)(lds + OFF_Q) + c * 8) = sq[j];
+                if constexpr (AUG) {          // rows of 32 slots: the 16 channels, then the statistics slots written below
+                    *(uint4*)((uint16_t*)(lds + OFF_Q) + (c >> 1) * QP + (c & 1) * 8) = sq[j];
+                    *(uint4*)((uint16_t*)(lds + OFF_DO) + (c >> 1) * QP + (c & 1) * 8) = sdo[j];
+                } else {
+                    if (!QG) *(uint4*)((uint16_t*)(lds + OFF_Q) + c * 8) = sq[j];
+                    if (!QG) *(uint4*)((uint16_t*)(lds + OFF_DO) + c * 8) = sdo[j];
+                }
                 *(uint4*)(Ks + c * 8) = sk[j];
                 *(uint4*)(Vs + c * 8) = sv[j];
-                if (!QG) *(uint4*)((uint16_t*)(lds + OFF_DO) + c * 8) = sdo[j];
             }
             // delta partial over this chunk's 8 channels, reduced over the CPR chunks of the row (adjacent lanes)
             float dl = 0.f;
@@ -435,9 +449,35 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
             }
 #pragma unroll
             for (int o = 1; o < CPR; o <<= 1) dl += __shfl_xor(dl, o);
-            if (c < CH && (c % CPR) == 0) DLs[c / CPR] = dl;
+            if constexpr (AUG) {
+                // slots 16..23 of the row (the even chunk's thread): A-operand side of the statistics -- lse / (sigma log2 e) in three
+                // bf16 parts, a constant 1 (padded-key flag), the query's mask-region flags -- and delta in three parts for the dO
+                // slab; slots 24..31 (the odd chunk's thread): zeros.  The B-operand side (-1, -1, -1, flags) is built per wave.
+                if (c < CH) {
+                    const int row = c >> 1;
+                    uint4 aq = make_uint4(0, 0, 0, 0), ad = make_uint4(0, 0, 0, 0);
+                    if (!(c & 1)) {
+                        const bool q_ok = row < L;
+                        const float lq = q_ok ? slse_row * inv_sc2 : 1.0e30f;            // padded query rows: P = 0
+                        uint16_t l0 = f2bf(lq);
+                        const float r1 = lq - bf2f(l0);
+                        uint16_t l1 = f2bf(r1), l2 = f2bf(r1 - bf2f(l1));
+                        if (!q_ok) l1 = l2 = 0;
+                        const uint16_t d0 = f2bf(dl);
+                        const float e1 = dl - bf2f(d0);
+                        const uint16_t d1 = f2bf(e1), d2 = f2bf(e1 - bf2f(d1));
+                        const uint32_t one = 0x3f80u, rqf = (row >= mask_thr) ? 0x3f80u : 0u;
+                        aq = make_uint4(l0 | ((uint32_t)l1 << 16), l2 | (one << 16), rqf | ((one - rqf) << 16), 0);
+                        ad = make_uint4(d0 | ((uint32_t)d1 << 16), d2, 0, 0);
+                    }
+                    *(uint4*)((uint16_t*)(lds + OFF_Q) + row * QP + 16 + (c & 1) * 8) = aq;
+                    *(uint4*)((uint16_t*)(lds + OFF_DO) + row * QP + 16 + (c & 1) * 8) = ad;
+                }
+            } else {
+                if (c < CH && (c % CPR) == 0) DLs[c / CPR] = dl;
+            }
         }
-        if (tid < Lp) LSEs[tid] = (tid < L) ? slse : 1.0e30f;
+        if (!AUG && tid < Lp) LSEs[tid] = (tid < L) ? slse : 1.0e30f;
     };
 
     int bw = blockIdx.x;
@@ -555,6 +595,58 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
                               SWV2_CASE(6) SWV2_CASE(7) SWV2_CASE(8) SWV2_CASE(9) SWV2_CASE(10) }
 #undef SWV2_CASE
             }
+        } else if constexpr (AUG) {
+            // statistics, padded keys and the shift mask inside the K = 32 operands (construction and exactness: attn3.hip); the
+            // same two-stage software pipeline as below, with two 16-byte operand reads per step instead of two 8-byte fragment
+            // reads + two 16-byte statistics reads, and  p = exp2(s * sc2), ds = p * dp  as the whole softmax backward
+            struct St { f32x4 s, dp; bf16x4 tq, td; };
+            const int key = 16 * tw + fr;
+            const float cmask = do_mask ? fmaxf(-100.f * SWV2_LOG2E * inv_sc2, -1.0e30f) : 0.f;
+            bf16x8 kf8, vf8;
+            {
+                const uint32_t m1 = 0xbf80u;                                       // -1
+                const uint32_t padk = (key < Lc) ? 0u : (uint32_t)f2bf(-1.0e30f);
+                const bool kreg = key >= mask_thr;
+                const uint32_t mk0 = f2bf(kreg ? 0.f : cmask), mk1 = f2bf(kreg ? cmask : 0.f);
+                const uint4 augk = make_uint4(m1 | (m1 << 16), m1 | (padk << 16), mk0 | (mk1 << 16), 0);
+                const uint4 augv = make_uint4(m1 | (m1 << 16), m1, 0, 0);
+                const uint4 rk = *(const uint4*)(Ks + key * DP + (g & 1) * 8), rv = *(const uint4*)(Vs + key * DP + (g & 1) * 8);
+                const uint4 z = make_uint4(0, 0, 0, 0);
+                kf8 = __builtin_bit_cast(bf16x8, g < 2 ? rk : (g == 2 ? augk : z));
+                vf8 = __builtin_bit_cast(bf16x8, g < 2 ? rv : (g == 2 ? augv : z));
+            }
+            const uint16_t* const Qa = (const uint16_t*)(lds + OFF_Q);
+            const uint16_t* const Da = (const uint16_t*)(lds + OFF_DO);
+            auto stageA = [&](const int qt, St& o) {
+                const bf16x8 qa = *(const bf16x8*)(Qa + (16 * qt + fr) * QP + 8 * g);
+                const bf16x8 da = *(const bf16x8*)(Da + (16 * qt + fr) * QP + 8 * g);
+                o.td = lds_tr_read(Da + (16 * qt + 4 * g + (fr >> 2)) * QP + (fr & 3) * 4);
+                o.tq = lds_tr_read(Qa + (16 * qt + 4 * g + (fr >> 2)) * QP + (fr & 3) * 4);
+                o.s = mfma32(qa, kf8, (f32x4){0.f, 0.f, 0.f, 0.f});
+                o.dp = mfma32(da, vf8, (f32x4){0.f, 0.f, 0.f, 0.f});
+            };
+            auto stageB = [&](const int qt, const St& in) {
+                f32x4 p, ds;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    p[r] = __builtin_amdgcn_exp2f(in.s[r] * sc2);
+                    ds[r] = p[r] * in.dp[r];
+                }
+                const bf16x4 pb = f2bf4(p), dsb = f2bf4(ds);
+                *(bf16x4*)(dSb + key * DSP + 16 * qt + 4 * g) = dsb;
+                dv[0][0] = mfma16(in.td, pb, dv[0][0]);
+                dk[0][0] = mfma16(in.tq, dsb, dk[0][0]);
+            };
+            St sa, sb;
+            stageA(0, sa);
+#pragma unroll 1
+            for (int qt = 0; qt + 1 < LT; qt += 2) {
+                stageA(qt + 1, sb);
+                stageB(qt, sa);
+                if (qt + 2 < LT) stageA(qt + 2, sa);
+                stageB(qt + 1, sb);
+            }
+            if (LT & 1) stageB(LT - 1, sa);
         } else if constexpr (TPW == 1) {
             // software-pipelined over the q tiles (two register sets used alternately): stage A of step qt + 1 (fragment
             // reads, S and dP MFMAs) is issued before stage B of step qt (softmax backward on the vector ALU, dV / dK
@@ -717,7 +809,7 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
                 float dot = 0.f;
 #pragma unroll
                 for (int dt = 0; dt < DK; ++dt) {
-                    qn[dt] = *(const bf16x4*)(Qs + q * DP + 16 * dt + 4 * g);
+                    qn[dt] = *(const bf16x4*)(Qs + q * QP + 16 * dt + 4 * g);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dot = fmaf(dq[i][dt][r], bf2f(qn[dt][r]), dot);
                 }
@@ -835,6 +927,13 @@ int launch_bwd(const swv2_attn_args* a, hipStream_t st) {
         // (224 us vs 178 us): kept as a template option, not used
         constexpr int TPW = 1;
         dim3 grid(nchunk, a->heads), block(64 * ((LT + TPW - 1) / TPW));
+        // 16-wide heads: statistics / mask inside the MFMA operands (dbg bit 13 keeps the kernel that reads them from LDS)
+        if (DK == 1 && !(a->dbg & 8192))
+            hipLaunchKernelGGL((attn_bwd_kernel<LT, DK, false, LFIX, TPW, true>), grid, block, 0, st, (const uint16_t*)a->qkvh,
+                               a->logit_scale, a->bias, (const uint16_t*)nullptr, (const uint16_t*)a->oh, (const uint16_t*)a->doh, a->lse,
+                               a->rnorm, (uint16_t*)a->dqkvh, a->dlogit_scale, a->dbias, a->Bw, a->heads, a->L, nW, a->nww, a->nwh,
+                               a->mask_thr, a->dbg, g_bw0, (float*)nullptr);
+        else
         hipLaunchKernelGGL((attn_bwd_kernel<LT, DK, false, LFIX, TPW>), grid, block, 0, st, (const uint16_t*)a->qkvh,
                            a->logit_scale, a->bias, (const uint16_t*)nullptr, (const uint16_t*)a->oh, (const uint16_t*)a->doh, a->lse, a->rnorm,
                            (uint16_t*)a->dqkvh, a->dlogit_scale, a->dbias, a->Bw, a->heads, a->L, nW, a->nww, a->nwh,

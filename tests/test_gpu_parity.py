@@ -327,14 +327,15 @@ def test_attention_kernel_generations_agree(dev, K, shifted):
         assert float((res[dbg][1][:, :, :Lw] - res[16][1][:, :, :Lw]).abs().max()) < 2e-2, dbg
     oh, lse = res[16]
     grads = {}
-    for dbg in (16, 64, 96, 256):                   # 256: one wave per (window, head), csrc/attn3.hip
+    for dbg in (16, 64, 96, 256, 16 | 8192):        # 256: one wave per (window, head), csrc/attn3.hip; 8192: the two-phase
+                                                    # kernel with the statistics read from LDS instead of riding in the operands
         dq = torch.zeros(Bw, h, 3, Lp, DP, dtype=BF, device=dev)
         dls = torch.zeros(h, device=dev)
         a = ops.attn_args(qkvh, ls, None, oh, lse, Bw, h, Lw, d, nwh, nww, mask_thr, doh=doh, rnorm=rnorm, dqkvh=dq, dlogit=dls)
         a.dbg = dbg
         ops.attn_bwd(a)
         grads[dbg] = (dq, dls)
-    for dbg in (64, 96, 256):
+    for dbg in (64, 96, 256, 16 | 8192):
         assert rel(grads[dbg][0], grads[16][0]) < 1e-2, dbg
         assert float(grads[dbg][1][-1]) == 0.0 and rel(grads[dbg][1], grads[16][1]) < 5e-2, dbg
 

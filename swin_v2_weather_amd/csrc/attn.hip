@@ -315,7 +315,9 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
     // image), the transposed ones as four 2-byte loads.  A coverage path for wide heads, not a tuned one.
     constexpr bool QG = (4 * SLAB * 2 + IROWS * DSP * 2 + Lp * 8 + 256 > 160 * 1024);
     constexpr bool AUG = AUGP && DK == 1 && !HAS_BIAS && TPW == 1 && !QG;
-    constexpr int QP = AUG ? 32 : DP;                        // row pitch of the q / dO slabs: AUG rows carry 16 more operand slots
+    // row pitch of the q / dO slabs: AUG rows carry 16 more operand slots, padded to 80 bytes (at 64 bytes the 16-byte operand
+    // reads of 16 consecutive rows fall on 4 bank groups: conflict cycles 39 % of the LDS index cycles)
+    constexpr int QP = AUG ? 40 : DP;
     constexpr int OFF_Q = 0, OFF_DO = OFF_Q + (QG ? 0 : Lp * QP * 2), OFF_LSE = OFF_DO + (QG ? 0 : Lp * QP * 2), OFF_DL = OFF_LSE + Lp * 4,
                   OFF_K = OFF_DL + Lp * 4, OFF_V = OFF_K + SLAB * 2, OFF_DS = OFF_V + SLAB * 2,
                   OFF_BIAS = OFF_DS + IROWS * DSP * 2, OFF_RED = OFF_BIAS + (BIAS_LDS ? Lp * DSP * 2 : 16),

@@ -1,7 +1,14 @@
 #!/usr/bin/env python3
 """Headline benchmark: ERA5 samples/sec of the swin_73var depth-12 training step on N MI355X (BASELINE.json).
 
-    python bench.py [--gpus N --steps K --warmup W]        # N > 1: launched by torch.distributed.run, one rank / GPU
+    python bench.py [--gpus N --steps K --warmup W]
+
+N > 1: one process per GPU over RCCL (reference launch contract: train.py:59-68, export_DDP_vars.sh:1-6).  Either the
+caller starts the N ranks itself (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`, i.e.
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), or -- plain `python bench.py --gpus N` with no WORLD_SIZE --
+this process starts them as CHILD processes before it has touched the GPU, relays rank 0's JSON line and exits with the
+children's return code.  A rank whose group size differs from --gpus, or that shares its device with another rank under
+RCCL, fails with a non-zero exit instead of printing a line for a smaller job.
 
 A "step" is one full optimisation step of the reference's loop (train.py:275-289) on synthetic N(0,1) fields already
 resident in HBM: zero_grad -> forward -> geometric l2 loss -> backward (+ RCCL gradient all-reduce under DDP) -> Adam.
@@ -12,6 +19,8 @@ Rank 0 prints ONE JSON line (see README / DESIGN.md for the fields).
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from types import SimpleNamespace
@@ -117,6 +126,28 @@ def roofline_entry(name, ktimes, a, pmc, B):
     return e
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start N ranks as child processes of THIS process, which has not
+    made a single HIP call (importing torch does not initialise the GPU; no exec of a GPU-initialised process anywhere), relay
+    rank 0's one JSON line and return the children's exit code."""
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip().startswith("{")]
+    for l in lines[-1:]:
+        print(l, flush=True)
+    if r.returncode == 0 and len(lines) != 1:
+        print(f"bench.py: expected one JSON line from rank 0, got {len(lines)}", file=sys.stderr)
+        return 1
+    return r.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,12 +175,19 @@ def main():
                          "input pipeline (pinned staging, async H2D, assembly kernels) and report it as `host_pipeline`")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:        # no launcher: become the launcher (before any GPU call)
+        raise SystemExit(self_launch(a.gpus))
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: refusing to print a line for a different job size")
+    n_dev = torch.cuda.device_count()                        # (counting devices does not initialise the GPU)
+    if a.backend == "nccl" and world > n_dev:
+        raise SystemExit(f"bench.py: {world} RCCL ranks need {world} GPUs, this node shows {n_dev} (one process per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    dev_index = local_rank % torch.cuda.device_count()       # gloo self-test: several ranks share the one GPU of the box
+    dev_index = local_rank % n_dev                           # gloo self-test only: several ranks share the one GPU of the box
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     use_ddp = world > 1 or a.force_ddp
@@ -270,10 +308,19 @@ def main():
             host_leg[label] = {"samples_per_s": world * B * n_done / dth, "ms_per_step": 1e3 * dth / n_done,
                                "h2d_gb_per_s_per_gpu": B * n_done * 2 * 73 * 721 * 1440 * 4 / dth / 1e9}
             del pipe, src
+    rank_ms = [1e3 * dt / a.steps]
     if use_ddp:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
+        if dist.get_world_size() != a.gpus:
+            raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {a.gpus}")
+        # every rank's own step time and device: value uses the MAX; two RCCL ranks on one device are an error
+        mine = torch.tensor([dt, float(dev_index)], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rank_ms = [1e3 * float(t_[0]) / a.steps for t_ in allr]
+        devs = [int(t_[1]) for t_ in allr]
+        if a.backend == "nccl" and len(set(devs)) != world:
+            raise SystemExit(f"bench.py: ranks share devices {devs}")
+        dt = max(float(t_[0]) for t_ in allr)
     if rank == 0:
         value = world * B * a.steps / dt
         flops = train_flops_per_sample(a)
@@ -303,6 +350,8 @@ def main():
             "host_pipeline": host_leg,
             "backend": a.backend if use_ddp else None,
             "rccl_nranks": dist.get_world_size() if use_ddp else None,   # self-check: ranks in the RCCL group that all-reduced
+            "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)},
+            "weak_scaling_local_batch": B,      # fixed per GPU at every N (BASELINE cfg 2's batch; cfg 3's 8 per GPU: --local-batch 8)
             "roofline": main_rf,
             "roofline_others": [roofline_entry(k, ktimes, a, pmc, B) for k in ROOFLINE_KERNELS if k != a.roofline_kernel],
         }

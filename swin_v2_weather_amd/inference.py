@@ -65,12 +65,15 @@ def load_model_state(model: torch.nn.Module, state: dict) -> None:
     raise KeyError(f"checkpoint keys do not match the model under any known prefix (first missing: {missing})")
 
 
-def load_registry_model(model_dir: str, device="cuda:0"):
-    """-> (single-step model in eval mode on `device`, params, (means, stds) or None)"""
+def load_registry_model(model_dir: str, device="cuda:0", trust_checkpoint: bool = False):
+    """-> (single-step model in eval mode on `device`, params, (means, stds) or None).
+    `weights.tar` is a published / third-party file: it is read with torch's restricted unpickler (tensors, state dicts and
+    plain containers only).  trust_checkpoint=True falls back to the full unpickler -- arbitrary code execution from the file --
+    for checkpoints that carry other objects; only for files you produced yourself."""
     p = load_hyperparams(os.path.join(model_dir, "hyperparams.yaml"))
     p["n_future"] = 0
     model = get_model(p)
-    ck = torch.load(os.path.join(model_dir, "weights.tar"), map_location="cpu", weights_only=False)
+    ck = torch.load(os.path.join(model_dir, "weights.tar"), map_location="cpu", weights_only=not trust_checkpoint)
     load_model_state(model, ck["model_state"] if "model_state" in ck else ck)
     stats = None
     gm, gs = os.path.join(model_dir, "global_means.npy"), os.path.join(model_dir, "global_stds.npy")
@@ -104,9 +107,10 @@ def main(argv=None):
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--init", default=None, help=".npy [B, Cin, H, W] normalised initial condition (default: seeded N(0,1))")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--trust-checkpoint", action="store_true", help="read weights.tar with the full unpickler (runs code from the file)")
     a = ap.parse_args(argv)
     dev = torch.device("cuda:0")
-    model, p, _ = load_registry_model(a.registry, dev)
+    model, p, _ = load_registry_model(a.registry, dev, trust_checkpoint=a.trust_checkpoint)
     H, W = p["img_size"]
     n_invar = 2 * int(bool(p["add_landmask"])) + int(bool(p["add_orography"]))
     if a.init:

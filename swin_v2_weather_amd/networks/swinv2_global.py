@@ -108,7 +108,11 @@ class _WeightCache:
         if hit is not None and hit[0] == ver:
             return hit[1]
         val = batch.add(w, out=None if hit is None else hit[1], **spec)
-        self._c[key] = (ver, val)
+        # the copy is only fresh once the batch's launch has succeeded: until then the entry is marked stale (version None;
+        # the output tensor is remembered for address reuse), so an exception between add and launch cannot leave a cache
+        # that reports torch.empty garbage / old weights as current
+        self._c[key] = (None, val)
+        batch.on_launched(lambda c=self._c, k=key, v=(ver, val): c.__setitem__(k, v))
         return val
 
 

@@ -197,7 +197,11 @@ class PrepBatch:
     _tables = {}
 
     def __init__(self):
-        self.jobs, self.keep = [], []
+        self.jobs, self.keep, self.done = [], [], []
+
+    def on_launched(self, fn):
+        """fn() runs after the launch that covers the jobs added so far has been enqueued successfully"""
+        self.done.append(fn)
 
     def add(self, w: torch.Tensor, transpose=False, row_map=None, out_rows=None, col_map=None, out_cols=None, out=None, f32=False):
         w2 = w.detach().reshape(w.shape[0], -1)
@@ -215,6 +219,9 @@ class PrepBatch:
 
     def launch(self):
         if not self.jobs:
+            for fn in self.done:
+                fn()
+            self.done = []
             return
         lib = L.load()
         key = tuple(self.jobs)
@@ -233,7 +240,9 @@ class PrepBatch:
                 PrepBatch._tables.clear()
             PrepBatch._tables[key] = t
         L.check(lib.swv2_prep_multi(_p(t[0]), _p(t[1]), t[2], _stream()), "swv2_prep_multi")
-        self.jobs, self.keep = [], []
+        for fn in self.done:
+            fn()
+        self.jobs, self.keep, self.done = [], [], []
 
 
 def ln_residual_fwd(a, res, gamma, beta, scale, rowidx, y, mean, rstd, M, Cc, res_mod, rows_per_sample, eps=1e-5):

@@ -226,13 +226,30 @@ class Era5HostPipeline:
         stop = threading.Event()
 
         def producer():
-            for i in range(self.steps):
-                slot = free.get()
-                if stop.is_set() or slot is None:
-                    return
-                if not self.direct:
-                    self._fill(slot, locs[i])
-                filled.put((i, slot))
+            # any failure (unreadable year file, missing h5py, a worker's exception re-raised by _fill) is handed to the
+            # consumer, which re-raises it: a dead producer must fail the job, not leave the consumer blocked
+            try:
+                for i in range(self.steps):
+                    slot = free.get()
+                    if stop.is_set() or slot is None:
+                        return
+                    if not self.direct:
+                        self._fill(slot, locs[i])
+                    filled.put((i, slot))
+            except BaseException as e:      # noqa: BLE001 -- forwarded, not swallowed
+                filled.put(e)
+
+        def next_filled():
+            while True:
+                try:
+                    item = filled.get(timeout=5.0)
+                except queue.Empty:
+                    if not th.is_alive() and filled.empty():
+                        raise RuntimeError("Era5HostPipeline: the producer thread ended without delivering a batch")
+                    continue
+                if isinstance(item, BaseException):
+                    raise RuntimeError(f"Era5HostPipeline: the producer thread failed: {item!r}") from item
+                return item
 
         th = threading.Thread(target=producer, daemon=True)
         th.start()
@@ -240,13 +257,13 @@ class Era5HostPipeline:
         ready = [None, None]
         inflight = []                                   # (H2D-done event, pinned slot) of submitted batches, oldest first
         try:
-            i0_, slot = filled.get()
+            i0_, slot = next_filled()
             assert i0_ == 0
             ready[0] = self._submit(slot, 0, locs[0])
             inflight.append((ready[0], slot))
             for i in range(self.steps):
                 if i + 1 < self.steps:
-                    j, slot = filled.get()
+                    j, slot = next_filled()
                     assert j == i + 1
                     # output / device slab (i + 1) % 2 was last read by step i - 1, whose kernels are enqueued by now
                     fr = torch.cuda.Event()

@@ -56,11 +56,20 @@ class HipAdam(torch.optim.Adam):
 
     @staticmethod
     def _refresh(t, ptrs, n):
-        """upload the pointer table (two pinned staging buffers used alternately: the previous upload may still be queued)"""
+        """upload the pointer table.  Two pinned staging buffers are used alternately, each guarded by an event recorded behind
+        its H2D copy: the host may run several steps ahead of the GPU (no per-step sync in bench.py / train.py), so a staging
+        buffer is rewritten only after the copy that last read it has executed (without the wait, step N's table
+        could be overwritten with step N + 2's pointers before step N's copy ran)."""
         t["flip"] = 1 - t.get("flip", 0)
         host = t["host"][t["flip"]]
+        ev = t.setdefault("events", [None, None])
+        if ev[t["flip"]] is not None:
+            ev[t["flip"]].synchronize()
         np.frombuffer(host.numpy(), dtype=np.int64).reshape(n, 5)[:] = np.asarray(ptrs, dtype=np.int64)
         t["dev"].copy_(host, non_blocking=True)
+        e = torch.cuda.Event()
+        e.record(torch.cuda.current_stream(t["dev"].device))
+        ev[t["flip"]] = e
         t["ptrs"] = ptrs
 
     def load_state_dict(self, state_dict):
@@ -124,6 +133,10 @@ class HipAdam(torch.optim.Adam):
             keep = self.param_groups
             try:
                 self.param_groups = [keep[i] for i in slow]
+                if grad_inv_scale != 1.0:           # torch's path knows no gradient scale: unscale these groups' gradients first
+                    gs = [p.grad for g_ in self.param_groups for p in g_["params"] if p.grad is not None]
+                    if gs:
+                        torch._foreach_mul_(gs, float(grad_inv_scale))
                 super().step()
             finally:
                 self.param_groups = keep

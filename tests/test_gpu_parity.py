@@ -1269,18 +1269,22 @@ def test_ddp_two_ranks_hip_model(dev, K, tmp_path):
 
 
 def test_bench_two_rank_code_path(dev):
-    """bench.py's N > 1 path exactly as the driver launches it (`python -m torch.distributed.run --nproc-per-node 2 ... bench.py
-    --gpus 2`), with the gloo self-test backend because both ranks share this box's one GPU: DDP with bucket-view gradients,
-    HipAdam, the MAX-over-ranks timing, ONE JSON line on stdout from rank 0, whole-job value = 2 ranks x local batch."""
+    """bench.py's N > 1 path as the driver invokes it: plain `python bench.py --gpus 2 ...` with NO launcher and no WORLD_SIZE --
+    bench.py starts the two ranks itself (child processes, before any GPU call) and relays rank 0's line.  gloo self-test
+    backend because both ranks share this box's one GPU: DDP with bucket-view gradients, HipAdam, the MAX-over-ranks timing, ONE
+    JSON line on stdout, whole-job value = 2 ranks x local batch.  With RCCL the same command must refuse (2 ranks, 1 GPU)."""
     import json
     import subprocess
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29561", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--settle", "1",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--settle", "1",
            "--depth", "2", "--height", "192", "--width", "288", "--window-ratio", "32", "--pool", "1", "--backend", "gloo",
            "--no-cpu-baseline"]
+    if torch.cuda.device_count() < 2:
+        bad = subprocess.run([c for c in cmd if c not in ("--backend", "gloo")], env=env, stdout=subprocess.PIPE,
+                             stderr=subprocess.PIPE, timeout=900)
+        assert bad.returncode != 0 and not bad.stdout.strip(), "2 RCCL ranks on a 1-GPU node must fail, not print a line"
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
@@ -1289,6 +1293,7 @@ def test_bench_two_rank_code_path(dev):
     assert d["n_gpus"] == 2 and d["rccl_nranks"] == 2 and d["backend"] == "gloo" and d["scaling"] == "weak"
     assert d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 2 * d["config"]["local_batch"]
     assert d["value"] > 0 and abs(d["value"] - 2 * d["config"]["local_batch"] * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    assert d["rank_ms_per_step"]["max"] == d["ms_per_step"] >= d["rank_ms_per_step"]["min"] > 0
 
 
 # ---------------------------------------------------------------------------------------------------------------

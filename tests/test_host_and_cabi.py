@@ -326,3 +326,22 @@ def test_hip_adam_on_cpu_parameters_takes_torchs_path():
         assert torch.equal(a, b)
     sa, sb = oa.state_dict(), ob.state_dict()
     assert sa["state"].keys() == sb["state"].keys() and all(float(sa["state"][k]["step"]) == 3.0 for k in sa["state"])
+
+
+def test_bench_launch_contract_without_a_gpu():
+    """`python bench.py --gpus N` as the driver invokes it: with WORLD_SIZE unset and N > 1 the process
+    becomes the launcher of N child ranks before any GPU call and returns THEIR exit code (here: non-zero, no GPU, and no
+    JSON line); with a launcher environment whose size differs from --gpus it refuses instead of printing a smaller job."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    bench = os.path.join(ROOT, "bench.py")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode != 0 and not r.stdout.strip()
+    assert b"needs an MI355X" in r.stderr            # printed by the CHILD ranks: the launch happened
+    r = subprocess.run([sys.executable, bench, "--gpus", "8"], env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode != 0 and not r.stdout.strip() and b"WORLD_SIZE=1" in r.stderr

@@ -243,7 +243,8 @@ def main():
     def step(i):
         inp, tar = pool[i % len(pool)]
         net.zero_grad()
-        gen = net(inp)
+        with loss_obj.fused_with(net, tar):      # as train.py's step: the loss sums ride in the head GEMM's epilogue
+            gen = net(inp)
         loss = loss_obj(gen, tar, inp)
         loss.backward()
         opt.step()
@@ -299,7 +300,9 @@ def main():
                     fence()
                     t1 = time.perf_counter()
                 net.zero_grad()
-                loss_h = loss_obj(net(inp), tar, inp)
+                with loss_obj.fused_with(net, tar):
+                    gen_h = net(inp)
+                loss_h = loss_obj(gen_h, tar, inp)
                 loss_h.backward()
                 opt.step()
                 n_done += int(bi >= 2)

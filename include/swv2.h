@@ -109,8 +109,14 @@ enum swv2_operand_kind {
     SWV2_OP_PATCH = 4,     /* im2col of x[B][Cin][H][W] fp32 for the 4x4/stride-4 conv: row=(b,i,j), col=cin*16+p*4+q
                               p[0]=Cin p[1]=H p[2]=W ; p[3] = channels per sample of the tensor holding the Cin planes
                               (0 = Cin) ; aux0 = optional second source added on load, ld = its channels per sample      */
-    SWV2_OP_MERGE_LN = 5   /* 2x2 PatchMerging gather of x[B][H][W][C] fp32 + LayerNorm(4C) on load:
+    SWV2_OP_MERGE_LN = 5,  /* 2x2 PatchMerging gather of x[B][H][W][C] fp32 + LayerNorm(4C) on load:
                               p[0]=H p[1]=W p[2]=C, aux0=mean aux1=rstd (swv2_merge_stats) aux2=gamma aux3=beta     */
+    SWV2_OP_BF16_CSCALE = 6 /* bf16 rows [rows][ld] scaled on load by an fp32 factor per (sample, group of 16 columns):
+                              value = bf16(ptr[row][col] * aux0[(row / p[0]) * p[2] + col / 16]) ; p[0] = rows per sample,
+                              p[2] = groups per sample in aux0.  The loss-gradient operand of the head's backward: ptr = the
+                              quadrature-weighted residual written by SWV2_EPI_UNPATCH_LOSS, aux0 = d loss / d S0 per
+                              (sample, channel) (losses.py:188-206).  Accepted by swv2_linear with SWV2_EPI_F32 and as dY of
+                              swv2_linear_wgrad* with an SWV2_OP_F32 X                                              */
 };
 
 typedef struct swv2_operand {
@@ -139,8 +145,20 @@ enum swv2_epilogue_kind {
                                second destination, ld = its channels per sample (rollout, helpers.py:26-41)          */
     SWV2_EPI_HEADS = 5,     /* out = [Bw][h][Lp][DP] bf16 split heads, no normalisation ; p as QKV_HEADS, N=heads*DP */
     SWV2_EPI_F32_ACC = 6,   /* out fp32 [M][ld] += acc ; optional rowidx scatter                                     */
-    SWV2_EPI_BF16_GELU = 7  /* out bf16 = acc + bias (pre-activation, kept for backward), aux_out bf16 = erf-GELU of it,
+    SWV2_EPI_BF16_GELU = 7, /* out bf16 = acc + bias (pre-activation, kept for backward), aux_out bf16 = erf-GELU of it,
                                both [M][ld] (fc1 of the timm Mlp, swinv2_global.py:381-386)                         */
+    SWV2_EPI_UNPATCH_LOSS = 8 /* SWV2_EPI_UNPATCH (single destination) that also evaluates the geometric l2 loss sums of
+                               the prediction it is writing (losses.py:188-206, grids.py:115-117) against the target
+                               loss_tar fp32 [B][q[0]][H][W] (channels q[1] .. q[1] + Cout): per (sample, channel)
+                               sum_hw qw[h] (y - tar)^2 and sum_hw qw[h] tar^2, left as per-row-group partial sums
+                               loss_part[g][slot][c][2] (g = 64-row group of the GEMM; slot 0 = rows of the sample of the
+                               group's first row, slot 1 = rows of the following sample, zero unless the group straddles a
+                               sample boundary; plain stores, no atomics: same-address float atomics from every workgroup
+                               measured 8 x the whole kernel) which swv2_loss_part_reduce folds in a fixed order.  Also
+                               writes loss_resid bf16 [M][N] = qw[h] (y - tar) in the GEMM's own row / column order -- the
+                               operand SWV2_OP_BF16_CSCALE feeds to the head's backward, so neither the prediction nor a
+                               materialised gradient is read again.  A operand: SWV2_OP_F32 only; at least 64 rows per
+                               sample; every tensor below 2^32 elements                                                 */
 };
 
 typedef struct swv2_epilogue {
@@ -152,6 +170,12 @@ typedef struct swv2_epilogue {
     const int32_t* rowidx; /* optional: logical row -> destination row, negative = skip */
     long ld;               /* output row pitch in elements */
     int p[5];
+    /* SWV2_EPI_UNPATCH_LOSS only (ignored by every other kind) */
+    const float* loss_tar;   /* target [B][q[0]][H][W] fp32 */
+    const float* loss_qw;    /* quadrature row weights [H] */
+    float* loss_part;        /* [ceil(M / 64)][2][Cout][2] fp32 per-group partial sums, overwritten */
+    void* loss_resid;        /* bf16 [M][N] */
+    int q[2];                /* channels per sample of loss_tar, first target channel of this prediction */
 } swv2_epilogue;
 
 int swv2_linear(const swv2_operand* a, const void* w_bf16, const swv2_epilogue* e, int N, void* stream);
@@ -259,7 +283,14 @@ int swv2_loss_grad(const float* prd, const float* tar, const float* quad_w, cons
 /* The scalar on top of the sums (losses.py:200-232): loss = sum_{b,c} chw[c] f(S0 / S1) (S0 alone when absolute; f = sqrt
  * unless squared) and coef[bc] = 2 d loss / d S0[bc], the factor swv2_loss_grad takes.  chw: [C] weights (channel weights x
  * multistep weights, normalised as LossHandler does); BC = B * C. */
-int swv2_loss_finalize(const float* sums, const float* chw, int BC, int C, int absolute, int squared, float* loss, float* coef,
+/* sums is [layers][BC][2]: the layers are added in order (layers = 1: swv2_loss_sums; SWV2_LOSS_PART_SLICES:
+ * swv2_loss_part_reduce). */
+#define SWV2_LOSS_PART_SLICES 8
+/* Folds the loss epilogue's per-group partial sums: sums[j][b][coff + c][k] = sum over the 64-row groups g with
+ * g % SWV2_LOSS_PART_SLICES == j of (slot 0 of g if g's first row lies in sample b) + (slot 1 of g if it lies in sample b - 1),
+ * ascending g; T rows per sample (T >= 64).  sums: [SWV2_LOSS_PART_SLICES][B][Ct][2], overwritten for the Cout channels from coff. */
+int swv2_loss_part_reduce(const float* part, int M, int T, int B, int Cout, int Ct, int coff, float* sums, void* stream);
+int swv2_loss_finalize(const float* sums, int layers, const float* chw, int BC, int C, int absolute, int squared, float* loss, float* coef,
                        void* stream);
 
 /* torch.optim.Adam step (train.py:176) over one flat fp32 buffer; step >= 1; grads are multiplied by grad_inv_scale */

@@ -78,7 +78,10 @@ class WgradItem(C.Structure):
 
 class Epilogue(C.Structure):
     _fields_ = [("kind", C.c_int), ("out", C.c_void_p), ("bias", C.c_void_p), ("aux", C.c_void_p),
-                ("aux_out", C.c_void_p), ("rowidx", C.c_void_p), ("ld", C.c_long), ("p", C.c_int * 5)]
+                ("aux_out", C.c_void_p), ("rowidx", C.c_void_p), ("ld", C.c_long), ("p", C.c_int * 5),
+                ("loss_tar", C.c_void_p), ("loss_qw", C.c_void_p), ("loss_part", C.c_void_p),
+                ("loss_resid", C.c_void_p),
+                ("q", C.c_int * 2)]
 
 
 class AttnBranchArgs(C.Structure):
@@ -117,6 +120,7 @@ class LnArgs(C.Structure):
 
 
 LN_BWD_MAX_BLOCKS = 512
+LOSS_PART_SLICES = 8          # SWV2_LOSS_PART_SLICES
 class BlockDesc(C.Structure):
     _fields_ = ([(n, C.c_int) for n in ("B", "T", "C", "heads", "head_dim", "hidden", "L", "Lp", "DP", "nwh", "nww", "mask_thr")] +
                 [(n, C.c_void_p) for n in (
@@ -133,8 +137,8 @@ class BlockDesc(C.Structure):
                  ("grad_zero_bytes", C.c_size_t), ("ln_ws_floats", C.c_size_t)])
 
 
-OP_F32, OP_BF16, OP_BF16_GELU, OP_HEADS, OP_PATCH, OP_MERGE_LN = range(6)
-EPI_BF16, EPI_F32, EPI_QKV_HEADS, EPI_GELU_GRAD, EPI_UNPATCH, EPI_HEADS, EPI_F32_ACC, EPI_BF16_GELU = range(8)
+OP_F32, OP_BF16, OP_BF16_GELU, OP_HEADS, OP_PATCH, OP_MERGE_LN, OP_BF16_CSCALE = range(7)
+EPI_BF16, EPI_F32, EPI_QKV_HEADS, EPI_GELU_GRAD, EPI_UNPATCH, EPI_HEADS, EPI_F32_ACC, EPI_BF16_GELU, EPI_UNPATCH_LOSS = range(9)
 
 # every symbol include/swv2.h declares: (name, restype, argtypes)
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_long, C.c_float
@@ -162,7 +166,8 @@ SYMBOLS = {
     "swv2_merge_ln_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "swv2_loss_sums": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "swv2_loss_grad": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
-    "swv2_loss_finalize": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "swv2_loss_part_reduce": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "swv2_loss_finalize": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P]),
     "swv2_prep_chunk": (_I, []),
     "swv2_prep_multi": (_I, [_P, _P, _I, _P]),
     "swv2_adam_chunk": (_I, []),

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <type_traits>
 
 #include "../../include/swv2.h"
 
@@ -52,6 +53,22 @@ __device__ __forceinline__ bf16x4 lds_tr_read(const uint16_t* p) {
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// wave64 sum on the vector ALU (DPP), total valid in lane 63 only: quad swaps, row mirrors, then the row broadcasts.  The
+// __shfl_xor form above goes through the LDS crossbar (ds_bpermute + lgkmcnt wait per step: ~1.2 us for 8 values measured);
+// use this one where only one lane consumes the sum.
+__device__ __forceinline__ float wave_sum_dpp63(float v) {
+    auto dpp = [](float x, auto ctrl, auto rmask) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, decltype(rmask)::value, 0xf, true));
+    };
+    v += dpp(v, std::integral_constant<int, 0xb1>{}, std::integral_constant<int, 0xf>{});     // quad_perm [1,0,3,2]
+    v += dpp(v, std::integral_constant<int, 0x4e>{}, std::integral_constant<int, 0xf>{});     // quad_perm [2,3,0,1]
+    v += dpp(v, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xf>{});    // row_half_mirror
+    v += dpp(v, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xf>{});    // row_mirror: every lane = its row's sum
+    v += dpp(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});    // row_bcast:15 into rows 1, 3
+    v += dpp(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});    // row_bcast:31 into rows 2, 3
     return v;
 }
 

@@ -41,9 +41,12 @@ struct EpiDesc {
     int M, N;
     int p0, p1, p2, p3, p4;
     uint32_t mg0, mg1, mg2; // fdiv magics (launch_nt2)
+    // E_UNPATCH_LOSS
+    const float* loss_tar; const float* loss_qw; float* loss_part; uint16_t* loss_resid; int q0, q1;
 };
 
-enum { E_BF16 = 0, E_F32 = 1, E_QKV_HEADS = 2, E_GELU_GRAD = 3, E_UNPATCH = 4, E_HEADS = 5, E_F32_ACC = 6, E_BF16_GELU = 7 };
+enum { E_BF16 = 0, E_F32 = 1, E_QKV_HEADS = 2, E_GELU_GRAD = 3, E_UNPATCH = 4, E_HEADS = 5, E_F32_ACC = 6, E_BF16_GELU = 7,
+       E_UNPATCH_LOSS = 8 };
 
 template <int KIND> struct Epi;
 
@@ -301,6 +304,99 @@ template <> struct Epi<E_UNPATCH> {
     }
 };
 
+// un-patchify (+ skip) that also evaluates the geometric l2 loss of the prediction while it is in registers
+// (losses.py:188-206: sum_hw q[h] (prd - tar)^2 and sum_hw q[h] tar^2 per (sample, channel); grids.py:115-117) and leaves the
+// quadrature-weighted residual q[h] (prd - tar) as a bf16 [M][N] matrix in the GEMM's own layout for the head's backward.
+// The reference (and rounds 1 - 2 here) read the 303 MB / sample prediction back twice (loss, loss gradient) and wrote a
+// gradient of the same size that both backward GEMMs of the head re-read through the 4 x 4 patch gather.
+//   tile_loss: one 16 x 64 staged sub-tile; item k of a lane = (row it & 15, channel n0/16 + k, image row p = lane >> 4),
+//              so the lane's four items are four different channels: ls[2k], ls[2k + 1] = that channel's partial sums
+//   flush    : per (N tile, wave) wave-reduce the sums and STORE them as the partial sums of the wave's 64-row group
+//              (swv2_loss_part_reduce adds the groups of a sample in a fixed order: the loss value is bit-reproducible).  The
+//              first version added them to the (sample, channel) sums with atomics: 146 addresses hit by 80 K wave-level
+//              atomics made the kernel 1071 us instead of 138 us.
+template <> struct Epi<E_UNPATCH_LOSS> {
+    EpiDesc d;
+    __device__ __forceinline__ void tile(const float*, int, int, int) const {}
+    __device__ __forceinline__ void tile_loss(float* st, int m0, int n0, int lane, float (&ls)[8], float (&ls2)[8], int b0) const {
+        const int Cout = d.p0, H = d.p1, W = d.p2, Cs = d.p3, gw = W >> 2, gh = H >> 2;
+        // this lane's row (patch) and image row are the same for its four items; only the channel differs.  ALL global loads
+        // of the four items first (unconditional, clamped), then the arithmetic and the stores: as  load, store, load, ...  the
+        // compiler may not move an item's target load above the previous item's store (the pointers may alias), and every
+        // item was a memory round trip of its own (548 us for the kernel).
+        const int r = lane & 15, p = lane >> 4, m = m0 + r;
+        const bool row_ok = m < d.M;
+        const int mc = min(m, d.M - 1);
+        const int b = fdiv(mc, gh * gw, d.mg0), ij = mc - b * gh * gw, i = fdiv(ij, gw, d.mg1), j = ij - i * gw;
+        // 32-bit element offsets from the (scalar) base pointers: the tensors of this epilogue are below 2^32 elements (checked by
+        // the launcher), and 64-bit per-lane addresses for four tensors cost ~20 VGPRs -- the kernel then spilled, and every
+        // spill reload in the epilogue waits with vmcnt(0) for ALL outstanding stores (300 us of a 500 us kernel)
+        const uint32_t pix = (uint32_t)((4 * i + p) * W + 4 * j), plane = (uint32_t)(H * W);
+        const float q = d.loss_qw[4 * i + p];
+        const float* __restrict__ tarp = d.loss_tar;
+        float* __restrict__ outp = (float*)d.out;
+        f32x4 t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t c = (uint32_t)min((n0 >> 4) + k, Cout - 1);
+            t[k] = *(const f32x4*)(tarp + (((uint32_t)b * d.q0 + d.q1 + c) * plane + pix));
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = (n0 >> 4) + k;
+            if (!row_ok || c >= Cout) continue;
+            f32x4 v = *(const f32x4*)(st + r * EP + k * 16 + p * 4);
+            if (Cs) v += *(const f32x4*)((const float*)d.aux + (((uint32_t)b * Cs + c) * plane + pix));     // (skip models only)
+            *(f32x4*)(outp + (((uint32_t)b * Cout + c) * plane + pix)) = v;
+            const f32x4 dd = v - t[k];
+            const float e0 = q * (dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2] + dd[3] * dd[3]);
+            const float e1 = q * (t[k][0] * t[k][0] + t[k][1] * t[k][1] + t[k][2] * t[k][2] + t[k][3] * t[k][3]);
+            // rows of the group's first sample -> ls, rows of the next sample (groups that straddle a sample boundary) -> ls2.
+            // Branch-free on purpose: with the minority rows under `else { atomicAdd }` the compiler closed every item with
+            // s_waitcnt vmcnt(0) at the merge point, i.e. every item waited for its own stores (+150 us on the kernel).
+            const bool same = (b == b0);
+            ls[2 * k] += same ? e0 : 0.f;
+            ls[2 * k + 1] += same ? e1 : 0.f;
+            ls2[2 * k] += same ? 0.f : e0;
+            ls2[2 * k + 1] += same ? 0.f : e1;
+            *(f32x4*)(st + r * EP + k * 16 + p * 4) = q * dd;       // residual back into the staging tile (this item's own slot)
+        }
+        // residual rows out as bf16, row-major: lane -> (row lane / 4, 16 columns), 128 contiguous bytes per row
+        const int r2 = lane >> 2, c0 = (lane & 3) * 16, m2 = m0 + r2, n = n0 + c0;
+        if (m2 < d.M && n < d.N) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) *(f32x4*)(v + 4 * u) = *(const f32x4*)(st + r2 * EP + c0 + 4 * u);
+            uint16_t* o = d.loss_resid + ((uint32_t)m2 * d.N + n);
+            *(uint4*)o = pack8(v);
+            *(uint4*)(o + 8) = pack8(v + 8);
+        }
+    }
+    // loss_part[group][slot][Cout][2]: slot 0 = rows of the sample of the group's first row, slot 1 = rows of the following
+    // sample (zero unless the group straddles a boundary).  Lane 63 holds the DPP sums and stores 8 floats per slot.
+    __device__ __forceinline__ void flush(float (&ls)[8], float (&ls2)[8], int m_first, int n0, int lane) const {
+        float a[8], b2[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { a[k] = wave_sum_dpp63(ls[k]); b2[k] = wave_sum_dpp63(ls2[k]); }
+        const int c0 = n0 >> 4;
+        if (lane == 63 && m_first < d.M && c0 < d.p0) {
+            float* sp = d.loss_part + ((long)(m_first >> 6) * 2 * d.p0 + c0) * 2;
+            if (c0 + 4 <= d.p0) {          // (Cout*2 floats per slot: 8-byte aligned pairs)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    *(f32x2*)(sp + 2 * k) = (f32x2){a[2 * k], a[2 * k + 1]};
+                    *(f32x2*)(sp + 2 * d.p0 + 2 * k) = (f32x2){b2[2 * k], b2[2 * k + 1]};
+                }
+            } else {
+                for (int k = 0; k < 4 && c0 + k < d.p0; ++k) {
+                    sp[2 * k] = a[2 * k]; sp[2 * k + 1] = a[2 * k + 1];
+                    sp[2 * d.p0 + 2 * k] = b2[2 * k]; sp[2 * d.p0 + 2 * k + 1] = b2[2 * k + 1];
+                }
+            }
+        }
+    }
+};
+
 // ------------------------------------------------------------------------------------------------
 // NT kernel
 // ------------------------------------------------------------------------------------------------
@@ -401,14 +497,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(ALoad<AK> al, cons
         __syncthreads();                                   // tile consumed: the next commit may overwrite it
         if (ks == ksteps - 1) {
             float* st = stage + wave * 16 * EP;            // wave-private: no further barrier needed
+            [[maybe_unused]] float ls[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ls2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            [[maybe_unused]] int b0 = 0;
+            if constexpr (EK == E_UNPATCH_LOSS)            // sample of the wave's first row (rows past M belong to no sample)
+                b0 = fdiv(min(m_base + wr * 16 * RT, M - 1), (ep.d.p1 >> 2) * (ep.d.p2 >> 2), ep.d.mg0);
 #pragma unroll
             for (int i = 0; i < RT; ++i) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) st[(4 * g + r) * EP + 16 * j + fr] = acc[i][j][r];
-                ep.tile(st, m_base + wr * 16 * RT + i * 16, nt * BN + wc * 64, lane);
+                if constexpr (EK == E_UNPATCH_LOSS) ep.tile_loss(st, m_base + wr * 16 * RT + i * 16, nt * BN + wc * 64, lane, ls, ls2, b0);
+                else ep.tile(st, m_base + wr * 16 * RT + i * 16, nt * BN + wc * 64, lane);
             }
+            if constexpr (EK == E_UNPATCH_LOSS) { static_assert(EK != E_UNPATCH_LOSS || RT == 4, "64-row groups"); ep.flush(ls, ls2, m_base + wr * 16 * RT, nt * BN + wc * 64, lane); }
         }
     }
 }
@@ -658,8 +760,13 @@ int launch_nt2(const swv2_operand* a, const void* w, const swv2_epilogue* e, int
     ep.d.ld = e->ld; ep.d.M = M; ep.d.N = N;
     ep.d.p0 = e->p[0]; ep.d.p1 = e->p[1]; ep.d.p2 = e->p[2]; ep.d.p3 = e->p[3]; ep.d.p4 = e->p[4];
     ep.d.mg0 = ep.d.mg1 = ep.d.mg2 = 0;
+    ep.d.loss_tar = nullptr; ep.d.loss_qw = nullptr; ep.d.loss_part = nullptr; ep.d.loss_resid = nullptr; ep.d.q0 = ep.d.q1 = 0;
     if (EK == E_QKV_HEADS || EK == E_HEADS) { ep.d.mg0 = fdiv_magic(e->p[2]); ep.d.mg1 = fdiv_magic(e->p[0]); }
-    if (EK == E_UNPATCH) { ep.d.mg0 = fdiv_magic((e->p[1] / 4) * (e->p[2] / 4)); ep.d.mg1 = fdiv_magic(e->p[2] / 4); }
+    if (EK == E_UNPATCH || EK == E_UNPATCH_LOSS) { ep.d.mg0 = fdiv_magic((e->p[1] / 4) * (e->p[2] / 4)); ep.d.mg1 = fdiv_magic(e->p[2] / 4); }
+    if (EK == E_UNPATCH_LOSS) {
+        ep.d.loss_tar = e->loss_tar; ep.d.loss_qw = e->loss_qw; ep.d.loss_part = e->loss_part; ep.d.loss_resid = (uint16_t*)e->loss_resid;
+        ep.d.q0 = e->q[0]; ep.d.q1 = e->q[1];
+    }
     // the two per-block products at the benchmark width: resident-weight persistent kernel
     static const int rw = getenv("SWV2_GEMM_RW") ? atoi(getenv("SWV2_GEMM_RW")) : 1;
     if constexpr (AK == A_F32 && EK == E_QKV_HEADS) {
@@ -698,6 +805,12 @@ int launch_nt2(const swv2_operand* a, const void* w, const swv2_epilogue* e, int
 
 template <int AK>
 int launch_nt1(const swv2_operand* a, const void* w, const swv2_epilogue* e, int M, int N, int K, hipStream_t st) {
+    if constexpr (AK == A_BF16_CS) {               // the loss-gradient operand feeds exactly one product: d(e) = G W_head, fp32 out
+        if (e->kind == SWV2_EPI_F32) return launch_nt2<AK, E_F32>(a, w, e, M, N, K, st);
+        swv2_set_error("swv2_linear: SWV2_OP_BF16_CSCALE supports SWV2_EPI_F32 only (got %d)", e->kind);
+        return SWV2_ERR_INVALID;
+    } else {
+    if constexpr (AK == A_F32) if (e->kind == SWV2_EPI_UNPATCH_LOSS) return launch_nt2<AK, E_UNPATCH_LOSS>(a, w, e, M, N, K, st);
     switch (e->kind) {
         case SWV2_EPI_BF16: return launch_nt2<AK, E_BF16>(a, w, e, M, N, K, st);
         case SWV2_EPI_F32: return launch_nt2<AK, E_F32>(a, w, e, M, N, K, st);
@@ -708,8 +821,9 @@ int launch_nt1(const swv2_operand* a, const void* w, const swv2_epilogue* e, int
         case SWV2_EPI_UNPATCH: return launch_nt2<AK, E_UNPATCH>(a, w, e, M, N, K, st);
         case SWV2_EPI_BF16_GELU: return launch_nt2<AK, E_BF16_GELU>(a, w, e, M, N, K, st);
     }
-    swv2_set_error("swv2_linear: unknown epilogue kind %d", e->kind);
+    swv2_set_error("swv2_linear: unknown epilogue kind %d (or not available for operand kind %d)", e->kind, a->kind);
     return SWV2_ERR_INVALID;
+    }
 }
 
 }  // namespace
@@ -733,7 +847,18 @@ extern "C" int swv2_linear(const swv2_operand* a, const void* w_bf16, const swv2
     if (e->kind == SWV2_EPI_QKV_HEADS || e->kind == SWV2_EPI_HEADS)
         SWV2_CHECK_ARG((e->p[3] == 16 || e->p[3] == 32 || e->p[3] == 64 || e->p[3] == 128) && N % e->p[3] == 0 && e->p[0] > 0 && e->p[2] > 0,
                        "swv2_linear: head-split epilogue needs DP in {16,32,64,128} and N a multiple of DP (DP=%d N=%d)", e->p[3], N);
-    if (e->kind == SWV2_EPI_UNPATCH) SWV2_CHECK_ARG(N == e->p[0] * 16, "swv2_linear: un-patchify needs N == Cout*16");
+    if (e->kind == SWV2_EPI_UNPATCH || e->kind == SWV2_EPI_UNPATCH_LOSS)
+        SWV2_CHECK_ARG(N == e->p[0] * 16, "swv2_linear: un-patchify needs N == Cout*16");
+    if (e->kind == SWV2_EPI_UNPATCH_LOSS) {
+        SWV2_CHECK_ARG(a->kind == SWV2_OP_F32 && !e->aux_out && e->p[4] == 0, "swv2_linear: the loss epilogue takes an fp32 operand and one dense destination");
+        SWV2_CHECK_ARG(e->loss_tar && e->loss_qw && e->loss_part && e->loss_resid && e->q[0] >= e->q[1] + e->p[0] && e->q[1] >= 0,
+                       "swv2_linear: the loss epilogue needs target, quadrature weights, sums, residual and q[1] + Cout <= q[0]");
+        SWV2_CHECK_ARG((((uintptr_t)e->loss_tar | (uintptr_t)e->loss_resid) & 15) == 0, "swv2_linear: unaligned loss pointer");
+        const double plane_ = (double)e->p[1] * e->p[2], nb_ = (double)a->rows / ((e->p[1] / 4) * (e->p[2] / 4));
+        SWV2_CHECK_ARG((e->p[1] / 4) * (e->p[2] / 4) >= 64, "swv2_linear: the loss epilogue needs at least 64 patches per sample");
+        SWV2_CHECK_ARG(nb_ * e->q[0] * plane_ < 4.29e9 && nb_ * (e->p[3] > e->p[0] ? e->p[3] : e->p[0]) * plane_ < 4.29e9 && (double)a->rows * N < 4.29e9,
+                       "swv2_linear: the loss epilogue indexes its tensors with 32-bit element offsets (tensor too large)");
+    }
     const int M = a->rows, K = a->cols;
     hipStream_t st = (hipStream_t)stream;
     switch (a->kind) {
@@ -743,6 +868,7 @@ extern "C" int swv2_linear(const swv2_operand* a, const void* w_bf16, const swv2
         case SWV2_OP_HEADS: return launch_nt1<A_HEADS>(a, w_bf16, e, M, N, K, st);
         case SWV2_OP_PATCH: return launch_nt1<A_PATCH>(a, w_bf16, e, M, N, K, st);
         case SWV2_OP_MERGE_LN: return launch_nt1<A_MERGE_LN>(a, w_bf16, e, M, N, K, st);
+        case SWV2_OP_BF16_CSCALE: return launch_nt1<A_BF16_CS>(a, w_bf16, e, M, N, K, st);
     }
     swv2_set_error("swv2_linear: unknown operand kind %d", a->kind);
     return SWV2_ERR_INVALID;

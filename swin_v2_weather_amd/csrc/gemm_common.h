@@ -106,7 +106,7 @@ struct LoadDesc {           // plain-data description shared by all loader kinds
 
 template <int KIND> struct ALoad;
 
-enum { A_F32 = 0, A_BF16 = 1, A_BF16_GELU = 2, A_HEADS = 3, A_PATCH = 4, A_MERGE_LN = 5 };
+enum { A_F32 = 0, A_BF16 = 1, A_BF16_GELU = 2, A_HEADS = 3, A_PATCH = 4, A_MERGE_LN = 5, A_BF16_CS = 6 };
 
 struct RawF32 { f32x4 a, b; };
 __device__ __forceinline__ uint4 cvt_f32x8(const RawF32& r) {
@@ -157,6 +157,36 @@ template <> struct ALoad<A_BF16> {
     __device__ __forceinline__ Raw raw_unc(int r, int k0) const { return *(const uint4*)((const uint16_t*)d.ptr + (long)r * d.ld + k0); }
     __device__ __forceinline__ Raw raw(int m, int k0) const { return raw_at(row_of(m), k0); }
     __device__ __forceinline__ uint4 chunk(int m, int k0) const { return raw(m, k0); }
+};
+// bf16 rows scaled on load by an fp32 factor per (sample, 16-column group): the head's loss-gradient operand
+//   G[m][n] = coef[b(m)][n / 16] * R[m][n],  R = quadrature-weighted residual written by the un-patchify + loss epilogue
+// p0 = rows per sample (mg0 its magic), p2 = groups per sample in aux0.  The factor is loaded with the data (raw), applied
+// when the tile is written to LDS (cvt).
+struct RawCS { uint4 v; float s; };
+template <> struct ALoad<A_BF16_CS> {
+    static constexpr bool ROW_FASTEST = false;
+    typedef RawCS Raw;
+    LoadDesc d;
+    __device__ __forceinline__ int row_of(int m) const { return m >= d.M ? -1 : m; }
+    __device__ __forceinline__ Raw raw_unc(int r, int k0) const {
+        const int b = fdiv(r, d.p0, d.mg0);
+        Raw o = {*(const uint4*)((const uint16_t*)d.ptr + (long)r * d.ld + k0), d.aux0[b * d.p2 + (k0 >> 4)]};
+        return o;
+    }
+    __device__ __forceinline__ Raw raw_at(int r, int k0) const {
+        Raw z = {make_uint4(0, 0, 0, 0), 0.f};
+        if (r < 0 || k0 >= d.K) return z;
+        return raw_unc(r, k0);
+    }
+    __device__ __forceinline__ Raw raw(int m, int k0) const { return raw_at(row_of(m), k0); }
+    __device__ __forceinline__ uint4 cvt(const Raw& r) const {
+        float v[8];
+        unpack8(r.v, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] *= r.s;
+        return pack8(v);
+    }
+    __device__ __forceinline__ uint4 chunk(int m, int k0) const { return cvt(raw(m, k0)); }
 };
 // bf16 rows through GELU (fc2 input = GELU(fc1 output); the pre-activation is what is kept for backward)
 template <> struct ALoad<A_BF16_GELU> {
@@ -292,6 +322,7 @@ ALoad<AK> make_loader(const swv2_operand* o) {
         l.d.p1 = o->p[3] == 16 ? 4 : o->p[3] == 32 ? 5 : o->p[3] == 64 ? 6 : 7;
     }
     if (AK == A_PATCH) { l.d.mg0 = fdiv_magic((o->p[1] / 4) * (o->p[2] / 4)); l.d.mg1 = fdiv_magic(o->p[2] / 4); }
+    if (AK == A_BF16_CS) l.d.mg0 = fdiv_magic(o->p[0]);
     return l;
 }
 
@@ -300,8 +331,11 @@ int check_operand(const swv2_operand* o, const char* who) {
     SWV2_CHECK_ARG(o->rows > 0 && o->cols > 0, "%s: empty operand", who);
     SWV2_CHECK_ARG(o->cols % 8 == 0, "%s: operand width %d must be a multiple of 8", who, o->cols);
     SWV2_CHECK_ARG(((uintptr_t)o->ptr & 15) == 0, "%s: operand pointer must be 16-byte aligned", who);
-    if (o->kind == SWV2_OP_F32 || o->kind == SWV2_OP_BF16 || o->kind == SWV2_OP_BF16_GELU)
+    if (o->kind == SWV2_OP_F32 || o->kind == SWV2_OP_BF16 || o->kind == SWV2_OP_BF16_GELU || o->kind == SWV2_OP_BF16_CSCALE)
         SWV2_CHECK_ARG(o->ld % 8 == 0 && o->ld >= o->cols, "%s: row pitch %ld must be a multiple of 8 and >= cols", who, o->ld);
+    if (o->kind == SWV2_OP_BF16_CSCALE)
+        SWV2_CHECK_ARG(o->aux0 && o->p[0] > 0 && o->p[2] * 16 >= o->cols && o->cols % 16 == 0 && !o->rowidx,
+                       "%s: scaled operand needs aux0, rows per sample p[0] > 0, p[2] >= cols / 16 groups, no gather", who);
     if (o->kind == SWV2_OP_HEADS)
         SWV2_CHECK_ARG(o->p[3] == 16 || o->p[3] == 32 || o->p[3] == 64 || o->p[3] == 128, "%s: head pad %d not in {16,32,64,128}", who, o->p[3]);
     if (o->kind == SWV2_OP_PATCH)

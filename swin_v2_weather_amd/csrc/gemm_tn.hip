@@ -403,6 +403,7 @@ extern "C" int swv2_linear_wgrad_ws(const swv2_operand* dy, const swv2_operand* 
         case SWV2_OP_BF16: return launch_tn1<A_BF16>(dy, x, dW, db, nmap, kmap, ldw, M, N, K, splits, w, ws_bytes, st);
         case SWV2_OP_HEADS: return launch_tn1<A_HEADS>(dy, x, dW, db, nmap, kmap, ldw, M, N, K, splits, w, ws_bytes, st);
         case SWV2_OP_PATCH: return launch_tn1<A_PATCH>(dy, x, dW, db, nmap, kmap, ldw, M, N, K, splits, w, ws_bytes, st);
+        case SWV2_OP_BF16_CSCALE: return launch_tn1<A_BF16_CS>(dy, x, dW, db, nmap, kmap, ldw, M, N, K, splits, w, ws_bytes, st);
     }
     swv2_set_error("swv2_linear_wgrad: unsupported dY operand kind %d", dy->kind);
     return SWV2_ERR_INVALID;

@@ -373,12 +373,14 @@ __global__ __launch_bounds__(256) void loss_sums_kernel(const float* __restrict_
 // loss = sum_{b,c} chw[c] f(S0 / S1)  (relative; S0 alone when absolute; f = sqrt unless squared) and the coefficient
 // the backward kernel multiplies in: coef[bc] = 2 d loss / d S0[bc].  One workgroup; replaces the half dozen elementwise /
 // reduction launches (and as many again in their autograd) that torch spent on this [B, C] tensor (losses.py:188-232).
-__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ chw,
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ sums, int layers, const float* __restrict__ chw,
                                                             int BC, int C, int absolute, int squared,
                                                             float* __restrict__ loss, float* __restrict__ coef) {
     float acc = 0.f;
     for (int i = threadIdx.x; i < BC; i += 256) {
-        const float s0 = sums[2 * i], s1 = sums[2 * i + 1], w = chw[i % C];
+        float s0 = 0.f, s1 = 0.f;
+        for (int l = 0; l < layers; ++l) { s0 += sums[((size_t)l * BC + i) * 2]; s1 += sums[((size_t)l * BC + i) * 2 + 1]; }
+        const float w = chw[i % C];
         const float den = absolute ? 1.f : s1;
         const float r = s0 / den;
         float f, df;                                    // f(r), f'(r)
@@ -391,6 +393,43 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) *loss = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// per-group partial sums of the head epilogue (gemm.hip, Epi<E_UNPATCH_LOSS>: part[g][slot][Cout][2]) -> sums[j][b][..].  grid =
+// (B, SWV2_LOSS_PART_SLICES), 4 sub-slices of 256 threads; thread v < 2 Cout owns one (channel, sum) value and adds the groups
+// of its sample, slice and sub-slice in ascending order (coalesced: the 2 Cout values of a group slot are contiguous); the
+// sub-slices are combined through LDS in a fixed order.  Slot 1 of the group in front of the sample's first group holds the
+// rows of this sample that sit in a group starting in the previous one.
+__global__ __launch_bounds__(1024) void loss_part_reduce_kernel(const float* __restrict__ part, int M, int T, int Cout, int Ct,
+                                                                int coff, int B, float* __restrict__ sums) {
+    const int b = blockIdx.x, j = blockIdx.y, nv = 2 * Cout;
+    const int ngroups = (M + 63) / 64;
+    const int g_lo = (b * T + 63) / 64, g_hi = min(((b + 1) * T + 63) / 64, ngroups);     // groups whose first row lies in sample b
+    constexpr int S = SWV2_LOSS_PART_SLICES;
+    const int sub = threadIdx.x >> 8, t = threadIdx.x & 255;
+    __shared__ float red[3][256];
+    const int g0 = g_lo + ((j - g_lo) % S + S) % S + sub * S;          // first g >= g_lo with g % S == j, then the sub's offset
+    const size_t gs = (size_t)2 * nv;                                  // floats per group
+    for (int v0 = 0; v0 < nv; v0 += 256) {
+        const int v = v0 + t;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        if (v < nv) {
+            int g = g0;
+            for (; g + 12 * S < g_hi; g += 16 * S) {
+                a0 += part[(size_t)g * gs + v];
+                a1 += part[(size_t)(g + 4 * S) * gs + v];
+                a2 += part[(size_t)(g + 8 * S) * gs + v];
+                a3 += part[(size_t)(g + 12 * S) * gs + v];
+            }
+            for (; g < g_hi; g += 4 * S) a0 += part[(size_t)g * gs + v];
+            if (sub == 0 && b > 0 && g_lo > 0 && (g_lo - 1) % S == j) a1 += part[(size_t)(g_lo - 1) * gs + nv + v];
+        }
+        const float tot = (a0 + a1) + (a2 + a3);
+        if (sub) red[sub - 1][t] = tot;
+        __syncthreads();
+        if (!sub && v < nv) sums[(((size_t)j * B + b) * Ct + coff) * 2 + v] = ((tot + red[0][t]) + red[1][t]) + red[2][t];
+        __syncthreads();
+    }
 }
 
 // grid = (plane / 4096, B * C): a workgroup handles 4 x 256 float4 units of one (b, c) plane, all eight loads in flight
@@ -640,10 +679,19 @@ extern "C" int swv2_loss_sums(const float* prd, const float* tar, const float* q
     return SWV2_OK;
 }
 
-extern "C" int swv2_loss_finalize(const float* sums, const float* chw, int BC, int C, int absolute, int squared, float* loss,
+extern "C" int swv2_loss_part_reduce(const float* part, int M, int T, int B, int Cout, int Ct, int coff, float* sums, void* stream) {
+    SWV2_CHECK_ARG(part && sums && M > 0 && T >= 64 && B > 0 && M == B * T && Cout > 0 && coff >= 0 && coff + Cout <= Ct,
+                   "loss_part_reduce: bad argument");
+    hipLaunchKernelGGL(loss_part_reduce_kernel, dim3(B, SWV2_LOSS_PART_SLICES), dim3(1024), 0, (hipStream_t)stream, part, M, T, Cout,
+                       Ct, coff, B, sums);
+    SWV2_CHECK_LAUNCH("swv2_loss_part_reduce");
+    return SWV2_OK;
+}
+
+extern "C" int swv2_loss_finalize(const float* sums, int layers, const float* chw, int BC, int C, int absolute, int squared, float* loss,
                                   float* coef, void* stream) {
-    SWV2_CHECK_ARG(sums && chw && loss && coef && BC > 0 && C > 0 && BC % C == 0, "loss_finalize: bad argument");
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sums, chw, BC, C, absolute, squared, loss,
+    SWV2_CHECK_ARG(sums && chw && loss && coef && BC > 0 && C > 0 && BC % C == 0 && layers > 0, "loss_finalize: bad argument");
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sums, layers, chw, BC, C, absolute, squared, loss,
                        coef);
     SWV2_CHECK_LAUNCH("swv2_loss_finalize");
     return SWV2_OK;

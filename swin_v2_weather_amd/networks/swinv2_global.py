@@ -753,7 +753,7 @@ class _HeadFn(torch.autograd.Function):
     filled by the same epilogue pass (the reference makes two torch.cat copies per step)."""
 
     @staticmethod
-    def forward(ctx, e, w, skip, mod, dst=None, extra=None):
+    def forward(ctx, e, w, skip, mod, dst=None, extra=None, lossctx=None):
         B, gh, gw, Cc = e.shape
         Cout = mod.out_chans
         H, W = gh * 4, gw * 4
@@ -765,10 +765,22 @@ class _HeadFn(torch.autograd.Function):
         if skip is not None:
             skip = skip.contiguous().float()
             Cs = skip.shape[1]
-        nxt = None
-        if dst is None:
+        nxt, sums, resid = None, None, None
+        if dst is None and lossctx is not None:
+            # the loss rides in the epilogue (LossHandler.fused_with): quadrature sums of (y - tar)^2, tar^2 per (sample,
+            # channel) while the prediction tile is in registers, and the weighted residual in the GEMM's layout for backward
+            tar, qw = lossctx
             y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=dev)
-            ops.linear(ops.op_f32(e2d), wb, ops.epilogue(L.EPI_UNPATCH, y, aux=skip, p=(Cout, H, W, Cs, 0)), Cout * 16)
+            M = B * gh * gw
+            sums = torch.empty(L.LOSS_PART_SLICES, B, Cout, 2, dtype=torch.float32, device=dev)
+            part = torch.empty((M + 63) // 64, 2, Cout, 2, dtype=torch.float32, device=dev)
+            resid = torch.empty(M, Cout * 16, dtype=ops.BF16, device=dev)
+            ops.linear(ops.op_f32(e2d), wb, ops.epilogue(L.EPI_UNPATCH_LOSS, y, aux=skip, p=(Cout, H, W, Cs, 0),
+                                                         loss=(tar, qw, part, resid, 0)), Cout * 16, tag="head_fwd")
+            ops.loss_part_reduce(part, M, gh * gw, B, Cout, 0, sums)
+        elif dst is None:
+            y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=dev)
+            ops.linear(ops.op_f32(e2d), wb, ops.epilogue(L.EPI_UNPATCH, y, aux=skip, p=(Cout, H, W, Cs, 0)), Cout * 16, tag="head_fwd")
         else:
             result, coff = dst
             Ct = result.shape[1]
@@ -783,6 +795,12 @@ class _HeadFn(torch.autograd.Function):
             ops.linear(ops.op_f32(e2d), wb, ep, Cout * 16)
         ctx.mod, ctx.has_skip, ctx.Cs, ctx.rollout = mod, skip is not None, Cs, dst is not None
         ctx.n_extra = 0 if (dst is None or extra is None) else extra.shape[1]
+        ctx.fused_loss = sums is not None
+        ctx.geom = (B, Cout, H, W)
+        if ctx.fused_loss:
+            ctx.set_materialize_grads(False)
+            ctx.save_for_backward(e2d, w, resid)
+            return y, sums
         ctx.save_for_backward(e2d, w)
         if dst is None:
             return y
@@ -790,37 +808,56 @@ class _HeadFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, dnxt=None):
-        e2d, w = ctx.saved_tensors
         mod = ctx.mod
-        B, Cout, H, W = dy.shape
+        B, Cout, H, W = ctx.geom
+        if ctx.fused_loss:
+            e2d, w, resid = ctx.saved_tensors
+            dsums, dnxt = dnxt, None
+        else:
+            e2d, w = ctx.saved_tensors
+            dsums = None
         Cc, dev = e2d.shape[1], e2d.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        perm = mod._head_perm(dev)
+        T = (H // 4) * (W // 4)
+        dw = torch.zeros(Cout * 16, Cc, **f32)
+        wt = mod._wcache.get("headt", (w,), lambda: ops.prep_weight(w, transpose=True, col_map=perm))
+        de = None
+        if dsums is not None:
+            # d loss / d y = coef[b, c] q[h] (y - tar) with coef = 2 d loss / d S0: the stored residual scaled on load
+            coef = (2.0 * dsums[0, :, :Cout, 0]).contiguous().float()
+            coef16 = coef
+            g = lambda: ops.op_bf16_cscale(resid, coef16, T)     # noqa: E731
+            ops.linear_wgrad(g(), ops.op_f32(e2d), dw, None, nmap=perm)
+            de = torch.empty(B * T, Cc, **f32)
+            ops.linear(g(), wt, ops.epilogue(L.EPI_F32, de, ld=Cc), Cc, tag="head_dx")
+        if dy is None:
+            if de is None:
+                de = torch.zeros(B * T, Cc, **f32)
+            return de.view(B, H // 4, W // 4, Cc), dw, None, None, None, None, None
         # dy may be a channel slice of the gradient of the concatenated rollout output: read in place through its batch stride
         if dy.dtype != torch.float32 or dy.stride()[1:] != (H * W, W, 1) or dy.stride(0) % (H * W):
             dy = dy.contiguous().float()
         Ct = dy.stride(0) // (H * W)
 
         def op_dy():
-            o = ops.operand(L.OP_PATCH, dy, B * (H // 4) * (W // 4), Cout * 16, 0, p=(Cout, H, W, 0 if Ct == Cout else Ct))
+            o = ops.operand(L.OP_PATCH, dy, B * T, Cout * 16, 0, p=(Cout, H, W, 0 if Ct == Cout else Ct))
             if dnxt is not None:           # + gradient that came back through the next step's input (its first Cout channels)
                 o.aux0, o.ld = dnxt.data_ptr(), dnxt.shape[1]
                 o._keep = (o._keep, dnxt)
             return o
         if dnxt is not None:
             dnxt = dnxt.contiguous().float()
-        perm = mod._head_perm(dev)
-        f32 = dict(dtype=torch.float32, device=dev)
-        dw = torch.zeros(Cout * 16, Cc, **f32)
         ops.linear_wgrad(op_dy(), ops.op_f32(e2d), dw, None, nmap=perm)
-        wt = mod._wcache.get("headt", (w,), lambda: ops.prep_weight(w, transpose=True, col_map=perm))
-        de = torch.empty(B * (H // 4) * (W // 4), Cc, **f32)
-        ops.linear(op_dy(), wt, ops.epilogue(L.EPI_F32, de, ld=Cc), Cc)
+        de2 = torch.empty(B * T, Cc, **f32)
+        ops.linear(op_dy(), wt, ops.epilogue(L.EPI_F32, de2, ld=Cc, aux=de), Cc, tag="head_dx")    # (+ the loss part, if any)
         dskip = None
         if ctx.has_skip and ctx.needs_input_grad[2]:
             dskip = torch.zeros(B, ctx.Cs, H, W, **f32)
             dskip[:, :Cout] = dy if dnxt is None else dy + dnxt[:, :Cout]
         # gradient of the re-appended channels (the invariants are a view of the step-0 input: helpers.py:28,39)
         dextra = dnxt[:, Cout:] if (dnxt is not None and ctx.n_extra and ctx.needs_input_grad[5]) else None
-        return de.view(B, H // 4, W // 4, Cc), dw, dskip, None, None, dextra
+        return de2.view(B, H // 4, W // 4, Cc), dw, dskip, None, None, dextra, None
 
 
 class _GatherFn(torch.autograd.Function):
@@ -992,9 +1029,17 @@ class SwinTransformerV2Cr(nn.Module):
     def forward_head(self, x: torch.Tensor, skip: Optional[torch.Tensor] = None) -> torch.Tensor:
         return _HeadFn.apply(bchw_to_bhwc(x), self.head.weight, skip, self)
 
+    _loss_ctx = None        # set by utils.losses.LossHandler.fused_with for the duration of one forward
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         _need_gpu(x, "SwinTransformerV2Cr")
         e = self._features_bhwc(x)
+        lc = self._loss_ctx
+        # (a skip connection whose input needs a gradient wants d loss / d y in image layout: the two-pass kernels serve that)
+        if lc is not None and torch.is_grad_enabled() and e.requires_grad and not (self.residual and x.requires_grad) and lc.fits(x, self):
+            y, sums = _HeadFn.apply(e, self.head.weight, x if self.residual else None, self, None, None, (lc.tar, lc.qw))
+            lc.offer(y, sums)
+            return y
         return _HeadFn.apply(e, self.head.weight, x if self.residual else None, self)
 
     def forward_rollout(self, x: torch.Tensor, result: torch.Tensor, coff: int, extra: Optional[torch.Tensor]):

@@ -119,6 +119,15 @@ def op_bf16(x2d: torch.Tensor, rows=None, rowidx=None, gelu=False):
                    x2d.shape[1], x2d.shape[1], rowidx)
 
 
+def op_bf16_cscale(x2d: torch.Tensor, coef: torch.Tensor, rows_per_sample: int):
+    """bf16 rows scaled on load by coef[row // rows_per_sample][col // 16] (fp32 [B, cols / 16])"""
+    _chk(x2d, BF16, "op_bf16_cscale"); _chk(coef, torch.float32, "op_bf16_cscale coef")
+    if coef.dim() != 2 or coef.shape[1] * 16 != x2d.shape[1] or coef.shape[0] * rows_per_sample != x2d.shape[0]:
+        raise L.Swv2Error(f"op_bf16_cscale: coef {tuple(coef.shape)} does not match rows {x2d.shape[0]} / {rows_per_sample}, cols {x2d.shape[1]}")
+    return operand(L.OP_BF16_CSCALE, x2d, x2d.shape[0], x2d.shape[1], x2d.shape[1], aux=(coef, None, None, None),
+                   p=(rows_per_sample, 0, coef.shape[1], 0))
+
+
 def op_heads(t: torch.Tensor, Bw, heads, parts, Lp, DP):
     _chk(t, BF16, "op_heads")
     return operand(L.OP_HEADS, t, Bw * Lp, parts * heads * DP, parts, p=(heads, 0, Lp, DP))
@@ -135,11 +144,19 @@ def op_merge_ln(x4d, mean, rstd, gamma, beta):
     return operand(L.OP_MERGE_LN, x4d, B * (H // 2) * (W // 2), 4 * Cc, 0, aux=(mean, rstd, gamma, beta), p=(H, W, Cc, 0))
 
 
-def epilogue(kind, out, ld=0, bias=None, aux=None, aux_out=None, rowidx=None, p=(0, 0, 0, 0, 0)) -> L.Epilogue:
+def epilogue(kind, out, ld=0, bias=None, aux=None, aux_out=None, rowidx=None, p=(0, 0, 0, 0, 0), loss=None) -> L.Epilogue:
+    """loss (EPI_UNPATCH_LOSS) = (tar [B, Ct, H, W] fp32, quadrature row weights [H], per-group partial sums
+    [ceil(M / 64), 2, Cout, 2] fp32, residual bf16 [M, N], first target channel); follow the launch with loss_part_reduce"""
     e = L.Epilogue()
     e.kind, e.out, e.bias, e.aux, e.aux_out, e.rowidx, e.ld = kind, _p(out), _p(bias), _p(aux), _p(aux_out), _p(rowidx), ld
     e.p = (C.c_int * 5)(*p)
-    e._keep = (out, bias, aux, aux_out, rowidx)
+    e._keep = (out, bias, aux, aux_out, rowidx, loss)
+    if loss is not None:
+        tar, qw, part, resid, coff = loss
+        _chk(tar, torch.float32, "loss target"); _chk(qw, torch.float32, "quadrature weights")
+        _chk(resid, BF16, "loss residual"); _chk(part, torch.float32, "loss partial sums")
+        e.loss_tar, e.loss_qw, e.loss_part, e.loss_resid = _p(tar), _p(qw), _p(part), _p(resid)
+        e.q = (C.c_int * 2)(tar.shape[1], coff)
     return e
 
 
@@ -314,9 +331,25 @@ def loss_sums(prd, tar, qw, sums):
 
 
 def loss_finalize(sums, chw, absolute: bool, squared: bool, loss, coef):
-    BC, Cc = sums.shape[0] * sums.shape[1], chw.numel()
-    L.check(L.load().swv2_loss_finalize(_p(sums), _p(chw), BC, Cc, int(absolute), int(squared), _p(loss), _p(coef), _stream()),
+    """sums [B, C, 2] or [layers, B, C, 2] (layers added in order)"""
+    layers = sums.shape[0] if sums.dim() == 4 else 1
+    BC, Cc = sums.shape[-3] * sums.shape[-2], chw.numel()
+    L.check(L.load().swv2_loss_finalize(_p(sums), layers, _p(chw), BC, Cc, int(absolute), int(squared), _p(loss), _p(coef), _stream()),
             "swv2_loss_finalize")
+
+
+def loss_part_reduce(part, M, T, B, Cout, coff, sums):
+    """per-group partial sums of the head's loss epilogue -> sums [LOSS_PART_SLICES, B, Ct, 2] (channels coff .. coff + Cout)"""
+    L.check(L.load().swv2_loss_part_reduce(_p(part), M, T, B, Cout, sums.shape[2], coff, _p(sums), _stream()), "swv2_loss_part_reduce")
+
+
+def loss_finalize_sums(sums, chw, absolute: bool, squared: bool):
+    """[B, C, 2] (or [layers, B, C, 2]) quadrature sums -> (loss [1], coef [B, C] = 2 d loss / d S0) in one launch"""
+    B, Cc = sums.shape[-3:-1]
+    buf = torch.empty(B * Cc + 1, dtype=torch.float32, device=sums.device)
+    coef, loss = buf[:B * Cc].view(B, Cc), buf[B * Cc:]
+    loss_finalize(sums, chw, absolute, squared, loss, coef)
+    return loss, coef
 
 
 def loss_grad(prd, tar, qw, coef, dprd):

@@ -61,6 +61,53 @@ class _GeoL2(torch.autograd.Function):
         return dprd, None, None, None, None, None
 
 
+class _FusedGeoL2(torch.autograd.Function):
+    """LossHandler value from the quadrature sums the head's un-patchify epilogue produced (SWV2_EPI_UNPATCH_LOSS): one
+    loss_finalize launch; backward hands d loss / d sums[..., 0] to the head's backward, which scales the stored residual."""
+
+    @staticmethod
+    def forward(ctx, sums, chw, absolute, squared):
+        loss, coef = ops.loss_finalize_sums(sums, chw, absolute, squared)
+        ctx.layers = sums.shape[0]
+        ctx.save_for_backward(coef)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        (coef,) = ctx.saved_tensors
+        ds = torch.zeros((ctx.layers,) + tuple(coef.shape) + (2,), dtype=torch.float32, device=coef.device)
+        ds[..., 0] = 0.5 * gout * coef               # coef = 2 d loss / d S0 (every layer of the sums alike); the relative
+        return ds, None, None, None                  # losses' d / d S1 has no consumer (the target needs no gradient)
+
+
+class _LossCtx:
+    """one forward's hand-over between LossHandler.fused_with and the model head"""
+
+    def __init__(self, tar, qw):
+        self.tar, self.qw, self.y, self.sums = tar, qw, None, None
+
+    def fits(self, x, net):
+        t = self.tar
+        return (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and not t.requires_grad and t.dim() == 4 and
+                t.shape[0] == x.shape[0] and t.shape[1] == net.out_chans and tuple(t.shape[2:]) == tuple(x.shape[2:]) and
+                self.qw.numel() == t.shape[2] and t.shape[3] % 4 == 0 and (t.shape[2] // 4) * (t.shape[3] // 4) >= 64 and
+                t.numel() < 2 ** 32 and x.numel() < 2 ** 32)
+
+    def offer(self, y, sums):
+        self.y, self.sums = y, sums
+
+
+def _core_net(model):
+    """the SwinTransformerV2Cr under DDP (`.module`) and the step wrappers (`.model`)"""
+    m, seen = model, 0
+    while seen < 4 and not hasattr(m, "_features_bhwc"):
+        m = getattr(m, "module", None) or getattr(m, "model", None)
+        if m is None:
+            return None
+        seen += 1
+    return m if hasattr(m, "_features_bhwc") else None
+
+
 def auto_channel_weights(channel_names, n_out):
     """losses.py:57-68"""
     w = torch.ones(n_out, dtype=torch.float32)
@@ -131,7 +178,36 @@ class LossHandler(nn.Module):
         ms = torch.ones(self.n_future + 1, dtype=torch.float32) / float(self.n_future + 1)
         self.register_buffer('multistep_weight', ms.reshape(-1, 1, 1, 1))
 
+    _fused = None
+
+    def fused_with(self, model, tar: torch.Tensor):
+        """`with loss_obj.fused_with(model, tar): gen = model(inp)` then `loss_obj(gen, tar, inp)` as usual: the model's head
+        evaluates this loss's quadrature sums in the epilogue that writes `gen` and keeps the weighted residual for its own
+        backward, so the prediction is not read back by the loss (2 passes) nor a gradient of its size written and re-read
+        (losses.py:188-206 on the output of swinv2_global.py:784-802).  Purely an accelerator: same value, same gradients;
+        when the shapes do not fit (rollouts, skip inputs that need gradients, eval) the two-pass kernels run instead."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            net = _core_net(model) if (self.training and os.environ.get("SWV2_LOSS_IN_HEAD", "1") != "0") else None
+            if net is None or self.n_future != 0:
+                yield
+                return
+            lc = _LossCtx(tar, self.quad_rows)
+            net._loss_ctx, self._fused = lc, lc
+            try:
+                yield
+            finally:
+                net._loss_ctx = None
+        return cm()
+
     def forward(self, prd: torch.Tensor, tar: torch.Tensor, inp: torch.Tensor = None):
+        lc, self._fused = self._fused, None
+        if (lc is not None and lc.y is not None and lc.tar is tar and self.training and
+                (lc.y is prd or (prd.data_ptr() == lc.y.data_ptr() and prd.shape == lc.y.shape and prd.dtype == lc.y.dtype))):
+            chw = (self.channel_weights * self.multistep_weight).reshape(-1).contiguous().float()
+            return _FusedGeoL2.apply(lc.sums, chw, self.absolute, self.squared)
         chw = self.channel_weights
         if self.training:
             chw = (chw * self.multistep_weight).reshape(1, -1)

@@ -753,6 +753,125 @@ def test_loss_handler_against_reference_values(dev, K, monkeypatch, fused):
             assert rel(pd.grad[:, ::9, ::5, ::7], ref) < 1e-5
 
 
+def test_head_epilogue_loss_sums_and_scaled_residual_operand(dev, K):
+    """SWV2_EPI_UNPATCH_LOSS / SWV2_OP_BF16_CSCALE at the kernel level: the un-patchify epilogue that also evaluates the
+    quadrature sums of losses.py:188-206 gives the same prediction as SWV2_EPI_UNPATCH, sums equal to an fp64 evaluation of
+    that prediction, and a residual matrix that -- scaled per (sample, channel) on load -- reproduces both backward products
+    of the gradient tensor the two-pass path materialises.  gh*gw = 216 rows per sample: the 128-row panels straddle the
+    sample boundaries (the per-item atomic path) and the last panel is ragged."""
+    ops, L = K["ops"], K["L"]
+    torch.manual_seed(11)
+    B, Cout, Cc, H, W, Cs = 3, 5, 96, 48, 72, 7
+    gh, gw = H // 4, W // 4
+    T, M, Nn = gh * gw, B * gh * gw, Cout * 16
+    e2d = torch.randn(M, Cc, device=dev)
+    w = (torch.randn(Nn, Cc) * 0.2).to(dev)
+    wb = ops.prep_weight(w)
+    skip = torch.randn(B, Cs, H, W, device=dev)
+    tar = torch.randn(B, Cout + 2, H, W, device=dev)                       # the prediction's target = channels 1 .. 1 + Cout
+    qw = torch.rand(H, device=dev) + 0.1
+    y0 = torch.empty(B, Cout, H, W, device=dev)
+    ops.linear(ops.op_f32(e2d), wb, ops.epilogue(L.EPI_UNPATCH, y0, aux=skip, p=(Cout, H, W, Cs, 0)), Nn)
+    y1 = torch.full((B, Cout, H, W), float("nan"), device=dev)
+    sums_l = torch.zeros(L.LOSS_PART_SLICES, B, Cout + 2, 2, device=dev)
+    part = torch.full(((M + 63) // 64, 2, Cout, 2), float("nan"), device=dev)
+    resid = torch.full((M, Nn), float("nan"), dtype=BF, device=dev)
+    ops.linear(ops.op_f32(e2d), wb, ops.epilogue(L.EPI_UNPATCH_LOSS, y1, aux=skip, p=(Cout, H, W, Cs, 0),
+                                                 loss=(tar, qw, part, resid, 1)), Nn)
+    ops.loss_part_reduce(part, M, T, B, Cout, 1, sums_l)
+    assert torch.equal(y0, y1) and bool(torch.isfinite(part).all())
+    assert int((part[:, 1].abs().sum((1, 2)) > 0).sum()) == B - 1      # exactly the groups that straddle a sample boundary
+    sums = sums_l.sum(0)
+    again = torch.zeros_like(sums_l)                                    # no atomics anywhere: bit-reproducible
+    ops.linear(ops.op_f32(e2d), wb, ops.epilogue(L.EPI_UNPATCH_LOSS, y1, aux=skip, p=(Cout, H, W, Cs, 0),
+                                                 loss=(tar, qw, part, resid, 1)), Nn)
+    ops.loss_part_reduce(part, M, T, B, Cout, 1, again)
+    assert torch.equal(again, sums_l)
+    t = tar[:, 1:1 + Cout].double()
+    q = qw.double().view(1, 1, H, 1)
+    s0 = (q * (y0.double() - t) ** 2).sum((2, 3))
+    s1 = (q * t ** 2).sum((2, 3))
+    assert rel(sums[:, 1:1 + Cout, 0], s0) < 1e-5 and rel(sums[:, 1:1 + Cout, 1], s1) < 1e-5
+    assert float(sums[:, 0].abs().max()) == 0.0 and float(sums[:, -1].abs().max()) == 0.0      # other targets' slots untouched
+    # residual in the GEMM's layout: row (b, i, j), column c*16 + p*4 + q
+    r_img = (q * (y0.double() - t)).float()                                                     # [B, Cout, H, W]
+    r_mat = r_img.view(B, Cout, gh, 4, gw, 4).permute(0, 2, 4, 1, 3, 5).reshape(M, Nn)
+    assert torch.equal(resid.float(), rb(r_mat)) or rel(resid.float(), rb(r_mat)) < 2e-3        # (bf16 ties of fp32 vs fp64 diffs)
+    # backward operand: coef[b, c] * residual against the materialised gradient through the patch loader
+    coef = (torch.randn(B, Cout, device=dev) * 0.3).contiguous()
+    grad = (coef.view(B, Cout, 1, 1) * r_img).contiguous()
+    wt = ops.prep_weight(w, transpose=True)
+    de_ref, de = torch.empty(M, Cc, device=dev), torch.empty(M, Cc, device=dev)
+    ops.linear(ops.operand(L.OP_PATCH, grad, M, Nn, 0, p=(Cout, H, W, 0)), wt, ops.epilogue(L.EPI_F32, de_ref, ld=Cc), Cc)
+    ops.linear(ops.op_bf16_cscale(resid, coef, T), wt, ops.epilogue(L.EPI_F32, de, ld=Cc), Cc)
+    assert rel(de, de_ref) < 6e-3                                                               # one extra bf16 rounding of the operand
+    dw_ref, dw = torch.zeros(Nn, Cc, device=dev), torch.zeros(Nn, Cc, device=dev)
+    ops.linear_wgrad(ops.operand(L.OP_PATCH, grad, M, Nn, 0, p=(Cout, H, W, 0)), ops.op_f32(e2d), dw_ref, None)
+    ops.linear_wgrad(ops.op_bf16_cscale(resid, coef, T), ops.op_f32(e2d), dw, None)
+    assert rel(dw, dw_ref) < 6e-3
+    exact = (coef.view(B, 1, 1, Cout, 1, 1).double() * r_mat.view(B, gh, gw, Cout, 4, 4).double().to(dev)).reshape(M, Nn)
+    assert rel(dw, exact.float().T @ e2d) < 6e-3
+
+
+@pytest.mark.parametrize("loss", ["l2", "squared geometric l2", "weighted absolute temp-std squared geometric l2",
+                                  "weighted relative temp-std squared geometric l2"])
+def test_loss_in_head_epilogue_equals_two_pass_loss(dev, K, loss):
+    """LossHandler.fused_with (the trainer's / bench's step): value, parameter gradients and -- with a skip connection --
+    the behaviour when the input needs a gradient (falls back) equal the two-pass loss kernels on the same model."""
+    from types import SimpleNamespace
+    from swin_v2_weather_amd.utils.losses import LossHandler
+    torch.manual_seed(5)
+    H, W, Cio = 48, 72, 6
+    names = ["u10m", "t2m", "z500", "q850", "tp", "v100"]
+    for residual in (False, True):
+        m = K["N"].SwinTransformerV2Cr(img_size=(H, W), patch_size=4, depths=(2,), num_heads=(2,), in_chans=Cio, out_chans=Cio,
+                                       embed_dim=32, img_window_ratio=8, drop_path_rate=0.0, full_pos_embed=True, rel_pos=False,
+                                       mlp_ratio=4, residual=residual).to(dev)
+        with torch.no_grad():
+            for n, p_ in m.named_parameters():
+                if n.endswith("norm1.weight") or n.endswith("norm2.weight"):
+                    p_.fill_(0.7)
+        lh = LossHandler(SimpleNamespace(n_future=0, img_shape_x=H, img_shape_y=W, loss=loss, channel_weights="auto",
+                                         n_out_channels=Cio, channel_names=names, out_channels=np.arange(Cio), dt=1,
+                                         model_grid_type="equiangular")).to(dev)
+        m.train(); lh.train()
+        x, tar = torch.randn(3, Cio, H, W, device=dev), torch.randn(3, Cio, H, W, device=dev)
+        m.zero_grad()
+        l0 = lh(m(x), tar, x)
+        l0.backward()
+        g0 = {n: p_.grad.clone() for n, p_ in m.named_parameters()}
+        m.zero_grad()
+        with lh.fused_with(m, tar):
+            gen = m(x)
+        assert m._loss_ctx is None and lh._fused is not None and lh._fused.sums is not None      # the epilogue path was taken
+        l1 = lh(gen, tar, x)
+        l1.backward()
+        assert abs(float(l1) - float(l0)) <= 2e-6 * abs(float(l0)), (float(l0), float(l1))
+        for n, p_ in m.named_parameters():
+            if float(g0[n].abs().max()) > 1e-6:
+                assert rel(p_.grad, g0[n]) < (0.03 if n.endswith("logit_scale") else 8e-3), (n, rel(p_.grad, g0[n]))
+        # gradient wrt the input over the skip connection: not served by the epilogue path -> same numbers from the two-pass one
+        xg = x.clone().requires_grad_(True)
+        with lh.fused_with(m, tar):
+            gen = m(xg)
+        assert (lh._fused.sums is None) == residual
+        lh(gen, tar, xg).backward()
+        if residual:
+            assert xg.grad is not None and float(xg.grad.abs().max()) > 0
+        # the prediction used differentiably beside the loss: both gradient sources arrive
+        m.zero_grad()
+        with lh.fused_with(m, tar):
+            gen = m(x)
+        (lh(gen, tar, x) + 0.5 * gen.square().mean()).backward()
+        g2 = {n: p_.grad.clone() for n, p_ in m.named_parameters()}
+        m.zero_grad()
+        gen = m(x)
+        (lh(gen, tar, x) + 0.5 * gen.square().mean()).backward()
+        for n, p_ in m.named_parameters():
+            if float(p_.grad.abs().max()) > 1e-6:
+                assert rel(g2[n], p_.grad) < (0.03 if n.endswith("logit_scale") else 8e-3), (n, rel(g2[n], p_.grad))
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # 100-step loss curve of BASELINE cfg 1 against the curve recorded from the real reference (fp32, CPU)
 # ---------------------------------------------------------------------------------------------------------------

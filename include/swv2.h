@@ -319,13 +319,15 @@ int swv2_adam_multi(const swv2_adam_item* items_dev, const int* chunks_dev, int 
  *        out[b][coff + s*Csel + c][i][j] = (raw[b][s][chan[c]][i][j] - mean[c]) / std[c]        i < H, j < W
  * replaces the host-side crop + channel select + z-score of utils/data_loader_era5.py:163-171,98-107 (bit-identical: same
  * operation order, IEEE division) and DALI's fn.normalize (utils/data_loader_era5_dali.py:77-90).
- * swv2_era5_zenith writes nz cos-zenith channels (hours[b*nz + k] = hours since Jan 1st 00:00 of the sample's year;
- * data_loader_era5.py:109-146 -- closed form on the 0.25 degree grid, stand-in for the absent modulus routine);
+ * swv2_era5_zenith writes nz cos-zenith channels, the per-pixel half of data_loader_era5.py:109-146 (modulus cos_zenith_angle):
+ * out[b][coff + k][i][j] = sin(lat_i) sun0 + cos(lat_i) sun1 cos(sun2 + lon_j) on the 0.25 degree grid (lat 90 .. -90, lon 0 ..),
+ * sun[(b*nz + k)*3 + {0, 1, 2}] = sin(declination), cos(declination), hour angle at longitude 0 of the time point -- the solar
+ * position is float64 host arithmetic (utils/data_loader_era5.py::sun_position; oracle/zenith.py restates the routine);
  * swv2_era5_static broadcasts Cs static feature planes [Cs][H][W] over the batch (utils/preprocess_utils.py:50-68).
  * ------------------------------------------------------------------------------------------------------------ */
 int swv2_era5_select_normalize(const float* raw, float* out, const int* chan, const float* mean, const float* stdv, int B, int S,
                                int Csel, int Craw, int Hraw, int Wraw, int H, int W, int Cout_total, int coff, void* stream);
-int swv2_era5_zenith(float* out, const float* hours, int B, int nz, int H, int W, int Cout_total, int coff, void* stream);
+int swv2_era5_zenith(float* out, const float* sun, int B, int nz, int H, int W, int Cout_total, int coff, void* stream);
 int swv2_era5_static(const float* stat, float* out, int B, int Cs, int H, int W, int Cout_total, int coff, void* stream);
 
 /* Fused attention branch, forward, for blocks WITHOUT the CPB bias (rel_pos = False, the yaml default):

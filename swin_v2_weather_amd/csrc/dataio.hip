@@ -29,17 +29,16 @@ __global__ __launch_bounds__(256) void era5_select_normalize_kernel(
     }
 }
 
-// cos of the solar zenith angle on the 0.25 degree grid (lat 90 .. -90, lon 0 .. 360): the same closed form as
-// utils/data_loader_era5.py::cos_zenith of this package (stand-in for the absent modulus cos_zenith_angle; data_loader_era5.py
-// :109-146 of the reference) -- out[b][coff + k][i][j] for k < nz time points, hours[b*nz + k] hours since Jan 1st
-__global__ __launch_bounds__(256) void era5_zenith_kernel(float* __restrict__ out, const float* __restrict__ hours, int nz,
+// cos of the solar zenith angle on the 0.25 degree grid (lat 90 .. -90, lon 0 .. 359.75): the per-pixel half of the
+// reference's zenith channel (data_loader_era5.py:109-146 -> modulus cos_zenith_angle):
+//     out[b][coff + k][i][j] = sin(lat_i) sin(dec) + cos(lat_i) cos(dec) cos(ha0 + lon_j)
+// sun[(b*nz + k)*3 + {0,1,2}] = sin(dec), cos(dec), hour angle at longitude 0 (reduced to (-pi, pi]) of time point k of
+// sample b: the solar position itself is a handful of float64 scalar operations per time point and stays on the host
+// (utils/data_loader_era5.py::sun_position), where the 1e5-hour arguments keep their precision.
+__global__ __launch_bounds__(256) void era5_zenith_kernel(float* __restrict__ out, const float* __restrict__ sun, int nz,
                                                           int H, int W, int Cout_total, int coff) {
     const int plane = blockIdx.y, k = plane % nz, b = plane / nz;
-    const float hr = hours[plane];
-    const float day = hr / 24.0f;
-    const float dec = -0.40910517666747087f * cosf(6.283185307179586f * (day + 10.0f) / 365.25f);     // radians(-23.44)
-    const float sd = sinf(dec), cd = cosf(dec);
-    const float ha0 = 6.283185307179586f * (fmodf(hr, 24.0f) / 24.0f) - 3.141592653589793f;
+    const float sd = sun[plane * 3], cd = sun[plane * 3 + 1], ha0 = sun[plane * 3 + 2];
     float* dst = out + ((size_t)b * Cout_total + coff + k) * (size_t)H * W;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < H * W; idx += gridDim.x * blockDim.x) {
         const int i = idx / W, j = idx - i * W;
@@ -75,11 +74,11 @@ extern "C" int swv2_era5_select_normalize(const float* raw, float* out, const in
     return SWV2_OK;
 }
 
-extern "C" int swv2_era5_zenith(float* out, const float* hours, int B, int nz, int H, int W, int Cout_total, int coff, void* stream) {
-    SWV2_CHECK_ARG(out && hours && B > 0 && nz > 0 && H > 0 && W > 0, "swv2_era5_zenith: bad argument");
+extern "C" int swv2_era5_zenith(float* out, const float* sun, int B, int nz, int H, int W, int Cout_total, int coff, void* stream) {
+    SWV2_CHECK_ARG(out && sun && B > 0 && nz > 0 && H > 0 && W > 0, "swv2_era5_zenith: bad argument");
     SWV2_CHECK_ARG(coff >= 0 && coff + nz <= Cout_total, "swv2_era5_zenith: channel range outside the output");
     dim3 grid(cdiv((long)H * W, 256 * 8), B * nz);
-    hipLaunchKernelGGL(era5_zenith_kernel, grid, dim3(256), 0, (hipStream_t)stream, out, hours, nz, H, W, Cout_total, coff);
+    hipLaunchKernelGGL(era5_zenith_kernel, grid, dim3(256), 0, (hipStream_t)stream, out, sun, nz, H, W, Cout_total, coff);
     SWV2_CHECK_LAUNCH("swv2_era5_zenith");
     return SWV2_OK;
 }

@@ -366,10 +366,14 @@ def era5_select_normalize(raw, out, chan, mean, std, coff=0, stream=None):
                                                 H, W, Ct, coff, stream if stream is not None else _stream()), "swv2_era5_select_normalize")
 
 
-def era5_zenith(out, hours, coff, stream=None):
-    """hours [B, nz] fp32 (hours since Jan 1st) -> out[:, coff : coff + nz] = cos zenith"""
+def era5_zenith(out, sun, coff, stream=None):
+    """sun [B, nz, 3] fp32 = (sin dec, cos dec, hour angle at longitude 0) per time point (utils/data_loader_era5.sun_position)
+    -> out[:, coff : coff + nz] = cos of the solar zenith angle"""
     B, Ct, H, W = out.shape
-    L.check(L.load().swv2_era5_zenith(_p(out), _p(hours), B, hours.shape[1], H, W, Ct, coff,
+    _chk(sun, torch.float32, "era5_zenith sun")
+    if sun.dim() != 3 or sun.shape[0] != B or sun.shape[2] != 3:
+        raise L.Swv2Error(f"era5_zenith: sun must be [B, nz, 3], got {tuple(sun.shape)}")
+    L.check(L.load().swv2_era5_zenith(_p(out), _p(sun), B, sun.shape[1], H, W, Ct, coff,
                                       stream if stream is not None else _stream()), "swv2_era5_zenith")
 
 

@@ -37,15 +37,38 @@ def _get(params, key, default):
     return params[key] if key in params else default
 
 
+def sun_position(year: int, hours: float):
+    """(sin dec, cos dec, hour angle at longitude 0) of the Sun `hours` after Jan 1st 00:00 UTC of `year`, float64 scalars.
+
+    The time-dependent part of the reference's zenith channel (data_loader_era5.py:109-146 -> modulus.utils.zenith_angle.
+    cos_zenith_angle, a dependency that is absent here): Greenwich mean sidereal time (IAU-82 polynomial), the Sun's true
+    ecliptic longitude (mean longitude + equation of centre), obliquity, then right ascension / declination;
+    hour angle(lon) = GMST + lon - RA.  Everything that varies per pixel is left to cos_zenith / the HIP kernel:
+    cos(zenith) = sin(lat) sin(dec) + cos(lat) cos(dec) cos(hour angle).  oracle/zenith.py restates the published routine
+    function by function; tests hold this implementation to it."""
+    import datetime
+    t = datetime.datetime(int(year), 1, 1) + datetime.timedelta(hours=float(hours)) - datetime.datetime(2000, 1, 1, 12)
+    jc = (t.days + t.seconds / 86400.0 + t.microseconds / 86400.0e6) / 36525.0           # Julian centuries since J2000.0
+    gmst = math.radians((67310.54841 + jc * (876600 * 3600 + 8640184.812866 + jc * (0.093104 - jc * 6.2 * 10e-6))) / 240.0) % (2 * math.pi)
+    m = math.radians(357.52910 + 35999.05030 * jc - 0.0001559 * jc * jc - 0.00000048 * jc ** 3)
+    lam = math.radians(280.46645 + 36000.76983 * jc + 0.0003032 * jc * jc) + math.radians(
+        (1.914600 - 0.004817 * jc - 0.000014 * jc * jc) * math.sin(m) + (0.019993 - 0.000101 * jc) * math.sin(2 * m) + 0.000290 * math.sin(3 * m))
+    eps = math.radians(23.0 + 26.0 / 60 + 21.406 / 3600.0 - (46.836769 * jc - 0.0001831 * jc ** 2 + 0.00200340 * jc ** 3
+                                                            - 0.576e-6 * jc ** 4 - 4.34e-8 * jc ** 5) / 3600.0)
+    x, y, z = math.cos(lam), math.cos(eps) * math.sin(lam), math.sin(eps) * math.sin(lam)
+    r = math.sqrt(1.0 - z * z)
+    dec, ra = math.atan2(z, r), 2.0 * math.atan2(y, x + r)
+    ha0 = math.remainder(gmst - ra, 2 * math.pi)            # reduced in float64: the kernel adds the longitude in fp32
+    return math.sin(dec), math.cos(dec), ha0
+
+
 def cos_zenith(year: int, hours: float, H: int, W: int) -> torch.Tensor:
-    """Smooth stand-in for modulus' cos_zenith_angle (absent): textbook declination / hour-angle formula on the
-    0.25-degree grid (lat 90..-90, lon 0..360), [H, W] float32 in [-1, 1]."""
-    lat = torch.deg2rad(torch.linspace(90.0, -90.0, 721)[:H]).view(-1, 1)
-    lon = torch.deg2rad(torch.arange(0, 360, 0.25)[:W]).view(1, -1)
-    day = hours / 24.0
-    dec = math.radians(-23.44) * math.cos(2 * math.pi * (day + 10.0) / 365.25)
-    hour_angle = 2 * math.pi * ((hours % 24.0) / 24.0) + lon - math.pi
-    return (torch.sin(lat) * math.sin(dec) + torch.cos(lat) * math.cos(dec) * torch.cos(hour_angle)).float()
+    """cos of the solar zenith angle on the 0.25-degree grid (lat 90 .. -90, lon 0 .. 359.75; data_loader_era5.py:60-64),
+    [H, W] float32 (rows cropped like :175-176), `hours` after Jan 1st of `year` (:127-131)."""
+    sd, cd, ha0 = sun_position(year, hours)
+    lat = torch.deg2rad(torch.linspace(90.0, -90.0, 721, dtype=torch.float64)[:H]).view(-1, 1)
+    lon = torch.deg2rad(torch.arange(0, 360, 0.25, dtype=torch.float64)[:W]).view(1, -1)
+    return (torch.sin(lat) * sd + torch.cos(lat) * cd * torch.cos(ha0 + lon)).float()
 
 
 class GetDataset(Dataset):

@@ -28,6 +28,7 @@ import numpy as np
 import torch
 
 from .. import ops
+from .data_loader_era5 import sun_position
 
 
 # ---- sources ---------------------------------------------------------------------------------------------------
@@ -155,7 +156,7 @@ class Era5HostPipeline:
         self.out = [(torch.empty(self.B, self.Cin_total, self.H, self.W, device=device),
                      torch.empty(self.B, self.S * self.n_out, self.H, self.W, device=device),
                      torch.empty(self.B, self.S, self.H, self.W, device=device) if self.add_zenith else None) for _ in range(2)]
-        self.hours = [torch.empty(self.B, 1 + self.S, dtype=torch.float32, pin_memory=True) for _ in range(ring + 1)]
+        self.hours = [torch.empty(self.B, 1 + self.S, 3, dtype=torch.float32, pin_memory=True) for _ in range(ring + 1)]    # sun positions
         self.copy_stream = torch.cuda.Stream(device=device)
         self.pool = ThreadPoolExecutor(max_workers=workers or max(1, int(g('num_data_workers', 8))))
         logging.info("ERA5 host pipeline: %d samples (%d years), shard %d/%d, %d steps/epoch, %s staging",
@@ -188,9 +189,11 @@ class Era5HostPipeline:
         cs = self.copy_stream
         inp, tar, tz = self.out[slot_dev]
         hrs = self.hours[slot_pin]
-        for b, (y, t) in enumerate(locs):
-            for s in range(1 + self.S):
-                hrs[b, s] = 6.0 * (t + s * self.dt)
+        if self.add_zenith:
+            for b, (y, t) in enumerate(locs):
+                for s in range(1 + self.S):
+                    sd, cd, ha0 = sun_position(self.src.years[y], 6.0 * (t + s * self.dt))
+                    hrs[b, s, 0], hrs[b, s, 1], hrs[b, s, 2] = sd, cd, ha0
         with torch.cuda.stream(cs):
             raw_in, raw_tar = self.raw[slot_dev]
             if self.direct:

@@ -531,15 +531,18 @@ def test_model_cfg4_shape_with_channel_weighted_loss(dev, K):
                       step=int(fx["gstep"]), logit_tol=0.05) < 8e-2
 
 
-def test_full_size_block_forward_backward_against_oracle(dev, K):
-    """ONE block at the BASELINE size (B = 2, 180 x 360 tokens, 800 windows of 9 x 18, 40 of them with the shift mask, C = 128,
-    8 heads) forward AND backward against the bf16-emulating oracle (the 400-window backward -- chunking over
-    windows, XCD slice maps, partial-tile weight gradients -- was only ever run by bench.py, unchecked)."""
+@pytest.mark.parametrize("Cc,rel_pos,B", [(128, False, 2), (128, True, 2), (192, False, 1)], ids=["cfg2", "cfg2_relpos", "cfg4"])
+def test_full_size_block_forward_backward_against_oracle(dev, K, Cc, rel_pos, B):
+    """ONE block at the BASELINE size (180 x 360 tokens, 400 windows of 9 x 18 per sample, 20 of them with the shift mask, 8
+    heads) forward AND backward against the bf16-emulating oracle (the 400-window backward -- chunking over
+    windows, XCD slice maps, partial-tile weight gradients -- was only ever run by bench.py, unchecked).  Round 3:
+    also with the CPB bias at 800 windows (d bias through 256 workgroups' scratch tables + the reduction, d meta-MLP) and at
+    cfg 4's width (C = 192, head dim 24 padded to 32: the unfused proj + LN path at 64 800 rows)."""
     N = K["N"]
     torch.manual_seed(11)
-    gh, gw, wh, ww, sh, sw, Cc, h, B = 180, 360, 9, 18, 4, 9, 128, 8, 2
+    gh, gw, wh, ww, sh, sw, h = 180, 360, 9, 18, 4, 9, 8
     blk = N.SwinTransformerV2CrBlock(dim=Cc, num_heads=h, feat_size=(gh, gw), window_size=(wh, ww), shift_size=(sh, sw),
-                                     rel_pos=False, drop_path=0.0)
+                                     rel_pos=rel_pos, drop_path=0.0)
     with torch.no_grad():
         for n_, p_ in blk.named_parameters():
             if n_.endswith("norm1.weight") or n_.endswith("norm2.weight"):
@@ -556,7 +559,7 @@ def test_full_size_block_forward_backward_against_oracle(dev, K):
     xo = x.clone().requires_grad_(True)
     O.set_rounding(O.bf16_round)
     try:
-        yo = O.block_forward(xo, p, "b.", block_cfg(gh, gw, wh, ww, sh, sw, Cc, h, False), 1, training=False)
+        yo = O.block_forward(xo, p, "b.", block_cfg(gh, gw, wh, ww, sh, sw, Cc, h, rel_pos), 1, training=False)
         yo.backward(gy)
     finally:
         O.set_rounding(None)
@@ -1457,7 +1460,9 @@ def test_bench_two_rank_code_path(dev):
 # ---------------------------------------------------------------------------------------------------------------
 def test_era5_assembly_kernels(dev, K):
     ops = K["ops"]
-    from swin_v2_weather_amd.utils.data_loader_era5 import cos_zenith
+    import datetime
+    from oracle import zenith as OZ
+    from swin_v2_weather_amd.utils.data_loader_era5 import sun_position
     rng = np.random.default_rng(1)
     B, S, Craw, Hraw, Wraw, H, W = 2, 2, 7, 21, 40, 20, 36
     raw = rng.standard_normal((B, S, Craw, Hraw, Wraw)).astype(np.float32) * 50 + 10
@@ -1473,15 +1478,45 @@ def test_era5_assembly_kernels(dev, K):
     got = out.cpu().numpy()
     assert np.array_equal(got[:, 1:9], ref.reshape(B, S * 4, H, W))                 # bit-exact
     assert np.all(got[:, 0] == -7.0) and np.all(got[:, 9:] == -7.0)                 # other channels untouched
-    hours = torch.tensor([[6.0, 12.0], [4380.0, 8754.0]], device=dev)
-    ops.era5_zenith(out, hours, 9)
+    # zenith channels against the ORACLE's restatement of the reference's routine (oracle/zenith.py: modulus cos_zenith_angle,
+    # data_loader_era5.py:109-146), not against the product's own host function: a full 721 x 1440 grid at four instants
+    hours = [[6.0, 12.0], [4380.0, 8754.0]]
+    zout = torch.full((2, 3, 720, 1440), -7.0, device=dev)
+    sun = torch.tensor([[sun_position(1979 + 39 * b, h) for h in hours[b]] for b in range(2)], dtype=torch.float32, device=dev)
+    ops.era5_zenith(zout, sun, 1)
+    lon_g, lat_g = OZ.era5_grids(720, 1440)
     for b in range(2):
         for k in range(2):
-            z = cos_zenith(1979, float(hours[b, k]), H, W)
-            assert float((out[b, 9 + k].cpu() - z).abs().max()) < 2e-5
+            when = datetime.datetime(1979 + 39 * b, 1, 1) + datetime.timedelta(hours=hours[b][k])
+            z = OZ.cos_zenith_angle(when, lon_g, lat_g)
+            assert float(np.abs(zout[b, 1 + k].cpu().numpy().astype(np.float64) - z).max()) < 2e-6
+    assert bool((zout[:, 0] == -7.0).all())
     stat = torch.randn(1, H, W, device=dev)
     ops.era5_static(stat, out, 0)
     assert torch.equal(out[:, 0], stat.expand(B, H, W))
+
+
+def test_host_pipeline_reader_failure_reaches_the_training_loop(dev, K):
+    """a year file that cannot be read (here: a source whose read raises for one time slab) must fail the job: the exception of
+    the producer thread / its worker pool is re-raised in the consuming loop (it used to die silently and the
+    consumer blocked forever in filled.get())"""
+    from swin_v2_weather_amd.utils import host_pipeline as hp
+
+    class Broken(hp.SyntheticYearSource):
+        def read(self, year_idx, t, out):
+            if t == 5:
+                raise OSError("bad time slab")
+            return super().read(year_idx, t, out)
+
+    class P(dict):
+        __getattr__ = dict.__getitem__
+    src = Broken(n_years=1, n_samples=12, seed=1, shape=(3, 21, 40))
+    params = P(local_batch_size=2, dt=1, n_future=0, img_size=(20, 36), in_channels=[0, 1, 2], out_channels=[0, 1, 2], add_zenith=False,
+               seed=3, data_num_shards=1, data_shard_id=0, num_data_workers=2)
+    pipe = hp.Era5HostPipeline(params, src, dev, train=False, steps_per_epoch=6)
+    with pytest.raises(RuntimeError, match="producer thread failed"):
+        for _ in pipe:
+            pass
 
 
 @pytest.mark.parametrize("pinned", [False, True])

@@ -413,6 +413,7 @@ typedef struct {
     float eps;
 } swv2_mlp_args;
 int swv2_mlp_supported(int C, int hidden);
+int swv2_mlp_recompute_supported(int C, int hidden);      /* the backward's recompute mode (swv2_mlp_bwd_args.hpre == NULL) */
 int swv2_mlp_fwd(const swv2_mlp_args* a, void* stream);
 
 /* Fused MLP branch, backward (the autograd of swv2_mlp_fwd w.r.t. x and the data-path intermediates):
@@ -427,7 +428,7 @@ typedef struct {
     const float* rstd;
     const float* gamma;    /* [C] */
     const float* scale;    /* per-sample drop-path factor or NULL */
-    const void* hpre;      /* bf16 [M][hidden] saved by the forward */
+    const void* hpre;      /* bf16 [M][hidden] saved by the forward, or NULL (recompute mode, below) */
     const void* w2t;       /* bf16 [hidden][C] = fc2.weight^T (swv2_prep_weight, transpose) */
     const void* w1t;       /* bf16 [C][hidden] = fc1.weight^T */
     void* da2;             /* out bf16 [M][C] */
@@ -437,6 +438,11 @@ typedef struct {
     float* dbeta;
     float* ws;
     int M, C, hidden, rows_per_sample;
+    /* recompute mode (hpre == NULL; w1t unused): the pre-activation is rebuilt from the forward's input instead of read back
+     * -- the forward (swv2_mlp_args.hpre == NULL) then never writes it: 16 bytes per token-channel less per block */
+    const float* x;        /* [M][C] the forward's input */
+    const void* w1;        /* bf16 [hidden][C] fc1.weight */
+    const float* b1;       /* [hidden] */
 } swv2_mlp_bwd_args;
 size_t swv2_mlp_bwd_ws_floats(int M, int C);
 int swv2_mlp_bwd(const swv2_mlp_bwd_args* a, void* stream);

@@ -108,7 +108,8 @@ class MlpArgs(C.Structure):
 
 class MlpBwdArgs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("dy", "a2", "mean", "rstd", "gamma", "scale", "hpre", "w2t", "w1t", "da2", "dh", "dx",
-                                           "dgamma", "dbeta", "ws")] + [(n, C.c_int) for n in ("M", "C", "hidden", "rows_per_sample")]
+                                           "dgamma", "dbeta", "ws")] + [(n, C.c_int) for n in ("M", "C", "hidden", "rows_per_sample")] + \
+               [(n, C.c_void_p) for n in ("x", "w1", "b1")]
 
 
 class LnArgs(C.Structure):
@@ -183,6 +184,7 @@ SYMBOLS = {
     "swv2_proj_ln_fwd": (_I, [C.POINTER(ProjLnArgs), _P]),
     "swv2_proj_ln_bwd": (_I, [C.POINTER(ProjLnBwdArgs), _P]),
     "swv2_mlp_supported": (_I, [_I, _I]),
+    "swv2_mlp_recompute_supported": (_I, [_I, _I]),
     "swv2_mlp_fwd": (_I, [C.POINTER(MlpArgs), _P]),
     "swv2_mlp_bwd_ws_floats": (C.c_size_t, [_I, _I]),
     "swv2_mlp_bwd": (_I, [C.POINTER(MlpBwdArgs), _P]),

@@ -19,6 +19,7 @@
 namespace {
 
 constexpr int MLP_MAX_HIDDEN = 2048;
+constexpr int MLP_RECOMP_MAX_HIDDEN = 1024;      // recompute mode of the backward: fc1 bias in the tail of the weight-chunk region
 
 struct MlpFwd {
     const float* x; const uint16_t* w1; const float* b1; const uint16_t* w2; const float* b2;
@@ -191,9 +192,11 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(const MlpFwd a) {
                 // the pre-activation leaves through a wave-private LDS tile, two chunks (64 hidden units = 128 bytes per
                 // row) at a time: straight from the accumulator layout a store instruction covers 16 rows x 32 bytes --
                 // quarter cache lines, measured 10 us of the 100 us kernel against the same bytes in 512-byte runs
-                *(bf16x4*)(Hst + (16 * mt + fr) * PHS + 32 * (ch & 1) + 16 * ht + 4 * g) = hrs[mt][ht];
+                if (a.hpre) *(bf16x4*)(Hst + (16 * mt + fr) * PHS + 32 * (ch & 1) + 16 * ht + 4 * g) = hrs[mt][ht];
             }
-        if (ch & 1) {                                   // two chunks staged: 8 rows x 128 bytes per store instruction
+        if (!a.hpre) {
+            // recompute mode (swv2_mlp_bwd / the fc2 weight gradient rebuild the pre-activation from x): nothing is kept
+        } else if (ch & 1) {                            // two chunks staged: 8 rows x 128 bytes per store instruction
 #pragma unroll
             for (int p_ = 0; p_ < 2 * MT; ++p_) {
                 const int u = lane + 64 * p_, row = u >> 3, c8 = u & 7;
@@ -325,9 +328,15 @@ struct MlpBwd {
     uint16_t* da2; uint16_t* dh; float* dx; float* ws;
     int M, hidden, rows_per_sample;
     float* zero; long zero_n;      // optional: a buffer this launch zeroes on the side (the block's parameter-gradient carve)
+    const float* x; const uint16_t* w1; const float* b1;      // RECOMP: the forward's input, fc1.weight [hid][C] bf16, fc1.bias
 };
 
-template <int C, int MT>
+// RECOMP: the fc1 pre-activation is not read back (16 T C bytes per block written by the forward and read here) but rebuilt
+// from the block's x1 rows exactly as the forward built it -- H^T chunk = W1 chunk . X^T + b1 on the same MFMA sequence, rounded
+// to bf16 like the value the forward fed to GELU -- at the price of one more product per chunk (the kernel is HBM-bound).  The
+// fc1 weight then serves BOTH products that need it from ONE row-major LDS chunk: as A operand of the recompute (row reads)
+// and, through transposed LDS reads, as A operand of dx^T = W1^T dH^T; the separately staged W1^T chunk goes away.
+template <int C, int MT, bool RECOMP>
 __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const MlpBwd a) {
     // swv2_block_bwd: this is the FIRST kernel of a block's backward, and everything that accumulates into the block's 13
     // parameter gradients runs behind it on the stream -- so it zeroes them (16 bytes per thread and pass, spread over all
@@ -345,10 +354,16 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const MlpBwd a) {
     constexpr int ROWS = 64 * MT, PX = C + 8;          // rows per workgroup, pitch (bf16) of the staged da2 tile
     constexpr int XBYTES = ROWS * PX * 2;
     constexpr int GBYTES = (256 / (C <= 32 ? 8 : C <= 64 ? 16 : C <= 128 ? 32 : 64)) * 2 * C * 4;      // d gamma / d beta row groups
-    constexpr int WBYTES = 2 * (W1E + W2E) * 2, EBYTES = 4 * 16 * PY * 4, PBYTES = XBYTES + GBYTES;
-    constexpr int SBYTES = WBYTES > EBYTES ? (WBYTES > PBYTES ? WBYTES : PBYTES) : (EBYTES > PBYTES ? EBYTES : PBYTES);
+    // RECOMP: the fc1 bias sits behind the weight chunk buffers during the chunk loop (a global load inside the loop would drain
+    // the weight prefetch, see the forward kernel); at C = 128 that tail of the prologue's region is free, so the LDS footprint
+    // -- two workgroups per CU at 79.9 KB each -- does not grow
+    constexpr int B1BYTES = RECOMP ? MLP_RECOMP_MAX_HIDDEN * 4 : 0;
+    constexpr int WBYTES = 2 * (W1E + W2E) * 2, EBYTES = 4 * 16 * PY * 4, PBYTES = XBYTES + GBYTES, WB1 = WBYTES + B1BYTES;
+    constexpr int SBYTES0 = WB1 > EBYTES ? (WB1 > PBYTES ? WB1 : PBYTES) : (EBYTES > PBYTES ? EBYTES : PBYTES);
+    constexpr int SBYTES = (SBYTES0 + 15) / 16 * 16;
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SBYTES];
     uint16_t* smem = (uint16_t*)smem_raw;
+    float* const b1s = (float*)(smem_raw + WBYTES);
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
@@ -365,13 +380,15 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const MlpBwd a) {
     if (GTAB)
         for (int i = tid; i < GT_N; i += 256) ggtab[i] = gelu_grad_f(bf2f(gelu_tab_arg(i)));
 
+    static_assert(32 * P1 <= W2E, "the row-major fc1 chunk of the recompute mode fits the W1^T chunk's slot");
     u32x4 s1[SPT], s2[SPT];
     auto issue = [&](int ch) {          // W2^T chunk: rows 32 ch .. + 32 of [hid][C];  W1^T chunk: columns of [C][hid]
 #pragma unroll
         for (int i = 0; i < SPT; ++i) {
             const int idx = min(tid + 256 * i, NCHUNK - 1);
             s1[i] = *(const u32x4*)(a.w2t + (size_t)(32 * ch + idx / (C / 8)) * C + 8 * (idx % (C / 8)));
-            s2[i] = *(const u32x4*)(a.w1t + (size_t)(idx >> 2) * hid + 32 * ch + 8 * (idx & 3));
+            if constexpr (RECOMP) s2[i] = *(const u32x4*)(a.w1 + (size_t)(32 * ch + idx / (C / 8)) * C + 8 * (idx % (C / 8)));     // W1 chunk, rows
+            else s2[i] = *(const u32x4*)(a.w1t + (size_t)(idx >> 2) * hid + 32 * ch + 8 * (idx & 3));
         }
     };
     auto commit = [&](int buf) {
@@ -382,7 +399,8 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const MlpBwd a) {
             const int idx = tid + 256 * i;
             if (NCHUNK % 256 == 0 || idx < NCHUNK) {
                 *(u32x4*)(W1s + (idx / (C / 8)) * P1 + 8 * (idx % (C / 8))) = s1[i];
-                *(u32x4*)(W2s + (idx >> 2) * P2 + 8 * (idx & 3)) = s2[i];
+                if constexpr (RECOMP) *(u32x4*)(W2s + (idx / (C / 8)) * P1 + 8 * (idx % (C / 8))) = s2[i];
+                else *(u32x4*)(W2s + (idx >> 2) * P2 + 8 * (idx & 3)) = s2[i];
             }
         }
     };
@@ -391,8 +409,9 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const MlpBwd a) {
     // wave-private tile Hst.  Loaded straight in the accumulator layout an instruction touched 16 rows x 32 bytes.
     // Hst is shared with the dh stores: within a chunk its hpre values are read before its dh values are written to the
     // same place, the pair's dh rows are flushed at the end of the odd chunk, and only then the next pair's hpre lands.
-    u32x4 hq[2 * MT];
+    u32x4 hq[RECOMP ? 1 : 2 * MT];
     auto issue_hq = [&](int pair) {
+        if constexpr (!RECOMP)
 #pragma unroll
         for (int p_ = 0; p_ < 2 * MT; ++p_) {
             const int u = lane + 64 * p_, row = u >> 3, c8 = u & 7;
@@ -401,17 +420,36 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const MlpBwd a) {
         }
     };
     auto commit_hq = [&]() {
+        if constexpr (!RECOMP)
 #pragma unroll
         for (int p_ = 0; p_ < 2 * MT; ++p_) {
             const int u = lane + 64 * p_, row = u >> 3, c8 = u & 7;
             *(u32x4*)(Hst + row * PHS + 8 * c8) = hq[p_];
         }
     };
+    // RECOMP: the x1 tile's fragments (B operand of the recompute) through the same LDS region the da2 tile uses afterwards
+    bf16x8 xf1[RECOMP ? MT : 1][KS];
 #ifdef SWV2_MLP_STAMPS
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
 #endif
     issue(0);
     issue_hq(0);
+    if constexpr (RECOMP) {
+        constexpr int UNITS = ROWS * (C / 4);
+#pragma unroll
+        for (int i = 0; i < UNITS / 256; ++i) {
+            const int u = tid + 256 * i, row = u / (C / 4), c4 = u % (C / 4);
+            const f32x4 v = *(const f32x4*)(a.x + (size_t)min(wg_row0 + row, a.M - 1) * C + 4 * c4);
+            *(bf16x4*)(smem + row * PX + 4 * c4) = f2bf4(v);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                xf1[mt][ks] = *(const bf16x8*)(smem + (wave * 16 * MT + 16 * mt + fr) * PX + 32 * ks + 8 * g);
+        __syncthreads();
+    }
 
     // ---- LayerNorm backward in ROW layout: LPR lanes per row (4 columns each), the workgroup's rows in passes of RPP
     // rows.  A thread keeps the same 4 columns in every pass, so d gamma / d beta are private register sums over the
@@ -500,6 +538,8 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const MlpBwd a) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) yacc[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    if constexpr (RECOMP)
+        for (int i = tid; i < hid; i += 256) b1s[i] = a.b1[i];        // (the prologue is done with this region)
     commit(0);
     __syncthreads();
     // one chunk; `cur` holds this chunk's saved pre-activation, `nxt` receives the next chunk's (two register sets used
@@ -522,12 +562,34 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const MlpBwd a) {
             }
         }
         STAMP(2);
+        // RECOMP: the pre-activation of this chunk, as the forward computed it (bias as the accumulator's start value, the
+        // same k order, rounded to bf16): only its table offsets are kept while the dH accumulators are finished
+        u32x2 hpw[RECOMP ? 2 : 1][RECOMP ? MT : 1];
+        if constexpr (RECOMP) {
+#pragma unroll
+            for (int ht = 0; ht < 2; ++ht) {
+                f32x4 hp[MT];
+                const f32x4 bias = *(const f32x4*)(b1s + 32 * ch + 16 * ht + 4 * g);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) hp[mt] = bias;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bf16x8 wf = *(const bf16x8*)(W2s + (16 * ht + fr) * P1 + 32 * ks + 8 * g);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) hp[mt] = mfma32(wf, xf1[mt][ks], hp[mt]);
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) hpw[ht][mt] = __builtin_bit_cast(u32x2, f2bf4(hp[mt]));
+            }
+        }
         bf16x4 hb[MT][2];
 #pragma unroll
         for (int ht = 0; ht < 2; ++ht)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const u32x2 cw = *(const u32x2*)(Hst + (16 * mt + fr) * PHS + 32 * (ch & 1) + 16 * ht + 4 * g);
+                u32x2 cw;
+                if constexpr (RECOMP) cw = hpw[ht][mt];
+                else cw = *(const u32x2*)(Hst + (16 * mt + fr) * PHS + 32 * (ch & 1) + 16 * ht + 4 * g);
                 const uint32_t w0 = cw[0], w1 = cw[1];
                 // GELU'(stored bf16 pre-activation): fp32 table in LDS (same entries as the forward's GELU table, filled
                 // with gelu_grad_f, so bit-identical to the formula); the formula -- an exp, a reciprocal and a dozen
@@ -554,8 +616,14 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const MlpBwd a) {
         for (int mt = 0; mt < MT; ++mt) hop[mt] = __builtin_shufflevector(hb[mt][0], hb[mt][1], 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const bf16x4 lo = *(const bf16x4*)(W2s + (16 * t + fr) * P2 + 4 * g);
-            const bf16x4 hi = *(const bf16x4*)(W2s + (16 * t + fr) * P2 + 16 + 4 * g);
+            bf16x4 lo, hi;
+            if constexpr (RECOMP) {     // W1^T fragments as transposed reads of the row-major chunk: element q = W1[4 g + q (+ 16)][16 t + fr]
+                lo = lds_tr_read(W2s + (4 * g + (fr >> 2)) * P1 + 16 * t + (fr & 3) * 4);
+                hi = lds_tr_read(W2s + (16 + 4 * g + (fr >> 2)) * P1 + 16 * t + (fr & 3) * 4);
+            } else {
+                lo = *(const bf16x4*)(W2s + (16 * t + fr) * P2 + 4 * g);
+                hi = *(const bf16x4*)(W2s + (16 * t + fr) * P2 + 16 + 4 * g);
+            }
             const bf16x8 wf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) yacc[mt][t] = mfma32(wf, hop[mt], yacc[mt][t]);
@@ -628,7 +696,8 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const MlpBwd a) {
 
 template <int C, int MT>
 void launch_mlp_bwd(const MlpBwd& k, hipStream_t st) {
-    hipLaunchKernelGGL((mlp_bwd_kernel<C, MT>), dim3(cdiv(k.M, 64 * MT)), dim3(256), 0, st, k);
+    if (k.hpre) hipLaunchKernelGGL((mlp_bwd_kernel<C, MT, false>), dim3(cdiv(k.M, 64 * MT)), dim3(256), 0, st, k);
+    else hipLaunchKernelGGL((mlp_bwd_kernel<C, MT, true>), dim3(cdiv(k.M, 64 * MT)), dim3(256), 0, st, k);
 }
 
 }  // namespace
@@ -637,9 +706,13 @@ extern "C" int swv2_mlp_supported(int C, int hidden) {
     return (C == 32 || C == 64 || C == 96 || C == 128 || C == 192 || C == 256) && hidden > 0 && hidden % 32 == 0 && hidden <= MLP_MAX_HIDDEN;
 }
 
+extern "C" int swv2_mlp_recompute_supported(int C, int hidden) {
+    return swv2_mlp_supported(C, hidden) && hidden <= MLP_RECOMP_MAX_HIDDEN;
+}
+
 extern "C" int swv2_mlp_fwd(const swv2_mlp_args* a, void* stream) {
-    SWV2_CHECK_ARG(a && a->x && a->w1 && a->b1 && a->w2 && a->b2 && a->gamma && a->beta && a->hpre && a->a2 && a->mean &&
-                       a->rstd && a->y, "swv2_mlp_fwd: null pointer");
+    SWV2_CHECK_ARG(a && a->x && a->w1 && a->b1 && a->w2 && a->b2 && a->gamma && a->beta && a->a2 && a->mean &&
+                       a->rstd && a->y, "swv2_mlp_fwd: null pointer");      // (hpre may be NULL: not kept, see swv2_mlp_bwd)
     SWV2_CHECK_ARG(a->M > 0 && a->rows_per_sample > 0, "swv2_mlp_fwd: M and rows_per_sample must be positive");
     if (!swv2_mlp_supported(a->C, a->hidden)) {
         swv2_set_error("swv2_mlp_fwd: C=%d hidden=%d not instantiated (C in {32,64,96,128,192,256}, hidden %% 32 == 0); "
@@ -671,8 +744,11 @@ extern "C" int swv2_mlp_bwd(const swv2_mlp_bwd_args* a, void* stream) { return s
 
 int swv2_mlp_bwd_impl(const swv2_mlp_bwd_args* a, void* stream, int* deferred, float* zero, long zero_n) {
     SWV2_CHECK_ARG(!zero || (zero_n % 4 == 0 && ((uintptr_t)zero & 15) == 0), "swv2_mlp_bwd: the zeroed buffer must be 16-byte aligned / sized");
-    SWV2_CHECK_ARG(a && a->dy && a->a2 && a->mean && a->rstd && a->gamma && a->hpre && a->w2t && a->w1t && a->da2 && a->dh &&
+    SWV2_CHECK_ARG(a && a->dy && a->a2 && a->mean && a->rstd && a->gamma && a->w2t && a->da2 && a->dh &&
                        a->dx && a->dgamma && a->dbeta && a->ws, "swv2_mlp_bwd: null pointer");
+    SWV2_CHECK_ARG((a->hpre && a->w1t) || (a->x && a->w1 && a->b1),
+                   "swv2_mlp_bwd: either the saved pre-activation (hpre, w1t) or the recompute inputs (x, w1, b1) are needed");
+    SWV2_CHECK_ARG(a->hpre || swv2_mlp_recompute_supported(a->C, a->hidden), "swv2_mlp_bwd: recompute mode needs hidden <= %d", MLP_RECOMP_MAX_HIDDEN);
     SWV2_CHECK_ARG(a->M > 0 && a->rows_per_sample > 0, "swv2_mlp_bwd: M and rows_per_sample must be positive");
     if (!swv2_mlp_supported(a->C, a->hidden)) {
         swv2_set_error("swv2_mlp_bwd: C=%d hidden=%d not instantiated; use swv2_ln_residual_bwd + swv2_linear", a->C, a->hidden);
@@ -680,7 +756,7 @@ int swv2_mlp_bwd_impl(const swv2_mlp_bwd_args* a, void* stream, int* deferred, f
     }
     MlpBwd k = {a->dy, (const uint16_t*)a->a2, a->mean, a->rstd, a->gamma, a->scale, (const uint16_t*)a->hpre,
                 (const uint16_t*)a->w2t, (const uint16_t*)a->w1t, (uint16_t*)a->da2, (uint16_t*)a->dh, a->dx, a->ws, a->M,
-                a->hidden, a->rows_per_sample, zero, zero_n};
+                a->hidden, a->rows_per_sample, zero, zero_n, a->x, (const uint16_t*)a->w1, a->b1};
     hipStream_t st = (hipStream_t)stream;
     static const int force_mt = getenv("SWV2_MLP_MT") ? atoi(getenv("SWV2_MLP_MT")) : 0;
     const bool mt2 = force_mt ? force_mt == 2 : a->M >= 128 * 256;      // measured at C = 128, M = 129600: 170 us vs 185 us

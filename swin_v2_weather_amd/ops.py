@@ -389,14 +389,15 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_inv_scale=1.0):
                                     _stream()), "swv2_adam_step")
 
 
-def mlp_fwd(x, w1, b1, w2, b2, gamma, beta, scale, rows_per_sample, eps=1e-5):
-    """Fused fc1 -> GELU -> fc2 -> LayerNorm -> drop-path -> +x.  Returns (y, hpre, a2, mean, rstd)."""
+def mlp_fwd(x, w1, b1, w2, b2, gamma, beta, scale, rows_per_sample, eps=1e-5, keep_hpre=True):
+    """Fused fc1 -> GELU -> fc2 -> LayerNorm -> drop-path -> +x.  Returns (y, hpre, a2, mean, rstd); keep_hpre=False: the
+    pre-activation is not written (hpre = None; the backward's recompute mode rebuilds it from x)."""
     M, Cc = x.shape
     hid = w1.shape[0]
     _chk(x, torch.float32, "mlp x"); _chk(w1, BF16, "mlp w1"); _chk(w2, BF16, "mlp w2")
     dev = x.device
     y = torch.empty(M, Cc, dtype=torch.float32, device=dev)
-    hpre = torch.empty(M, hid, dtype=BF16, device=dev)
+    hpre = torch.empty(M, hid, dtype=BF16, device=dev) if keep_hpre else None
     a2 = torch.empty(M, Cc, dtype=BF16, device=dev)
     mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
     a = L.MlpArgs()
@@ -407,10 +408,11 @@ def mlp_fwd(x, w1, b1, w2, b2, gamma, beta, scale, rows_per_sample, eps=1e-5):
     return y, hpre, a2, mean, rstd
 
 
-def mlp_bwd(dy, a2, mean, rstd, gamma, scale, hpre, w2t, w1t, dgamma, dbeta, rows_per_sample):
-    """Fused LN backward -> dh = (da2 W2) * GELU'(hpre) -> dx = dy + dh W1.  Returns (dx, da2, dh); dgamma/dbeta accumulated."""
+def mlp_bwd(dy, a2, mean, rstd, gamma, scale, hpre, w2t, w1t, dgamma, dbeta, rows_per_sample, x=None, w1=None, b1=None):
+    """Fused LN backward -> dh = (da2 W2) * GELU'(hpre) -> dx = dy + dh W1.  Returns (dx, da2, dh); dgamma/dbeta accumulated.
+    hpre=None: recompute mode -- the pre-activation is rebuilt from the forward's input x, fc1.weight w1 (bf16 [hid, C]), b1."""
     M, Cc = dy.shape
-    hid = hpre.shape[1]
+    hid = w2t.shape[0]
     dev = dy.device
     da2 = torch.empty(M, Cc, dtype=BF16, device=dev)
     dh = torch.empty(M, hid, dtype=BF16, device=dev)
@@ -420,6 +422,7 @@ def mlp_bwd(dy, a2, mean, rstd, gamma, scale, hpre, w2t, w1t, dgamma, dbeta, row
     a.dy, a.a2, a.mean, a.rstd, a.gamma, a.scale, a.hpre, a.w2t, a.w1t = (_p(t) for t in (dy, a2, mean, rstd, gamma, scale, hpre, w2t, w1t))
     a.da2, a.dh, a.dx, a.dgamma, a.dbeta, a.ws = (_p(t) for t in (da2, dh, dx, dgamma, dbeta, ws))
     a.M, a.C, a.hidden, a.rows_per_sample = M, Cc, hid, rows_per_sample
+    a.x, a.w1, a.b1 = _p(x), _p(w1), _p(b1)
     L.check(_timed("mlp_bwd", L.load().swv2_mlp_bwd, C.byref(a), _stream()), "swv2_mlp_bwd")
     return dx, da2, dh
 

@@ -1192,6 +1192,16 @@ def test_fused_mlp_backward_matches_autograd(dev, K, M, Cc, hid, T):
     assert rel(dh.float(), hp.grad) < 5e-3
     dx_ref = dy.double() + rb(dh.float().cpu()).double() @ rb(w1).double()
     assert rel(dx, dx_ref) < 1e-5
+    # recompute mode (round 3): the forward keeps no pre-activation, the backward rebuilds it from x on the forward's own MFMA
+    # sequence -- same bits in, same bits out
+    if L.load().swv2_mlp_recompute_supported(Cc, hid):
+        y2, none_, a2b, mean2, rstd2 = ops.mlp_fwd(xd, ops.prep_weight(w1d), b1.to(dev), ops.prep_weight(w2d), b2.to(dev), gm.to(dev),
+                                                  bt.to(dev), sc.to(dev), T, keep_hpre=False)
+        assert none_ is None and torch.equal(y2, y) and torch.equal(a2b, a2) and torch.equal(mean2, mean)
+        dgm2, dbt2 = torch.zeros(Cc, device=dev), torch.zeros(Cc, device=dev)
+        dx2, da22, dh2 = ops.mlp_bwd(dy.to(dev), a2, mean, rstd, gm.to(dev), sc.to(dev), None, ops.prep_weight(w2d, transpose=True), None,
+                                     dgm2, dbt2, T, x=xd, w1=ops.prep_weight(w1d), b1=b1.to(dev))
+        assert torch.equal(da22, da2) and torch.equal(dh2, dh) and torch.equal(dx2, dx) and torch.equal(dgm2, dgm)
 
 
 @pytest.mark.parametrize("knob,value", [("SWV2_FUSE_MLP", "0"), ("SWV2_FUSE_MLP", "1"), ("SWV2_FUSE_PROJ_LN", "0"),

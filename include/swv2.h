@@ -151,14 +151,16 @@ enum swv2_epilogue_kind {
                                the prediction it is writing (losses.py:188-206, grids.py:115-117) against the target
                                loss_tar fp32 [B][q[0]][H][W] (channels q[1] .. q[1] + Cout): per (sample, channel)
                                sum_hw qw[h] (y - tar)^2 and sum_hw qw[h] tar^2, left as per-row-group partial sums
-                               loss_part[g][slot][c][2] (g = 64-row group of the GEMM; slot 0 = rows of the sample of the
+                               loss_part[g][slot][c][2] (g = group of SWV2_LOSS_GROUP_ROWS rows of the GEMM; slot 0 = rows of the sample of the
                                group's first row, slot 1 = rows of the following sample, zero unless the group straddles a
                                sample boundary; plain stores, no atomics: same-address float atomics from every workgroup
                                measured 8 x the whole kernel) which swv2_loss_part_reduce folds in a fixed order.  Also
                                writes loss_resid bf16 [M][N] = qw[h] (y - tar) in the GEMM's own row / column order -- the
                                operand SWV2_OP_BF16_CSCALE feeds to the head's backward, so neither the prediction nor a
-                               materialised gradient is read again.  A operand: SWV2_OP_F32 only; at least 64 rows per
-                               sample; every tensor below 2^32 elements                                                 */
+                               materialised gradient is read again.  A operand: SWV2_OP_F32 only; at least
+                               SWV2_LOSS_GROUP_ROWS rows per sample; every tensor below 2^32 elements; `out` and loss_resid must be
+                               followed by SWV2_LOSS_DUMP_BYTES of write-only scratch (masked lanes store there, so that the
+                               epilogue is branch-free)                                                 */
 };
 
 typedef struct swv2_epilogue {
@@ -173,7 +175,7 @@ typedef struct swv2_epilogue {
     /* SWV2_EPI_UNPATCH_LOSS only (ignored by every other kind) */
     const float* loss_tar;   /* target [B][q[0]][H][W] fp32 */
     const float* loss_qw;    /* quadrature row weights [H] */
-    float* loss_part;        /* [ceil(M / 64)][2][Cout][2] fp32 per-group partial sums, overwritten */
+    float* loss_part;        /* [ceil(M / SWV2_LOSS_GROUP_ROWS)][2][Cout][2] fp32 per-group partial sums, overwritten */
     void* loss_resid;        /* bf16 [M][N] */
     int q[2];                /* channels per sample of loss_tar, first target channel of this prediction */
 } swv2_epilogue;
@@ -286,9 +288,11 @@ int swv2_loss_grad(const float* prd, const float* tar, const float* quad_w, cons
 /* sums is [layers][BC][2]: the layers are added in order (layers = 1: swv2_loss_sums; SWV2_LOSS_PART_SLICES:
  * swv2_loss_part_reduce). */
 #define SWV2_LOSS_PART_SLICES 8
-/* Folds the loss epilogue's per-group partial sums: sums[j][b][coff + c][k] = sum over the 64-row groups g with
+#define SWV2_LOSS_GROUP_ROWS 32
+#define SWV2_LOSS_DUMP_BYTES 2048
+/* Folds the loss epilogue's per-group partial sums: sums[j][b][coff + c][k] = sum over the SWV2_LOSS_GROUP_ROWS-row groups g with
  * g % SWV2_LOSS_PART_SLICES == j of (slot 0 of g if g's first row lies in sample b) + (slot 1 of g if it lies in sample b - 1),
- * ascending g; T rows per sample (T >= 64).  sums: [SWV2_LOSS_PART_SLICES][B][Ct][2], overwritten for the Cout channels from coff. */
+ * ascending g; T rows per sample (T >= SWV2_LOSS_GROUP_ROWS).  sums: [SWV2_LOSS_PART_SLICES][B][Ct][2], overwritten for the Cout channels from coff. */
 int swv2_loss_part_reduce(const float* part, int M, int T, int B, int Cout, int Ct, int coff, float* sums, void* stream);
 int swv2_loss_finalize(const float* sums, int layers, const float* chw, int BC, int C, int absolute, int squared, float* loss, float* coef,
                        void* stream);

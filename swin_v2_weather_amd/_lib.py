@@ -122,6 +122,8 @@ class LnArgs(C.Structure):
 
 LN_BWD_MAX_BLOCKS = 512
 LOSS_PART_SLICES = 8          # SWV2_LOSS_PART_SLICES
+LOSS_GROUP_ROWS = 32          # SWV2_LOSS_GROUP_ROWS
+LOSS_DUMP_BYTES = 2048        # SWV2_LOSS_DUMP_BYTES
 class BlockDesc(C.Structure):
     _fields_ = ([(n, C.c_int) for n in ("B", "T", "C", "heads", "head_dim", "hidden", "L", "Lp", "DP", "nwh", "nww", "mask_thr")] +
                 [(n, C.c_void_p) for n in (

@@ -42,11 +42,11 @@ struct EpiDesc {
     int p0, p1, p2, p3, p4;
     uint32_t mg0, mg1, mg2; // fdiv magics (launch_nt2)
     // E_UNPATCH_LOSS
-    const float* loss_tar; const float* loss_qw; float* loss_part; uint16_t* loss_resid; int q0, q1;
+    const float* loss_tar; const float* loss_qw; float* loss_part; uint16_t* loss_resid; int q0, q1, q2;
 };
 
 enum { E_BF16 = 0, E_F32 = 1, E_QKV_HEADS = 2, E_GELU_GRAD = 3, E_UNPATCH = 4, E_HEADS = 5, E_F32_ACC = 6, E_BF16_GELU = 7,
-       E_UNPATCH_LOSS = 8 };
+       E_UNPATCH_LOSS = 8, E_UNPATCH_LOSS_SKIP = 9 };      // (9: the same epilogue with a skip tensor; compile-time, see the kernel)
 
 template <int KIND> struct Epi;
 
@@ -318,84 +318,89 @@ template <> struct Epi<E_UNPATCH> {
 template <> struct Epi<E_UNPATCH_LOSS> {
     EpiDesc d;
     __device__ __forceinline__ void tile(const float*, int, int, int) const {}
-    __device__ __forceinline__ void tile_loss(float* st, int m0, int n0, int lane, float (&ls)[8], float (&ls2)[8], int b0) const {
+    // What one 16 x 64 tile needs from global memory: this lane's four target float4 (its row / image row, the four channels
+    // of the wave's column block) and its quadrature weight.  Requested ONE TILE AHEAD of its use -- before the previous tile's
+    // stores are issued, across the MFMA phase between two N tiles -- because vmcnt retires in order and counts stores: waiting
+    // for a load that was issued behind a store is waiting for that store to complete (SQ_WAIT_ANY was 79 % of the kernel's
+    // wave-cycles with the loads at the top of each tile, profiles/r03_pmc_wait.json).  Everything in load_tar / tile_loss is
+    // straight-line code, so the waits are counted vmcnt(N): masked rows / channels load from clamped addresses and store into
+    // small dump areas BEHIND the prediction and the residual (same scalar base + 32-bit offset; a select between two base
+    // pointers needs 64-bit per-lane addresses, and the kernel spills).
+    struct Tar { f32x4 t[4]; float q; };
+    __device__ __forceinline__ void load_tar(int m0, int n0, int lane, Tar& o) const {
+        const int Cout = d.p0, H = d.p1, W = d.p2, gw = W >> 2, gh = H >> 2;
+        const int r = lane & 15, p = lane >> 4, mc = min(m0 + r, d.M - 1);
+        const int b = fdiv(mc, gh * gw, d.mg0), ij = mc - b * gh * gw, i = fdiv(ij, gw, d.mg1), j = ij - i * gw;
+        const uint32_t pix = (uint32_t)((4 * i + p) * W + 4 * j), plane = (uint32_t)(H * W);
+        o.q = d.loss_qw[4 * i + p];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t c = (uint32_t)min((n0 >> 4) + k, Cout - 1);
+            o.t[k] = *(const f32x4*)(d.loss_tar + (((uint32_t)b * d.q0 + d.q1 + c) * plane + pix));
+        }
+    }
+    template <bool HAS_SKIP>
+    __device__ __forceinline__ void tile_loss(float* st, int m0, int n0, int lane, float (&ls)[8], float (&ls2)[8], int b0, const Tar& in) const {
         const int Cout = d.p0, H = d.p1, W = d.p2, Cs = d.p3, gw = W >> 2, gh = H >> 2;
-        // this lane's row (patch) and image row are the same for its four items; only the channel differs.  ALL global loads
-        // of the four items first (unconditional, clamped), then the arithmetic and the stores: as  load, store, load, ...  the
-        // compiler may not move an item's target load above the previous item's store (the pointers may alias), and every
-        // item was a memory round trip of its own (548 us for the kernel).
         const int r = lane & 15, p = lane >> 4, m = m0 + r;
         const bool row_ok = m < d.M;
         const int mc = min(m, d.M - 1);
         const int b = fdiv(mc, gh * gw, d.mg0), ij = mc - b * gh * gw, i = fdiv(ij, gw, d.mg1), j = ij - i * gw;
-        // 32-bit element offsets from the (scalar) base pointers: the tensors of this epilogue are below 2^32 elements (checked by
-        // the launcher), and 64-bit per-lane addresses for four tensors cost ~20 VGPRs -- the kernel then spilled, and every
-        // spill reload in the epilogue waits with vmcnt(0) for ALL outstanding stores (300 us of a 500 us kernel)
         const uint32_t pix = (uint32_t)((4 * i + p) * W + 4 * j), plane = (uint32_t)(H * W);
-        const float q = d.loss_qw[4 * i + p];
-        const float* __restrict__ tarp = d.loss_tar;
-        float* __restrict__ outp = (float*)d.out;
-        f32x4 t[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t c = (uint32_t)min((n0 >> 4) + k, Cout - 1);
-            t[k] = *(const f32x4*)(tarp + (((uint32_t)b * d.q0 + d.q1 + c) * plane + pix));
-        }
+        const float q = in.q;
+        float* outp = (float*)d.out;
+        const uint32_t ydump = (uint32_t)d.q2 + lane * 4, rdump = (uint32_t)d.M * d.N + lane * 16;
+        const bool same = (b == b0);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int c = (n0 >> 4) + k;
-            if (!row_ok || c >= Cout) continue;
+            const bool ok = row_ok && c < Cout;
             f32x4 v = *(const f32x4*)(st + r * EP + k * 16 + p * 4);
-            if (Cs) v += *(const f32x4*)((const float*)d.aux + (((uint32_t)b * Cs + c) * plane + pix));     // (skip models only)
-            *(f32x4*)(outp + (((uint32_t)b * Cout + c) * plane + pix)) = v;
-            const f32x4 dd = v - t[k];
+            if constexpr (HAS_SKIP) v += *(const f32x4*)((const float*)d.aux + (((uint32_t)b * Cs + min(c, Cout - 1)) * plane + pix));
+            *(f32x4*)(outp + (ok ? ((uint32_t)b * Cout + c) * plane + pix : ydump)) = v;
+            const f32x4 dd = v - in.t[k];
             const float e0 = q * (dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2] + dd[3] * dd[3]);
-            const float e1 = q * (t[k][0] * t[k][0] + t[k][1] * t[k][1] + t[k][2] * t[k][2] + t[k][3] * t[k][3]);
+            const float e1 = q * (in.t[k][0] * in.t[k][0] + in.t[k][1] * in.t[k][1] + in.t[k][2] * in.t[k][2] + in.t[k][3] * in.t[k][3]);
             // rows of the group's first sample -> ls, rows of the next sample (groups that straddle a sample boundary) -> ls2.
             // Branch-free on purpose: with the minority rows under `else { atomicAdd }` the compiler closed every item with
             // s_waitcnt vmcnt(0) at the merge point, i.e. every item waited for its own stores (+150 us on the kernel).
-            const bool same = (b == b0);
-            ls[2 * k] += same ? e0 : 0.f;
-            ls[2 * k + 1] += same ? e1 : 0.f;
-            ls2[2 * k] += same ? 0.f : e0;
-            ls2[2 * k + 1] += same ? 0.f : e1;
+            ls[2 * k] += (ok && same) ? e0 : 0.f;
+            ls[2 * k + 1] += (ok && same) ? e1 : 0.f;
+            ls2[2 * k] += (ok && !same) ? e0 : 0.f;
+            ls2[2 * k + 1] += (ok && !same) ? e1 : 0.f;
             *(f32x4*)(st + r * EP + k * 16 + p * 4) = q * dd;       // residual back into the staging tile (this item's own slot)
         }
         // residual rows out as bf16, row-major: lane -> (row lane / 4, 16 columns), 128 contiguous bytes per row
         const int r2 = lane >> 2, c0 = (lane & 3) * 16, m2 = m0 + r2, n = n0 + c0;
-        if (m2 < d.M && n < d.N) {
-            float v[16];
+        float v[16];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) *(f32x4*)(v + 4 * u) = *(const f32x4*)(st + r2 * EP + c0 + 4 * u);
-            uint16_t* o = d.loss_resid + ((uint32_t)m2 * d.N + n);
-            *(uint4*)o = pack8(v);
-            *(uint4*)(o + 8) = pack8(v + 8);
-        }
+        for (int u = 0; u < 4; ++u) *(f32x4*)(v + 4 * u) = *(const f32x4*)(st + r2 * EP + c0 + 4 * u);
+        uint16_t* o = d.loss_resid + ((m2 < d.M && n < d.N) ? (uint32_t)m2 * d.N + n : rdump);
+        *(uint4*)o = pack8(v);
+        *(uint4*)(o + 8) = pack8(v + 8);
     }
     // loss_part[group][slot][Cout][2]: slot 0 = rows of the sample of the group's first row, slot 1 = rows of the following
     // sample (zero unless the group straddles a boundary).  Lane 63 holds the DPP sums and stores 8 floats per slot.
-    __device__ __forceinline__ void flush(float (&ls)[8], float (&ls2)[8], int m_first, int n0, int lane) const {
+    template <int GR> __device__ __forceinline__ void flush(float (&ls)[8], float (&ls2)[8], int m_first, int n0, int lane) const {
         float a[8], b2[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) { a[k] = wave_sum_dpp63(ls[k]); b2[k] = wave_sum_dpp63(ls2[k]); }
+        // lane 63 holds the sums and stores them, 8 bytes per (slot, channel); every other lane -- and lane 63 for channels past
+        // Cout / rows past M -- stores the same instruction into the dump area behind the residual: no branch, so the waits of
+        // the main loop behind this epilogue stay counted
         const int c0 = n0 >> 4;
-        if (lane == 63 && m_first < d.M && c0 < d.p0) {
-            float* sp = d.loss_part + ((long)(m_first >> 6) * 2 * d.p0 + c0) * 2;
-            if (c0 + 4 <= d.p0) {          // (Cout*2 floats per slot: 8-byte aligned pairs)
+        float* const dump = (float*)(d.loss_resid + (size_t)d.M * d.N) + 2 * lane;
+        float* const sp = d.loss_part + ((long)(m_first / GR) * 2 * d.p0 + c0) * 2;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    *(f32x2*)(sp + 2 * k) = (f32x2){a[2 * k], a[2 * k + 1]};
-                    *(f32x2*)(sp + 2 * d.p0 + 2 * k) = (f32x2){b2[2 * k], b2[2 * k + 1]};
-                }
-            } else {
-                for (int k = 0; k < 4 && c0 + k < d.p0; ++k) {
-                    sp[2 * k] = a[2 * k]; sp[2 * k + 1] = a[2 * k + 1];
-                    sp[2 * d.p0 + 2 * k] = b2[2 * k]; sp[2 * d.p0 + 2 * k + 1] = b2[2 * k + 1];
-                }
-            }
+        for (int k = 0; k < 4; ++k) {
+            const bool ok = lane == 63 && m_first < d.M && c0 + k < d.p0;
+            *(f32x2*)(ok ? sp + 2 * k : dump) = (f32x2){a[2 * k], a[2 * k + 1]};
+            *(f32x2*)(ok ? sp + 2 * d.p0 + 2 * k : dump) = (f32x2){b2[2 * k], b2[2 * k + 1]};
         }
     }
 };
+
+template <> struct Epi<E_UNPATCH_LOSS_SKIP> : Epi<E_UNPATCH_LOSS> {};
 
 // ------------------------------------------------------------------------------------------------
 // NT kernel
@@ -469,7 +474,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(ALoad<AK> al, cons
     };
 
     f32x4 acc[RT][4];
+    constexpr bool LOSS = EK == E_UNPATCH_LOSS || EK == E_UNPATCH_LOSS_SKIP;
+    [[maybe_unused]] typename std::conditional<LOSS, typename Epi<E_UNPATCH_LOSS>::Tar, int>::type ltar0, ltar1;
+    if constexpr (LOSS) ep.load_tar(m_base + wr * 16 * RT, wc * 64, lane, ltar0);
     issue(0);
+    if constexpr (LOSS) commit(0);
     for (int s = 0; s < steps; ++s) {
         const int nt = s / ksteps, ks = s - nt * ksteps;
         if (ks == 0) {
@@ -478,7 +487,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(ALoad<AK> al, cons
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        commit(s);
+        // LOSS: the tile of step s was committed at the end of step s - 1 -- inside the branch that ran (or did not run) the
+        // epilogue, so the wait for the prefetched weight tile is a counted vmcnt(N) behind the epilogue's straight-line
+        // loads / stores instead of the vmcnt(0) a wait behind the merge of the two paths gets (which would wait for every store
+        // of the epilogue to complete)
+        if constexpr (!LOSS) commit(s);
         __syncthreads();
         if (s + 1 < steps) issue(s + 1);
         const uint16_t* As = As0 + (a_res ? ks * BMT * BK : 0);
@@ -497,20 +510,37 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(ALoad<AK> al, cons
         __syncthreads();                                   // tile consumed: the next commit may overwrite it
         if (ks == ksteps - 1) {
             float* st = stage + wave * 16 * EP;            // wave-private: no further barrier needed
-            [[maybe_unused]] float ls[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ls2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            [[maybe_unused]] int b0 = 0;
-            if constexpr (EK == E_UNPATCH_LOSS)            // sample of the wave's first row (rows past M belong to no sample)
-                b0 = fdiv(min(m_base + wr * 16 * RT, M - 1), (ep.d.p1 >> 2) * (ep.d.p2 >> 2), ep.d.mg0);
+            const int m_w = m_base + wr * 16 * RT, n_w = nt * BN + wc * 64;
+            if constexpr (LOSS) {
+                static_assert(!LOSS || RT == 2 || RT == 4, "even number of row tiles: two named target sets");
+                float ls[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ls2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                const int b0 = fdiv(min(m_w, M - 1), (ep.d.p1 >> 2) * (ep.d.p2 >> 2), ep.d.mg0);      // sample of the wave's first row
 #pragma unroll
-            for (int i = 0; i < RT; ++i) {
+                for (int i = 0; i < RT; ++i) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) st[(4 * g + r) * EP + 16 * j + fr] = acc[i][j][r];
-                if constexpr (EK == E_UNPATCH_LOSS) ep.tile_loss(st, m_base + wr * 16 * RT + i * 16, nt * BN + wc * 64, lane, ls, ls2, b0);
-                else ep.tile(st, m_base + wr * 16 * RT + i * 16, nt * BN + wc * 64, lane);
+                        for (int r = 0; r < 4; ++r) st[(4 * g + r) * EP + 16 * j + fr] = acc[i][j][r];
+                    // request the NEXT tile's targets (next row tile, or the first row tile of the next N tile) before this
+                    // tile's stores; ltar0 serves the even, ltar1 the odd row tiles
+                    if (i + 1 < RT) ep.load_tar(m_w + 16 * (i + 1), n_w, lane, (i & 1) ? ltar0 : ltar1);
+                    else ep.load_tar(m_w, n_w + BN, lane, ltar0);         // (clamped inside: unconditional also behind the last N tile)
+                    ep.template tile_loss<EK == E_UNPATCH_LOSS_SKIP>(st, m_w + 16 * i, n_w, lane, ls, ls2, b0, (i & 1) ? ltar1 : ltar0);
+                }
+                ep.template flush<16 * RT>(ls, ls2, m_w, n_w, lane);
+                if (s + 1 < steps) commit(s + 1);
+            } else {
+#pragma unroll
+                for (int i = 0; i < RT; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) st[(4 * g + r) * EP + 16 * j + fr] = acc[i][j][r];
+                    ep.tile(st, m_w + i * 16, n_w, lane);
+                }
             }
-            if constexpr (EK == E_UNPATCH_LOSS) { static_assert(EK != E_UNPATCH_LOSS || RT == 4, "64-row groups"); ep.flush(ls, ls2, m_base + wr * 16 * RT, nt * BN + wc * 64, lane); }
+        } else if constexpr (LOSS) {
+            if (s + 1 < steps) commit(s + 1);
         }
     }
 }
@@ -760,12 +790,13 @@ int launch_nt2(const swv2_operand* a, const void* w, const swv2_epilogue* e, int
     ep.d.ld = e->ld; ep.d.M = M; ep.d.N = N;
     ep.d.p0 = e->p[0]; ep.d.p1 = e->p[1]; ep.d.p2 = e->p[2]; ep.d.p3 = e->p[3]; ep.d.p4 = e->p[4];
     ep.d.mg0 = ep.d.mg1 = ep.d.mg2 = 0;
-    ep.d.loss_tar = nullptr; ep.d.loss_qw = nullptr; ep.d.loss_part = nullptr; ep.d.loss_resid = nullptr; ep.d.q0 = ep.d.q1 = 0;
+    ep.d.loss_tar = nullptr; ep.d.loss_qw = nullptr; ep.d.loss_part = nullptr; ep.d.loss_resid = nullptr; ep.d.q0 = ep.d.q1 = ep.d.q2 = 0;
     if (EK == E_QKV_HEADS || EK == E_HEADS) { ep.d.mg0 = fdiv_magic(e->p[2]); ep.d.mg1 = fdiv_magic(e->p[0]); }
-    if (EK == E_UNPATCH || EK == E_UNPATCH_LOSS) { ep.d.mg0 = fdiv_magic((e->p[1] / 4) * (e->p[2] / 4)); ep.d.mg1 = fdiv_magic(e->p[2] / 4); }
-    if (EK == E_UNPATCH_LOSS) {
+    if (EK == E_UNPATCH || EK == E_UNPATCH_LOSS || EK == E_UNPATCH_LOSS_SKIP) { ep.d.mg0 = fdiv_magic((e->p[1] / 4) * (e->p[2] / 4)); ep.d.mg1 = fdiv_magic(e->p[2] / 4); }
+    if (EK == E_UNPATCH_LOSS || EK == E_UNPATCH_LOSS_SKIP) {
         ep.d.loss_tar = e->loss_tar; ep.d.loss_qw = e->loss_qw; ep.d.loss_part = e->loss_part; ep.d.loss_resid = (uint16_t*)e->loss_resid;
         ep.d.q0 = e->q[0]; ep.d.q1 = e->q[1];
+        ep.d.q2 = (int)((long)(M / ((e->p[1] / 4) * (e->p[2] / 4))) * e->p[0] * e->p[1] * e->p[2]);      // first float behind the prediction
     }
     // the two per-block products at the benchmark width: resident-weight persistent kernel
     static const int rw = getenv("SWV2_GEMM_RW") ? atoi(getenv("SWV2_GEMM_RW")) : 1;
@@ -796,6 +827,12 @@ int launch_nt2(const swv2_operand* a, const void* w, const swv2_epilogue* e, int
             hipLaunchKernelGGL((gemm_nt_kernel<AK, EK, BM / 2>), dim3(cdiv(M, BM / 2)), dim3(NTHREADS), 0, st, make_loader<AK>(a),
                                (const uint16_t*)w, ep, M, N, K);
     }
+    if constexpr (EK == E_UNPATCH_LOSS || EK == E_UNPATCH_LOSS_SKIP) {              // 64-row workgroups: 32-row partial-sum groups (swv2_loss_group_rows)
+        half = true;
+        hipLaunchKernelGGL((gemm_nt_kernel<AK, EK, BM / 2>), dim3(cdiv(M, BM / 2)), dim3(NTHREADS), 0, st, make_loader<AK>(a),
+                           (const uint16_t*)w, ep, M, N, K);
+    }
+    if constexpr (EK != E_UNPATCH_LOSS && EK != E_UNPATCH_LOSS_SKIP)
     if (!half)
         hipLaunchKernelGGL((gemm_nt_kernel<AK, EK>), dim3(cdiv(M, BM)), dim3(NTHREADS), 0, st, make_loader<AK>(a),
                            (const uint16_t*)w, ep, M, N, K);
@@ -810,7 +847,8 @@ int launch_nt1(const swv2_operand* a, const void* w, const swv2_epilogue* e, int
         swv2_set_error("swv2_linear: SWV2_OP_BF16_CSCALE supports SWV2_EPI_F32 only (got %d)", e->kind);
         return SWV2_ERR_INVALID;
     } else {
-    if constexpr (AK == A_F32) if (e->kind == SWV2_EPI_UNPATCH_LOSS) return launch_nt2<AK, E_UNPATCH_LOSS>(a, w, e, M, N, K, st);
+    if constexpr (AK == A_F32) if (e->kind == SWV2_EPI_UNPATCH_LOSS)
+        return e->p[3] ? launch_nt2<AK, E_UNPATCH_LOSS_SKIP>(a, w, e, M, N, K, st) : launch_nt2<AK, E_UNPATCH_LOSS>(a, w, e, M, N, K, st);
     switch (e->kind) {
         case SWV2_EPI_BF16: return launch_nt2<AK, E_BF16>(a, w, e, M, N, K, st);
         case SWV2_EPI_F32: return launch_nt2<AK, E_F32>(a, w, e, M, N, K, st);
@@ -855,7 +893,7 @@ extern "C" int swv2_linear(const swv2_operand* a, const void* w_bf16, const swv2
                        "swv2_linear: the loss epilogue needs target, quadrature weights, sums, residual and q[1] + Cout <= q[0]");
         SWV2_CHECK_ARG((((uintptr_t)e->loss_tar | (uintptr_t)e->loss_resid) & 15) == 0, "swv2_linear: unaligned loss pointer");
         const double plane_ = (double)e->p[1] * e->p[2], nb_ = (double)a->rows / ((e->p[1] / 4) * (e->p[2] / 4));
-        SWV2_CHECK_ARG((e->p[1] / 4) * (e->p[2] / 4) >= 64, "swv2_linear: the loss epilogue needs at least 64 patches per sample");
+        SWV2_CHECK_ARG((e->p[1] / 4) * (e->p[2] / 4) >= SWV2_LOSS_GROUP_ROWS, "swv2_linear: the loss epilogue needs at least %d patches per sample", SWV2_LOSS_GROUP_ROWS);
         SWV2_CHECK_ARG(nb_ * e->q[0] * plane_ < 4.29e9 && nb_ * (e->p[3] > e->p[0] ? e->p[3] : e->p[0]) * plane_ < 4.29e9 && (double)a->rows * N < 4.29e9,
                        "swv2_linear: the loss epilogue indexes its tensors with 32-bit element offsets (tensor too large)");
     }

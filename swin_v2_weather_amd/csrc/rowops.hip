@@ -403,8 +403,9 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
 __global__ __launch_bounds__(1024) void loss_part_reduce_kernel(const float* __restrict__ part, int M, int T, int Cout, int Ct,
                                                                 int coff, int B, float* __restrict__ sums) {
     const int b = blockIdx.x, j = blockIdx.y, nv = 2 * Cout;
-    const int ngroups = (M + 63) / 64;
-    const int g_lo = (b * T + 63) / 64, g_hi = min(((b + 1) * T + 63) / 64, ngroups);     // groups whose first row lies in sample b
+    constexpr int GR = SWV2_LOSS_GROUP_ROWS;
+    const int ngroups = (M + GR - 1) / GR;
+    const int g_lo = (b * T + GR - 1) / GR, g_hi = min(((b + 1) * T + GR - 1) / GR, ngroups);     // groups whose first row lies in sample b
     constexpr int S = SWV2_LOSS_PART_SLICES;
     const int sub = threadIdx.x >> 8, t = threadIdx.x & 255;
     __shared__ float red[3][256];
@@ -680,7 +681,7 @@ extern "C" int swv2_loss_sums(const float* prd, const float* tar, const float* q
 }
 
 extern "C" int swv2_loss_part_reduce(const float* part, int M, int T, int B, int Cout, int Ct, int coff, float* sums, void* stream) {
-    SWV2_CHECK_ARG(part && sums && M > 0 && T >= 64 && B > 0 && M == B * T && Cout > 0 && coff >= 0 && coff + Cout <= Ct,
+    SWV2_CHECK_ARG(part && sums && M > 0 && T >= SWV2_LOSS_GROUP_ROWS && B > 0 && M == B * T && Cout > 0 && coff >= 0 && coff + Cout <= Ct,
                    "loss_part_reduce: bad argument");
     hipLaunchKernelGGL(loss_part_reduce_kernel, dim3(B, SWV2_LOSS_PART_SLICES), dim3(1024), 0, (hipStream_t)stream, part, M, T, Cout,
                        Ct, coff, B, sums);

@@ -770,11 +770,14 @@ class _HeadFn(torch.autograd.Function):
             # the loss rides in the epilogue (LossHandler.fused_with): quadrature sums of (y - tar)^2, tar^2 per (sample,
             # channel) while the prediction tile is in registers, and the weighted residual in the GEMM's layout for backward
             tar, qw = lossctx
-            y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=dev)
-            M = B * gh * gw
+            M, GRP = B * gh * gw, L.LOSS_GROUP_ROWS
+            # the prediction and the residual carry SWV2_LOSS_DUMP_BYTES of scratch behind them (the epilogue's masked lanes)
+            ybuf = torch.empty(B * Cout * H * W + L.LOSS_DUMP_BYTES // 4, dtype=torch.float32, device=dev)
+            y = ybuf[:B * Cout * H * W].view(B, Cout, H, W)
             sums = torch.empty(L.LOSS_PART_SLICES, B, Cout, 2, dtype=torch.float32, device=dev)
-            part = torch.empty((M + 63) // 64, 2, Cout, 2, dtype=torch.float32, device=dev)
-            resid = torch.empty(M, Cout * 16, dtype=ops.BF16, device=dev)
+            part = torch.empty((M + GRP - 1) // GRP, 2, Cout, 2, dtype=torch.float32, device=dev)
+            rbuf = torch.empty(M * Cout * 16 + L.LOSS_DUMP_BYTES // 2, dtype=ops.BF16, device=dev)
+            resid = rbuf[:M * Cout * 16].view(M, Cout * 16)
             ops.linear(ops.op_f32(e2d), wb, ops.epilogue(L.EPI_UNPATCH_LOSS, y, aux=skip, p=(Cout, H, W, Cs, 0),
                                                          loss=(tar, qw, part, resid, 0)), Cout * 16, tag="head_fwd")
             ops.loss_part_reduce(part, M, gh * gw, B, Cout, 0, sums)

@@ -146,7 +146,8 @@ def op_merge_ln(x4d, mean, rstd, gamma, beta):
 
 def epilogue(kind, out, ld=0, bias=None, aux=None, aux_out=None, rowidx=None, p=(0, 0, 0, 0, 0), loss=None) -> L.Epilogue:
     """loss (EPI_UNPATCH_LOSS) = (tar [B, Ct, H, W] fp32, quadrature row weights [H], per-group partial sums
-    [ceil(M / 64), 2, Cout, 2] fp32, residual bf16 [M, N], first target channel); follow the launch with loss_part_reduce"""
+    [ceil(M / LOSS_GROUP_ROWS), 2, Cout, 2] fp32, residual bf16 [M, N], first target channel); `out` and the residual must be
+    views with LOSS_DUMP_BYTES of allocated memory behind them; follow the launch with loss_part_reduce"""
     e = L.Epilogue()
     e.kind, e.out, e.bias, e.aux, e.aux_out, e.rowidx, e.ld = kind, _p(out), _p(bias), _p(aux), _p(aux_out), _p(rowidx), ld
     e.p = (C.c_int * 5)(*p)
@@ -155,6 +156,10 @@ def epilogue(kind, out, ld=0, bias=None, aux=None, aux_out=None, rowidx=None, p=
         tar, qw, part, resid, coff = loss
         _chk(tar, torch.float32, "loss target"); _chk(qw, torch.float32, "quadrature weights")
         _chk(resid, BF16, "loss residual"); _chk(part, torch.float32, "loss partial sums")
+        for t_, nm in ((out, "out"), (resid, "residual")):      # room behind the tensors for the masked lanes' stores
+            room = t_.untyped_storage().nbytes() - (t_.storage_offset() + t_.numel()) * t_.element_size()
+            if room < L.LOSS_DUMP_BYTES:
+                raise L.Swv2Error(f"loss epilogue: {nm} needs {L.LOSS_DUMP_BYTES} bytes of allocated scratch behind it ({room} found)")
         e.loss_tar, e.loss_qw, e.loss_part, e.loss_resid = _p(tar), _p(qw), _p(part), _p(resid)
         e.q = (C.c_int * 2)(tar.shape[1], coff)
     return e

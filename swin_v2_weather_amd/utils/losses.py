@@ -90,7 +90,7 @@ class _LossCtx:
         t = self.tar
         return (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and not t.requires_grad and t.dim() == 4 and
                 t.shape[0] == x.shape[0] and t.shape[1] == net.out_chans and tuple(t.shape[2:]) == tuple(x.shape[2:]) and
-                self.qw.numel() == t.shape[2] and t.shape[3] % 4 == 0 and (t.shape[2] // 4) * (t.shape[3] // 4) >= 64 and
+                self.qw.numel() == t.shape[2] and t.shape[3] % 4 == 0 and (t.shape[2] // 4) * (t.shape[3] // 4) >= 32 and
                 t.numel() < 2 ** 32 and x.numel() < 2 ** 32)
 
     def offer(self, y, sums):

@@ -811,10 +811,10 @@ def test_head_epilogue_loss_sums_and_scaled_residual_operand(dev, K):
     qw = torch.rand(H, device=dev) + 0.1
     y0 = torch.empty(B, Cout, H, W, device=dev)
     ops.linear(ops.op_f32(e2d), wb, ops.epilogue(L.EPI_UNPATCH, y0, aux=skip, p=(Cout, H, W, Cs, 0)), Nn)
-    y1 = torch.full((B, Cout, H, W), float("nan"), device=dev)
+    y1 = torch.full((B * Cout * H * W + L.LOSS_DUMP_BYTES // 4,), float("nan"), device=dev)[:B * Cout * H * W].view(B, Cout, H, W)
     sums_l = torch.zeros(L.LOSS_PART_SLICES, B, Cout + 2, 2, device=dev)
-    part = torch.full(((M + 63) // 64, 2, Cout, 2), float("nan"), device=dev)
-    resid = torch.full((M, Nn), float("nan"), dtype=BF, device=dev)
+    part = torch.full(((M + L.LOSS_GROUP_ROWS - 1) // L.LOSS_GROUP_ROWS, 2, Cout, 2), float("nan"), device=dev)
+    resid = torch.full((M * Nn + L.LOSS_DUMP_BYTES // 2,), float("nan"), dtype=BF, device=dev)[:M * Nn].view(M, Nn)
     ops.linear(ops.op_f32(e2d), wb, ops.epilogue(L.EPI_UNPATCH_LOSS, y1, aux=skip, p=(Cout, H, W, Cs, 0),
                                                  loss=(tar, qw, part, resid, 1)), Nn)
     ops.loss_part_reduce(part, M, T, B, Cout, 1, sums_l)

@@ -19,9 +19,9 @@ e2d = torch.randn(M, Cc, device=dev)
 wb = ops.prep_weight((torch.randn(Nn, Cc) * 0.1).to(dev))
 tar = torch.randn(B, Cout, H, W, device=dev)
 qw = torch.rand(H, device=dev)
-y = torch.empty(B, Cout, H, W, device=dev)
-part = torch.empty((M + 63) // 64, 2, Cout, 2, device=dev)
-resid = torch.empty(M, Nn, dtype=torch.bfloat16, device=dev)
+y = torch.empty(B * Cout * H * W + 512, device=dev)[:B * Cout * H * W].view(B, Cout, H, W)
+part = torch.empty((M + 31) // 32, 2, Cout, 2, device=dev)
+resid = torch.empty(M * Nn + 1024, dtype=torch.bfloat16, device=dev)[:M * Nn].view(M, Nn)
 print("plain un-patchify:", round(timeit(lambda: ops.linear(ops.op_f32(e2d), wb, ops.epilogue(L.EPI_UNPATCH, y, p=(Cout, H, W, 0, 0)), Nn)), 1), "us")
 f = lambda: ops.linear(ops.op_f32(e2d), wb, ops.epilogue(L.EPI_UNPATCH_LOSS, y, p=(Cout, H, W, 0, 0), loss=(tar, qw, part, resid, 0)), Nn)
 print("loss epilogue:", round(timeit(f), 1), "us")

@@ -130,12 +130,20 @@ def roofline_entry(name, ktimes, a, pmc, B):
     n_l, k_ms = ktimes.get(name, (0, 0.0))
     alg = bpe * T * a.embed_dim * B
     achieved = alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    # counter traffic: only from a profile of THESE kernel sources (hash recorded by profiles/summarize.py), at this local batch,
+    # and only when exactly one profiled kernel carries the name fragment -- otherwise null with the reason
     traffic, src = None, None
-    if pmc is not None and B == pmc[1].get("_local_batch", 2):
-        for k, v in pmc[1].items():
-            if frag in k and isinstance(v, dict) and "hbm_bytes_per_launch" in v:
-                traffic, src = v["hbm_bytes_per_launch"], pmc[0]
-                break
+    if pmc is not None:
+        from swin_v2_weather_amd import _lib as L_
+        hits = [k for k, v in pmc[1].items() if frag in k and isinstance(v, dict) and "hbm_bytes_per_launch" in v]
+        if pmc[1].get("_source_hash") != L_.source_hash():
+            src = f"{pmc[0]}: taken from other kernel sources than the library being timed -- not reported"
+        elif B != pmc[1].get("_local_batch", 2):
+            src = f"{pmc[0]}: profiled at local batch {pmc[1].get('_local_batch', 2)} -- not reported"
+        elif len(hits) != 1:
+            src = f"{pmc[0]}: {len(hits)} profiled kernels match '{frag}' -- not reported"
+        else:
+            traffic, src = pmc[1][hits[0]]["hbm_bytes_per_launch"], f"{pmc[0]}: {hits[0]}"
     e = {"kernel": name, "bound": bound, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
          "traffic": traffic, "traffic_source": src, "launches_timed": n_l, "avg_ms": k_ms, "algorithmic_bytes_per_launch": alg}
     if fpe:

@@ -48,6 +48,9 @@ const char* swv2_last_error(void);
  * ------------------------------------------------------------------------------------------------------------ */
 int swv2_attn_geometry(int L, int head_dim, int* Lp, int* DP);
 
+#define SWV2_ATTN_FIRST_GEN 16
+#define SWV2_ATTN_PLAIN_STATS 8192
+
 typedef struct swv2_attn_args {
     const void* qkvh;         /* in  */
     const float* logit_scale; /* in  [heads] raw tau; sigma = exp(min(tau, ln 100))   (swinv2_global.py:305) */
@@ -69,11 +72,11 @@ typedef struct swv2_attn_args {
                                  0 = no mask. */
     int max_chunks;           /* workgroups per head (each loops over windows); 64 is a good default (swv2_block_bwd uses
                                  256 / heads at the 176-token window: one persistent workgroup per CU) */
-    int dbg;                  /* 0 in production.  Kernel-selection switches of the parity tests and probes: bit 4 = first-
-                                 generation kernels only, bit 6 / 5 = second-generation backward (+ variant), bit 7 = fwd3
-                                 with pinned fragments, bit 8 = wave-per-head backward (csrc/attn3.hip), bit 9 = without
-                                 handing its remainder to the two-phase kernel, bit 13 = two-phase backward with the softmax
-                                 statistics read from LDS instead of riding in the MFMA operands; other bits: timing probes */
+    int dbg;                  /* 0 in production.  Kernel-selection switches used by the parity tests (each selects a kernel that is
+                                 also the product path of other shapes): SWV2_ATTN_FIRST_GEN = the first-generation kernels of
+                                 csrc/attn.hip instead of the small-workgroup forward of csrc/attn2.hip; SWV2_ATTN_PLAIN_STATS =
+                                 the two-phase backward with the softmax statistics read from LDS instead of riding in the
+                                 MFMA operands */
     void* dbias_ws;           /* bwd, optional scratch of dbias_ws_bytes >= swv2_attn_dbias_ws_bytes(heads, L, max_chunks): the
                                  workgroups store their d bias tables there and one more launch sums them into dbias (in a
                                  fixed order); NULL / too small = 31 K float atomics per workgroup instead */
@@ -334,33 +337,6 @@ int swv2_era5_select_normalize(const float* raw, float* out, const int* chan, co
 int swv2_era5_zenith(float* out, const float* sun, int B, int nz, int H, int W, int Cout_total, int coff, void* stream);
 int swv2_era5_static(const float* stat, float* out, int B, int Cs, int H, int W, int Cout_total, int coff, void* stream);
 
-/* Fused attention branch, forward, for blocks WITHOUT the CPB bias (rel_pos = False, the yaml default):
- *   y = x + scale[b] * LayerNorm1(proj(W-MSA(roll / partition(x))))   scattered back through window-reverse / un-roll
- * (swinv2_global.py:446-478, 170-198, 490) as one kernel.  Writes everything the unfused kernels save for the backward
- * in the same layouts (qkvh, rnorm, oh, lse, a1, mean, rstd), so swv2_attn_bwd etc. run unchanged.  C in {32,64,96,128},
- * head_dim <= 16, an even number of heads with heads * 16 <= 128, L <= 176 (swv2_attn_branch_supported), else SWV2_ERR_UNSUPPORTED. */
-typedef struct {
-    const float* x;            /* [B*T][C] fp32 block input, image order: GEMM input (gathered) and residual */
-    const int32_t* rowidx;     /* [Bw*Lp] window row -> image row, negative = padding */
-    const void* wqkv;          /* bf16 [3*heads*16][C], rows (part, head, j) with the head dim padded to 16 */
-    const float* bqkv;         /* [3*heads*16] padded alike */
-    const void* wproj;         /* bf16 [C][heads*16] */
-    const float* bproj;        /* [C] */
-    const float* logit_scale;  /* [heads] */
-    const float* gamma;        /* LayerNorm1 weight / bias [C] */
-    const float* beta;
-    const float* scale;        /* per-sample drop-path factor or NULL */
-    void* qkvh; float* rnorm; void* oh; float* lse;   /* out: saved for swv2_attn_bwd (layouts above) */
-    void* a1;                  /* out bf16 [Bw*Lp][C] proj output, window order */
-    float* mean;               /* out [Bw*Lp] */
-    float* rstd;
-    float* y;                  /* out fp32 [B*T][C] */
-    int Bw, heads, L, head_dim, C, nwh, nww, mask_thr, rows_per_sample;
-    float eps;
-} swv2_attn_branch_args;
-int swv2_attn_branch_supported(int C, int heads, int L, int head_dim);
-int swv2_attn_branch_fwd(const swv2_attn_branch_args* a, void* stream);
-
 /* Output projection of the attention branch fused with LayerNorm1 (swinv2_global.py:318-319, 468-476, 490):
  *   forward : y[dst] = x[dst] + scale[b] * LN(merge_heads(oh) Wp^T + bp),  dst = rowidx[m] (negative = padded row, skipped);
  *             saves a1 = bf16(proj output) [Bw*Lp][C] (window order), mean, rstd            (replaces swv2_linear + swv2_ln_residual_fwd)
@@ -504,7 +480,8 @@ typedef struct swv2_block_desc {
     void* ev_stop;
     int fuse_proj_ln;        /* 1: proj + LN1 run as swv2_proj_ln_fwd / _bwd when the shape is supported (forward steps 3-4,
                                 backward steps 16, 18) */
-    int fuse_attn;           /* 1: forward steps 1-4 run as swv2_attn_branch_fwd when there is no bias and the shape is supported */
+    int fuse_attn;           /* reserved, must be 0 (the one-kernel attention branch of round 2 did not beat the four kernels and
+                                lives in tools/experiments/attn_fused.hip, outside the library) */
     int fuse_mlp;            /* 1: forward steps 5-7 run as swv2_mlp_fwd when the shape is supported (hact is then neither
                                 written nor read: the backward applies GELU to hpre on load); 0: three launches.  The backward
                                 likewise runs steps 11, 13, 15 as swv2_mlp_bwd */

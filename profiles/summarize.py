@@ -3,6 +3,9 @@
 
   python profiles/summarize.py stats <dir with *_kernel_stats.csv> <steps profiled> <out.md>
   python profiles/summarize.py pmc   <dir with FETCH pass> <dir with WRITE pass> <out.json>
+  python profiles/summarize.py counters <dir with PMC passes> <out.json>
+  python profiles/summarize.py mfma  <sq counters json> <out.json>
+  python profiles/summarize.py check <kernel_stats.md> <pmc_hbm.json> <pmc_mfma.json>     # same kernels in all three, or exit 1
 """
 import csv
 import glob
@@ -46,9 +49,48 @@ def pmc(dfetch, dwrite, out):
         # MI355X_MICROARCH.md (HBM): FETCH_SIZE reads exactly 1/2 of a wide coalesced stream on gfx950; WRITE_SIZE exact; unit KB
         fe, wr = v.get("FETCH_SIZE", {}).get("mean_kb", 0.0), v.get("WRITE_SIZE", {}).get("mean_kb", 0.0)
         v["hbm_bytes_per_launch"] = (2.0 * fe + wr) * 1024.0
+    res["_source_hash"] = source_hash()            # bench.py reports `traffic` only for the kernel sources these counters came from
+    res["_local_batch"] = int(os.environ.get("SWV2_PROFILE_BATCH", 2))
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
-    for n in sorted(res, key=lambda k: -res[k]["hbm_bytes_per_launch"])[:12]:
+    for n in sorted((k for k in res if not k.startswith("_")), key=lambda k: -res[k]["hbm_bytes_per_launch"])[:12]:
         print(f"{res[n]['hbm_bytes_per_launch'] / 1e6:10.1f} MB/launch  {n}")
+
+
+def source_hash():
+    """sha256 over the kernel sources + the C header (the same function as swin_v2_weather_amd._lib.source_hash)"""
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(root, "swin_v2_weather_amd", "csrc", "*"))) + [os.path.join(root, "include", "swv2.h")]
+    for f in files:
+        if os.path.isfile(f):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+# the kernels bench.py reports roofline objects for (name fragments)
+ROOFLINE_FRAGMENTS = ("attn_bwd_kernel", "attn_fwd3_kernel", "mlp_bwd_kernel", "mlp_fwd_kernel", "gemm_tn_group_kernel")
+
+
+def check(stats_md, hbm_json, mfma_json):
+    """the three summaries of a round must talk about the SAME kernel instantiations (round 2 shipped a derived MFMA file for
+    the kernel variant before the last commit): for every roofline kernel exactly one name per file, identical across files"""
+    import re
+    names = {"stats": set(re.findall(r"^\| `([^`]+)`", open(stats_md).read(), flags=re.M)),
+             "hbm": {k for k in json.load(open(hbm_json)) if not k.startswith("_")},
+             "mfma": set(json.load(open(mfma_json))["kernels"])}
+    bad = []
+    for frag in ROOFLINE_FRAGMENTS:
+        per = {src: sorted(n for n in ns if frag in n) for src, ns in names.items()}
+        flat = {tuple(v) for v in per.values()}
+        if len(flat) != 1 or any(len(v) != 1 for v in per.values()):
+            bad.append((frag, per))
+    for frag, per in bad:
+        print(f"MISMATCH {frag}: {per}")
+    if bad:
+        sys.exit(1)
+    print("ok: the roofline kernels carry the same names in", stats_md, hbm_json, mfma_json)
 
 
 def counters(root, out):
@@ -94,7 +136,9 @@ def mfma(sq_json, out):
 
 
 if __name__ == "__main__":
-    if sys.argv[1] == "mfma":
+    if sys.argv[1] == "check":
+        check(sys.argv[2], sys.argv[3], sys.argv[4])
+    elif sys.argv[1] == "mfma":
         mfma(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "counters":
         counters(sys.argv[2], sys.argv[3])

@@ -13,7 +13,7 @@ import threading
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("SWV2_LIB") or os.path.join(HERE, "libswv2.so")     # SWV2_LIB: a privately built variant (tools/ab_macro.sh)
-SOURCES = ["capi.hip", "attn.hip", "attn2.hip", "attn3.hip", "gemm.hip", "gemm_tn.hip", "rowops.hip", "block.hip", "cpb.hip", "mlp.hip", "attn_fused.hip", "proj_ln.hip", "dataio.hip"]
+SOURCES = ["capi.hip", "attn.hip", "attn2.hip", "gemm.hip", "gemm_tn.hip", "rowops.hip", "block.hip", "cpb.hip", "mlp.hip", "proj_ln.hip", "dataio.hip"]
 
 _lib = None
 _lock = threading.Lock()
@@ -50,6 +50,20 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+def source_hash() -> str:
+    """sha256 (16 hex digits) over the kernel sources + the C header: profiles/rNN_pmc_hbm.json records it, bench.py reports
+    counter traffic only when it matches the library it is timing (same function as profiles/summarize.py::source_hash)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(CSRC, "*"))) + [os.path.join(HERE, "..", "include", "swv2.h")]
+    for f in files:
+        if os.path.isfile(f):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 # ---- structures (mirror include/swv2.h) ---------------------------------------------------------------------
 class AttnArgs(C.Structure):
     _fields_ = [("qkvh", C.c_void_p), ("logit_scale", C.c_void_p), ("bias", C.c_void_p), ("bias_pack", C.c_void_p), ("oh", C.c_void_p),
@@ -84,13 +98,6 @@ class Epilogue(C.Structure):
                 ("q", C.c_int * 2)]
 
 
-class AttnBranchArgs(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("x", "rowidx", "wqkv", "bqkv", "wproj", "bproj", "logit_scale", "gamma", "beta", "scale",
-                                           "qkvh", "rnorm", "oh", "lse", "a1", "mean", "rstd", "y")] + \
-               [(n, C.c_int) for n in ("Bw", "heads", "L", "head_dim", "C", "nwh", "nww", "mask_thr", "rows_per_sample")] + \
-               [("eps", C.c_float)]
-
-
 class ProjLnArgs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("oh", "wp", "bp", "gamma", "beta", "scale", "rowidx", "x", "a1", "mean", "rstd", "y")] + \
                [(n, C.c_int) for n in ("Bw", "Lp", "heads", "C", "rows_per_sample")] + [("eps", C.c_float)]
@@ -121,6 +128,7 @@ class LnArgs(C.Structure):
 
 
 LN_BWD_MAX_BLOCKS = 512
+ATTN_FIRST_GEN, ATTN_PLAIN_STATS = 16, 8192      # swv2_attn_args.dbg switches (SWV2_ATTN_FIRST_GEN / _PLAIN_STATS)
 LOSS_PART_SLICES = 8          # SWV2_LOSS_PART_SLICES
 LOSS_GROUP_ROWS = 32          # SWV2_LOSS_GROUP_ROWS
 LOSS_DUMP_BYTES = 2048        # SWV2_LOSS_DUMP_BYTES
@@ -179,8 +187,6 @@ SYMBOLS = {
     "swv2_era5_select_normalize": (_I, [_P, _P, _P, _P, _P] + [_I] * 10 + [_P]),
     "swv2_era5_zenith": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "swv2_era5_static": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "swv2_attn_branch_supported": (_I, [_I, _I, _I, _I]),
-    "swv2_attn_branch_fwd": (_I, [C.POINTER(AttnBranchArgs), _P]),
     "swv2_proj_ln_supported": (_I, [_I, _I, _I]),
     "swv2_proj_ln_bwd_ws_floats": (C.c_size_t, [_I, _I]),
     "swv2_proj_ln_fwd": (_I, [C.POINTER(ProjLnArgs), _P]),

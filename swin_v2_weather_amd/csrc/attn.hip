@@ -291,7 +291,7 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
     uint16_t* __restrict__ dqkvh,          // [Bw][h][3][Lp][DP]  grads w.r.t. the UN-normalised q, k and v
     float* __restrict__ dlogit,            // [h]      (atomically accumulated)
     float* __restrict__ dbias,             // [h][L][L] (atomically accumulated) or null
-    int Bw, int h, int L, int nW, int nww, int nwh, int mask_thr, int dbg, int bw0,
+    int Bw, int h, int L, int nW, int nww, int nwh, int mask_thr,
     float* __restrict__ dbws) {          // [gridDim.x][h][L][L] partial d bias tables (summed by dbias_reduce_kernel) or null
     using C = AttnCfg<LT, DK>;
     static_assert(TPW == 1 || !HAS_BIAS, "the bias-gradient rows are sized for one key tile per wave");
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
                 dv[i][kk] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
-        const bool do_mask = (mask_thr > 0) && ((((bw + bw0) % nW) / nww) == nwh - 1);     // bw0: see swv2_attn1_bwd_range
+        const bool do_mask = (mask_thr > 0) && (((bw % nW) / nww) == nwh - 1);
         // one q-tile step; `br` / `dbrow`: this lane's bias row / bias-gradient row of the tile (TPW = 1 only)
         // MASKED / PADT (shift-mask window / a key tile with padded keys) are wave-uniform and loop-invariant: separate
         // instantiations, so the common case carries no per-element selects
@@ -756,7 +756,7 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
         GSTAMP(3);                      // barrier 1
 
         // ================= phase 2: wave = query tile(s) =================
-        if (!(dbg & 1)) {
+        {
             f32x4 dq[TPW][DK];
 #pragma unroll
             for (int i = 0; i < TPW; ++i)
@@ -899,9 +899,6 @@ __global__ __launch_bounds__(256) void dbias_reduce_kernel(const float* __restri
     dbias[i] += (s0 + s1) + (s2 + s3);
 }
 
-// first window of a sub-range launch (swv2_attn1_bwd_range): the pointers of `a` are advanced, the shift-mask row is computed
-// from the window's index in the whole batch
-static thread_local int g_bw0 = 0;
 
 template <int LT, int DK, int LFIX>
 int launch_bwd(const swv2_attn_args* a, hipStream_t st) {
@@ -919,7 +916,7 @@ int launch_bwd(const swv2_attn_args* a, hipStream_t st) {
         hipLaunchKernelGGL((attn_bwd_kernel<LT, DK, true, LFIX, 1>), grid, block, 0, st, (const uint16_t*)a->qkvh, a->logit_scale,
                            a->bias, bimg, (const uint16_t*)a->oh, (const uint16_t*)a->doh, a->lse, a->rnorm,
                            (uint16_t*)a->dqkvh, a->dlogit_scale, a->dbias, a->Bw, a->heads, a->L, nW, a->nww, a->nwh,
-                           a->mask_thr, a->dbg, g_bw0, dbws);
+                           a->mask_thr, dbws);
         if (dbws) {
             const int n = a->heads * a->L * a->L;
             hipLaunchKernelGGL(dbias_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)dbws, a->dbias, n, nchunk);
@@ -929,17 +926,17 @@ int launch_bwd(const swv2_attn_args* a, hipStream_t st) {
         // (224 us vs 178 us): kept as a template option, not used
         constexpr int TPW = 1;
         dim3 grid(nchunk, a->heads), block(64 * ((LT + TPW - 1) / TPW));
-        // 16-wide heads: statistics / mask inside the MFMA operands (dbg bit 13 keeps the kernel that reads them from LDS)
-        if (DK == 1 && !(a->dbg & 8192))
+        // 16-wide heads: statistics / mask inside the MFMA operands (SWV2_ATTN_PLAIN_STATS keeps the kernel that reads them from LDS)
+        if (DK == 1 && !(a->dbg & SWV2_ATTN_PLAIN_STATS))
             hipLaunchKernelGGL((attn_bwd_kernel<LT, DK, false, LFIX, TPW, true>), grid, block, 0, st, (const uint16_t*)a->qkvh,
                                a->logit_scale, a->bias, (const uint16_t*)nullptr, (const uint16_t*)a->oh, (const uint16_t*)a->doh, a->lse,
                                a->rnorm, (uint16_t*)a->dqkvh, a->dlogit_scale, a->dbias, a->Bw, a->heads, a->L, nW, a->nww, a->nwh,
-                               a->mask_thr, a->dbg, g_bw0, (float*)nullptr);
+                               a->mask_thr, (float*)nullptr);
         else
         hipLaunchKernelGGL((attn_bwd_kernel<LT, DK, false, LFIX, TPW>), grid, block, 0, st, (const uint16_t*)a->qkvh,
                            a->logit_scale, a->bias, (const uint16_t*)nullptr, (const uint16_t*)a->oh, (const uint16_t*)a->doh, a->lse, a->rnorm,
                            (uint16_t*)a->dqkvh, a->dlogit_scale, a->dbias, a->Bw, a->heads, a->L, nW, a->nww, a->nwh,
-                           a->mask_thr, a->dbg, g_bw0, (float*)nullptr);
+                           a->mask_thr, (float*)nullptr);
     }
     SWV2_CHECK_LAUNCH("swv2_attn_bwd");
     return SWV2_OK;
@@ -1022,16 +1019,13 @@ extern "C" int swv2_attn_pack_bias(const float* bias, int heads, int L, void* ou
     return SWV2_OK;
 }
 
-// second-generation kernels (attn2.hip): 0 / negative = handled (ok / error), 1 = shape not covered
+// the small-workgroup forward of attn2.hip: 0 / negative = handled (ok / error), 1 = shape not covered
 int swv2_attn2_fwd(const swv2_attn_args* a, int Lp, int DP, void* stream);
-int swv2_attn2_bwd(const swv2_attn_args* a, int Lp, int DP, void* stream);
-// third generation (attn3.hip): one wave per (window, head), head dims <= 16 without bias
-int swv2_attn3_bwd(const swv2_attn_args* a, int Lp, int DP, void* stream);
 
 extern "C" int swv2_attn_fwd(const swv2_attn_args* a, void* stream) {
     int rc0 = check_args(a, false);
     if (rc0) return rc0;
-    if (!(a->dbg & 16)) {                     // dbg bit 4: force the first-generation kernel (tools/perf_probe.py A/B runs)
+    if (!(a->dbg & SWV2_ATTN_FIRST_GEN)) {
         int Lp2, DP2;
         int rc2 = swv2_attn_geometry(a->L, a->head_dim, &Lp2, &DP2);
         if (rc2) return rc2;
@@ -1041,37 +1035,8 @@ extern "C" int swv2_attn_fwd(const swv2_attn_args* a, void* stream) {
     SWV2_ATTN_DISPATCH(launch_fwd)
 }
 
-// two-phase kernel on the windows [w0, Bw) only (no CPB bias): the remainder that the wave-per-head kernel of attn3.hip
-// leaves to it when the (window, head) units do not fill its last round of waves
-int swv2_attn1_bwd_range(const swv2_attn_args* a0, int w0, void* stream) {
-    int Lp0, DP0;
-    int rc0 = swv2_attn_geometry(a0->L, a0->head_dim, &Lp0, &DP0);
-    if (rc0) return rc0;
-    swv2_attn_args b = *a0;
-    const size_t u0 = (size_t)w0 * b.heads, slab = (size_t)Lp0 * DP0;
-    b.qkvh = (const uint16_t*)b.qkvh + u0 * 3 * slab;
-    b.oh = (uint16_t*)b.oh + u0 * slab;
-    b.doh = (const uint16_t*)b.doh + u0 * slab;
-    b.lse = b.lse + u0 * Lp0;
-    b.rnorm = b.rnorm + u0 * 2 * Lp0;
-    b.dqkvh = (uint16_t*)b.dqkvh + u0 * 3 * slab;
-    b.Bw = a0->Bw - w0;
-    const swv2_attn_args* a = &b;
-    struct Guard { Guard(int v) { g_bw0 = v; } ~Guard() { g_bw0 = 0; } } guard(w0);
-    SWV2_ATTN_DISPATCH(launch_bwd)
-}
-
 extern "C" int swv2_attn_bwd(const swv2_attn_args* a, void* stream) {
     int rc0 = check_args(a, true);
     if (rc0) return rc0;
-    if (!(a->dbg & 16)) {
-        int Lp2, DP2;
-        int rc2 = swv2_attn_geometry(a->L, a->head_dim, &Lp2, &DP2);
-        if (rc2) return rc2;
-        rc2 = swv2_attn2_bwd(a, Lp2, DP2, stream);
-        if (rc2 <= 0) return rc2;
-        rc2 = swv2_attn3_bwd(a, Lp2, DP2, stream);
-        if (rc2 <= 0) return rc2;
-    }
     SWV2_ATTN_DISPATCH(launch_bwd)
 }

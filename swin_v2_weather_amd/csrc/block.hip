@@ -78,17 +78,7 @@ inline void join_from(SideStream* ss, hipStream_t main) {
 extern "C" int swv2_block_fwd(const swv2_block_desc* d, void* st) {
     SWV2_CHECK_ARG(d && d->x && d->x2 && d->qkvh && d->rowidx, "swv2_block_fwd: null descriptor field");
     const int BT = d->B * d->T, Bw = d->B * d->nwh * d->nww, Mw = Bw * d->Lp, C = d->C, h = d->heads, hid = d->hidden;
-    const bool fused_attn = d->fuse_attn && !d->bias && swv2_attn_branch_supported(C, h, d->L, d->head_dim);
-    if (fused_attn) {
-        // 1-4 fused: gather, qkv, attention core, proj, LN1 + drop-path + residual + scatter in one kernel
-        swv2_attn_branch_args m = {};
-        m.x = d->x; m.rowidx = d->rowidx; m.wqkv = d->w_qkv; m.bqkv = d->qkv_b_pad; m.wproj = d->w_proj; m.bproj = d->proj_b;
-        m.logit_scale = d->logit_scale; m.gamma = d->n1_w; m.beta = d->n1_b; m.scale = d->dp1; m.qkvh = d->qkvh; m.rnorm = d->rnorm;
-        m.oh = d->oh; m.lse = d->lse; m.a1 = d->a1; m.mean = d->mean1; m.rstd = d->rstd1; m.y = d->x1;
-        m.Bw = Bw; m.heads = h; m.L = d->L; m.head_dim = d->head_dim; m.C = C; m.nwh = d->nwh; m.nww = d->nww;
-        m.mask_thr = d->mask_thr; m.rows_per_sample = d->T; m.eps = 1e-5f;
-        LAUNCH(2, swv2_attn_branch_fwd(&m, st));
-    } else {
+    SWV2_CHECK_ARG(!d->fuse_attn, "swv2_block_fwd: fuse_attn is reserved (0)");
     // 1. roll + partition gather | qkv GEMM | + bias, split heads, L2-normalise q, k
     {
         swv2_operand a = op(SWV2_OP_F32, d->x, Mw, C, C, d->rowidx);
@@ -130,7 +120,6 @@ extern "C" int swv2_block_fwd(const swv2_block_desc* d, void* st) {
         l.a = d->a1; l.res = d->x; l.gamma = d->n1_w; l.beta = d->n1_b; l.scale = d->dp1; l.rowidx = d->rowidx; l.y = d->x1;
         l.mean = d->mean1; l.rstd = d->rstd1; l.M = Mw; l.C = C; l.res_mod = 0; l.rows_per_sample = d->T; l.eps = 1e-5f;
         LAUNCH(4, swv2_ln_residual_fwd(&l, st));
-    }
     }
     }
     // 5-7 fused: fc1, GELU, fc2, LN2 + drop-path + residual in one kernel (the hidden activation stays in registers)

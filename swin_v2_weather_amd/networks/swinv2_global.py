@@ -175,9 +175,7 @@ class _BlockRunner:
         d.wgrad_side_stream = int(os.environ.get("SWV2_WGRAD_SIDE_STREAM", "0"))
         d.fuse_mlp = int(os.environ.get("SWV2_FUSE_MLP", "1"))
         d.fuse_proj_ln = int(os.environ.get("SWV2_FUSE_PROJ_LN", "1"))
-        # fused attention branch (swv2_attn_branch_fwd): parity-green but not yet faster than the four separate kernels
-        # (B = 2: 213 vs 210 us per block; B = 8: -8 % of the block forward) -- opt-in
-        d.fuse_attn = int(os.environ.get("SWV2_FUSE_ATTN", "0"))
+        d.fuse_attn = 0         # (reserved: the one-kernel attention branch lives in tools/experiments/, LABNOTES.md)
         fused = bool(d.fuse_mlp) and bool(L.load().swv2_mlp_supported(Cc, hid))
         self.desc = d
         act_sizes = [Bw * h * 3 * Lp * DP * 2, Bw * h * 2 * Lp * 4, Bw * h * Lp * DP * 2, Bw * h * Lp * 4, Mw * Cc * 2, Mw * 4,

@@ -227,7 +227,7 @@ def from_heads(xh, Bw, Lw, h, d, parts):
     (9, 18, 2, 16, 1, 2, True, True),   # one window row: every window carries the shift mask
 ])
 def test_attention_core_fwd_bwd(dev, K, wh, ww, h, d, nwh, nww, shifted, use_bias):
-    ops = K["ops"]
+    ops, L = K["ops"], K["L"]
     torch.manual_seed(0)
     B, Lw, nW, Cc = 2, wh * ww, nwh * nww, h * d
     Lp, DP = ops.attn_geometry(Lw, d)
@@ -313,7 +313,7 @@ def test_attention_core_fwd_bwd(dev, K, wh, ww, h, d, nwh, nww, shifted, use_bia
         ops.attn_fwd(ops.attn_args(qkvh, lsd, bd, oh2, lse2, Bw, h, Lw, d, nwh, nww, mask_thr, bias_pack=pk))
         assert rel(oh2, oh) < 4e-3 and float((lse2 - lse).abs().max()) < 1e-4
         a1 = ops.attn_args(qkvh, lsd, bd, oh2, lse2, Bw, h, Lw, d, nwh, nww, mask_thr, bias_pack=pk)
-        a1.dbg = 16                                     # first-generation kernel on the packed table: bit-identical
+        a1.dbg = L.ATTN_FIRST_GEN                       # first-generation kernel on the packed table: bit-identical
         ops.attn_fwd(a1)
         assert torch.equal(oh2, oh) and torch.equal(lse2, lse)
         dq2, dls2, db2 = torch.empty_like(dqkvh), torch.zeros_like(dls), torch.zeros_like(dbias)
@@ -332,10 +332,12 @@ def test_attention_core_fwd_bwd(dev, K, wh, ww, h, d, nwh, nww, shifted, use_bia
 
 @pytest.mark.parametrize("shifted", [False, True])
 def test_attention_kernel_generations_agree(dev, K, shifted):
-    """Every attention kernel build selectable through `dbg` (first generation, the small-workgroup forward / backward of
-    csrc/attn2.hip, the MFMA-folded forward with fragments from LDS or pinned in registers) computes the same function: the
-    non-default ones stay parity-tested here.  Shape of the benchmark (9x18 windows, 8 heads of 16), incl. the masked branch."""
-    ops = K["ops"]
+    """The attention kernels that serve different shapes compute the same function where their domains overlap: the
+    first-generation forward (csrc/attn.hip: CPB bias, wide heads, small windows) against the MFMA-folded forward of the
+    benchmark head geometry (csrc/attn2.hip), and the two-phase backward with the softmax statistics riding in the MFMA
+    operands (default at 16-wide heads) against the one that reads them from LDS (wider heads).  Shape of the benchmark
+    (9x18 windows, 8 heads of 16), incl. the masked branch and a head at the sigma = 100 clamp."""
+    ops, L = K["ops"], K["L"]
     torch.manual_seed(3)
     wh, ww, h, d, nwh, nww, B = 9, 18, 8, 16, 2, 3, 2
     Lw, nW = wh * ww, nwh * nww
@@ -351,69 +353,26 @@ def test_attention_kernel_generations_agree(dev, K, shifted):
     doh[:, :, Lw:] = 0
     mask_thr = (wh - wh // 2) * ww if shifted else 0
     res = {}
-    for dbg in (16, 64, 0, 128):
+    for dbg in (L.ATTN_FIRST_GEN, 0):
         oh = torch.zeros(Bw, h, Lp, DP, dtype=BF, device=dev)
         lse = torch.zeros(Bw, h, Lp, device=dev)
         a = ops.attn_args(qkvh, ls, None, oh, lse, Bw, h, Lw, d, nwh, nww, mask_thr)
         a.dbg = dbg
         ops.attn_fwd(a)
         res[dbg] = (oh, lse)
-    for dbg in (64, 0, 128):
-        assert rel(res[dbg][0], res[16][0]) < 5e-3, dbg
-        assert float((res[dbg][1][:, :, :Lw] - res[16][1][:, :, :Lw]).abs().max()) < 2e-2, dbg
-    oh, lse = res[16]
+    assert rel(res[0][0], res[L.ATTN_FIRST_GEN][0]) < 5e-3
+    assert float((res[0][1][:, :, :Lw] - res[L.ATTN_FIRST_GEN][1][:, :, :Lw]).abs().max()) < 2e-2
+    oh, lse = res[L.ATTN_FIRST_GEN]
     grads = {}
-    for dbg in (16, 64, 96, 256, 16 | 8192):        # 256: one wave per (window, head), csrc/attn3.hip; 8192: the two-phase
-                                                    # kernel with the statistics read from LDS instead of riding in the operands
+    for dbg in (0, L.ATTN_PLAIN_STATS):
         dq = torch.zeros(Bw, h, 3, Lp, DP, dtype=BF, device=dev)
         dls = torch.zeros(h, device=dev)
         a = ops.attn_args(qkvh, ls, None, oh, lse, Bw, h, Lw, d, nwh, nww, mask_thr, doh=doh, rnorm=rnorm, dqkvh=dq, dlogit=dls)
         a.dbg = dbg
         ops.attn_bwd(a)
         grads[dbg] = (dq, dls)
-    for dbg in (64, 96, 256, 16 | 8192):
-        assert rel(grads[dbg][0], grads[16][0]) < 1e-2, dbg
-        assert float(grads[dbg][1][-1]) == 0.0 and rel(grads[dbg][1], grads[16][1]) < 5e-2, dbg
-
-
-def test_attention_backward_wave_per_head_with_remainder(dev, K):
-    """The wave-per-head backward (csrc/attn3.hip, `dbg` bit 8: one wave per (window, head), persistent waves, K / V tiles by
-    LDS-DMA) gives the (window, head) units beyond its last full round of 2048 waves to the two-phase kernel: 264 windows x 8
-    heads = one round + 64 units, with shift-masked windows on both sides of the split; compared with the two-phase kernel
-    alone and with the wave-per-head kernel alone (dbg bit 9)."""
-    ops = K["ops"]
-    torch.manual_seed(5)
-    wh, ww, h, d, nwh, nww, B = 9, 18, 8, 16, 2, 3, 44
-    Lw, nW = wh * ww, nwh * nww
-    Lp, DP = ops.attn_geometry(Lw, d)
-    Bw = B * nW
-    qkvh = torch.randn(Bw, h, 3, Lp, DP, device=dev)
-    qkvh[:, :, :2] = torch.nn.functional.normalize(qkvh[:, :, :2], dim=-1)
-    qkvh[:, :, :, Lw:] = 0
-    qkvh = qkvh.to(BF).contiguous()
-    ls = torch.log(torch.tensor([3.0, 8.0, 10.0, 12.0, 20.0, 27.0, 30.0, 200.0], device=dev))
-    rnorm = torch.rand(Bw, h, 2, Lp, device=dev) + 0.5
-    doh = torch.randn(Bw, h, Lp, DP, device=dev).to(BF)
-    doh[:, :, Lw:] = 0
-    mask_thr = (wh - wh // 2) * ww
-    oh = torch.zeros(Bw, h, Lp, DP, dtype=BF, device=dev)
-    lse = torch.zeros(Bw, h, Lp, device=dev)
-    a = ops.attn_args(qkvh, ls, None, oh, lse, Bw, h, Lw, d, nwh, nww, mask_thr)
-    a.dbg = 16
-    ops.attn_fwd(a)
-    grads = {}
-    for dbg in (16, 256, 768):
-        dq = torch.zeros(Bw, h, 3, Lp, DP, dtype=BF, device=dev)
-        dls = torch.zeros(h, device=dev)
-        a = ops.attn_args(qkvh, ls, None, oh, lse, Bw, h, Lw, d, nwh, nww, mask_thr, doh=doh, rnorm=rnorm, dqkvh=dq, dlogit=dls)
-        a.dbg = dbg
-        ops.attn_bwd(a)
-        grads[dbg] = (dq, dls)
-    for dbg in (256, 768):
-        assert rel(grads[dbg][0], grads[16][0]) < 1e-2, dbg
-        assert rel(grads[dbg][0][256:], grads[16][0][256:]) < 1e-2, dbg             # the windows behind the split
-        assert float(grads[dbg][1][-1]) == 0.0 and rel(grads[dbg][1], grads[16][1]) < 5e-2, dbg
-    assert torch.equal(grads[256][0][256:], grads[16][0][256:])                      # the remainder IS the two-phase kernel
+    assert rel(grads[0][0], grads[L.ATTN_PLAIN_STATS][0]) < 1e-2
+    assert float(grads[0][1][-1]) == 0.0 and rel(grads[0][1], grads[L.ATTN_PLAIN_STATS][1]) < 5e-2
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -1302,66 +1261,6 @@ def test_grouped_weight_gradients_match_separate_launches(dev, K, monkeypatch, g
     for n_, g1 in grads["1"].items():
         g0 = grads["0"][n_]
         assert float((g1 - g0).abs().max()) <= 2e-5 * float(g0.abs().max()) + 1e-12, n_
-
-
-@pytest.mark.parametrize("gh,gw,wh,ww,sh,sw,Cc,h,fixture", [
-    (18, 36, 9, 18, 0, 0, 32, 2, "nopos_noshift_eval"),     # reference fixture: also checked against the oracle
-    (18, 36, 9, 18, 4, 9, 128, 8, None),                    # benchmark window / width, shifted (mask in the last window row)
-    (12, 27, 6, 9, 3, 4, 64, 4, None),                      # small window (LT = 4), shifted
-    (12, 18, 6, 9, 0, 0, 96, 8, None),                      # head_dim 12 padded to 16
-])
-def test_block_fused_attention_branch(dev, K, monkeypatch, gh, gw, wh, ww, sh, sw, Cc, h, fixture):
-    """SWV2_FUSE_ATTN=1: gather + qkv + cosine attention + proj + LN1 + residual scatter as ONE kernel
-    (swv2_attn_branch_fwd) against the unfused path (same saved tensors, so the unchanged backward must give the same
-    gradients) and, on the reference fixture, against the bf16-emulating oracle."""
-    N = K["N"]
-    B = 2
-    assert K["L"].load().swv2_attn_branch_supported(Cc, h, wh * ww, Cc // h) == 1
-    if fixture:
-        fx = np.load(os.path.join(GOLD, f"block_{fixture}.npz"))
-        assert [int(v) for v in fx["meta"]][:8] == [gh, gw, wh, ww, sh, sw, Cc, h]
-        x0, gy0 = torch.from_numpy(fx["x"]), torch.from_numpy(fx["gy"])
-    else:
-        g = torch.Generator().manual_seed(gh * 7 + Cc)
-        x0, gy0 = torch.randn(B, gh, gw, Cc, generator=g), torch.randn(B, gh, gw, Cc, generator=g)
-    outs, state = {}, None
-    for fuse in ("0", "1"):
-        monkeypatch.setenv("SWV2_FUSE_ATTN", fuse)
-        torch.manual_seed(5)
-        blk = N.SwinTransformerV2CrBlock(dim=Cc, num_heads=h, feat_size=(gh, gw), window_size=(wh, ww), shift_size=(sh, sw),
-                                         rel_pos=False, drop_path=0.0)
-        if fixture:
-            load_params(blk, fx)
-        else:
-            if state is None:
-                with torch.no_grad():
-                    for n_, p_ in blk.named_parameters():
-                        if n_.startswith("norm"):
-                            p_.copy_(torch.rand_like(p_) + 0.5 if n_.endswith("weight") else 0.1 * torch.randn_like(p_))
-                state = {k_: v_.clone() for k_, v_ in blk.state_dict().items()}
-            blk.load_state_dict(state)
-        blk = blk.to(dev).eval()
-        x = x0.to(dev).requires_grad_(True)
-        y = blk(x)
-        y.backward(gy0.to(dev))
-        assert blk._runner(B, x.device).desc.fuse_attn == int(fuse)
-        outs[fuse] = (y.detach(), x.grad.detach(), {n_: p_.grad.detach().clone() for n_, p_ in blk.named_parameters()})
-    # (the unfused path's forward normalises by the sum of the bf16-rounded exponentials with a fixed reference point, the
-    # fused branch kernel by the fp32 sum around the row maximum: two bf16-level roundings of the same softmax)
-    assert rel(outs["1"][0], outs["0"][0]) < 4e-3 and rel(outs["1"][1], outs["0"][1]) < 1.5e-2, (rel(outs["1"][0], outs["0"][0]), rel(outs["1"][1], outs["0"][1]))
-    for n_ in outs["0"][2]:
-        tol = 0.15 if "logit_scale" in n_ else 3e-2
-        assert rel(outs["1"][2][n_], outs["0"][2][n_]) < tol, n_
-    if fixture:
-        p = {"b." + k[2:]: torch.from_numpy(fx[k]).clone().requires_grad_(True) for k in fx.files if k.startswith("p:")}
-        xo = x0.clone().requires_grad_(True)
-        O.set_rounding(O.bf16_round)
-        try:
-            yo = O.block_forward(xo, p, "b.", block_cfg(gh, gw, wh, ww, sh, sw, Cc, h, False), 1, training=False)
-            yo.backward(gy0)
-        finally:
-            O.set_rounding(None)
-        assert rel(outs["1"][0], yo) < 3e-3 and rel(outs["1"][1], xo.grad) < 1.5e-2
 
 
 def _ddp_run(tmp_path, tag, world, backend, mode, n_future, port, opt="sgd"):

@@ -60,7 +60,7 @@ def test_ctypes_structs_follow_the_header_field_order():
     the C structs, in order -- a missing member shifts every later pointer by one slot (`bias_pack`)"""
     pairs = {"swv2_attn_args": L.AttnArgs, "swv2_operand": L.Operand, "swv2_epilogue": L.Epilogue, "swv2_block_desc": L.BlockDesc,
              "swv2_mlp_args": L.MlpArgs, "swv2_mlp_bwd_args": L.MlpBwdArgs, "swv2_proj_ln_args": L.ProjLnArgs,
-             "swv2_proj_ln_bwd_args": L.ProjLnBwdArgs, "swv2_attn_branch_args": L.AttnBranchArgs, "swv2_ln_args": L.LnArgs,
+             "swv2_proj_ln_bwd_args": L.ProjLnBwdArgs, "swv2_ln_args": L.LnArgs,
              "swv2_wgrad_item": L.WgradItem}
     from swin_v2_weather_amd.utils.optim import _Item
     pairs["swv2_adam_item"] = _Item

@@ -49,7 +49,7 @@ def probe_attn(B=2, rel_pos=False):
     dls = torch.zeros(h, device=dev)
     dbias = torch.zeros(h, Lw, Lw, device=dev) if rel_pos else None
     pk = ops.attn_pack_bias(bias) if rel_pos else None
-    for gen, dbg in (("gen1", 16), ("fwd2 / bwd2", 64), ("default (fwd3 / gen1 bwd)", 0), ("fwd3 pinned fragments", 128)):
+    for gen, dbg in (("first generation (csrc/attn.hip)", L.ATTN_FIRST_GEN), ("default", 0), ("statistics from LDS (backward)", L.ATTN_PLAIN_STATS)):
         a = ops.attn_args(qkvh, ls, bias, oh, lse, Bw, h, Lw, 16, plan.nwh, plan.nww, plan.mask_thr, max_chunks=32 if rel_pos else 64, bias_pack=pk)
         a.dbg = dbg
         say(f"attn_fwd  {gen} B={B} bias={rel_pos}: {timeit(lambda: ops.attn_fwd(a), n=20):.1f} us")
@@ -137,23 +137,7 @@ def probe_mlp(B=2):
     say(f"mlp_bwd M={M}: {t:.1f} us ({M * (Cc * 4 * 2 + hid * 2 * 2 + Cc * 2 * 2) / t / 1e3:.0f} GB/s)")
 
 
-def probe_branch(B=2):
-    import ctypes
-    from swin_v2_weather_amd.networks import swinv2_global as N
-    blk = N.SwinTransformerV2CrBlock(dim=128, num_heads=8, feat_size=(180, 360), window_size=(9, 18), shift_size=(0, 0), rel_pos=False,
-                                     drop_path=0.0).to(dev)
-    x = torch.randn(B, 180, 360, 128, device=dev)
-    for fuse in ("0", "1"):
-        os.environ["SWV2_FUSE_ATTN"] = fuse
-        blk._runners.clear()
-        with torch.no_grad():
-            t = timeit(lambda: blk(x), n=10)
-        say(f"block forward B={B} fuse_attn={fuse}: {t:.1f} us")
-
-
 if __name__ == "__main__":
-    if "branch" in (sys.argv[1] if len(sys.argv) > 1 else ""):
-        probe_branch(2); probe_branch(8)
     if "mlp" in (sys.argv[1] if len(sys.argv) > 1 else ""):
         probe_mlp(2)
     flt = sys.argv[1] if len(sys.argv) > 1 else ""

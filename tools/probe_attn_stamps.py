@@ -22,7 +22,7 @@ a.dbg = dbg
 for _ in range(3):
     ops.attn_fwd(a)
 torch.cuda.synchronize()
-nchunk = 256 // h if dbg & 2048 else (512 // h if dbg & 4096 or not dbg & 128 else (3 * 256 + h - 1) // h)
+nchunk = (3 * 256 + h - 1) // h
 print("dbg", dbg, "workgroups per head", nchunk)
 st = lse[:nchunk, :, Lw:].contiguous().view(torch.int64).view(-1, 7).cpu().double()
 names = ["q operand prep", "QK mfma (11 x K=32)", "exp pass", "cvt + PV + row-sum mfma", "normalise + store", "item prologue (fragments, masks)", "barrier"]

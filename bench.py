@@ -120,7 +120,14 @@ ROOFLINE_KERNELS = {
     # the block's four weight gradients in one launch: dY + X streams of fc2 (2 + 8), fc1 (8 + 4), proj (2 + 2), qkv (6 + 4)
     # bytes per token-channel; the event bracket also covers the ~10 us partial-tile reduction that follows it
     "wgrad_group": ("gemm_tn_group_kernel", "hbm", 36.0, 0.0),
+    # the rest of the attention module: gather + qkv + head split + normalise; proj + LN1 (+ residual, scatter) and
+    # its backward; d(qkv) -> dx.  Padded window rows (176 / 162) are in the per-token-channel figures.
+    "qkv": ("gemm_rw_kernel<0, 2", "hbm", 10.0, 0.0),
+    "proj_ln_fwd": ("proj_ln_fwd_kernel", "hbm", 12.3, 0.0),
+    "proj_ln_bwd": ("proj_ln_bwd_kernel", "hbm", 10.5, 0.0),
+    "dx": ("gemm_rw_kernel<3, 1", "hbm", 14.0, 0.0),
 }
+ATTENTION_MODULE = ("qkv", "attn_fwd", "proj_ln_fwd", "proj_ln_bwd", "attn_bwd", "dx")
 
 
 def roofline_entry(name, ktimes, a, pmc, B):
@@ -173,6 +180,39 @@ def self_launch(n):
         print(f"bench.py: expected one JSON line from rank 0, got {len(lines)}", file=sys.stderr)
         return 1
     return r.returncode
+
+
+def attention_module(ktimes, a, B):
+    """qkv + attention core + proj / LN1, forward + backward data path (SURVEY 8d: fwd T (8 C^2 + 4 L C), x3 with the backward;
+    the weight gradients of qkv / proj are inside the grouped launch and not separable): MFMA flops over the event-timed launch
+    durations, and the counter-based pipe utilisation of the same kernels from the committed profile (null when the profile
+    was taken from other sources)."""
+    T = (a.height // 4) * (a.width // 4)
+    Lw = (a.height // a.window_ratio) * (a.width // a.window_ratio)
+    C = a.embed_dim
+    t_ms = sum(ktimes.get(k, (0, 0.0))[1] for k in ATTENTION_MODULE)
+    if t_ms <= 0 or any(ktimes.get(k, (0, 0.0))[0] == 0 for k in ATTENTION_MODULE):
+        return None
+    # data path only: forward 8 C^2 + 4 L C per token, backward the same again for dX (dW excluded) -> x2
+    flops = 2.0 * T * (8.0 * C * C + 4.0 * Lw * C) * B
+    out = {"kernels": list(ATTENTION_MODULE), "ms_per_block": t_ms, "data_path_flops_per_block": flops,
+           "mfma_frac_by_flops": flops / (t_ms * 1e-3) / 2.5e15, "mfma_pipe_busy_frac": None, "counter_source": None}
+    try:
+        import glob
+        from swin_v2_weather_amd import _lib as L_
+        f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_mfma.json")))[-1]
+        d = json.load(open(f))
+        frags = [ROOFLINE_KERNELS[k][0] for k in ATTENTION_MODULE]
+        hits = [[n for n in d["kernels"] if fr in n] for fr in frags]
+        if d.get("_source_hash") == L_.source_hash() and all(len(h) == 1 for h in hits):
+            busy = sum(d["kernels"][h[0]]["SQ_VALU_MFMA_BUSY_CYCLES"] for h in hits)
+            simd = sum(d["kernels"][h[0]]["SQ_BUSY_CYCLES"] * 32.0 for h in hits)
+            out["mfma_pipe_busy_frac"], out["counter_source"] = busy / simd, os.path.relpath(f, ROOT)
+        else:
+            out["counter_source"] = f"{os.path.relpath(f, ROOT)}: other kernel sources or ambiguous kernel names -- not reported"
+    except Exception:
+        pass
+    return out
 
 
 def main():
@@ -386,6 +426,7 @@ def main():
             "weak_scaling_local_batch": B,      # fixed per GPU at every N (BASELINE cfg 2's batch; cfg 3's 8 per GPU: --local-batch 8)
             "roofline": main_rf,
             "roofline_others": [roofline_entry(k, ktimes, a, pmc, B) for k in ROOFLINE_KERNELS if k != a.roofline_kernel],
+            "attention_module": attention_module(ktimes, a, B),
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a)

@@ -130,7 +130,7 @@ def mfma(sq_json, out):
                   "kernel_shader_clocks": v["SQ_BUSY_CYCLES"] / 32.0,
                   "mfma_pipe_busy_frac": v["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles,
                   "valu_issue_frac": (v.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0) / simd_cycles}
-    json.dump({"_formula": mfma.__doc__, "kernels": res}, open(out, "w"), indent=1, sort_keys=True)
+    json.dump({"_formula": mfma.__doc__, "_source_hash": source_hash(), "kernels": res}, open(out, "w"), indent=1, sort_keys=True)
     for n in sorted(res, key=lambda k: -res[k]["SQ_VALU_MFMA_BUSY_CYCLES"])[:14]:
         print(f"{res[n]['mfma_pipe_busy_frac']:6.3f} mfma  {res[n]['valu_issue_frac']:6.3f} valu  {n}")
 

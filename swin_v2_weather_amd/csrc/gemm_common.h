@@ -121,8 +121,15 @@ __device__ __forceinline__ uint4 cvt_f32x8(const RawF32& r) {
 // fp32 rows (optionally gathered): the residual stream x[B*T][C]
 template <> struct ALoad<A_F32> {
     static constexpr bool ROW_FASTEST = false;
+    static constexpr bool LINEAR = true;      // un-gathered rows are ptr + row * ld: the kernels may form the offsets incrementally
     typedef RawF32 Raw;
     LoadDesc d;
+    // element offset (row * ld + k0, below 2^32: checked by the launchers) -> unconditional load, scalar base + 32-bit offset
+    __device__ __forceinline__ Raw raw_lin(uint32_t off) const {
+        const float* p = (const float*)d.ptr + off;
+        Raw o = {*(const f32x4*)p, *(const f32x4*)(p + 4)};
+        return o;
+    }
     // source row of logical row m (-1 = zero row): ONE dependent load for gathered operands, hoisted by the kernels
     __device__ __forceinline__ int row_of(int m) const { return m >= d.M ? -1 : (d.rowidx ? d.rowidx[m] : m); }
     __device__ __forceinline__ Raw raw_at(int r, int k0) const {
@@ -146,8 +153,10 @@ template <> struct ALoad<A_F32> {
 // bf16 rows (optionally gathered)
 template <> struct ALoad<A_BF16> {
     static constexpr bool ROW_FASTEST = false;
+    static constexpr bool LINEAR = true;
     typedef uint4 Raw;
     LoadDesc d;
+    __device__ __forceinline__ Raw raw_lin(uint32_t off) const { return *(const uint4*)((const uint16_t*)d.ptr + off); }
     __device__ __forceinline__ uint4 cvt(const Raw& r) const { return r; }
     __device__ __forceinline__ int row_of(int m) const { return m >= d.M ? -1 : (d.rowidx ? d.rowidx[m] : m); }
     __device__ __forceinline__ Raw raw_at(int r, int k0) const {
@@ -165,6 +174,7 @@ template <> struct ALoad<A_BF16> {
 struct RawCS { uint4 v; float s; };
 template <> struct ALoad<A_BF16_CS> {
     static constexpr bool ROW_FASTEST = false;
+    static constexpr bool LINEAR = false;
     typedef RawCS Raw;
     LoadDesc d;
     __device__ __forceinline__ int row_of(int m) const { return m >= d.M ? -1 : m; }
@@ -191,6 +201,8 @@ template <> struct ALoad<A_BF16_CS> {
 // bf16 rows through GELU (fc2 input = GELU(fc1 output); the pre-activation is what is kept for backward)
 template <> struct ALoad<A_BF16_GELU> {
     static constexpr bool ROW_FASTEST = false;
+    static constexpr bool LINEAR = true;
+    __device__ __forceinline__ uint4 raw_lin(uint32_t off) const { return *(const uint4*)((const uint16_t*)d.ptr + off); }
     __device__ __forceinline__ int row_of(int m) const { return m >= d.M ? -1 : m; }
     __device__ __forceinline__ auto raw_at(int r, int k0) const { return raw(r < 0 ? d.M : r, k0); }
     typedef uint4 Raw;
@@ -231,6 +243,7 @@ template <> struct ALoad<A_BF16_GELU> {
 // p0 = heads, p2 = Lp, p3 = DP ; ld = number of parts S (1 for oh, 3 for dqkvh)
 template <> struct ALoad<A_HEADS> {
     static constexpr bool ROW_FASTEST = false;
+    static constexpr bool LINEAR = false;
     __device__ __forceinline__ int row_of(int m) const { return m >= d.M ? -1 : m; }
     __device__ __forceinline__ auto raw_at(int r, int k0) const { return raw(r < 0 ? d.M : r, k0); }
     typedef uint4 Raw;
@@ -248,11 +261,31 @@ template <> struct ALoad<A_HEADS> {
         const int part = (h == 1) ? ph : fdiv(ph, h, d.mg1), hd = ph - part * h;
         return *(const uint4*)((const uint16_t*)d.ptr + ((((long)bw * h + hd) * S + part) * Lp + t) * DP + j);
     }
+    // Walking rows m, m + 16, m + 32, ... of ONE chunk column (the weight-gradient kernel's staging): the window / token split
+    // once per step (step_base), then adds -- a row block that runs past its window's Lp rows continues (h S - 1) Lp DP
+    // elements further, in the same (head, part) slab of the next window.  Valid while a step spans at most one window
+    // boundary (16 * chunks <= Lp, checked by the caller); 32-bit element offsets.
+    struct Step { uint32_t off0; int t0; };
+    __device__ __forceinline__ Step step_base(int m, int k0) const {
+        const int h = d.p0, Lp = d.p2, DP = d.p3, S = (int)d.ld;
+        const int bw = fdiv(m, Lp, d.mg0), t = m - bw * Lp;
+        const int ph = k0 >> d.p1, j = k0 - ph * DP;
+        const int part = (h == 1) ? ph : fdiv(ph, h, d.mg1), hd = ph - part * h;
+        Step o = {(uint32_t)((((bw * h + hd) * S + part) * Lp + t) * DP + j), t};
+        return o;
+    }
+    __device__ __forceinline__ uint32_t step_off(const Step& b, int i) const {
+        const int Lp = d.p2, DP = d.p3;
+        const uint32_t hop = (uint32_t)((d.p0 * (int)d.ld - 1) * Lp * DP);
+        return b.off0 + (uint32_t)(16 * i * DP) + ((b.t0 + 16 * i >= Lp) ? hop : 0u);
+    }
+    __device__ __forceinline__ uint4 raw_lin(uint32_t off) const { return *(const uint4*)((const uint16_t*)d.ptr + off); }
 };
 // PatchEmbed im2col: x[B][Cin][H][W] fp32, row m = (b, i, j) patch, k = cin*16 + p*4 + q (conv weight order)
 // p0 = Cin, p1 = H, p2 = W ; patch = 4.  Adjacent rows are adjacent 16-byte groups -> row-fastest thread map.
 template <> struct ALoad<A_PATCH> {
     static constexpr bool ROW_FASTEST = true;
+    static constexpr bool LINEAR = false;
     __device__ __forceinline__ int row_of(int m) const { return m >= d.M ? -1 : m; }
     __device__ __forceinline__ auto raw_at(int r, int k0) const { return raw(r < 0 ? d.M : r, k0); }
     typedef RawF32 Raw;
@@ -285,6 +318,7 @@ template <> struct ALoad<A_PATCH> {
 // k = (wp*2 + hp)*C + c  (swinv2_global.py:520) ; p0 = H, p1 = W, p2 = C ; aux = mean, rstd, gamma, beta
 template <> struct ALoad<A_MERGE_LN> {
     static constexpr bool ROW_FASTEST = false;
+    static constexpr bool LINEAR = false;
     __device__ __forceinline__ int row_of(int m) const { return m >= d.M ? -1 : m; }
     __device__ __forceinline__ auto raw_at(int r, int k0) const { return raw(r < 0 ? d.M : r, k0); }
     typedef uint4 Raw;
@@ -333,6 +367,8 @@ int check_operand(const swv2_operand* o, const char* who) {
     SWV2_CHECK_ARG(((uintptr_t)o->ptr & 15) == 0, "%s: operand pointer must be 16-byte aligned", who);
     if (o->kind == SWV2_OP_F32 || o->kind == SWV2_OP_BF16 || o->kind == SWV2_OP_BF16_GELU || o->kind == SWV2_OP_BF16_CSCALE)
         SWV2_CHECK_ARG(o->ld % 8 == 0 && o->ld >= o->cols, "%s: row pitch %ld must be a multiple of 8 and >= cols", who, o->ld);
+    if (o->kind == SWV2_OP_F32 || o->kind == SWV2_OP_BF16 || o->kind == SWV2_OP_BF16_GELU)
+        SWV2_CHECK_ARG((double)o->rows * (double)o->ld < 4.29e9, "%s: row-major operands are indexed with 32-bit element offsets (%d x %ld too large)", who, o->rows, o->ld);
     if (o->kind == SWV2_OP_BF16_CSCALE)
         SWV2_CHECK_ARG(o->aux0 && o->p[0] > 0 && o->p[2] * 16 >= o->cols && o->cols % 16 == 0 && !o->rowidx,
                        "%s: scaled operand needs aux0, rows per sample p[0] > 0, p[2] >= cols / 16 groups, no gather", who);

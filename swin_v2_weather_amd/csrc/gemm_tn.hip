@@ -34,7 +34,7 @@ constexpr int TN_SMEM = 2 * TM * TP;
 
 // one 128 x 128 output tile over the row chunks of one slice (body shared by the single-product and the grouped kernel)
 // XG: the X rows are gathered through xl.d.rowidx (compile time, so the un-gathered products carry no index load at all)
-template <int YK, int XK, bool XG = false>
+template <int YK, int XK, bool XG = false, bool HINC = false>
 __device__ __forceinline__ void tn_tile(const ALoad<YK>& yl, const ALoad<XK>& xl_arg, const TnOut& o, int tile, int slice,
                                         int chunk_stride, uint16_t* smem, float* dbs, uint16_t* gtab) {
     float* __restrict__ dW = o.dW;
@@ -90,8 +90,28 @@ __device__ __forceinline__ void tn_tile(const ALoad<YK>& yl, const ALoad<XK>& xl
     int yrow[TCH], xrow[TCH];          // source rows of the next issue (X gathered: raw table entries)
     uint32_t xin = 0;                  // X gathered: bit i = chunk row i of the next issue lies inside [0, M)
     uint32_t okmask = 0;               // chunks in flight: bit i = Y chunk i valid, bit 16 + i = X chunk i valid
+    // LINEAR operands (plain row-major rows, not gathered): chunk i of a step sits at  (m0 + srow + 16 i) * ld + column  -- one
+    // 32-bit multiply per operand and step, then adds.  Formed per chunk as  ptr + (long)row * ld + k  the staging loop carried
+    // 64 v_mul_lo_u32 + 40 v_mad_u64_u32 + 8 v_mul_hi per step (quarter-rate instructions: about as many vector-issue cycles as the
+    // step's 64 MFMAs, found in the ISA of the grouped kernel); chunks past M load from the operand's first rows (masked at commit).
+    constexpr bool YLIN = ALoad<YK>::LINEAR && !YRF, XLIN = ALoad<XK>::LINEAR && !XRF && !XG;
+    const uint32_t ycol = (uint32_t)min(n_base + scol * 8, max(N - 8, 0)), xcol = (uint32_t)min(k_base + scol * 8, max(K - 8, 0));
+    const uint32_t ystep = 16u * (uint32_t)yl.d.ld, xstep = 16u * (uint32_t)xl.d.ld;
+    uint32_t yoff0 = 0, xoff0 = 0;     // element offset of chunk 0 of the next issue
+    // head-major operands ([Bw][h][S][Lp][DP]): the window / token split once per step, then adds (ALoad<A_HEADS>::Step); needs a
+    // step (TM rows) to span at most one window boundary
+    // (HINC: selected by the kernel when Lp >= TM; column offsets of masked chunks: the operand's first row)
+    constexpr bool YHD = YK == A_HEADS && HINC, XHD = XK == A_HEADS && HINC;
+    typename ALoad<A_HEADS>::Step yst = {0u, 0}, xst = {0u, 0};
     auto resolve = [&](int s) {
         xin = 0;
+        if constexpr (YLIN || XLIN || YHD || XHD) {
+            const int m0 = (slice + s * chunk_stride) * TM + srow;
+            if constexpr (YLIN) yoff0 = (uint32_t)m0 * (uint32_t)yl.d.ld + ycol;
+            if constexpr (XLIN) xoff0 = (uint32_t)m0 * (uint32_t)xl.d.ld + xcol;
+            if constexpr (YHD) yst = yl.step_base(min(m0, M - 1), (int)ycol);
+            if constexpr (XHD) xst = xl.step_base(min(m0, M - 1), (int)xcol);
+        }
 #pragma unroll
         for (int i = 0; i < TCH; ++i) {
             const int m0 = (slice + s * chunk_stride) * TM, my = m0 + yr_(i), mx = m0 + xr_(i);
@@ -112,8 +132,13 @@ __device__ __forceinline__ void tn_tile(const ALoad<YK>& yl, const ALoad<XK>& xl
             const int yk = n_base + yc_(i) * 8, xk = k_base + xc_(i) * 8;
             const int xr = XG ? (((xin >> i) & 1) ? xrow[i] : -1) : xrow[i];
             const bool yok = yrow[i] >= 0 && yk < N, xok = xr >= 0 && xk < K;
-            ry[i] = yl.raw_unc(max(yrow[i], 0), yk < N ? yk : 0);
-            rx[i] = xl.raw_unc(max(xr, 0), xk < K ? xk : 0);
+            if constexpr (YLIN) ry[i] = yl.raw_lin(yrow[i] >= 0 ? yoff0 + i * ystep : ycol);
+            else if constexpr (YHD) ry[i] = yl.raw_lin(yrow[i] >= 0 ? yl.step_off(yst, i) : 0u);
+            else ry[i] = yl.raw_unc(max(yrow[i], 0), yk < N ? yk : 0);
+            if constexpr (XLIN) rx[i] = xl.raw_lin(xr >= 0 ? xoff0 + i * xstep : xcol);
+            else if constexpr (XHD) rx[i] = xl.raw_lin(xr >= 0 ? xl.step_off(xst, i) : 0u);
+            else if constexpr (XG && XK == A_F32) rx[i] = xl.raw_lin((uint32_t)max(xr, 0) * (uint32_t)xl.d.ld + xcol);     // gathered rows: one 32-bit multiply
+            else rx[i] = xl.raw_unc(max(xr, 0), xk < K ? xk : 0);
             okmask |= ((uint32_t)yok << i) | ((uint32_t)xok << (16 + i));
         }
     };
@@ -262,8 +287,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_group_kernel(TnGroup a) {
     const int t = rest % tt, slice = (rest / tt) * 8 + x8;
     if (t < a.first[1]) tn_tile<A_BF16, A_BF16_GELU>(a.y0, a.x0, a.o[0], t, slice, a.slices, smem, dbs, gtab);
     else if (t < a.first[2]) tn_tile<A_BF16, A_F32>(a.y1, a.x1, a.o[1], t - a.first[1], slice, a.slices, smem, dbs, gtab);
-    else if (t < a.first[3]) tn_tile<A_BF16, A_HEADS>(a.y2, a.x2, a.o[2], t - a.first[2], slice, a.slices, smem, dbs, gtab);
-    else tn_tile<A_HEADS, A_F32, true>(a.y3, a.x3, a.o[3], t - a.first[3], slice, a.slices, smem, dbs, gtab);
+    else if (a.x2.d.p2 >= TM) {       // head-major operands walked incrementally (a step spans at most one window boundary)
+        if (t < a.first[3]) tn_tile<A_BF16, A_HEADS, false, true>(a.y2, a.x2, a.o[2], t - a.first[2], slice, a.slices, smem, dbs, gtab);
+        else tn_tile<A_HEADS, A_F32, true, true>(a.y3, a.x3, a.o[3], t - a.first[3], slice, a.slices, smem, dbs, gtab);
+    } else {
+        if (t < a.first[3]) tn_tile<A_BF16, A_HEADS>(a.y2, a.x2, a.o[2], t - a.first[2], slice, a.slices, smem, dbs, gtab);
+        else tn_tile<A_HEADS, A_F32, true>(a.y3, a.x3, a.o[3], t - a.first[3], slice, a.slices, smem, dbs, gtab);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

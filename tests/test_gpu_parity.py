@@ -870,6 +870,46 @@ def test_loss_in_head_epilogue_equals_two_pass_loss(dev, K, loss):
                 assert rel(g2[n], p_.grad) < (0.03 if n.endswith("logit_scale") else 8e-3), (n, rel(g2[n], p_.grad))
 
 
+def test_loss_in_head_epilogue_at_the_baseline_size(dev, K):
+    """the loss epilogue at BASELINE cfg 2's size (73 x 720 x 1440, local batch 2: 2 025 row groups per sample, none straddling,
+    ten N tiles with a ragged last one): value against an fp64 evaluation of the prediction it wrote, bit-reproducibility of the
+    value (no atomics anywhere), and head-weight / feature gradients against the two-pass kernels on the same model"""
+    from types import SimpleNamespace
+    from swin_v2_weather_amd.utils.losses import LossHandler
+    torch.manual_seed(9)
+    H, W, Cio, B = 720, 1440, 73, 2
+    m = K["N"].SwinTransformerV2Cr(img_size=(H, W), patch_size=4, depths=(1,), num_heads=(8,), in_chans=Cio, out_chans=Cio, embed_dim=128,
+                                   img_window_ratio=80, drop_path_rate=0.0, full_pos_embed=True, rel_pos=False, mlp_ratio=4,
+                                   residual=False).to(dev)
+    lh = LossHandler(SimpleNamespace(n_future=0, img_shape_x=H, img_shape_y=W, loss="l2", channel_weights="none", n_out_channels=Cio,
+                                     model_grid_type="equiangular")).to(dev)
+    m.train(); lh.train()
+    x, tar = torch.randn(B, Cio, H, W, device=dev), torch.randn(B, Cio, H, W, device=dev)
+    vals, grads = [], []
+    for rep in range(2):
+        m.zero_grad()
+        with lh.fused_with(m, tar):
+            gen = m(x)
+        assert lh._fused.sums is not None
+        loss = lh(gen, tar, x)
+        loss.backward()
+        vals.append(float(loss))
+        grads.append(m.head.weight.grad.clone())
+    assert vals[0] == vals[1]                                   # bit-reproducible value
+    q = lh.quad_rows.double().view(1, 1, H, 1)
+    s0 = (q * (gen.detach().double() - tar.double()) ** 2).sum((2, 3))
+    s1 = (q * tar.double() ** 2).sum((2, 3))
+    ref = float((lh.channel_weights.double().view(1, -1) * torch.sqrt(s0 / s1)).sum())
+    assert abs(vals[0] - ref) <= 2e-6 * abs(ref), (vals[0], ref)
+    m.zero_grad()
+    l2 = lh(m(x), tar, x)                                       # two-pass kernels
+    l2.backward()
+    assert abs(float(l2) - vals[0]) <= 2e-6 * abs(vals[0])
+    assert rel(grads[0], m.head.weight.grad) < 8e-3
+    del m, x, tar, gen
+    torch.cuda.empty_cache()
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # 100-step loss curve of BASELINE cfg 1 against the curve recorded from the real reference (fp32, CPU)
 # ---------------------------------------------------------------------------------------------------------------

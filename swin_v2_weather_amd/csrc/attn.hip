@@ -280,8 +280,18 @@ __device__ unsigned long long attn1_stamps[512 * 8];
 // zero block)][Lp + 4]) so that TWO workgroups fit one CU's LDS (2 x 77 KB): 12 waves = 3 per SIMD, and one workgroup's
 // barriers / staging overlap the other's MFMA + softmax work.  TPW = 1 is the one-tile-per-wave layout (11 waves).
 // AUGP (16-wide heads, no bias, one key tile per wave): the softmax statistics, the padded-key flag and the shift mask ride in
-// the unused half of K = 32 MFMA operands (see attn3.hip for the construction), so phase 1 reads no lse / delta rows and has no
-// per-element selects: two LDS reads and ~6 vector instructions less per 16 x 16 tile in the kernel's LDS-bound phase.
+// the unused half of K = 32 MFMA operands, so phase 1 reads no lse / delta rows and has no per-element selects: two LDS reads and
+// ~6 vector instructions less per 16 x 16 tile in the kernel's LDS-bound phase.  Construction (head dim 16 fills k = 0 .. 15 of
+// the K = 32 operand, the same 16 issue cycles as K = 16):
+//   A operand (query side, one 32-slot row per query in the Q / dO slabs, written by the staging threads):
+//       Q slab : k 0..15 q^ | k 16..18 lse / (sigma log2 e) as three bf16 parts hi + lo + lolo (|error| <= 2^-24 |v|) | k 19: 1 |
+//                k 20, 21: the query's mask-region flags (region 1, region 0) | zeros
+//       dO slab: k 0..15 dO | k 16..18 delta = rowsum(dO O) in three parts | zeros
+//   B operand (key side, built once per wave): k 0..15 k^ resp. v | k 16..18: -1, -1, -1 | k 19: -1e30 on padded keys (K only) |
+//                k 20, 21: the key's mask terms (c if the key is in region 0 resp. 1, with c = -100 log2 e / (sigma log2 e)) | zeros
+//   so  S' = Q_aug K_aug^T = cos - lse / (sigma log2 e) + [pad] + [mask]  and  dP' = dO_aug V_aug^T = dP - delta  come out of the
+//   matrix pipe, and the softmax backward is  p = exp2(S' sigma log2 e),  dS = p dP'.  The reference's mask (-100 where the query's
+//   and the key's regions differ, swinv2_global.py:403-424) is bilinear in the two region flags, hence two slots.
 template <int LT, int DK, bool HAS_BIAS, int LFIX, int TPW, bool AUGP = false>
 __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
     const uint16_t* __restrict__ qkvh, const float* __restrict__ logit_scale, const float* __restrict__ bias,
@@ -598,7 +608,7 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
 #undef SWV2_CASE
             }
         } else if constexpr (AUG) {
-            // statistics, padded keys and the shift mask inside the K = 32 operands (construction and exactness: attn3.hip); the
+            // statistics, padded keys and the shift mask inside the K = 32 operands (construction: the comment above the kernel); the
             // same two-stage software pipeline as below, with two 16-byte operand reads per step instead of two 8-byte fragment
             // reads + two 16-byte statistics reads, and  p = exp2(s * sc2), ds = p * dp  as the whole softmax backward
             struct St { f32x4 s, dp; bf16x4 tq, td; };

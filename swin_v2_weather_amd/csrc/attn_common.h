@@ -1,4 +1,5 @@
-// Pieces shared by the attention kernels (attn.hip: core forward / backward; attn_fused.hip: fused attention branch).
+// Pieces shared by the attention kernels (attn.hip: first-generation forward / two-phase backward; attn2.hip: the small-workgroup
+// forward of the benchmark head geometry).
 #pragma once
 #include "common.h"
 

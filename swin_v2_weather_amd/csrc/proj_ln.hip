@@ -5,8 +5,8 @@
 // Each replaces a GEMM launch + a LayerNorm launch (forward 72 + 168 MB -> 204 MB, backward 140 + 72 MB -> 174 MB).  The
 // products are single-pass (K, N <= 128): the whole weight sits in LDS, a wave owns 16 * MT rows, products are computed
 // transposed (accumulator tile = rows of the next layout, see mlp.hip).  The forward's A rows come straight from the
-// head-major attention output (16 tokens x 32 B = 512 B contiguous per head), its epilogue is the LN + scatter epilogue
-// of attn_fused.hip; the backward's prologue is the row-layout LayerNorm backward of mlp_bwd_kernel with a row gather,
+// head-major attention output (16 tokens x 32 B = 512 B contiguous per head), its epilogue is the LayerNorm epilogue of
+// mlp_fwd_kernel with the window-reverse / un-roll row table; the backward's prologue is the row-layout LayerNorm backward of mlp_bwd_kernel with a row gather,
 // and its output tiles (rows = one head's 16 channels, column = token) store directly as 512-byte head-major runs.
 #include <cstdlib>
 #include "gemm_common.h"

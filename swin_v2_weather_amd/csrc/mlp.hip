@@ -77,7 +77,14 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(const MlpFwd a) {
             const int idx = tid + 256 * i;
             if (NCHUNK % 256 == 0 || idx < NCHUNK) {
                 *(u32x4*)(W1s + (idx / (C / 8)) * P1 + 8 * (idx % (C / 8))) = s1[i];
-                *(u32x4*)(W2s + (idx >> 2) * P2 + 8 * (idx & 3)) = s2[i];
+                // the 32 hidden units of a W2 row are stored in the ORDER the K = 32 operand wants them -- position
+                // 8 g + 4 half + j holds hidden 16 half + 4 g + j -- so a lane's whole A fragment is one 16-byte read (it was two
+                // 8-byte reads per MFMA pair: 16 of the 48 LDS instructions per chunk and wave of a kernel bound by the LDS
+                // instruction rate); the 16-byte source piece q (hidden 8 q .. 8 q + 7) lands as two 8-byte halves
+                const int q = idx & 3;
+                uint16_t* row = W2s + (idx >> 2) * P2 + 4 * (q >> 1);
+                *(u32x2*)(row + 16 * (q & 1)) = (u32x2){s2[i][0], s2[i][1]};
+                *(u32x2*)(row + 16 * (q & 1) + 8) = (u32x2){s2[i][2], s2[i][3]};
             }
         }
     };
@@ -174,9 +181,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(const MlpFwd a) {
         for (int mt = 0; mt < MT; ++mt) hop[mt] = __builtin_shufflevector(hb[mt][0], hb[mt][1], 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const bf16x4 lo = *(const bf16x4*)(W2s + (16 * t + fr) * P2 + 4 * g);
-            const bf16x4 hi = *(const bf16x4*)(W2s + (16 * t + fr) * P2 + 16 + 4 * g);
-            const bf16x8 wf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            const bf16x8 wf = *(const bf16x8*)(W2s + (16 * t + fr) * P2 + 8 * g);       // (hidden 4 g .. + 3, 16 + 4 g .. + 3: see commit)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) yacc[mt][t] = mfma32(wf, hop[mt], yacc[mt][t]);
         }
@@ -399,8 +404,14 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const MlpBwd a) {
             const int idx = tid + 256 * i;
             if (NCHUNK % 256 == 0 || idx < NCHUNK) {
                 *(u32x4*)(W1s + (idx / (C / 8)) * P1 + 8 * (idx % (C / 8))) = s1[i];
-                if constexpr (RECOMP) *(u32x4*)(W2s + (idx / (C / 8)) * P1 + 8 * (idx % (C / 8))) = s2[i];
-                else *(u32x4*)(W2s + (idx >> 2) * P2 + 8 * (idx & 3)) = s2[i];
+                if constexpr (RECOMP) {
+                    *(u32x4*)(W2s + (idx / (C / 8)) * P1 + 8 * (idx % (C / 8))) = s2[i];
+                } else {        // K = 32 operand order within a row, as in the forward kernel's commit
+                    const int q = idx & 3;
+                    uint16_t* row = W2s + (idx >> 2) * P2 + 4 * (q >> 1);
+                    *(u32x2*)(row + 16 * (q & 1)) = (u32x2){s2[i][0], s2[i][1]};
+                    *(u32x2*)(row + 16 * (q & 1) + 8) = (u32x2){s2[i][2], s2[i][3]};
+                }
             }
         }
     };
@@ -616,15 +627,14 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const MlpBwd a) {
         for (int mt = 0; mt < MT; ++mt) hop[mt] = __builtin_shufflevector(hb[mt][0], hb[mt][1], 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            bf16x4 lo, hi;
+            bf16x8 wf;
             if constexpr (RECOMP) {     // W1^T fragments as transposed reads of the row-major chunk: element q = W1[4 g + q (+ 16)][16 t + fr]
-                lo = lds_tr_read(W2s + (4 * g + (fr >> 2)) * P1 + 16 * t + (fr & 3) * 4);
-                hi = lds_tr_read(W2s + (16 + 4 * g + (fr >> 2)) * P1 + 16 * t + (fr & 3) * 4);
+                const bf16x4 lo = lds_tr_read(W2s + (4 * g + (fr >> 2)) * P1 + 16 * t + (fr & 3) * 4);
+                const bf16x4 hi = lds_tr_read(W2s + (16 + 4 * g + (fr >> 2)) * P1 + 16 * t + (fr & 3) * 4);
+                wf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             } else {
-                lo = *(const bf16x4*)(W2s + (16 * t + fr) * P2 + 4 * g);
-                hi = *(const bf16x4*)(W2s + (16 * t + fr) * P2 + 16 + 4 * g);
+                wf = *(const bf16x8*)(W2s + (16 * t + fr) * P2 + 8 * g);
             }
-            const bf16x8 wf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) yacc[mt][t] = mfma32(wf, hop[mt], yacc[mt][t]);
         }

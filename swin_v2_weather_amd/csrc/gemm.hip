@@ -201,8 +201,10 @@ __device__ __forceinline__ void heads_item(const EpiDesc& d, const float* st, in
 // here.  Each half adds its partial sum of squares into rnorm (zeroed by the caller; two addends -> order-independent)
 // and writes the UN-normalised bf16 values; swv2_qk_normalize then turns the sums into 1 / |.| and rescales q, k in
 // place (one extra bf16 rounding of q^, k^ compared with the narrow-head epilogue).  lane = (row, 16-column quarter).
-template <bool NORM>
-__device__ __forceinline__ void heads_item_wide(const EpiDesc& d, const float* st, int m0, int n0, int lane) {
+// PB: the lane's 16 bias values were loaded by the caller (once per tile: the wide kernels; a load inside this function sits
+// under a condition and makes the compiler wait for every earlier store with s_waitcnt vmcnt(0)); zeros without a bias
+template <bool NORM, bool PB = false>
+__device__ __forceinline__ void heads_item_wide(const EpiDesc& d, const float* st, int m0, int n0, int lane, const f32x4* pb = nullptr) {
     const int h = d.p0, Lp = d.p2, L = d.p4, S = NORM ? 3 : 1;
     const int r = lane & 15, qd = lane >> 4, nb = n0 + 16 * qd, m = m0 + r;
     const bool in = (m < d.M) && (nb < d.N);
@@ -214,7 +216,8 @@ __device__ __forceinline__ void heads_item_wide(const EpiDesc& d, const float* s
 #pragma unroll
     for (int j = 0; j < 16; j += 4) {
         f32x4 x = *(const f32x4*)(st + r * EP + 16 * qd + j);
-        if (d.bias && in) x += *(const f32x4*)(d.bias + nb + j);
+        if constexpr (PB) x += pb[j >> 2];
+        else if (d.bias && in) x += *(const f32x4*)(d.bias + nb + j);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             v[j + e] = valid ? x[e] : 0.f;
@@ -546,6 +549,406 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(ALoad<AK> al, cons
 }
 
 // ------------------------------------------------------------------------------------------------
+// Wide NT kernel: 256 x 256 x 64 tiles for the MFMA-bound products of wide models (the reference's own swin_73var is
+// embed_dim 768: K and N of 768 .. 3072, where gemm_nt_kernel's 64 x 64 wave tiles and its single LDS buffer with two
+// barriers per k-step reach 8 - 23 % of the matrix peak).  One 8-wave workgroup per CU, wave tile 128 x 64 (128 fp32
+// accumulators; per K = 32: 12 ds_read_b128 for 32 MFMAs), two LDS tile buffers (2 x 64 KB) with the next k-step's global
+// loads in flight in registers across the MFMAs and ONE barrier per k-step.  All staging loads are unconditional (rows
+// past M: the operand's first row, zeroed at commit), so the compiler can count them in s_waitcnt.
+// Grid: one workgroup per output tile.  Workgroups are dispatched round-robin over the 8 XCDs (blockIdx % 8), each XCD
+// with its own L2; the index is decoded so that the ~32 tiles an XCD runs concurrently are 8 row panels x 4 column tiles:
+// every A line is then fetched from HBM / Infinity Cache once per 4 and every weight line once per 8 workgroups instead of
+// once each (speed only: any mapping is correct).
+// ------------------------------------------------------------------------------------------------
+constexpr int WBM = 256, WBN = 256, WTH = 512;
+// LDS-DMA load: 16 bytes per lane from (scalar base + 32-bit byte offset) to LDS at m0 + 16 * lane, no register.  Inline assembly
+// on purpose: through the builtin the compiler orders every later LDS access behind the load with s_waitcnt vmcnt(0).  The
+// compiler does not count these in its own vmcnt bookkeeping; VMEM operations return in order, so an uncounted operation can
+// only make a compiler-placed wait longer, never too short; the waits for the DMA'd tiles are placed by hand.
+__device__ __forceinline__ void dma_x4(const void* base, uint32_t byte_off, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(byte_off), "s"(base), "s"(lds_addr) : "memory");
+}
+// Epilogue of a wave's 128 x 64 accumulator tile in the wide kernels.  Epi<>::tile loads its bias / residual / pre-activation
+// operands under conditions, which costs an s_waitcnt vmcnt(0) per 16-row sub-tile -- a wait for the acknowledgement of every
+// store of the previous sub-tile (measured: 20 us per tile for 256 KB, half the kernel at K = 768).  Here everything a lane needs
+// for all eight sub-tiles is loaded up front (bias: the lane's columns are the same in every sub-tile; scatter rows), the
+// per-sub-tile operands are loaded unconditionally (clamped rows) one sub-tile ahead, and only stores sit under the row mask:
+// the waits are counted and the stores of a tile leave back to back.  Same arithmetic, in the same order, as Epi<>::tile.
+template <int EK>
+__device__ __forceinline__ void wide_epilogue(const Epi<EK>& ep, const f32x4 (&acc)[8][4], float* st, int m_w, int n_w, int lane) {
+    const EpiDesc& d = ep.d;
+    const int fr = lane & 15, g = lane >> 4;
+    auto stage = [&](int i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st[(4 * g + r) * EP + 16 * j + fr] = acc[i][j][r];
+    };
+    if constexpr (EK == E_F32 || EK == E_BF16 || EK == E_BF16_GELU || EK == E_GELU_GRAD) {
+        // Row-major outputs.  A store instruction writes WHOLE 128-byte lines: fp32: 4 rows x 256 bytes (lane -> row 4 q + (lane >> 4),
+        // 4 columns), bf16: 8 rows x 128 bytes (lane -> row 8 q + (lane >> 3), 8 columns).  With Epi<>::tile's map (a lane owns 16
+        // columns of one row: an instruction writes 16-byte pieces 64 bytes apart) a line is completed by four instructions, and once
+        // the stores leave back to back lines are evicted half written: measured 67 us per tile of 256 KB instead of 20.
+        // N is a multiple of 256 here: no column tail.
+        constexpr bool F32O = EK == E_F32;
+        constexpr int NQ = F32O ? 4 : 2, RQ = 16 / NQ, CW = F32O ? 4 : 8;      // instructions per sub-tile, rows per instruction, columns per lane
+        const int rl = F32O ? (lane >> 4) : (lane >> 3), cl = F32O ? (lane & 15) * 4 : (lane & 7) * 8;
+        const int n = n_w + cl;
+        f32x4 b4[CW / 4];
+#pragma unroll
+        for (int q = 0; q < CW / 4; ++q) b4[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (d.bias) {
+#pragma unroll
+            for (int q = 0; q < CW / 4; ++q) b4[q] = *(const f32x4*)(d.bias + n + 4 * q);
+        }
+        const bool scatter = (EK == E_F32 || EK == E_BF16) && d.rowidx != nullptr;
+        // (compile-time variants for the two uniform run-time conditions, so that every load of a variant is unconditional)
+        auto body = [&](auto scat, auto has_aux) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                long off[NQ];
+                bool ok[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int m = m_w + 16 * i + RQ * q + rl, mc = min(m, d.M - 1);
+                    int dst = mc;
+                    if constexpr (decltype(scat)::value) dst = d.rowidx[mc];
+                    ok[q] = m < d.M && dst >= 0;
+                    off[q] = (long)max(dst, 0) * d.ld + n;
+                }
+                stage(i);
+                if constexpr (EK == E_F32) {
+                    float* out = (float*)d.out;
+                    const float* ax = (const float*)d.aux;
+                    [[maybe_unused]] f32x4 a[NQ];
+                    if constexpr (decltype(has_aux)::value) {
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) a[q] = *(const f32x4*)(ax + off[q]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        f32x4 v = *(const f32x4*)(st + (RQ * q + rl) * EP + cl);
+                        v += b4[0];
+                        if constexpr (decltype(has_aux)::value) v += a[q];
+                        if (ok[q]) *(f32x4*)(out + off[q]) = v;
+                    }
+                } else {
+                    uint16_t* out = (uint16_t*)d.out;
+                    [[maybe_unused]] uint16_t* out2 = (uint16_t*)d.aux_out;
+                    [[maybe_unused]] uint4 pv[NQ];
+                    if constexpr (EK == E_GELU_GRAD) {
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) pv[q] = *(const uint4*)((const uint16_t*)d.aux + off[q]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        float v[8];
+                        *(f32x4*)v = *(const f32x4*)(st + (RQ * q + rl) * EP + cl);
+                        *(f32x4*)(v + 4) = *(const f32x4*)(st + (RQ * q + rl) * EP + cl + 4);
+                        if constexpr (EK == E_GELU_GRAD) {
+                            float hv[8];
+                            unpack8(pv[q], hv);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(hv[e]);
+                            if (ok[q]) *(uint4*)(out + off[q]) = pack8(v);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += b4[e >> 2][e & 3];
+                            if constexpr (EK == E_BF16_GELU) {
+                                float gl[8];
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) gl[e] = gelu_f(bf2f(f2bf(v[e])));   // GELU of the stored (bf16) pre-activation
+                                if (ok[q]) { *(uint4*)(out + off[q]) = pack8(v); *(uint4*)(out2 + off[q]) = pack8(gl); }
+                            } else {
+                                if (ok[q]) *(uint4*)(out + off[q]) = pack8(v);
+                            }
+                        }
+                    }
+                }
+            }
+        };
+        const bool aux = EK == E_F32 && d.aux != nullptr;
+        if (scatter) { if (aux) body(std::true_type{}, std::true_type{}); else body(std::true_type{}, std::false_type{}); }
+        else { if (aux) body(std::false_type{}, std::true_type{}); else body(std::false_type{}, std::false_type{}); }
+    } else if constexpr (EK == E_QKV_HEADS || EK == E_HEADS) {
+        if (d.p3 == 128) {               // lane -> (row lane & 15, 16-column quarter lane >> 4)
+            const int nb = n_w + 16 * g;
+            f32x4 b4[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            if (d.bias) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) b4[q] = *(const f32x4*)(d.bias + nb + 4 * q);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                stage(i);
+                heads_item_wide<EK == E_QKV_HEADS, true>(d, st, m_w + 16 * i, n_w, lane, b4);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { stage(i); ep.tile(st, m_w + 16 * i, n_w, lane); }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { stage(i); ep.tile(st, m_w + 16 * i, n_w, lane); }
+    }
+}
+
+__device__ __forceinline__ int swz32(int r, int c) { return r * 32 + ((c ^ ((0 - (r >> 2)) & 3)) << 3); }
+
+// decode the v-th tile of XCD x (see the header comment): false = past the matrix
+__device__ __forceinline__ bool wide_tile(int x, int v, int mtiles, int ntn, int& mt, int& nt) {
+    const int per_group = 8 * ntn;
+    const int gl = v / per_group, r = v - gl * per_group;
+    const int nb = r >> 5, rr = r & 31;               // column block of 4 tiles; (panel, column) inside it: rr < 8 * min(4, ntn - 4 nb)
+    mt = (gl * 8 + x) * 8 + (rr & 7);
+    nt = 4 * nb + (rr >> 3);
+    return mt < mtiles && nt < ntn;
+}
+
+// ---- raw bf16 operands (A_BF16 without a gather table, A_HEADS): both operands reach LDS by DMA, no staging registers ----
+// Persistent workgroups (32 per XCD) walk their XCD's tile sequence; the DMA pipeline runs THROUGH the tile boundaries.
+//   LDS: four stage slots of 32 k (A[256][32] | B[256][32] bf16 = 32 KB each; 64-byte rows, chunk c of row r at physical chunk
+//   c ^ ((-(r >> 2)) & 3): the 16 lanes ds_read_b128 serves per cycle ({0-3, 12-15, 20-27}, ...) then fall on 16 different 16-byte
+//   bank groups) + a 2 KB pad behind slot 3 (the epilogue's staging = slot 3 + pad).  Global stage q = (tile, 32-k step) lives in
+//   slot q & 3; K is a multiple of 128, so a tile's last stage sits in slot 3 and the next tile's stages 0, 1, 2 -- issued during
+//   the last three steps of this tile -- in slots 0, 1, 2.
+// Two wave groups (waves 0-3: rows 0-127 of the tile, waves 4-7: rows 128-255; waves w and w + 4 share a SIMD) run the same loop
+// one barrier apart: while one group issues its 32 MFMAs of a stage, the other issues DMA and reads its fragments from LDS, so
+// each SIMD's matrix pipe always has one wave feeding it.  Per stage t and wave:
+//     LOAD(t): 4 DMA instructions of stage t + 3 -> slot (t + 3) & 3 | 12 ds_read_b128 of stage t | vmcnt(8) | lgkmcnt(0)
+//     barrier | MFMA(t): 32 MFMAs | barrier
+// group 0 runs LOAD(t) in section 2 t and MFMA(t) in section 2 t + 1, group 1 one section later (sections = the intervals between
+// workgroup barriers).  RAW: a wave retires its own DMA of stage t + 1 with the counted vmcnt(8) at the end of LOAD(t) (stages
+// t + 2, t + 3 = 8 instructions stay in flight; VMEM operations retire in order, so older epilogue stores only make the wait
+// longer), i.e. by the end of section 2 t + 1 at the latest; the first read of stage t + 1 is in section 2 t + 2, behind that
+// section's opening barrier.  WAR: slot (t + 3) & 3 held stage t - 1, whose last reads (group 1, LOAD(t - 1), retired by its
+// lgkmcnt(0)) are in section 2 t - 1; the DMA into it is issued in sections 2 t (group 0) and 2 t + 1 (group 1).  Every wave issues
+// exactly 4 DMA instructions per stage, in stage order; behind the last tile the last stage is re-read into slots nobody reads.
+// Tile end (last stage L in slot 3): group 0 waits one section, BOTH groups run the epilogue in the same section (staging in
+// slot 3 + pad: the last reads of slot 3 are two sections back, the next DMA into it is issued in LOAD(0) of the next tile, one
+// barrier later), then group 1 waits one section: the stagger is restored.  Two idle sections per tile buy the epilogues of all
+// eight waves side by side and a prologue that is already in LDS.
+constexpr int WSTG = (WBM + WBN) * 32;                 // elements per stage slot
+constexpr int WSM_BYTES = 4 * WSTG * 2 + 2048;
+template <int AK, int EK>
+__global__ __launch_bounds__(WTH) void gemm_nt_wide_dma_kernel(ALoad<AK> al, const uint16_t* __restrict__ Wb, Epi<EK> ep,
+                                                               int M, int N, int K, int mtiles, int ntn, int vmax) {
+    static_assert(AK == A_BF16 || AK == A_HEADS, "DMA needs a raw bf16 operand");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem_b[WSM_BYTES];
+    static_assert(3 * WSTG * 2 + 8 * 16 * EP * 4 <= WSM_BYTES, "epilogue staging = slot 3 + pad");
+    uint16_t* const smem = (uint16_t*)smem_b;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, g = lane >> 4;
+    const int wr = wave >> 2, wc = wave & 3;              // 2 x 4 waves, 128 x 64 each
+    const int xcd = blockIdx.x & 7, nper = gridDim.x >> 3, stages = K / 32;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+    // DMA geometry: one wave instruction fills 16 stage rows x 64 bytes (1 KB of LDS); instruction i (of 2 per operand) of this
+    // wave covers rows 32 wave + 16 i .. + 15; lane -> (row + (lane >> 2), physical chunk lane & 3)
+    const int drow = wave * 32 + (lane >> 2);
+    int dkc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) dkc[i] = (lane & 3) ^ ((0 - ((drow + 16 * i) >> 2)) & 3);
+    struct Tile { int m_base, n_base; uint32_t boff[2], aoff[2]; };
+    auto make_tile = [&](int mt, int nt) {
+        Tile t;
+        t.m_base = mt * WBM; t.n_base = nt * WBN;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = drow + 16 * i;
+#ifdef SWV2_WIDE_SAME_TILE          // (timing ablation: every workgroup streams the first tile's operands -- all L2 hits; wrong results)
+            t.boff[i] = 2u * (uint32_t)(row * K + dkc[i] * 8);
+            t.aoff[i] = AK == A_BF16 ? 2u * (uint32_t)(row * (int)al.d.ld + dkc[i] * 8) : 0u;
+#else
+            t.boff[i] = 2u * (uint32_t)((t.n_base + row) * K + dkc[i] * 8);
+            t.aoff[i] = AK == A_BF16 ? 2u * (uint32_t)(min(t.m_base + row, M - 1) * (int)al.d.ld + dkc[i] * 8) : 0u;
+#endif
+        }
+        return t;
+    };
+    auto issue = [&](const Tile& tl, int t, int slot) {
+        const uint32_t la = lds0 + (uint32_t)(slot * WSTG * 2) + (uint32_t)(wave * 2048), lb = la + WBM * 32 * 2;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) dma_x4(Wb + t * 32, tl.boff[i], lb + 1024 * i);
+        if constexpr (AK == A_BF16) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) dma_x4((const uint16_t*)al.d.ptr + t * 32, tl.aoff[i], la + 1024 * i);
+        } else {                             // head-major rows: the element offset of (row, k) is not affine in k
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                dma_x4(al.d.ptr, 2u * al.elem_off(min(tl.m_base + drow + 16 * i, M - 1), t * 32 + dkc[i] * 8), la + 1024 * i);
+        }
+    };
+    // first tile of this workgroup
+    int v = blockIdx.x >> 3, mt = 0, nt = 0;
+    while (v < vmax && !wide_tile(xcd, v, mtiles, ntn, mt, nt)) v += nper;
+    if (v >= vmax) return;
+    Tile cur = make_tile(mt, nt);
+    issue(cur, 0, 0); issue(cur, 1, 1); issue(cur, 2, 2);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // stage 0 has landed (this wave's part)
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();             // group 1 starts one section later
+    for (;;) {
+        int v2 = v + nper, mt2 = 0, nt2 = 0;
+        while (v2 < vmax && !wide_tile(xcd, v2, mtiles, ntn, mt2, nt2)) v2 += nper;
+        const bool has_next = v2 < vmax;
+        const Tile nxt = has_next ? make_tile(mt2, nt2) : cur;
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < stages; ++t) {
+            // ---- LOAD(t)
+#ifndef SWV2_WIDE_NO_DMA            // (timing ablations, tools/ab_build.sh: wrong results)
+            if (t + 3 < stages) issue(cur, t + 3, (t + 3) & 3);
+            else issue(nxt, has_next ? t + 3 - stages : stages - 1, (t + 3) & 3);
+#endif
+            const uint16_t* As = smem + (t & 3) * WSTG;
+            const uint16_t* Bs = As + WBM * 32;
+            bf16x8 af[8], bf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = *(const bf16x8*)(Bs + swz32(wc * 64 + j * 16 + fr, g));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) af[i] = *(const bf16x8*)(As + swz32(wr * 128 + i * 16 + fr, g));
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- MFMA(t)
+            __builtin_amdgcn_s_setprio(1);
+#ifdef SWV2_WIDE_NO_MMA
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("" :: "v"(af[i]), "v"(bf[i & 3]));
+#else
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
+#endif
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- tile end
+        if (wr == 0) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            float* st = (float*)(smem + 3 * WSTG) + wave * 16 * EP;
+#ifndef SWV2_WIDE_NO_EPI            // (timing ablation)
+            wide_epilogue<EK>(ep, acc, st, cur.m_base + wr * 128, cur.n_base + wc * 64, lane);
+#else
+            for (int i = 0; i < 8; ++i) asm volatile("" :: "v"(acc[i][0]), "v"(acc[i][1]), "v"(acc[i][2]), "v"(acc[i][3]));
+#endif
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the staging reads are done before slot 3 is handed back
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        if (wr == 1) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (!has_next) break;
+        cur = nxt; v = v2;
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();             // (every wave passes the same number of barriers)
+}
+
+// ---- register-staged A (fp32 rows, gathered rows with zero rows): weights by DMA, two 64-k buffers, one tile per workgroup ----
+template <int AK, int EK>
+__global__ __launch_bounds__(WTH) void gemm_nt_wide_kernel(ALoad<AK> al, const uint16_t* __restrict__ Wb, Epi<EK> ep,
+                                                           int M, int N, int K, int mtiles, int ntn) {
+    static_assert(!ALoad<AK>::ROW_FASTEST, "row-major staging map only");
+    constexpr int TILE = (WBM + WBN) * BK;                 // elements per 64-k buffer (A | B)
+    __shared__ __attribute__((aligned(1024))) uint16_t smem[2 * TILE];
+    static_assert(2 * TILE * 2 >= 8 * 16 * EP * 4, "the epilogue staging re-uses the tile buffers");
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, g = lane >> 4;
+    const int wr = wave >> 2, wc = wave & 3;              // 2 x 4 waves, 128 x 64 each
+    int mt, nt;
+    if (!wide_tile(blockIdx.x & 7, blockIdx.x >> 3, mtiles, ntn, mt, nt)) return;
+    const int m_base = mt * WBM, n_base = nt * WBN;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+        const int ksteps = K / BK;
+        // DMA geometry (weights): one wave instruction fills 8 tile rows x 128 bytes; instruction i of this wave covers tile
+        // rows 32 wave + 8 i .. + 7; lane -> (row + (lane >> 3), physical chunk lane & 7), which holds logical chunk (lane & 7) ^ swizzle
+        const int drow = wave * 32 + (lane >> 3);
+        uint32_t boff[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = drow + 8 * i, kcl = (lane & 7) ^ ((row >> 1) & 7);
+            boff[i] = 2u * (uint32_t)((n_base + row) * K + kcl * 8);
+        }
+        // register staging of A: 4 chunks of 16 bytes per thread per k-step; chunk c = tid + 512 i -> (row c >> 3, chunk column c & 7)
+        typename ALoad<AK>::Raw ra[4];
+        int arow[4];
+        uint32_t aok = 0;
+        const int kc = tid & 7;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int src = al.row_of(m_base + (tid >> 3) + 64 * i);
+            arow[i] = max(src, 0);
+            aok |= (src >= 0 ? 1u : 0u) << i;
+        }
+        auto issue = [&](int s, int buf) {
+            const uint32_t lb = lds0 + (uint32_t)(buf * TILE * 2) + (uint32_t)(wave * 4096) + WBM * BK * 2;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dma_x4(Wb + s * BK, boff[i], lb + 1024 * i);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ra[i] = al.raw_unc(arow[i], s * BK + kc * 8);
+        };
+        auto commit = [&](int buf) {
+            uint16_t* As = smem + buf * TILE;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint4 v = al.cvt(ra[i]);
+                if (!((aok >> i) & 1)) v = make_uint4(0, 0, 0, 0);
+                *(uint4*)(As + swz((tid >> 3) + 64 * i, kc)) = v;
+            }
+        };
+        auto compute = [&](int buf) {
+            const uint16_t* As = smem + buf * TILE;
+            const uint16_t* Bs = As + WBM * BK;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 bf[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bf[j] = *(const bf16x8*)(Bs + swz(wc * 64 + j * 16 + fr, kk * 4 + g));
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const bf16x8 af = *(const bf16x8*)(As + swz(wr * 128 + i * 16 + fr, kk * 4 + g));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = mfma32(af, bf[j], acc[i][j]);
+                }
+            }
+        };
+        issue(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        commit(0);
+        __syncthreads();
+        for (int s = 0; s + 1 < ksteps; ++s) {
+            issue(s + 1, (s + 1) & 1);
+            // (without the fences the scheduler sinks the loads behind the MFMAs, next to the waits of commit, or re-issues them
+            // there: found in the ISA, 7 400 cycles per k-step against 2 048 of MFMA work)
+            __builtin_amdgcn_sched_barrier(0);
+            compute(s & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the DMA'd weight tile of step s + 1 has landed
+            commit((s + 1) & 1);
+            __syncthreads();           // step s + 1 is complete in its buffer; every wave is done reading buffer s & 1
+        }
+        compute((ksteps - 1) & 1);
+        __syncthreads();               // the staging below overwrites the tile buffers
+    }
+    wide_epilogue<EK>(ep, acc, (float*)smem + wave * 16 * EP, m_base + wr * 128, n_base + wc * 64, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Resident-weight kernel for the two per-block row-streaming products at the benchmark width (qkv: N = 384, K = 128 and
 // d(qkv) -> dx: N = 128, K = 384).  gemm_nt_kernel above is latency-bound there (measured: ~20 us workgroup lifetime for
 // 64 rows = one HBM round trip for the A panel + six dependent L2 round trips for the weight tiles + three epilogues, at
@@ -812,6 +1215,31 @@ int launch_nt2(const swv2_operand* a, const void* w, const swv2_epilogue* e, int
         if (rw && N == 128 && K == 384 && M >= 256 * 64 && e->rowidx && e->aux && !a->rowidx) {
             hipLaunchKernelGGL((gemm_rw_kernel<AK, EK, 128, 384, 64>), dim3(256), dim3(512), 0, st, make_loader<AK>(a),
                                (const uint16_t*)w, ep, M);
+            SWV2_CHECK_LAUNCH("swv2_linear");
+            return SWV2_OK;
+        }
+    }
+    // wide products (K, N >= 512, N a multiple of 256): 256 x 256 tiles
+    if constexpr ((AK == A_F32 || AK == A_BF16 || AK == A_HEADS) &&
+                  (EK == E_BF16 || EK == E_F32 || EK == E_F32_ACC || EK == E_QKV_HEADS || EK == E_HEADS || EK == E_GELU_GRAD || EK == E_BF16_GELU)) {
+        const int wide = getenv("SWV2_GEMM_WIDE") ? atoi(getenv("SWV2_GEMM_WIDE")) : 1;      // (read per call: the tests toggle it)
+        if (wide && N % WBN == 0 && K % BK == 0 && N >= 512 && K >= 512 && M >= 16 * WBM) {
+            const int mtiles = cdiv(M, WBM), ntn = N / WBN, groups = cdiv(mtiles, 8);
+            const int grid = 8 * cdiv(groups, 8) * 8 * ntn;
+            // 32-bit byte offsets in the DMA addressing: weights and operand below 4 GB (the operand: checked for its kind below)
+            SWV2_CHECK_ARG((double)N * K * 2 < 4.29e9, "swv2_linear: weight too large for the wide kernel's 32-bit offsets");
+            const bool small = (double)a->rows * (AK == A_HEADS ? a->cols : a->ld) * 2 < 4.29e9;
+            constexpr bool CAN_DMA = AK == A_BF16 || AK == A_HEADS;
+            const int vmax = cdiv(groups, 8) * 8 * ntn;            // tile sequence length per XCD
+            const int persist = getenv("SWV2_WIDE_PERSIST") ? atoi(getenv("SWV2_WIDE_PERSIST")) : 1;
+            if (CAN_DMA && small && K % 128 == 0 && (AK == A_HEADS || !a->rowidx)) {
+                if constexpr (CAN_DMA)
+                    hipLaunchKernelGGL((gemm_nt_wide_dma_kernel<AK, EK>), dim3(8 * (vmax < 32 || !persist ? vmax : 32)), dim3(WTH), 0, st, make_loader<AK>(a),
+                                       (const uint16_t*)w, ep, M, N, K, mtiles, ntn, vmax);
+            } else {
+                hipLaunchKernelGGL((gemm_nt_wide_kernel<AK, EK>), dim3(grid), dim3(WTH), 0, st, make_loader<AK>(a), (const uint16_t*)w,
+                                   ep, M, N, K, mtiles, ntn);
+            }
             SWV2_CHECK_LAUNCH("swv2_linear");
             return SWV2_OK;
         }

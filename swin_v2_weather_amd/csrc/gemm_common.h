@@ -261,6 +261,14 @@ template <> struct ALoad<A_HEADS> {
         const int part = (h == 1) ? ph : fdiv(ph, h, d.mg1), hd = ph - part * h;
         return *(const uint4*)((const uint16_t*)d.ptr + ((((long)bw * h + hd) * S + part) * Lp + t) * DP + j);
     }
+    // element offset of (row m, column k0) for callers that address with 32 bits (tensor below 2^32 bytes, checked by them)
+    __device__ __forceinline__ uint32_t elem_off(int m, int k0) const {
+        const int h = d.p0, Lp = d.p2, DP = d.p3, S = (int)d.ld;
+        const int bw = fdiv(m, Lp, d.mg0), t = m - bw * Lp;
+        const int ph = k0 >> d.p1, j = k0 - ph * DP;
+        const int part = (h == 1) ? ph : fdiv(ph, h, d.mg1), hd = ph - part * h;
+        return (uint32_t)((((bw * h + hd) * S + part) * Lp + t) * DP + j);
+    }
     // Walking rows m, m + 16, m + 32, ... of ONE chunk column (the weight-gradient kernel's staging): the window / token split
     // once per step (step_base), then adds -- a row block that runs past its window's Lp rows continues (h S - 1) Lp DP
     // elements further, in the same (head, part) slab of the next window.  Valid while a step spans at most one window

@@ -127,6 +127,146 @@ def test_linear_loaders_and_epilogues(dev, K):
         assert rel(o32, exp) < 1e-5
 
 
+def _with_wide(flag, fn):
+    old = os.environ.get("SWV2_GEMM_WIDE")
+    os.environ["SWV2_GEMM_WIDE"] = flag
+    try:
+        fn()
+    finally:
+        if old is None:
+            os.environ.pop("SWV2_GEMM_WIDE", None)
+        else:
+            os.environ["SWV2_GEMM_WIDE"] = old
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("persist", ["1", "0"])
+def test_wide_gemm_kernels_equal_the_128_tile_kernel_bit_for_bit(dev, K, persist, monkeypatch):
+    """The 256 x 256 kernels of the wide widths (reference swin.yaml: embed_dim 768) -- LDS-DMA pipeline for raw bf16 operands,
+    register-staged fp32 / gathered rows, full-line epilogue -- against gemm_nt_kernel on the same inputs: same k order per output
+    element and the same epilogue arithmetic, so the results must be IDENTICAL; plus a torch reference per product.  Every
+    loader x epilogue pair the width-768 block uses; ragged M (last row tile partly outside), gather tables with zero rows, scatter."""
+    ops, L = K["ops"], K["L"]
+    monkeypatch.setenv("SWV2_WIDE_PERSIST", persist)
+    torch.manual_seed(11)
+    M, Kd = 4500, 512
+
+    def both(run, outs):
+        got = []
+        for flag in ("0", "1"):
+            for o in outs:
+                o.fill_(float("nan")) if o.dtype != torch.int32 else None
+            _with_wide(flag, run)
+            got.append([o.clone() for o in outs])
+        for a, b in zip(*got):
+            assert torch.equal(a, b), (a.shape, float((a.float() - b.float()).abs().max()))
+        return got[1]
+
+    x = torch.randn(M, Kd)
+    xb = x.to(BF).to(dev)
+    for Nn in (512, 768):
+        w, b = torch.randn(Nn, Kd) * 0.05, torch.randn(Nn)
+        wb = ops.prep_weight(w.to(dev))
+        ref = rb(x) @ rb(w).T + b
+        # bf16 rows -> fp32 (+ bias, + residual, scatter) and -> bf16
+        idx = torch.randperm(M)
+        ri = idx.to(torch.int32).to(dev)
+        ri[::5] = -1                                          # rows that are dropped by the scatter
+        aux = torch.randn(M, Nn, device=dev)
+        o32 = torch.empty(M, Nn, device=dev)
+        (g,) = both(lambda: ops.linear(ops.op_bf16(xb), wb, ops.epilogue(L.EPI_F32, o32, ld=Nn, bias=b.to(dev)), Nn), [o32])
+        assert rel(g, ref) < 1e-5
+        o32.zero_()
+        sc = torch.zeros(M, Nn, device=dev)
+        def run_scatter():
+            sc.zero_()
+            ops.linear(ops.op_bf16(xb), wb, ops.epilogue(L.EPI_F32, sc, ld=Nn, aux=aux, rowidx=ri), Nn)
+        got = []
+        for flag in ("0", "1"):
+            _with_wide(flag, run_scatter)
+            got.append(sc.clone())
+        assert torch.equal(got[0], got[1])
+        exp = torch.zeros(M, Nn)
+        keep = (ri >= 0).cpu()
+        exp[idx[keep]] = (rb(x) @ rb(w).T)[keep] + aux.cpu()[idx[keep]]
+        assert rel(got[1], exp) < 1e-5
+        ob = torch.empty(M, Nn, dtype=BF, device=dev)
+        (g,) = both(lambda: ops.linear(ops.op_bf16(xb), wb, ops.epilogue(L.EPI_BF16, ob, ld=Nn, bias=b.to(dev)), Nn), [ob])
+        assert rel(g.float(), ref) < 4e-3
+        # fp32 rows (register-staged): gathered with zero rows -> bf16 ; fc1 epilogue (pre-activation + GELU)
+        ri2 = torch.randperm(M).to(torch.int32)
+        ri2[::7] = -1
+        (g,) = both(lambda: ops.linear(ops.op_f32(x.to(dev), rowidx=ri2.to(dev)), wb, ops.epilogue(L.EPI_BF16, ob, ld=Nn), Nn), [ob])
+        exp = (rb(x) @ rb(w).T)[ri2.clamp(min=0).long()]
+        exp[ri2 < 0] = 0
+        assert rel(g.float(), exp) < 4e-3
+        act = torch.empty(M, Nn, dtype=BF, device=dev)
+        g_pre, g_act = both(lambda: ops.linear(ops.op_f32(x.to(dev)), wb, ops.epilogue(L.EPI_BF16_GELU, ob, ld=Nn, bias=b.to(dev), aux_out=act), Nn),
+                            [ob, act])
+        assert rel(g_pre.float(), ref) < 4e-3 and rel(g_act.float(), O.gelu_erf(g_pre.float().cpu())) < 4e-3
+        # dh = (dy W) * GELU'(pre-activation)
+        hpre = torch.randn(M, Nn).to(BF).to(dev)
+        (g,) = both(lambda: ops.linear(ops.op_bf16(xb), wb, ops.epilogue(L.EPI_GELU_GRAD, ob, ld=Nn, aux=hpre), Nn), [ob])
+        hp = hpre.float().cpu().double().requires_grad_(True)
+        O.gelu_erf(hp).backward((rb(x) @ rb(w).T).double())
+        assert rel(g.float(), hp.grad) < 4e-3
+
+    # more tiles than workgroups: the persistent workgroups walk tile sequences (the DMA pipeline runs through the tile ends)
+    Mb = 24000
+    xl = torch.randn(Mb, Kd).to(BF).to(dev)
+    wl = torch.randn(768, Kd) * 0.05
+    wlb = ops.prep_weight(wl.to(dev))
+    o32 = torch.empty(Mb, 768, device=dev)
+    (g,) = both(lambda: ops.linear(ops.op_bf16(xl), wlb, ops.epilogue(L.EPI_F32, o32, ld=768), 768), [o32])
+    assert rel(g, xl.float().cpu() @ rb(wl).T) < 1e-5
+    ob = torch.empty(Mb, 768, dtype=BF, device=dev)
+    (g,) = both(lambda: ops.linear(ops.op_bf16(xl), wlb, ops.epilogue(L.EPI_BF16, ob, ld=768), 768), [ob])
+    assert rel(g.float(), xl.float().cpu() @ rb(wl).T) < 4e-3
+
+    # head-major layouts at the padded head width 128 (width 768 = 8 heads of 96): qkv epilogue, head split, head-major operand
+    h, Lp, Lv, DP, Bw = 2, 176, 162, 128, 27
+    Mw = Bw * Lp
+    xw = torch.randn(Mw, Kd)
+    ri3 = torch.arange(Mw, dtype=torch.int32)
+    ri3[(torch.arange(Mw) % Lp) >= Lv] = -1                   # the padded rows of a window are zero rows of the gather
+    wq, bq = torch.randn(3 * h * DP, Kd) * 0.05, torch.randn(3 * h * DP)
+    wqb = ops.prep_weight(wq.to(dev))
+    qkvh = torch.empty(Bw, h, 3, Lp, DP, dtype=BF, device=dev)
+    rn = torch.zeros(Bw, h, 2, Lp, device=dev)
+    def run_qkv():
+        rn.zero_()
+        ops.linear(ops.op_f32(xw.to(dev), rowidx=ri3.to(dev)), wqb,
+                   ops.epilogue(L.EPI_QKV_HEADS, qkvh, bias=bq.to(dev), aux_out=rn, p=(h, 0, Lp, DP, Lv)), 3 * h * DP)
+    got = []
+    for flag in ("0", "1"):
+        qkvh.fill_(float("nan"))
+        _with_wide(flag, run_qkv)
+        got.append((qkvh.clone(), rn.clone()))
+    assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1])
+    full = (rb(xw) @ rb(wq).T + bq).view(Bw, Lp, 3, h, DP).permute(0, 3, 2, 1, 4)          # [Bw][h][3][Lp][DP]
+    valid = (torch.arange(Lp) < Lv).view(1, 1, 1, Lp, 1)
+    assert rel(got[1][0].float(), torch.where(valid, full, torch.zeros(()))) < 4e-3
+    assert rel(got[1][1], torch.where(valid.view(1, 1, 1, Lp), (full[:, :, :2] ** 2).sum(-1), torch.zeros(()))) < 1e-4   # sums of squares (DP = 128)
+    # d(oh) = da1 Wp^T -> head-major split ; proj forward from the head-major operand ; dx = dqkv Wqkv (+ residual, scatter)
+    da1 = torch.randn(Mw, Kd).to(BF).to(dev)
+    wp = torch.randn(h * DP, Kd) * 0.05
+    doh = torch.empty(Bw, h, 1, Lp, DP, dtype=BF, device=dev)
+    (g,) = both(lambda: ops.linear(ops.op_bf16(da1), ops.prep_weight(wp.to(dev)), ops.epilogue(L.EPI_HEADS, doh, p=(h, 0, Lp, DP, Lv)), h * DP), [doh])
+    fullp = (da1.float().cpu() @ rb(wp).T).view(Bw, Lp, 1, h, DP).permute(0, 3, 2, 1, 4)
+    assert rel(g.float(), torch.where(valid, fullp, torch.zeros(()))) < 4e-3
+    for parts, Nn in ((1, 512), (3, 768)):
+        src = torch.randn(Bw, h, parts, Lp, DP).to(BF).to(dev)
+        wo = torch.randn(Nn, parts * h * DP) * 0.05
+        wob = ops.prep_weight(wo.to(dev))
+        o32 = torch.empty(Mw, Nn, device=dev)
+        (g,) = both(lambda: ops.linear(ops.op_heads(src, Bw, h, parts, Lp, DP), wob, ops.epilogue(L.EPI_F32, o32, ld=Nn), Nn), [o32])
+        rows = src.float().cpu().permute(0, 3, 2, 1, 4).reshape(Mw, parts * h * DP)
+        assert rel(g, rows @ rb(wo).T) < 1e-5
+        ob = torch.empty(Mw, Nn, dtype=BF, device=dev)
+        (g,) = both(lambda: ops.linear(ops.op_heads(src, Bw, h, parts, Lp, DP), wob, ops.epilogue(L.EPI_BF16, ob, ld=Nn), Nn), [ob])
+        assert rel(g.float(), rows @ rb(wo).T) < 4e-3
+
+
 def test_gelu_paths_and_weight_gradients(dev, K):
     ops, L = K["ops"], K["L"]
     torch.manual_seed(2)

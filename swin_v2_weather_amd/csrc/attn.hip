@@ -1032,6 +1032,10 @@ extern "C" int swv2_attn_pack_bias(const float* bias, int heads, int L, void* ou
 // the small-workgroup forward of attn2.hip: 0 / negative = handled (ok / error), 1 = shape not covered
 int swv2_attn2_fwd(const swv2_attn_args* a, int Lp, int DP, void* stream);
 
+// the kernels for 65 .. 96-channel heads of attn_wide.hip: 0 / negative = handled (ok / error), 1 = shape not covered
+int swv2_attn_fwd_wide(const swv2_attn_args* a, int Lp, int DP, void* stream);
+int swv2_attn_bwd_wide(const swv2_attn_args* a, int Lp, int DP, void* stream);
+
 extern "C" int swv2_attn_fwd(const swv2_attn_args* a, void* stream) {
     int rc0 = check_args(a, false);
     if (rc0) return rc0;
@@ -1041,12 +1045,11 @@ extern "C" int swv2_attn_fwd(const swv2_attn_args* a, void* stream) {
         if (rc2) return rc2;
         rc2 = swv2_attn2_fwd(a, Lp2, DP2, stream);
         if (rc2 <= 0) return rc2;
+        rc2 = swv2_attn_fwd_wide(a, Lp2, DP2, stream);
+        if (rc2 <= 0) return rc2;
     }
     SWV2_ATTN_DISPATCH(launch_fwd)
 }
-
-// the backward for 65 .. 96-channel heads of attn_wide.hip: 0 / negative = handled (ok / error), 1 = shape not covered
-int swv2_attn_bwd_wide(const swv2_attn_args* a, int Lp, int DP, void* stream);
 
 extern "C" int swv2_attn_bwd(const swv2_attn_args* a, void* stream) {
     int rc0 = check_args(a, true);

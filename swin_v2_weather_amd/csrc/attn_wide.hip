@@ -268,6 +268,147 @@ __global__ __launch_bounds__(64 * LT) void attn_bwd_wide_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// forward for the same head widths: wave = query tile, swapped product S^T = K Q^T (a lane owns one query column), exactly the
+// arithmetic of attn_fwd_kernel; K and V tiles of the real channels in LDS (pitch 112), the Q fragments straight from global
+// memory into the K = 32 B operands, O^T = V^T P^T over PAIRS of key tiles (K = 32).  attn_fwd_kernel at 128 columns keeps one
+// 90 KB K | V buffer, refills it between two barriers from 8 prefetch registers per thread and spills 36: 670 us per launch.
+// ------------------------------------------------------------------------------------------------
+template <int LT, int DKR, int LFIX>
+__global__ __launch_bounds__(64 * LT) void attn_fwd_wide_kernel(
+    const uint16_t* __restrict__ qkvh, const float* __restrict__ logit_scale, uint16_t* __restrict__ oh, float* __restrict__ lse,
+    int Bw, int h, int L, int nW, int nww, int nwh, int mask_thr) {
+    constexpr int Lp = 16 * LT, DP = 128, SLAB = Lp * DP, NT = 64 * LT;
+    constexpr int QP = 16 * DKR + 16, KS = DKR / 2;
+    __shared__ __attribute__((aligned(16))) uint16_t smem[2 * Lp * QP];
+    uint16_t* const Ks = smem;
+    uint16_t* const Vs = smem + Lp * QP;
+    const int tid = threadIdx.x, lane = tid & 63, qt = tid >> 6;
+    const int fr = lane & 15, g = lane >> 4;
+    const int hd = blockIdx.y;
+    const int q = 16 * qt + fr;
+    const float sc2 = __expf(fminf(logit_scale[hd], SWV2_LN100)) * SWV2_LOG2E;
+    constexpr int RPP = NT / 16, PASSES = (Lp + RPP - 1) / RPP;
+    const int srow = tid >> 4, scc = tid & 15;
+    const bool sact = scc < 2 * DKR;
+    const uint32_t nobias[LT][2] = {};
+
+    for (int bw = blockIdx.x; bw < Bw; bw += gridDim.x) {
+        const size_t slab0 = ((size_t)bw * h + hd) * 3 * SLAB;
+        bf16x8 qf[KS];
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) qf[kk] = *(const bf16x8*)(qkvh + slab0 + (size_t)q * DP + 32 * kk + 8 * g);
+        {
+            uint4 sk[PASSES], sv[PASSES];
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) {
+                const int row = min(srow + RPP * p, Lp - 1), cc = sact ? scc : 0;      // unconditional (clamped) loads
+                sk[p] = *(const uint4*)(qkvh + slab0 + SLAB + (size_t)row * DP + cc * 8);
+                sv[p] = *(const uint4*)(qkvh + slab0 + 2 * SLAB + (size_t)row * DP + cc * 8);
+            }
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) {
+                const int row = srow + RPP * p;
+                if (row < Lp && sact) {
+                    *(uint4*)(Ks + row * QP + scc * 8) = sk[p];
+                    *(uint4*)(Vs + row * QP + scc * 8) = sv[p];
+                }
+            }
+        }
+        __syncthreads();
+
+        // S^T tiles: rows = keys 16 t + 4 g + r, column = query fr
+        f32x4 acc[LT];
+#pragma unroll
+        for (int t = 0; t < LT; ++t) {
+            acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                const bf16x8 kf = *(const bf16x8*)(Ks + (16 * t + fr) * QP + 32 * kk + 8 * g);
+                acc[t] = mfma32(kf, qf[kk], acc[t]);
+            }
+        }
+        const bool do_mask = (mask_thr > 0) && (((bw % nW) / nww) == nwh - 1);
+        float mx, sum = 0.f;
+        if (!do_mask) {          // sigma > 0 commutes with the maximum: the scale is folded into the exponent's fma (attn_fwd_kernel)
+            const int Lc = LFIX > 0 ? LFIX : L;
+            mx = SWV2_NEG_BIG;
+#pragma unroll
+            for (int t = 0; t < LT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (16 * t + 16 > Lc) acc[t][r] = (16 * t + 4 * g + r < Lc) ? acc[t][r] : SWV2_NEG_BIG;
+                    mx = fmaxf(mx, acc[t][r]);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            mx *= sc2;
+#pragma unroll
+            for (int t = 0; t < LT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(acc[t][r], sc2, -mx));
+                    acc[t][r] = p;
+                    sum += p;
+                }
+        } else {
+            mx = score_pass<LT, false, true, LFIX>(acc, nobias, sc2, L, g, mask_thr, q >= mask_thr);
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+#pragma unroll
+            for (int t = 0; t < LT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(acc[t][r] - mx);
+                    acc[t][r] = p;
+                    sum += p;
+                }
+        }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+
+        // O^T[d][q] = sum_keys V^T[d][key] P^T[key][q]: key tiles in pairs (the two tiles' fragments concatenate to one K = 32
+        // operand, same k order on both sides); the odd last tile as a K = 16 product into its own accumulator
+        f32x4 o[DKR];
+#pragma unroll
+        for (int dt = 0; dt < DKR; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t + 1 < LT; t += 2) {
+            const bf16x8 pb = __builtin_shufflevector(f2bf4(acc[t]), f2bf4(acc[t + 1]), 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+            for (int dt = 0; dt < DKR; ++dt) {
+                const bf16x4 v0 = lds_tr_read(Vs + (16 * t + 4 * g + (fr >> 2)) * QP + 16 * dt + (fr & 3) * 4);
+                const bf16x4 v1 = lds_tr_read(Vs + (16 * (t + 1) + 4 * g + (fr >> 2)) * QP + 16 * dt + (fr & 3) * 4);
+                o[dt] = mfma32(__builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7), pb, o[dt]);
+            }
+        }
+        if (LT & 1) {
+            const bf16x4 pb = f2bf4(acc[LT - 1]);
+#pragma unroll
+            for (int dt = 0; dt < DKR; ++dt) {
+                const bf16x4 vf = lds_tr_read(Vs + (16 * (LT - 1) + 4 * g + (fr >> 2)) * QP + 16 * dt + (fr & 3) * 4);
+                const f32x4 tail = mfma16(vf, pb, (f32x4){0.f, 0.f, 0.f, 0.f});
+                o[dt] += tail;
+            }
+        }
+        const float inv = (q < L) ? 1.f / sum : 0.f;
+        uint16_t* orow = oh + ((size_t)bw * h + hd) * SLAB + (size_t)q * DP;
+        const bf16x4 z4 = {0, 0, 0, 0};
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) {
+            bf16x4 ov = z4;                                    // the pad columns of the 128-wide layout are written as zeros
+            if (dt < DKR) {
+                f32x4 v = o[dt < DKR ? dt : 0];
+                v[0] *= inv; v[1] *= inv; v[2] *= inv; v[3] *= inv;
+                ov = f2bf4(v);
+            }
+            *(bf16x4*)(orow + 16 * dt + 4 * g) = ov;
+        }
+        if (g == 0) lse[((size_t)bw * h + hd) * Lp + q] = (q < L) ? mx + __log2f(sum) : 0.f;
+        __syncthreads();                                          // the next window's staging overwrites the tiles
+    }
+}
+
 }  // namespace
 
 // 0 = launched, 1 = shape not covered (the caller falls back to attn_bwd_kernel), negative = error
@@ -289,5 +430,24 @@ int swv2_attn_bwd_wide(const swv2_attn_args* a, int Lp, int DP, void* stream) {
     else return 1;
 #undef SWV2_LAUNCH_WIDE
     SWV2_CHECK_LAUNCH("swv2_attn_bwd");
+    return SWV2_OK;
+}
+
+// the matching forward: same return convention
+int swv2_attn_fwd_wide(const swv2_attn_args* a, int Lp, int DP, void* stream) {
+    if (a->bias || Lp != 176 || DP != 128 || a->head_dim > 96 || a->head_dim <= 64 || (a->dbg & SWV2_ATTN_FIRST_GEN)) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    const int nW = a->nwh * a->nww;
+    int chunks = 256 / a->heads;            // 79 KB of LDS: one workgroup of 11 waves per CU (two would leave 85 registers per wave)
+    if (chunks < 1) chunks = 1;
+    if (chunks > a->Bw) chunks = a->Bw;
+    dim3 grid(chunks, a->heads), block(64 * 11);
+    if (a->L == 162)
+        hipLaunchKernelGGL((attn_fwd_wide_kernel<11, 6, 162>), grid, block, 0, st, (const uint16_t*)a->qkvh, a->logit_scale, (uint16_t*)a->oh,
+                           a->lse, a->Bw, a->heads, a->L, nW, a->nww, a->nwh, a->mask_thr);
+    else
+        hipLaunchKernelGGL((attn_fwd_wide_kernel<11, 6, 0>), grid, block, 0, st, (const uint16_t*)a->qkvh, a->logit_scale, (uint16_t*)a->oh,
+                           a->lse, a->Bw, a->heads, a->L, nW, a->nww, a->nwh, a->mask_thr);
+    SWV2_CHECK_LAUNCH("swv2_attn_fwd");
     return SWV2_OK;
 }

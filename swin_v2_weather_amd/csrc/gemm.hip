@@ -853,6 +853,144 @@ __global__ __launch_bounds__(WTH) void gemm_nt_wide_dma_kernel(ALoad<AK> al, con
     if (wr == 0) __builtin_amdgcn_s_barrier();             // (every wave passes the same number of barriers)
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wide TN kernel: weight-gradient partial sums  P_s[n][k] = sum over the rows m of slice s of dY[m][n] X[m][k]  for the wide widths,
+// 256 x 256 output tiles, both operands raw bf16 (row-major rows or the head-major layout) by LDS-DMA.  The pipeline is the one
+// of gemm_nt_wide_dma_kernel (four stages of 32 rows, loads three stages ahead, two wave groups one barrier apart, counted
+// vmcnt); what differs is the contraction index: it is the ROW index of both operands, so a stage is a [32][256] slab of each
+// and every fragment is a transposed LDS read (ds_read_b64_tr_b16: two per K = 32 operand, rows 0-15 and 16-31 of the slab;
+// the same k order on both sides).
+//   LDS stage: dY[32][256] | X[32][256] bf16, 512-byte rows; the 32-byte unit u of row r sits at unit u ^ (r & 7) of its 256-byte
+//   half, so the 8 rows x 32 bytes a transposed read touches per 32 lanes fall on 8 different bank groups.  The DMA writes
+//   linearly and fetches the permuted source chunk.
+//   Rows: the M / 32 stages are cut into S contiguous slices, one workgroup per (slice, tile), S * tiles <= 256: one round.
+//   Workgroups of one XCD hold consecutive (slice, tile) indices: about one slice per XCD, whose tiles share the slabs in its L2.
+//   Bias gradient (column sums of dY): the workgroup with column tile tk adds up the slab columns of the stages t with
+//   t mod ntk = tk from LDS -- 2 ds_read_b128 per thread on 1 / ntk of the stages, shared evenly by all workgroups of a row of
+//   tiles -- and writes a partial row; swv2's reduction adds slices and column tiles.
+// The partial tiles go to the workspace as S plain [N][K] fp32 matrices through wide_epilogue (whole-line stores).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int tn_pchunk(int row, int c) { return ((((c >> 1) ^ (row & 7)) << 1) | (c & 1)); }    // involution per row
+template <int YK, int XK>
+__global__ __launch_bounds__(WTH) void gemm_tn_wide_kernel(ALoad<YK> yl, ALoad<XK> xl, float* __restrict__ part, float* __restrict__ dbpart,
+                                                           int M, int N, int K, int S, int wgs, int per_xcd) {
+    static_assert((YK == A_BF16 || YK == A_HEADS) && (XK == A_BF16 || XK == A_HEADS), "raw bf16 operands");
+    constexpr int SLABE = 32 * 256;                          // elements per operand slab
+    __shared__ __attribute__((aligned(1024))) unsigned char smem_b[WSM_BYTES];
+    uint16_t* const smem = (uint16_t*)smem_b;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, g = lane >> 4;
+    const int wr = wave >> 2, wc = wave & 3;              // 2 x 4 waves, 128 (n) x 64 (k) each
+    const int w = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || w >= wgs) return;
+    const int ntk = K / WBN, tiles = (N / WBM) * ntk;
+    const int slice = w / tiles, tile = w - slice * tiles, tn = tile / ntk, tk = tile - tn * ntk;
+    const int n_base = tn * WBM, k_base = tk * WBN;
+    const int T = M / 32, t0 = (int)((long)slice * T / S), t1 = (int)((long)(slice + 1) * T / S), stages = t1 - t0;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+    // DMA: instruction i (of 2 per operand) of this wave fills slab rows 4 wave + 2 i, + 1; lane -> (row + (lane >> 5), physical chunk lane & 31)
+    int drw[2], dcl[2];
+    uint32_t yoff[2], xoff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        drw[i] = wave * 4 + 2 * i + (lane >> 5);
+        dcl[i] = tn_pchunk(drw[i], lane & 31) * 8;                                   // logical column (elements) inside the slab
+        yoff[i] = YK == A_BF16 ? 2u * (uint32_t)((t0 * 32 + drw[i]) * (int)yl.d.ld + n_base + dcl[i]) : 0u;
+        xoff[i] = XK == A_BF16 ? 2u * (uint32_t)((t0 * 32 + drw[i]) * (int)xl.d.ld + k_base + dcl[i]) : 0u;
+    }
+    const long ystep = 32 * (long)yl.d.ld, xstep = 32 * (long)xl.d.ld;              // elements per stage (row-major operands)
+    auto issue = [&](int t, int slot) {          // t = stage index inside the slice
+        const uint32_t ly = lds0 + (uint32_t)(slot * WSTG * 2) + (uint32_t)(wave * 2048), lx = ly + SLABE * 2;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if constexpr (YK == A_BF16) dma_x4((const uint16_t*)yl.d.ptr + t * ystep, yoff[i], ly + 1024 * i);
+            else dma_x4(yl.d.ptr, 2u * yl.elem_off((t0 + t) * 32 + drw[i], n_base + dcl[i]), ly + 1024 * i);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if constexpr (XK == A_BF16) dma_x4((const uint16_t*)xl.d.ptr + t * xstep, xoff[i], lx + 1024 * i);
+            else dma_x4(xl.d.ptr, 2u * xl.elem_off((t0 + t) * 32 + drw[i], k_base + dcl[i]), lx + 1024 * i);
+        }
+    };
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // transposed fragment of slab columns c0 .. c0 + 15, rows r0 .. r0 + 15: lane (g, fr) <- rows r0 + 4 g .. + 3 of column c0 + fr
+    auto trf = [&](const uint16_t* slab, int r0, int c0) -> bf16x4 {
+        const int row = r0 + 4 * g + (fr >> 2), col = c0 + (fr & 3) * 4;
+        return lds_tr_read(slab + row * 256 + tn_pchunk(row, col >> 3) * 8 + (col & 7));
+    };
+    // bias-gradient partial: thread -> (slab row tid >> 5 (+ 16), logical chunk tid & 31): the same 8 columns in every stage
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int cs_off = (tid >> 5) * 256 + tn_pchunk(tid >> 5, tid & 31) * 8;      // (rows r and r + 16 share r & 7)
+    const bool want_db = dbpart != nullptr;
+
+    if (stages > 0) {
+        issue(0, 0); issue(min(1, stages - 1), 1); issue(min(2, stages - 1), 2);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (wr == 1) __builtin_amdgcn_s_barrier();             // group 1 runs one section behind (see gemm_nt_wide_dma_kernel)
+        for (int t = 0; t < stages; ++t) {
+            // ---- LOAD(t)
+            issue(min(t + 3, stages - 1), (t + 3) & 3);
+            const uint16_t* Ys = smem + (t & 3) * WSTG;
+            const uint16_t* Xs = Ys + SLABE;
+            bf16x8 af[8], bf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                bf[j] = __builtin_shufflevector(trf(Xs, 0, wc * 64 + 16 * j), trf(Xs, 16, wc * 64 + 16 * j), 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                af[i] = __builtin_shufflevector(trf(Ys, 0, wr * 128 + 16 * i), trf(Ys, 16, wr * 128 + 16 * i), 0, 1, 2, 3, 4, 5, 6, 7);
+            if (want_db && ((t0 + t) % ntk) == tk) {           // (workgroup-uniform)
+                const uint4 a = *(const uint4*)(Ys + cs_off), b = *(const uint4*)(Ys + cs_off + 16 * 256);
+                float va[8], vb[8];
+                unpack8(a, va); unpack8(b, vb);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) cs[e] += va[e] + vb[e];
+            }
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- MFMA(t)
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (wr == 0) __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();                               // every wave is done with the slots: staging below
+    // ---- partial tile -> workspace matrix of this slice (rows n, columns k)
+    Epi<E_F32> ep;
+    ep.d.out = part + (size_t)slice * N * K; ep.d.bias = nullptr; ep.d.aux = nullptr; ep.d.aux_out = nullptr; ep.d.rowidx = nullptr;
+    ep.d.ld = K; ep.d.M = N; ep.d.N = K;
+    wide_epilogue<E_F32>(ep, acc, (float*)smem + wave * 16 * EP, n_base + wr * 128, k_base + wc * 64, lane);
+    if (want_db) {                                 // 16 row-threads per chunk -> 256 column sums -> dbpart[slice][tk][n]
+        __syncthreads();
+        float* red = (float*)smem;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[(tid >> 5) * 256 + (tid & 31) * 8 + e] = cs[e];
+        __syncthreads();
+        if (tid < 256) {
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum += red[r * 256 + tid];
+            dbpart[((size_t)slice * ntk + tk) * N + n_base + tid] = sum;
+        }
+    }
+}
+
 // ---- register-staged A (fp32 rows, gathered rows with zero rows): weights by DMA, two 64-k buffers, one tile per workgroup ----
 template <int AK, int EK>
 __global__ __launch_bounds__(WTH) void gemm_nt_wide_kernel(ALoad<AK> al, const uint16_t* __restrict__ Wb, Epi<EK> ep,
@@ -1293,6 +1431,22 @@ int launch_nt1(const swv2_operand* a, const void* w, const swv2_epilogue* e, int
 }
 
 }  // namespace
+
+// launched by gemm_tn.hip (swv2_linear_wgrad_ws): partial matrices part[S][N][K] (+ dbpart[S][K / 256][N]); the operands are
+// raw bf16 (SWV2_OP_BF16 without a gather table, SWV2_OP_HEADS), M % 32 == 0, N % 256 == 0, K % 256 == 0, S * tiles <= 256
+int swv2_tn_wide_launch(const swv2_operand* y, const swv2_operand* x, float* part, float* dbpart, int M, int N, int K, int S, hipStream_t st) {
+    const int tiles = (N / WBM) * (K / WBN), wgs = S * tiles, per_xcd = cdiv(wgs, 8);
+#define SWV2_TNW(YK_, XK_)                                                                                                           \
+    hipLaunchKernelGGL((gemm_tn_wide_kernel<YK_, XK_>), dim3(8 * per_xcd), dim3(WTH), 0, st, make_loader<YK_>(y), make_loader<XK_>(x), part, \
+                       dbpart, M, N, K, S, wgs, per_xcd)
+    if (y->kind == SWV2_OP_BF16 && x->kind == SWV2_OP_BF16) SWV2_TNW(A_BF16, A_BF16);
+    else if (y->kind == SWV2_OP_BF16 && x->kind == SWV2_OP_HEADS) SWV2_TNW(A_BF16, A_HEADS);
+    else if (y->kind == SWV2_OP_HEADS && x->kind == SWV2_OP_BF16) SWV2_TNW(A_HEADS, A_BF16);
+    else { swv2_set_error("swv2_linear_wgrad: wide kernel: operand pair (%d, %d) not instantiated", y->kind, x->kind); return SWV2_ERR_UNSUPPORTED; }
+#undef SWV2_TNW
+    SWV2_CHECK_LAUNCH("swv2_linear_wgrad");
+    return SWV2_OK;
+}
 
 #ifdef SWV2_RW_STAMPS
 extern "C" int swv2_debug_rw_stamps(void* out) {

@@ -3,6 +3,9 @@
 #pragma once
 #include "common.h"
 
+// gemm.hip: the wide weight-gradient kernel (partial matrices), launched by gemm_tn.hip
+int swv2_tn_wide_launch(const swv2_operand* y, const swv2_operand* x, float* part, float* dbpart, int M, int N, int K, int S, hipStream_t st);
+
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;

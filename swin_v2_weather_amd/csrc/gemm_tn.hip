@@ -336,6 +336,81 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(TnReduce a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wide weight gradients (N, K multiples of 256, both >= 512: the reference's embed_dim 768 model): gemm.hip's gemm_tn_wide_kernel
+// writes S partial matrices, tn_wide_reduce_kernel adds them into dW / db through the row / column maps.  An fp32 X operand
+// (x, x1: the residual stream) is first cast -- and gathered -- into a bf16 matrix in the workspace (the wide kernel's operands
+// are raw bf16 by LDS-DMA).
+// ------------------------------------------------------------------------------------------------
+struct TnWidePlan { bool ok; int S; size_t part_bytes, db_bytes, cast_bytes, total; };
+TnWidePlan tn_wide_plan(int M, int N, int K) {
+    TnWidePlan p = {};
+    p.ok = (N % 256 == 0) && (K % 256 == 0) && N >= 512 && K >= 512 && (M % 32 == 0) && M >= 8192 &&
+           (double)M * (N > K ? N : K) * 2 < 4.29e9 && (double)N * K < 2.0e9;
+    if (!p.ok) return p;
+    const int tiles = (N / 256) * (K / 256);
+    p.S = std::max(1, 256 / tiles);
+    if (p.S > M / 32) p.S = M / 32;
+    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    p.part_bytes = up((size_t)p.S * N * K * 4);
+    p.db_bytes = up((size_t)p.S * (K / 256) * N * 4);
+    p.cast_bytes = up((size_t)M * K * 2);                    // (needed for an fp32 X only; always budgeted)
+    p.total = p.part_bytes + p.db_bytes + p.cast_bytes;
+    return p;
+}
+// bf16 copy of fp32 rows, optionally gathered (table entry < 0: a zero row); 8 elements per thread
+__global__ __launch_bounds__(256) void cast_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ rowidx, uint16_t* __restrict__ dst,
+                                                        int M, int C, long ld) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x, per_row = C / 8;
+    if (i >= (long)M * per_row) return;
+    const int m = (int)(i / per_row), c = (int)(i - (long)m * per_row) * 8;
+    const int r = rowidx ? rowidx[m] : m;
+    uint4 o = make_uint4(0, 0, 0, 0);
+    if (r >= 0) {
+        const float* p = src + (long)r * ld + c;
+        RawF32 v = {*(const f32x4*)p, *(const f32x4*)(p + 4)};
+        o = cvt_f32x8(v);
+    }
+    *(uint4*)(dst + (long)m * C + c) = o;
+}
+// dW[nmap(n)][kmap(k)] += sum_s part[s][n][k] ; db[nmap(n)] += sum_{s, tk} dbpart[s][tk][n]     (fixed order: deterministic)
+__global__ __launch_bounds__(256) void tn_wide_reduce_kernel(const float* __restrict__ part, const float* __restrict__ dbpart, float* __restrict__ dW,
+                                                             float* __restrict__ db, const int32_t* __restrict__ nmap,
+                                                             const int32_t* __restrict__ kmap, int ldw, int N, int K, int S) {
+    const int i = (blockIdx.x * 256 + threadIdx.x) * 4, NK = N * K;          // (N K < 2^31: checked by the plan)
+    if (i < NK) {
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+        int sl = 0;
+        for (; sl + 1 < S; sl += 2) { s0 += *(const f32x4*)(part + (size_t)sl * NK + i); s1 += *(const f32x4*)(part + (size_t)(sl + 1) * NK + i); }
+        if (sl < S) s0 += *(const f32x4*)(part + (size_t)sl * NK + i);
+        s0 += s1;
+        int n = i / K;
+        const int k = i - n * K;
+        if (nmap) n = nmap[n];
+        if (n >= 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int kk = kmap ? kmap[k + e] : k + e;
+                if (kk >= 0) dW[(long)n * ldw + kk] += s0[e];
+            }
+        }
+    }
+    // bias gradient: the first N / 256 workgroups own 256 entries each; the S * ntk partial rows in four independent chains
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (db && dbpart && n < N) {
+        const int rows = S * (K / 256);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int j = 0;
+        for (; j + 3 < rows; j += 4) {
+            a0 += dbpart[(size_t)j * N + n]; a1 += dbpart[(size_t)(j + 1) * N + n];
+            a2 += dbpart[(size_t)(j + 2) * N + n]; a3 += dbpart[(size_t)(j + 3) * N + n];
+        }
+        for (; j < rows; ++j) a0 += dbpart[(size_t)j * N + n];
+        const int nn = nmap ? nmap[n] : n;
+        if (nn >= 0) db[nn] += (a0 + a1) + (a2 + a3);
+    }
+}
+
 struct TnPlan { int ntn, ntk, tiles, real_slices, slices; size_t ws_bytes; };
 TnPlan tn_plan(int M, int N, int K, int splits) {
     TnPlan p;
@@ -359,6 +434,31 @@ TnOut tn_out(float* dW, float* db, const int32_t* nmap, const int32_t* kmap, int
 template <int YK, int XK>
 int launch_tn2(const swv2_operand* y, const swv2_operand* x, float* dW, float* db, const int32_t* nmap,
                const int32_t* kmap, int ldw, int M, int N, int K, int splits, float* ws, size_t ws_bytes, hipStream_t st) {
+    // wide widths: 256 x 256 tiles by LDS-DMA (gemm.hip), workspace path only
+    if constexpr ((YK == A_BF16 || YK == A_HEADS) && (XK == A_BF16 || XK == A_HEADS || XK == A_F32)) {
+        const TnWidePlan wp = tn_wide_plan(M, N, K);
+        const int wide = getenv("SWV2_GEMM_WIDE") ? atoi(getenv("SWV2_GEMM_WIDE")) : 1;
+        const bool kinds = !(YK == A_HEADS && XK == A_HEADS) && !y->rowidx && (XK == A_F32 || !x->rowidx);
+        if (wide && wp.ok && kinds && ws && ws_bytes >= wp.total) {
+            float* part = ws;
+            float* dbpart = db ? (float*)((char*)ws + wp.part_bytes) : nullptr;
+            swv2_operand xb = *x;
+            if constexpr (XK == A_F32) {           // bf16 (gathered) copy of the fp32 rows
+                uint16_t* cb = (uint16_t*)((char*)ws + wp.part_bytes + wp.db_bytes);
+                const long chunks = (long)M * (K / 8);
+                hipLaunchKernelGGL(cast_rows_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, (const float*)x->ptr, x->rowidx, cb,
+                                   M, K, x->ld);
+                xb.kind = SWV2_OP_BF16; xb.ptr = cb; xb.rowidx = nullptr; xb.ld = K;
+            }
+            int rc = swv2_tn_wide_launch(y, &xb, part, dbpart, M, N, K, wp.S, st);
+            if (rc) return rc;
+            const long quads = (long)N * K / 4;
+            hipLaunchKernelGGL(tn_wide_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, (const float*)part,
+                               (const float*)dbpart, dW, db, nmap, kmap, ldw, N, K, wp.S);
+            SWV2_CHECK_LAUNCH("swv2_linear_wgrad");
+            return SWV2_OK;
+        }
+    }
     const TnPlan p = tn_plan(M, N, K, splits);
     if (ws && ws_bytes < p.ws_bytes) {
         swv2_set_error("swv2_linear_wgrad_ws: workspace of %zu bytes, %zu needed (swv2_linear_wgrad_ws_bytes)", ws_bytes, p.ws_bytes);
@@ -413,7 +513,9 @@ int launch_tn1(const swv2_operand* y, const swv2_operand* x, float* dW, float* d
 }  // namespace
 
 extern "C" size_t swv2_linear_wgrad_ws_bytes(int M, int N, int K, int splits) {
-    return (M > 0 && N > 0 && K > 0 && splits > 0) ? tn_plan(M, N, K, splits).ws_bytes : 0;
+    if (!(M > 0 && N > 0 && K > 0 && splits > 0)) return 0;
+    const TnWidePlan w = tn_wide_plan(M, N, K);
+    return std::max(tn_plan(M, N, K, splits).ws_bytes, w.ok ? w.total : (size_t)0);
 }
 
 extern "C" int swv2_linear_wgrad_ws(const swv2_operand* dy, const swv2_operand* x, float* dW, float* db, const int32_t* nmap,

@@ -267,6 +267,88 @@ def test_wide_gemm_kernels_equal_the_128_tile_kernel_bit_for_bit(dev, K, persist
         assert rel(g.float(), rows @ rb(wo).T) < 4e-3
 
 
+def test_wide_weight_gradient_kernel(dev, K):
+    """gemm_tn_wide_kernel (256 x 256 tiles by LDS-DMA, transposed fragment reads, partial matrices + reduction) against torch and
+    against the 128-tile kernel: every operand pair of the width-768 block -- bf16 x bf16, bf16 x fp32 (cast pre-pass), head-major
+    dY x gathered fp32 rows with zero rows (qkv), bf16 x head-major X with a column map (proj) -- with bias gradients and maps."""
+    ops, L = K["ops"], K["L"]
+    torch.manual_seed(12)
+
+    def both(run):
+        out = []
+        for flag in ("0", "1"):
+            res = []
+            _with_wide(flag, lambda: res.extend(run()))
+            out.append(res)
+        return out
+
+    M, N, Kx = 9024, 768, 512
+    dy, x = torch.randn(M, N) * 0.5, torch.randn(M, Kx)
+    dyb, xb = dy.to(BF).to(dev), x.to(BF).to(dev)
+    ref, refb = rb(dy).T @ rb(x), rb(dy).sum(0)
+    def run_bb():
+        dW, db = torch.ones(N, Kx, device=dev), torch.full((N,), 2.0, device=dev)          # accumulated into
+        ops.linear_wgrad(ops.op_bf16(dyb), ops.op_bf16(xb), dW, db)
+        return [dW, db]
+    narrow, wide = both(run_bb)
+    for dW, db in (narrow, wide):
+        assert rel(dW - 1.0, ref) < 1e-5 and rel(db - 2.0, refb) < 1e-5
+    assert rel(wide[0], narrow[0]) < 1e-6
+    # deterministic: two runs of the wide path agree bit for bit
+    again = both(run_bb)[1]
+    assert torch.equal(again[0], wide[0]) and torch.equal(again[1], wide[1])
+    # fp32 X (cast pre-pass inside the call)
+    def run_bf():
+        dW, db = torch.zeros(N, Kx, device=dev), torch.zeros(N, device=dev)
+        ops.linear_wgrad(ops.op_bf16(dyb), ops.op_f32(x.to(dev)), dW, db)
+        return [dW, db]
+    narrow, wide = both(run_bf)
+    for dW, db in (narrow, wide):
+        assert rel(dW, ref) < 1e-5 and rel(db, refb) < 1e-5
+    # qkv: head-major dY (3 parts x 2 heads x 128 columns, row map onto 96 real channels per head) x gathered fp32 rows
+    h, Lp, Lv, DP, d, Bw = 2, 176, 162, 128, 96, 52
+    Mw, Cc = Bw * Lp, 512
+    dq = torch.zeros(Bw, h, 3, Lp, DP)
+    dq[:, :, :, :Lv, :d] = torch.randn(Bw, h, 3, Lv, d) * 0.5
+    dqb = dq.to(BF).to(dev)
+    xs = torch.randn(Bw * Lv, Cc)
+    ri = torch.full((Mw,), -1, dtype=torch.int32)
+    tok = torch.randperm(Bw * Lv).to(torch.int32)
+    ri.view(Bw, Lp)[:, :Lv] = tok.view(Bw, Lv)
+    nmap = torch.full((3 * h * DP,), -1, dtype=torch.int32)
+    for part in range(3):
+        for hh in range(h):
+            nmap[(part * h + hh) * DP:(part * h + hh) * DP + d] = torch.arange(d, dtype=torch.int32) + (part * h + hh) * d
+    def run_qkv():
+        dW, db = torch.zeros(3 * h * d, Cc, device=dev), torch.zeros(3 * h * d, device=dev)
+        ops.linear_wgrad(ops.op_heads(dqb, Bw, h, 3, Lp, DP), ops.op_f32(xs.to(dev), rows=Mw, rowidx=ri.to(dev)), dW, db, nmap=nmap.to(dev))
+        return [dW, db]
+    rows = dqb.float().cpu().permute(0, 3, 2, 1, 4)[:, :Lv, :, :, :d].reshape(Bw * Lv, 3 * h * d)          # [token][part, head, channel]
+    xg = rb(xs)[tok.long()]
+    narrow, wide = both(run_qkv)
+    for dW, db in (narrow, wide):
+        assert rel(dW, rows.T @ xg) < 1e-5 and rel(db, rows.sum(0)) < 1e-5
+    # proj: bf16 dY x head-major X (2 x 2 heads of 128 columns -> 512 padded columns) with a column map onto the real channels
+    h2 = 4
+    oh = torch.zeros(Bw, h2, 1, Lp, DP)
+    oh[:, :, :, :Lv, :d] = torch.randn(Bw, h2, 1, Lv, d)
+    ohb = oh.to(BF).to(dev)
+    da = torch.zeros(Bw, Lp, Cc)
+    da[:, :Lv] = torch.randn(Bw, Lv, Cc) * 0.5
+    dab = da.reshape(Mw, Cc).to(BF).to(dev)
+    kmap = torch.full((h2 * DP,), -1, dtype=torch.int32)
+    for hh in range(h2):
+        kmap[hh * DP:hh * DP + d] = torch.arange(d, dtype=torch.int32) + hh * d
+    def run_proj():
+        dW, db = torch.zeros(Cc, h2 * d, device=dev), torch.zeros(Cc, device=dev)
+        ops.linear_wgrad(ops.op_bf16(dab), ops.op_heads(ohb, Bw, h2, 1, Lp, DP), dW, db, kmap=kmap.to(dev))
+        return [dW, db]
+    xo = ohb.float().cpu()[:, :, 0].permute(0, 2, 1, 3)[..., :d].reshape(Mw, h2 * d)
+    narrow, wide = both(run_proj)
+    for dW, db in (narrow, wide):
+        assert rel(dW, dab.float().cpu().T @ xo) < 1e-5 and rel(db, dab.float().cpu().sum(0)) < 1e-5
+
+
 def test_gelu_paths_and_weight_gradients(dev, K):
     ops, L = K["ops"], K["L"]
     torch.manual_seed(2)

@@ -13,6 +13,7 @@
 //     phases (the normalisation backward of dQ re-reads its q^ rows from global memory / L2);
 //   * no cross-window register prefetch: a workgroup's loads are issued at the start of the window and consumed at once.
 // LDS: 2 x 38.5 KB + 62 KB + 1.4 KB = 141 KB, one workgroup of 11 waves per CU, no spills.
+#include <cstdlib>
 #include <type_traits>
 
 #include "attn_common.h"
@@ -412,7 +413,10 @@ __global__ __launch_bounds__(64 * LT) void attn_fwd_wide_kernel(
 }  // namespace
 
 // 0 = launched, 1 = shape not covered (the caller falls back to attn_bwd_kernel), negative = error
+static bool wide_off() { const char* e = getenv("SWV2_ATTN_WIDE"); return e && atoi(e) == 0; }      // (read per call: A/B and tests)
+
 int swv2_attn_bwd_wide(const swv2_attn_args* a, int Lp, int DP, void* stream) {
+    if (wide_off()) return 1;
     if (a->bias || Lp != 176 || DP != 128 || a->head_dim > 96 || (a->dbg & SWV2_ATTN_FIRST_GEN)) return 1;
     hipStream_t st = (hipStream_t)stream;
     const int nW = a->nwh * a->nww;
@@ -435,6 +439,7 @@ int swv2_attn_bwd_wide(const swv2_attn_args* a, int Lp, int DP, void* stream) {
 
 // the matching forward: same return convention
 int swv2_attn_fwd_wide(const swv2_attn_args* a, int Lp, int DP, void* stream) {
+    if (wide_off()) return 1;
     if (a->bias || Lp != 176 || DP != 128 || a->head_dim > 96 || a->head_dim <= 64 || (a->dbg & SWV2_ATTN_FIRST_GEN)) return 1;
     hipStream_t st = (hipStream_t)stream;
     const int nW = a->nwh * a->nww;

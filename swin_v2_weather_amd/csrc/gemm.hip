@@ -603,43 +603,65 @@ __device__ __forceinline__ void wide_epilogue(const Epi<EK>& ep, const f32x4 (&a
         }
         const bool scatter = (EK == E_F32 || EK == E_BF16) && d.rowidx != nullptr;
         // (compile-time variants for the two uniform run-time conditions, so that every load of a variant is unconditional)
+        // Load order: the scatter rows of all eight sub-tiles first; the per-sub-tile operand (residual / pre-activation) of
+        // sub-tile i + 1 BEFORE the stores of sub-tile i -- VMEM operations retire in order, so a load issued behind a store is
+        // waited for together with that store's acknowledgement.
         auto body = [&](auto scat, auto has_aux) {
+            constexpr bool OPL = decltype(has_aux)::value || EK == E_GELU_GRAD;       // a per-sub-tile operand is loaded
+            constexpr bool SC = decltype(scat)::value;
+            [[maybe_unused]] int dstv[3][NQ];                 // scatter rows of sub-tiles i, i + 1, i + 2 (ring; loaded two ahead)
+            auto rows = [&](int i) {
+                if constexpr (SC) {
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) dstv[i % 3][q] = d.rowidx[min(m_w + 16 * i + RQ * q + rl, d.M - 1)];
+                }
+            };
+            rows(0); rows(1);
+            auto offs = [&](int i, long (&off)[NQ], bool (&ok)[NQ]) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int m = m_w + 16 * i + RQ * q + rl;
+                    int dst = min(m, d.M - 1);
+                    if constexpr (SC) dst = dstv[i % 3][q];
+                    ok[q] = m < d.M && dst >= 0;
+                    off[q] = (long)max(dst, 0) * d.ld + n;
+                }
+            };
+            [[maybe_unused]] f32x4 a[2][NQ];
+            [[maybe_unused]] uint4 pv[2][NQ];
+            auto opload = [&](int i) {
+                if constexpr (OPL) {
+                    long off[NQ];
+                    bool ok[NQ];
+                    offs(i, off, ok);
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        if constexpr (EK == E_F32) a[i & 1][q] = *(const f32x4*)((const float*)d.aux + off[q]);
+                        else pv[i & 1][q] = *(const uint4*)((const uint16_t*)d.aux + off[q]);
+                    }
+                }
+            };
+            opload(0);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 long off[NQ];
                 bool ok[NQ];
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    const int m = m_w + 16 * i + RQ * q + rl, mc = min(m, d.M - 1);
-                    int dst = mc;
-                    if constexpr (decltype(scat)::value) dst = d.rowidx[mc];
-                    ok[q] = m < d.M && dst >= 0;
-                    off[q] = (long)max(dst, 0) * d.ld + n;
-                }
+                offs(i, off, ok);
+                if (i + 2 < 8) rows(i + 2);
+                if (i + 1 < 8) opload(i + 1);
                 stage(i);
                 if constexpr (EK == E_F32) {
                     float* out = (float*)d.out;
-                    const float* ax = (const float*)d.aux;
-                    [[maybe_unused]] f32x4 a[NQ];
-                    if constexpr (decltype(has_aux)::value) {
-#pragma unroll
-                        for (int q = 0; q < NQ; ++q) a[q] = *(const f32x4*)(ax + off[q]);
-                    }
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) {
                         f32x4 v = *(const f32x4*)(st + (RQ * q + rl) * EP + cl);
                         v += b4[0];
-                        if constexpr (decltype(has_aux)::value) v += a[q];
+                        if constexpr (decltype(has_aux)::value) v += a[i & 1][q];
                         if (ok[q]) *(f32x4*)(out + off[q]) = v;
                     }
                 } else {
                     uint16_t* out = (uint16_t*)d.out;
                     [[maybe_unused]] uint16_t* out2 = (uint16_t*)d.aux_out;
-                    [[maybe_unused]] uint4 pv[NQ];
-                    if constexpr (EK == E_GELU_GRAD) {
-#pragma unroll
-                        for (int q = 0; q < NQ; ++q) pv[q] = *(const uint4*)((const uint16_t*)d.aux + off[q]);
-                    }
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) {
                         float v[8];
@@ -647,7 +669,7 @@ __device__ __forceinline__ void wide_epilogue(const Epi<EK>& ep, const f32x4 (&a
                         *(f32x4*)(v + 4) = *(const f32x4*)(st + (RQ * q + rl) * EP + cl + 4);
                         if constexpr (EK == E_GELU_GRAD) {
                             float hv[8];
-                            unpack8(pv[q], hv);
+                            unpack8(pv[i & 1][q], hv);
 #pragma unroll
                             for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(hv[e]);
                             if (ok[q]) *(uint4*)(out + off[q]) = pack8(v);

@@ -89,6 +89,23 @@ def test_argument_errors_are_reported_without_touching_the_gpu():
         L.check(lib.swv2_linear(None, None, None, 4, None), "swv2_linear")
 
 
+def test_weight_gradient_workspace_budget_covers_the_wide_path():
+    """Host-only sizing (no GPU call): from N, K = 512 the 256 x 256 weight-gradient kernel writes S = 256 / tiles partial [N][K]
+    matrices + S * (K / 256) bias-gradient rows and casts an fp32 X operand to a bf16 [M][K] copy -- all inside the workspace the
+    caller sizes with swv2_linear_wgrad_ws_bytes; narrow shapes and ragged row counts keep the 128-tile plan."""
+    lib = L.load()
+    lib.swv2_linear_wgrad_ws_bytes.restype = ctypes.c_size_t
+    up = lambda b: (b + 255) // 256 * 256
+    for (M, N, K) in ((64800, 768, 3072), (70400, 3072, 768), (70400, 768, 1024)):
+        S = max(1, 256 // ((N // 256) * (K // 256)))
+        need = up(S * N * K * 4) + up(S * (K // 256) * N * 4) + up(M * K * 2)
+        assert lib.swv2_linear_wgrad_ws_bytes(M, N, K, 16) >= need, (M, N, K)
+    narrow = lib.swv2_linear_wgrad_ws_bytes(129600, 384, 128, 40)
+    assert 0 < narrow <= 40 * 3 * 128 * 128 * 4                                   # 3 tiles x 40 slices of 64 KB: the 128-tile plan only
+    assert lib.swv2_linear_wgrad_ws_bytes(64801, 768, 3072, 16) < 64801 * 3072 * 2      # ragged M: no wide path, no cast buffer
+    assert lib.swv2_linear_wgrad_ws_bytes(0, 768, 768, 8) == 0
+
+
 def test_model_refuses_cpu_tensors():
     m = N.SwinTransformerV2Cr(img_size=(24, 36), patch_size=4, depths=(1,), num_heads=(2,), in_chans=3, out_chans=3,
                               embed_dim=16, img_window_ratio=4, full_pos_embed=True, rel_pos=False)

@@ -331,7 +331,9 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
     constexpr int OFF_Q = 0, OFF_DO = OFF_Q + (QG ? 0 : Lp * QP * 2), OFF_LSE = OFF_DO + (QG ? 0 : Lp * QP * 2), OFF_DL = OFF_LSE + Lp * 4,
                   OFF_K = OFF_DL + Lp * 4, OFF_V = OFF_K + SLAB * 2, OFF_DS = OFF_V + SLAB * 2,
                   OFF_BIAS = OFF_DS + IROWS * DSP * 2, OFF_RED = OFF_BIAS + (BIAS_LDS ? Lp * DSP * 2 : 16),
-                  LDS_BYTES = OFF_RED + ((WAVES * 4 + 15) / 16) * 16;
+                  OFF_DLP = OFF_RED + ((WAVES * 4 + 15) / 16) * 16,
+                  // chunks per row not a power of two (96 columns = 12 chunks): the per-chunk parts of delta go through LDS
+                  LDS_BYTES = OFF_DLP + (((CPR & (CPR - 1)) != 0) ? CH * 4 : 0);
     static_assert(OFF_DS % 16 == 0 && OFF_BIAS % 16 == 0 && OFF_RED % 16 == 0, "16-byte aligned sub-arrays");
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
     const uint16_t* Qs = (const uint16_t*)(lds + OFF_Q);       // QG: re-pointed at the window's global slabs below
@@ -343,6 +345,8 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
     uint16_t* const dSb = (uint16_t*)(lds + OFF_DS);
     uint16_t* const biasS = (uint16_t*)(lds + OFF_BIAS);
     float* const red = (float*)(lds + OFF_RED);
+    constexpr bool CPR_P2 = (CPR & (CPR - 1)) == 0;
+    [[maybe_unused]] float* const DLp = (float*)(lds + OFF_DLP);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -459,8 +463,12 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
                     dl = fmaf(__uint_as_float(a[e] & 0xffff0000u), __uint_as_float(b[e] & 0xffff0000u), dl);
                 }
             }
+            if constexpr (CPR_P2) {
 #pragma unroll
-            for (int o = 1; o < CPR; o <<= 1) dl += __shfl_xor(dl, o);
+                for (int o = 1; o < CPR; o <<= 1) dl += __shfl_xor(dl, o);
+            } else {
+                if (c < CH) DLp[c] = dl;            // summed per row by finish_delta() behind the barrier (a row's chunks straddle lane groups)
+            }
             if constexpr (AUG) {
                 // slots 16..23 of the row (the even chunk's thread): A-operand side of the statistics -- lse / (sigma log2 e) in three
                 // bf16 parts, a constant 1 (padded-key flag), the query's mask-region flags -- and delta in three parts for the dO
@@ -485,18 +493,30 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
                     *(uint4*)((uint16_t*)(lds + OFF_Q) + row * QP + 16 + (c & 1) * 8) = aq;
                     *(uint4*)((uint16_t*)(lds + OFF_DO) + row * QP + 16 + (c & 1) * 8) = ad;
                 }
-            } else {
+            } else if constexpr (CPR_P2) {
                 if (c < CH && (c % CPR) == 0) DLs[c / CPR] = dl;
             }
         }
         if (!AUG && tid < Lp) LSEs[tid] = (tid < L) ? slse : 1.0e30f;
     };
 
+    auto finish_delta = [&]() {              // (behind the barrier that follows commit())
+        if constexpr (!CPR_P2) {
+            if (tid < Lp) {
+                float a = 0.f;
+#pragma unroll
+                for (int e = 0; e < CPR; ++e) a += DLp[tid * CPR + e];
+                DLs[tid] = a;
+            }
+            __syncthreads();
+        }
+    };
     int bw = blockIdx.x;
     if (bw >= Bw) return;
     issue(bw);
     commit();
     __syncthreads();
+    finish_delta();
 
     const int Lc = LFIX > 0 ? LFIX : L;
     GSTAMP_DECL
@@ -842,6 +862,7 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
         if (bw_next < Bw) commit();
         GSTAMP(6);                      // commit (wait for the prefetch + LDS writes + delta)
         __syncthreads();
+        if (bw_next < Bw) finish_delta();
         GSTAMP(7);                      // barrier 3
     }
 #ifdef SWV2_ATTN1_STAMPS
@@ -972,8 +993,9 @@ int check_args(const swv2_attn_args* a, bool bwd) {
 extern "C" int swv2_attn_geometry(int L, int head_dim, int* Lp, int* DP) {
     int LT = 0, DK = 0;
     if (L <= 64) LT = 4; else if (L <= 176) LT = 11;
-    // head dims are padded to 16, 32, 64 or 128 columns (e.g. the yaml default 768 / 8 = 96 runs as 128)
-    if (head_dim <= 16) DK = 1; else if (head_dim <= 32) DK = 2; else if (head_dim <= 64) DK = 4; else if (head_dim <= 128) DK = 8;
+    // head dims are padded to 16, 32, 64, 96 or 128 columns (the yaml default 768 / 8 = 96 runs unpadded)
+    if (head_dim <= 16) DK = 1; else if (head_dim <= 32) DK = 2; else if (head_dim <= 64) DK = 4; else if (head_dim <= 96) DK = 6;
+    else if (head_dim <= 128) DK = 8;
     SWV2_CHECK_ARG(LT && DK, "attention: unsupported window area L=%d (<=176) or head_dim=%d (<=128)", L, head_dim);
     if (Lp) *Lp = 16 * LT;
     if (DP) *DP = 16 * DK;
@@ -994,6 +1016,8 @@ extern "C" int swv2_attn_geometry(int L, int head_dim, int* Lp, int* DP) {
     if (Lp == 176 && DP == 16) return FN<11, 1, 0>(a, st);                             \
     if (Lp == 176 && DP == 32) return FN<11, 2, 0>(a, st);                             \
     if (Lp == 64 && DP == 64) return FN<4, 4, 0>(a, st);                               \
+    if (Lp == 64 && DP == 96) return FN<4, 6, 0>(a, st);                               \
+    if (Lp == 176 && DP == 96) return FN<11, 6, 0>(a, st);                             \
     if (Lp == 64 && DP == 128) return FN<4, 8, 0>(a, st);                              \
     if (Lp == 176 && DP == 64) return FN<11, 4, 0>(a, st);                             \
     if (Lp == 176 && DP == 128) return FN<11, 8, 0>(a, st);                            \

@@ -1,5 +1,5 @@
-// Window-attention backward for wide heads (65 .. 96 channels in the 128-column head layout: the reference's own swin_73var is
-// 768 / 8 = 96), no CPB bias.  Same algorithm, data layout and phase structure as attn_bwd_kernel (attn.hip): wave = key tile in
+// Window-attention backward for wide heads (65 .. 96 channels in the 96-column head layout -- or the 128-column one -- : the
+// reference's own swin_73var is 768 / 8 = 96), no CPB bias.  Same algorithm, data layout and phase structure as attn_bwd_kernel (attn.hip): wave = key tile in
 // phase 1 (S = Q K^T, dP = dO V^T, P = exp2(S' - LSE'), dS = P (dP - delta), dV^T += dO^T P, dK^T += Q^T dS, bf16 dS image
 // [key][q] in LDS), wave = query tile in phase 2 (dQ^T = sum_t K_t^T dS_t^T), the L2-normalisation backward in both epilogues.
 // What differs is where the operands live.  At 128 columns attn_bwd_kernel cannot keep Q and dO in LDS beside K, V and the dS
@@ -20,13 +20,14 @@
 
 namespace {
 
-template <int LT, int DKR, int LFIX>
+template <int LT, int DKR, int LFIX, int DP>
 __global__ __launch_bounds__(64 * LT) void attn_bwd_wide_kernel(
     const uint16_t* __restrict__ qkvh, const float* __restrict__ logit_scale, const uint16_t* __restrict__ oh,
     const uint16_t* __restrict__ doh, const float* __restrict__ lse, const float* __restrict__ rnorm,
     uint16_t* __restrict__ dqkvh, float* __restrict__ dlogit, int Bw, int h, int L, int nW, int nww, int nwh, int mask_thr) {
     static_assert(DKR % 2 == 0 && DKR <= 6, "pairs of 16-channel tiles (K = 32 MFMA), at most 96 channels (LDS)");
-    constexpr int Lp = 16 * LT, DP = 128, SLAB = Lp * DP, NT = 64 * LT;
+    constexpr int Lp = 16 * LT, SLAB = Lp * DP, NT = 64 * LT;      // DP = columns of the head layout in memory (96 or 128)
+    static_assert(DP >= 16 * DKR && DP % 16 == 0, "layout width");
     constexpr int QP = 16 * DKR + 16;                        // row pitch (elements) of the staged tiles
     constexpr int DSP = Lp + 4;                              // row pitch of the [key][q] dS image
     constexpr int KS = DKR / 2;                              // K = 32 steps over the channels
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(64 * LT) void attn_bwd_wide_kernel(
             const float rks = rk * sigma;
             const bf16x4 z4 = {0, 0, 0, 0};
 #pragma unroll
-            for (int dt = 0; dt < 8; ++dt) {
+            for (int dt = 0; dt < DP / 16; ++dt) {
                 bf16x4 ok = z4, ov = z4;                          // the pad columns of the 128-wide layout are written as zeros
                 if (dt < DKR) {
                     f32x4 v;
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(64 * LT) void attn_bwd_wide_kernel(
             dot += __shfl_xor(dot, 32);
             const bf16x4 z4 = {0, 0, 0, 0};
 #pragma unroll
-            for (int dt = 0; dt < 8; ++dt) {
+            for (int dt = 0; dt < DP / 16; ++dt) {
                 bf16x4 o = z4;
                 if (dt < DKR) {
                     f32x4 v;
@@ -275,11 +276,11 @@ __global__ __launch_bounds__(64 * LT) void attn_bwd_wide_kernel(
 // memory into the K = 32 B operands, O^T = V^T P^T over PAIRS of key tiles (K = 32).  attn_fwd_kernel at 128 columns keeps one
 // 90 KB K | V buffer, refills it between two barriers from 8 prefetch registers per thread and spills 36: 670 us per launch.
 // ------------------------------------------------------------------------------------------------
-template <int LT, int DKR, int LFIX>
+template <int LT, int DKR, int LFIX, int DP>
 __global__ __launch_bounds__(64 * LT) void attn_fwd_wide_kernel(
     const uint16_t* __restrict__ qkvh, const float* __restrict__ logit_scale, uint16_t* __restrict__ oh, float* __restrict__ lse,
     int Bw, int h, int L, int nW, int nww, int nwh, int mask_thr) {
-    constexpr int Lp = 16 * LT, DP = 128, SLAB = Lp * DP, NT = 64 * LT;
+    constexpr int Lp = 16 * LT, SLAB = Lp * DP, NT = 64 * LT;
     constexpr int QP = 16 * DKR + 16, KS = DKR / 2;
     __shared__ __attribute__((aligned(16))) uint16_t smem[2 * Lp * QP];
     uint16_t* const Ks = smem;
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(64 * LT) void attn_fwd_wide_kernel(
         uint16_t* orow = oh + ((size_t)bw * h + hd) * SLAB + (size_t)q * DP;
         const bf16x4 z4 = {0, 0, 0, 0};
 #pragma unroll
-        for (int dt = 0; dt < 8; ++dt) {
+        for (int dt = 0; dt < DP / 16; ++dt) {
             bf16x4 ov = z4;                                    // the pad columns of the 128-wide layout are written as zeros
             if (dt < DKR) {
                 f32x4 v = o[dt < DKR ? dt : 0];
@@ -415,9 +416,13 @@ __global__ __launch_bounds__(64 * LT) void attn_fwd_wide_kernel(
 // 0 = launched, 1 = shape not covered (the caller falls back to attn_bwd_kernel), negative = error
 static bool wide_off() { const char* e = getenv("SWV2_ATTN_WIDE"); return e && atoi(e) == 0; }      // (read per call: A/B and tests)
 
+static bool wide_shape(const swv2_attn_args* a, int Lp, int DP) {
+    return !wide_off() && !a->bias && Lp == 176 && (DP == 96 || DP == 128) && a->head_dim > 64 && a->head_dim <= 96 &&
+           !(a->dbg & SWV2_ATTN_FIRST_GEN);
+}
+
 int swv2_attn_bwd_wide(const swv2_attn_args* a, int Lp, int DP, void* stream) {
-    if (wide_off()) return 1;
-    if (a->bias || Lp != 176 || DP != 128 || a->head_dim > 96 || (a->dbg & SWV2_ATTN_FIRST_GEN)) return 1;
+    if (!wide_shape(a, Lp, DP)) return 1;
     hipStream_t st = (hipStream_t)stream;
     const int nW = a->nwh * a->nww;
     // one workgroup (11 waves, 141 KB of LDS) per CU: persistent over the windows of its head
@@ -425,13 +430,12 @@ int swv2_attn_bwd_wide(const swv2_attn_args* a, int Lp, int DP, void* stream) {
     if (chunks < 1) chunks = 1;
     if (chunks > a->Bw) chunks = a->Bw;
     dim3 grid(chunks, a->heads), block(64 * 11);
-#define SWV2_LAUNCH_WIDE(DKR, LFIX)                                                                                                    \
-    hipLaunchKernelGGL((attn_bwd_wide_kernel<11, DKR, LFIX>), grid, block, 0, st, (const uint16_t*)a->qkvh, a->logit_scale,            \
+#define SWV2_LAUNCH_WIDE(LFIX, DPL)                                                                                                    \
+    hipLaunchKernelGGL((attn_bwd_wide_kernel<11, 6, LFIX, DPL>), grid, block, 0, st, (const uint16_t*)a->qkvh, a->logit_scale,         \
                        (const uint16_t*)a->oh, (const uint16_t*)a->doh, a->lse, a->rnorm, (uint16_t*)a->dqkvh, a->dlogit_scale, a->Bw, \
                        a->heads, a->L, nW, a->nww, a->nwh, a->mask_thr)
-    if (a->head_dim > 64 && a->L == 162) SWV2_LAUNCH_WIDE(6, 162);
-    else if (a->head_dim > 64) SWV2_LAUNCH_WIDE(6, 0);
-    else return 1;
+    if (DP == 96) { if (a->L == 162) SWV2_LAUNCH_WIDE(162, 96); else SWV2_LAUNCH_WIDE(0, 96); }
+    else { if (a->L == 162) SWV2_LAUNCH_WIDE(162, 128); else SWV2_LAUNCH_WIDE(0, 128); }
 #undef SWV2_LAUNCH_WIDE
     SWV2_CHECK_LAUNCH("swv2_attn_bwd");
     return SWV2_OK;
@@ -439,20 +443,19 @@ int swv2_attn_bwd_wide(const swv2_attn_args* a, int Lp, int DP, void* stream) {
 
 // the matching forward: same return convention
 int swv2_attn_fwd_wide(const swv2_attn_args* a, int Lp, int DP, void* stream) {
-    if (wide_off()) return 1;
-    if (a->bias || Lp != 176 || DP != 128 || a->head_dim > 96 || a->head_dim <= 64 || (a->dbg & SWV2_ATTN_FIRST_GEN)) return 1;
+    if (!wide_shape(a, Lp, DP)) return 1;
     hipStream_t st = (hipStream_t)stream;
     const int nW = a->nwh * a->nww;
     int chunks = 256 / a->heads;            // 79 KB of LDS: one workgroup of 11 waves per CU (two would leave 85 registers per wave)
     if (chunks < 1) chunks = 1;
     if (chunks > a->Bw) chunks = a->Bw;
     dim3 grid(chunks, a->heads), block(64 * 11);
-    if (a->L == 162)
-        hipLaunchKernelGGL((attn_fwd_wide_kernel<11, 6, 162>), grid, block, 0, st, (const uint16_t*)a->qkvh, a->logit_scale, (uint16_t*)a->oh,
-                           a->lse, a->Bw, a->heads, a->L, nW, a->nww, a->nwh, a->mask_thr);
-    else
-        hipLaunchKernelGGL((attn_fwd_wide_kernel<11, 6, 0>), grid, block, 0, st, (const uint16_t*)a->qkvh, a->logit_scale, (uint16_t*)a->oh,
-                           a->lse, a->Bw, a->heads, a->L, nW, a->nww, a->nwh, a->mask_thr);
+#define SWV2_LAUNCH_WIDE(LFIX, DPL)                                                                                                    \
+    hipLaunchKernelGGL((attn_fwd_wide_kernel<11, 6, LFIX, DPL>), grid, block, 0, st, (const uint16_t*)a->qkvh, a->logit_scale,         \
+                       (uint16_t*)a->oh, a->lse, a->Bw, a->heads, a->L, nW, a->nww, a->nwh, a->mask_thr)
+    if (DP == 96) { if (a->L == 162) SWV2_LAUNCH_WIDE(162, 96); else SWV2_LAUNCH_WIDE(0, 96); }
+    else { if (a->L == 162) SWV2_LAUNCH_WIDE(162, 128); else SWV2_LAUNCH_WIDE(0, 128); }
+#undef SWV2_LAUNCH_WIDE
     SWV2_CHECK_LAUNCH("swv2_attn_fwd");
     return SWV2_OK;
 }

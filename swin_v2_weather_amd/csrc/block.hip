@@ -84,14 +84,14 @@ extern "C" int swv2_block_fwd(const swv2_block_desc* d, void* st) {
         swv2_operand a = op(SWV2_OP_F32, d->x, Mw, C, C, d->rowidx);
         swv2_epilogue e = epi(SWV2_EPI_QKV_HEADS, d->qkvh, 0, d->qkv_b_pad, nullptr, d->rnorm);
         e.p[0] = h; e.p[2] = d->Lp; e.p[3] = d->DP; e.p[4] = d->L;
-        if (d->DP == 128) {      // wide heads: squared norms accumulate in rnorm, finished by swv2_qk_normalize
+        if (d->DP > 64) {        // wide heads (96 / 128 columns): squared norms accumulate in rnorm, finished by swv2_qk_normalize
             if (hipMemsetAsync(d->rnorm, 0, (size_t)Bw * h * 2 * d->Lp * sizeof(float), (hipStream_t)st) != hipSuccess) {
                 swv2_set_error("swv2_block_fwd: hipMemsetAsync(rnorm) failed");
                 return SWV2_ERR_LAUNCH;
             }
         }
         LAUNCH(1, swv2_linear(&a, d->w_qkv, &e, 3 * h * d->DP, st));
-        if (d->DP == 128) TRY(swv2_qk_normalize(d->qkvh, (float*)d->rnorm, Bw, h, d->Lp, d->L, d->DP, st));
+        if (d->DP > 64) TRY(swv2_qk_normalize(d->qkvh, (float*)d->rnorm, Bw, h, d->Lp, d->L, d->DP, st));
     }
     // 2. cosine attention core (the CPB table is packed once into the kernels' layouts; the backward reuses it)
     {

@@ -197,7 +197,7 @@ __device__ __forceinline__ void heads_item(const EpiDesc& d, const float* st, in
         }
     }
 }
-// DP = 128 (head dims 65 .. 128): a wave's 64-column sub-tile is HALF a head, so the squared norm cannot be finished
+// DP = 96 / 128 (head dims 65 .. 128): a wave's 64-column sub-tile is PART of a head, so the squared norm cannot be finished
 // here.  Each half adds its partial sum of squares into rnorm (zeroed by the caller; two addends -> order-independent)
 // and writes the UN-normalised bf16 values; swv2_qk_normalize then turns the sums into 1 / |.| and rescales q, k in
 // place (one extra bf16 rounding of q^, k^ compared with the narrow-head epilogue).  lane = (row, 16-column quarter).
@@ -208,7 +208,7 @@ __device__ __forceinline__ void heads_item_wide(const EpiDesc& d, const float* s
     const int h = d.p0, Lp = d.p2, L = d.p4, S = NORM ? 3 : 1;
     const int r = lane & 15, qd = lane >> 4, nb = n0 + 16 * qd, m = m0 + r;
     const bool in = (m < d.M) && (nb < d.N);
-    const int ph = nb >> 7, part = (h == 1) ? ph : fdiv(ph, h, d.mg1), hd = ph - part * h;
+    const int DPv = d.p3, ph = DPv == 128 ? (nb >> 7) : fdiv(nb, DPv, d.mg2), part = (h == 1) ? ph : fdiv(ph, h, d.mg1), hd = ph - part * h;
     const int bw = fdiv(min(m, d.M - 1), Lp, d.mg0), t = min(m, d.M - 1) - bw * Lp;
     const bool valid = in && t < L;
     float v[16];
@@ -225,12 +225,16 @@ __device__ __forceinline__ void heads_item_wide(const EpiDesc& d, const float* s
         }
     }
     if (NORM) {
-        ss += __shfl_xor(ss, 16);
-        ss += __shfl_xor(ss, 32);
-        if (in && qd == 0 && part < 2 && valid) atomicAdd(d.aux_out + (((long)bw * h + hd) * 2 + part) * Lp + t, ss);
+        if (DPv == 128) {                 // the wave's 64 columns lie in ONE head: one addend per row
+            ss += __shfl_xor(ss, 16);
+            ss += __shfl_xor(ss, 32);
+            if (in && qd == 0 && part < 2 && valid) atomicAdd(d.aux_out + (((long)bw * h + hd) * 2 + part) * Lp + t, ss);
+        } else {                          // 96-wide heads: a 64-column sub-tile may straddle two heads -- one addend per 16-column group
+            if (in && part < 2 && valid) atomicAdd(d.aux_out + (((long)bw * h + hd) * 2 + part) * Lp + t, ss);
+        }
     }
     if (in) {
-        uint16_t* o = (uint16_t*)d.out + ((((long)bw * h + hd) * S + part) * Lp + t) * 128 + (nb & 127);
+        uint16_t* o = (uint16_t*)d.out + ((((long)bw * h + hd) * S + part) * Lp + t) * DPv + (nb - ph * DPv);
         *(uint4*)o = pack8(v);
         *(uint4*)(o + 8) = pack8(v + 8);
     }
@@ -693,7 +697,7 @@ __device__ __forceinline__ void wide_epilogue(const Epi<EK>& ep, const f32x4 (&a
         if (scatter) { if (aux) body(std::true_type{}, std::true_type{}); else body(std::true_type{}, std::false_type{}); }
         else { if (aux) body(std::false_type{}, std::true_type{}); else body(std::false_type{}, std::false_type{}); }
     } else if constexpr (EK == E_QKV_HEADS || EK == E_HEADS) {
-        if (d.p3 == 128) {               // lane -> (row lane & 15, 16-column quarter lane >> 4)
+        if (d.p3 > 64) {                 // lane -> (row lane & 15, 16-column quarter lane >> 4)
             const int nb = n_w + 16 * g;
             f32x4 b4[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
             if (d.bias) {
@@ -1354,7 +1358,7 @@ int launch_nt2(const swv2_operand* a, const void* w, const swv2_epilogue* e, int
     ep.d.p0 = e->p[0]; ep.d.p1 = e->p[1]; ep.d.p2 = e->p[2]; ep.d.p3 = e->p[3]; ep.d.p4 = e->p[4];
     ep.d.mg0 = ep.d.mg1 = ep.d.mg2 = 0;
     ep.d.loss_tar = nullptr; ep.d.loss_qw = nullptr; ep.d.loss_part = nullptr; ep.d.loss_resid = nullptr; ep.d.q0 = ep.d.q1 = ep.d.q2 = 0;
-    if (EK == E_QKV_HEADS || EK == E_HEADS) { ep.d.mg0 = fdiv_magic(e->p[2]); ep.d.mg1 = fdiv_magic(e->p[0]); }
+    if (EK == E_QKV_HEADS || EK == E_HEADS) { ep.d.mg0 = fdiv_magic(e->p[2]); ep.d.mg1 = fdiv_magic(e->p[0]); ep.d.mg2 = fdiv_magic(e->p[3]); }
     if (EK == E_UNPATCH || EK == E_UNPATCH_LOSS || EK == E_UNPATCH_LOSS_SKIP) { ep.d.mg0 = fdiv_magic((e->p[1] / 4) * (e->p[2] / 4)); ep.d.mg1 = fdiv_magic(e->p[2] / 4); }
     if (EK == E_UNPATCH_LOSS || EK == E_UNPATCH_LOSS_SKIP) {
         ep.d.loss_tar = e->loss_tar; ep.d.loss_qw = e->loss_qw; ep.d.loss_part = e->loss_part; ep.d.loss_resid = (uint16_t*)e->loss_resid;
@@ -1487,8 +1491,8 @@ extern "C" int swv2_linear(const swv2_operand* a, const void* w_bf16, const swv2
     if (e->kind == SWV2_EPI_F32 || e->kind == SWV2_EPI_F32_ACC)
         SWV2_CHECK_ARG(e->ld % 4 == 0 && e->ld >= N, "swv2_linear: output pitch %ld must be a multiple of 4 and >= N", e->ld);
     if (e->kind == SWV2_EPI_QKV_HEADS || e->kind == SWV2_EPI_HEADS)
-        SWV2_CHECK_ARG((e->p[3] == 16 || e->p[3] == 32 || e->p[3] == 64 || e->p[3] == 128) && N % e->p[3] == 0 && e->p[0] > 0 && e->p[2] > 0,
-                       "swv2_linear: head-split epilogue needs DP in {16,32,64,128} and N a multiple of DP (DP=%d N=%d)", e->p[3], N);
+        SWV2_CHECK_ARG((e->p[3] == 16 || e->p[3] == 32 || e->p[3] == 64 || e->p[3] == 96 || e->p[3] == 128) && N % e->p[3] == 0 && e->p[0] > 0 && e->p[2] > 0,
+                       "swv2_linear: head-split epilogue needs DP in {16,32,64,96,128} and N a multiple of DP (DP=%d N=%d)", e->p[3], N);
     if (e->kind == SWV2_EPI_UNPATCH || e->kind == SWV2_EPI_UNPATCH_LOSS)
         SWV2_CHECK_ARG(N == e->p[0] * 16, "swv2_linear: un-patchify needs N == Cout*16");
     if (e->kind == SWV2_EPI_UNPATCH_LOSS) {

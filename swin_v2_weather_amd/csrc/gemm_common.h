@@ -242,7 +242,7 @@ template <> struct ALoad<A_BF16_GELU> {
     __device__ __forceinline__ uint4 chunk(int m, int k0) const { return cvt(raw(m, k0)); }
 };
 // head-major window layout [Bw][h][S][Lp][DP] -> logical row m = bw*Lp + t, logical k = (part*h + head)*DP + j
-// (head dim padded to DP; the matching weights are padded by swv2_prep_weight).
+// (head dim padded to DP in {16, 32, 64, 96, 128}; the matching weights are padded by swv2_prep_weight).
 // p0 = heads, p2 = Lp, p3 = DP ; ld = number of parts S (1 for oh, 3 for dqkvh)
 template <> struct ALoad<A_HEADS> {
     static constexpr bool ROW_FASTEST = false;
@@ -260,7 +260,7 @@ template <> struct ALoad<A_HEADS> {
     __device__ __forceinline__ uint4 raw_unc(int m, int k0) const {
         const int h = d.p0, Lp = d.p2, DP = d.p3, S = (int)d.ld;
         const int bw = fdiv(m, Lp, d.mg0), t = m - bw * Lp;
-        const int ph = k0 >> d.p1, j = k0 - ph * DP;                 // p1 = log2(DP), set by make_loader
+        const int ph = d.p1 >= 0 ? (k0 >> d.p1) : fdiv(k0, DP, d.mg2), j = k0 - ph * DP;      // p1 = log2(DP) or -1 (DP = 96), set by make_loader
         const int part = (h == 1) ? ph : fdiv(ph, h, d.mg1), hd = ph - part * h;
         return *(const uint4*)((const uint16_t*)d.ptr + ((((long)bw * h + hd) * S + part) * Lp + t) * DP + j);
     }
@@ -268,7 +268,7 @@ template <> struct ALoad<A_HEADS> {
     __device__ __forceinline__ uint32_t elem_off(int m, int k0) const {
         const int h = d.p0, Lp = d.p2, DP = d.p3, S = (int)d.ld;
         const int bw = fdiv(m, Lp, d.mg0), t = m - bw * Lp;
-        const int ph = k0 >> d.p1, j = k0 - ph * DP;
+        const int ph = d.p1 >= 0 ? (k0 >> d.p1) : fdiv(k0, DP, d.mg2), j = k0 - ph * DP;
         const int part = (h == 1) ? ph : fdiv(ph, h, d.mg1), hd = ph - part * h;
         return (uint32_t)((((bw * h + hd) * S + part) * Lp + t) * DP + j);
     }
@@ -280,7 +280,7 @@ template <> struct ALoad<A_HEADS> {
     __device__ __forceinline__ Step step_base(int m, int k0) const {
         const int h = d.p0, Lp = d.p2, DP = d.p3, S = (int)d.ld;
         const int bw = fdiv(m, Lp, d.mg0), t = m - bw * Lp;
-        const int ph = k0 >> d.p1, j = k0 - ph * DP;
+        const int ph = d.p1 >= 0 ? (k0 >> d.p1) : fdiv(k0, DP, d.mg2), j = k0 - ph * DP;
         const int part = (h == 1) ? ph : fdiv(ph, h, d.mg1), hd = ph - part * h;
         Step o = {(uint32_t)((((bw * h + hd) * S + part) * Lp + t) * DP + j), t};
         return o;
@@ -364,7 +364,8 @@ ALoad<AK> make_loader(const swv2_operand* o) {
     l.d.mg0 = l.d.mg1 = l.d.mg2 = 0;
     if (AK == A_HEADS) {
         l.d.mg0 = fdiv_magic(o->p[2]); l.d.mg1 = fdiv_magic(o->p[0]);
-        l.d.p1 = o->p[3] == 16 ? 4 : o->p[3] == 32 ? 5 : o->p[3] == 64 ? 6 : 7;
+        l.d.p1 = o->p[3] == 16 ? 4 : o->p[3] == 32 ? 5 : o->p[3] == 64 ? 6 : o->p[3] == 128 ? 7 : -1;
+        l.d.mg2 = fdiv_magic(o->p[3]);
     }
     if (AK == A_PATCH) { l.d.mg0 = fdiv_magic((o->p[1] / 4) * (o->p[2] / 4)); l.d.mg1 = fdiv_magic(o->p[2] / 4); }
     if (AK == A_BF16_CS) l.d.mg0 = fdiv_magic(o->p[0]);
@@ -384,7 +385,7 @@ int check_operand(const swv2_operand* o, const char* who) {
         SWV2_CHECK_ARG(o->aux0 && o->p[0] > 0 && o->p[2] * 16 >= o->cols && o->cols % 16 == 0 && !o->rowidx,
                        "%s: scaled operand needs aux0, rows per sample p[0] > 0, p[2] >= cols / 16 groups, no gather", who);
     if (o->kind == SWV2_OP_HEADS)
-        SWV2_CHECK_ARG(o->p[3] == 16 || o->p[3] == 32 || o->p[3] == 64 || o->p[3] == 128, "%s: head pad %d not in {16,32,64,128}", who, o->p[3]);
+        SWV2_CHECK_ARG(o->p[3] == 16 || o->p[3] == 32 || o->p[3] == 64 || o->p[3] == 96 || o->p[3] == 128, "%s: head pad %d not in {16,32,64,96,128}", who, o->p[3]);
     if (o->kind == SWV2_OP_PATCH)
         SWV2_CHECK_ARG(o->p[1] % 4 == 0 && o->p[2] % 4 == 0 && o->cols == o->p[0] * 16, "%s: bad patch geometry", who);
     if (o->kind == SWV2_OP_MERGE_LN)

@@ -591,9 +591,9 @@ extern "C" int swv2_ln_residual_bwd(const swv2_ln_args* a, void* stream) {
 // ------------------------------------------------------------------------------------------------
 namespace {
 __global__ __launch_bounds__(256) void qk_normalize_kernel(uint16_t* __restrict__ qkvh, float* __restrict__ rnorm, long rows,
-                                                           int h, int Lp, int L) {
+                                                           int h, int Lp, int L, int DP) {
     const long i = (long)blockIdx.x * 16 + (threadIdx.x >> 4);        // row index over [Bw][h][2][Lp]
-    const int c = threadIdx.x & 15;
+    const int c = threadIdx.x & 15;                                   // 16-byte chunk of the row (DP / 8 of them: 12 or 16)
     if (i >= rows) return;
     const int t = (int)(i % Lp);
     const long bh2 = i / Lp;
@@ -601,22 +601,24 @@ __global__ __launch_bounds__(256) void qk_normalize_kernel(uint16_t* __restrict_
     const long bh = bh2 >> 1;
     const float ss = rnorm[i];
     const float rn = (t < L) ? 1.f / fmaxf(sqrtf(ss), 1e-12f) : 0.f;
-    uint16_t* row = qkvh + ((bh * 3 + part) * Lp + t) * 128 + c * 8;
-    float v[8];
-    unpack8f(*(const uint4*)row, v);
+    if (c * 8 < DP) {
+        uint16_t* row = qkvh + ((bh * 3 + part) * Lp + t) * DP + c * 8;
+        float v[8];
+        unpack8f(*(const uint4*)row, v);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] *= rn;
-    *(uint4*)row = pack8f(v);
+        for (int e = 0; e < 8; ++e) v[e] *= rn;
+        *(uint4*)row = pack8f(v);
+    }
     if (c == 0) rnorm[i] = rn;
 }
 }  // namespace
 
 extern "C" int swv2_qk_normalize(void* qkvh, float* rnorm, int Bw, int heads, int Lp, int L, int DP, void* stream) {
     SWV2_CHECK_ARG(qkvh && rnorm && Bw > 0 && heads > 0 && Lp > 0 && L > 0 && L <= Lp, "swv2_qk_normalize: bad argument");
-    SWV2_CHECK_ARG(DP == 128, "swv2_qk_normalize: only the 128-wide head layout needs this pass (DP=%d)", DP);
+    SWV2_CHECK_ARG(DP == 96 || DP == 128, "swv2_qk_normalize: only the 96- and 128-wide head layouts need this pass (DP=%d)", DP);
     const long rows = (long)Bw * heads * 2 * Lp;
     hipLaunchKernelGGL(qk_normalize_kernel, dim3((unsigned)cdiv(rows, 16)), dim3(256), 0, (hipStream_t)stream, (uint16_t*)qkvh,
-                       rnorm, rows, heads, Lp, L);
+                       rnorm, rows, heads, Lp, L, DP);
     SWV2_CHECK_LAUNCH("swv2_qk_normalize");
     return SWV2_OK;
 }

@@ -79,7 +79,9 @@ def test_argument_errors_are_reported_without_touching_the_gpu():
     lp, dp = ctypes.c_int(), ctypes.c_int()
     assert lib.swv2_attn_geometry(162, 16, ctypes.byref(lp), ctypes.byref(dp)) == 0 and (lp.value, dp.value) == (176, 16)
     assert lib.swv2_attn_geometry(54, 24, ctypes.byref(lp), ctypes.byref(dp)) == 0 and (lp.value, dp.value) == (64, 32)
-    assert lib.swv2_attn_geometry(54, 96, ctypes.byref(lp), ctypes.byref(dp)) == 0 and (lp.value, dp.value) == (64, 128)   # yaml default 768 / 8
+    assert lib.swv2_attn_geometry(54, 96, ctypes.byref(lp), ctypes.byref(dp)) == 0 and (lp.value, dp.value) == (64, 96)    # yaml default 768 / 8: unpadded
+    assert lib.swv2_attn_geometry(162, 80, ctypes.byref(lp), ctypes.byref(dp)) == 0 and (lp.value, dp.value) == (176, 96)
+    assert lib.swv2_attn_geometry(162, 112, ctypes.byref(lp), ctypes.byref(dp)) == 0 and (lp.value, dp.value) == (176, 128)
     assert lib.swv2_attn_geometry(162, 48, ctypes.byref(lp), ctypes.byref(dp)) == 0 and (lp.value, dp.value) == (176, 64)
     assert lib.swv2_attn_geometry(400, 16, ctypes.byref(lp), ctypes.byref(dp)) == -1
     assert lib.swv2_attn_geometry(54, 160, ctypes.byref(lp), ctypes.byref(dp)) == -1

@@ -214,7 +214,7 @@ typedef struct swv2_wgrad_item {
 size_t swv2_block_wgrad_ws_bytes(int C, int hidden, int heads_dp, int slices);
 int swv2_block_wgrad(const swv2_wgrad_item* items4, int slices, void* ws, size_t ws_bytes, void* stream);
 
-/* Head dims 65 .. 128 (padded to DP = 128): SWV2_EPI_QKV_HEADS then leaves the squared norms of q, k in rnorm (which the
+/* Head dims 65 .. 128 (DP = 96 up to 96 channels, else 128): SWV2_EPI_QKV_HEADS then leaves the squared norms of q, k in rnorm (which the
  * caller zeroes first) and un-normalised values in qkvh; this pass finishes F.normalize (swinv2_global.py:300-304):
  * rnorm <- 1 / max(|.|, 1e-12) (0 on rows >= L) and q, k rescaled in place. */
 int swv2_qk_normalize(void* qkvh_bf16, float* rnorm, int Bw, int heads, int Lp, int L, int DP, void* stream);

@@ -1472,7 +1472,7 @@ def test_block_fused_and_unfused_paths(dev, K, monkeypatch, knob, value):
 
 
 @pytest.mark.parametrize("gh,gw,wh,ww,sh,sw,Cc,h,relpos", [
-    (12, 18, 6, 9, 3, 4, 192, 2, False),     # head dim 96 -> padded to 128, 54-token window
+    (12, 18, 6, 9, 3, 4, 192, 2, False),     # head dim 96 (96-column layout), 54-token window
     (18, 36, 9, 18, 4, 9, 128, 2, False),    # head dim 64, 162-token window, shifted (mask)
     (18, 36, 9, 18, 0, 0, 192, 2, True),     # head dim 96 at the 162-token window: single-buffer forward, q / dO from L2 in backward; CPB bias
     (12, 18, 6, 9, 0, 0, 96, 2, True),       # head dim 48 -> 64
@@ -1496,7 +1496,7 @@ def test_block_wide_heads_against_oracle(dev, K, gh, gw, wh, ww, sh, sw, Cc, h, 
     x = x0.to(dev).requires_grad_(True)
     y = blk(x)
     y.backward(gy0.to(dev))
-    assert blk._runner(B, x.device).plan.DP == (64 if Cc // h <= 64 else 128)
+    assert blk._runner(B, x.device).plan.DP == (64 if Cc // h <= 64 else 96 if Cc // h <= 96 else 128)
     p = {"b." + k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
     xo = x0.clone().requires_grad_(True)
     O.set_rounding(O.bf16_round)

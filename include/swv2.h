@@ -239,6 +239,9 @@ typedef struct swv2_prep_item {
     int out_f32;
 } swv2_prep_item;
 int swv2_prep_chunk(void);
+/* number of workgroups (chunk indices 0 .. n - 1 of the pair table) item needs: linear chunks of swv2_prep_chunk() outputs, or
+ * 64 x 64 output tiles for transposed copies of matrices with both dimensions >= 64 (turned in LDS) */
+int swv2_prep_item_chunks(int out_rows, int out_cols, int transpose);
 int swv2_prep_multi(const swv2_prep_item* items_dev, const int* chunks_dev, int n_chunks, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------

@@ -180,6 +180,7 @@ SYMBOLS = {
     "swv2_loss_part_reduce": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "swv2_loss_finalize": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P]),
     "swv2_prep_chunk": (_I, []),
+    "swv2_prep_item_chunks": (_I, [_I, _I, _I]),
     "swv2_prep_multi": (_I, [_P, _P, _I, _P]),
     "swv2_adam_chunk": (_I, []),
     "swv2_adam_multi": (_I, [_P, _P, _I, _F, _F, _F, _F, _I, _F, _P]),

@@ -250,12 +250,11 @@ class PrepBatch:
         t = PrepBatch._tables.get(key)
         dev = self.keep[0][3].device
         if t is None:
-            chunk = lib.swv2_prep_chunk()
             arr = (L.PrepItem * len(self.jobs))()
             pairs = []
             for i, j in enumerate(self.jobs):
-                arr[i] = L.PrepItem(*j)
-                pairs += [(i, c) for c in range((j[5] * j[7] + chunk - 1) // chunk)]
+                arr[i] = L.PrepItem(*j)                        # (w, rows, cols, transpose, row_map, out_rows, col_map, out_cols, out, f32)
+                pairs += [(i, c) for c in range(lib.swv2_prep_item_chunks(j[5], j[7], j[3]))]
             host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
             t = (host.to(dev), torch.tensor(pairs, dtype=torch.int32).to(dev), len(pairs))
             if len(PrepBatch._tables) > 64:

@@ -353,6 +353,42 @@ def test_wide_weight_gradient_kernel(dev, K):
         assert rel(dW, dab.float().cpu().T @ xo) < 1e-5 and rel(db, dab.float().cpu().sum(0)) < 1e-5
 
 
+def test_batched_weight_preparation_equals_the_single_launches(dev, K):
+    """swv2_prep_multi (one launch for every prepared copy of a model; transposed copies of large matrices as 64 x 64 tiles turned
+    in LDS) against swv2_prep_weight per item and against torch: cast, transpose, row / column maps with -1 entries (head padding),
+    fp32 outputs, ragged and small shapes."""
+    ops = K["ops"]
+    torch.manual_seed(13)
+    cases = []
+    for (rows, cols) in ((768, 3072), (2304, 768), (100, 70), (64, 64), (130, 257), (5, 300)):
+        w = torch.randn(rows, cols, device=dev)
+        rm = torch.randperm(rows)[: max(1, rows - 3)].to(torch.int32)
+        rm[::7] = -1
+        cm = torch.arange(cols, dtype=torch.int32)
+        cm[::5] = -1
+        cases += [(w, False, None, None), (w, True, None, None), (w, False, rm.to(dev), None), (w, True, None, rm.to(dev)),
+                  (w, True, cm.to(dev), None), (w, False, rm.to(dev), cm.to(dev))]
+    batch = ops.PrepBatch()
+    outs = []
+    for (w, tr, rmap, cmap) in cases:
+        r_t, c_t = (w.shape[1], w.shape[0]) if tr else tuple(w.shape)
+        orows = rmap.numel() if rmap is not None else r_t
+        ocols = cmap.numel() if cmap is not None else c_t
+        outs.append(batch.add(w, transpose=tr, row_map=rmap, out_rows=orows, col_map=cmap, out_cols=ocols))
+    f32o = batch.add(cases[1][0], transpose=True, f32=True)
+    batch.launch()
+    torch.cuda.synchronize()
+    for (w, tr, rmap, cmap), got in zip(cases, outs):
+        one = ops.prep_weight(w, transpose=tr, row_map=rmap, out_rows=got.shape[0], col_map=cmap, out_cols=got.shape[1])
+        assert torch.equal(got, one)
+        src = w.t() if tr else w
+        ri = (rmap if rmap is not None else torch.arange(src.shape[0], device=dev)).long()
+        ci = (cmap if cmap is not None else torch.arange(src.shape[1], device=dev)).long()
+        ref = src[ri.clamp(min=0)][:, ci.clamp(min=0)] * (ri >= 0).view(-1, 1) * (ci >= 0).view(1, -1)
+        assert torch.equal(got, ref.to(BF))
+    assert torch.equal(f32o, cases[1][0].t().contiguous())
+
+
 def test_gelu_paths_and_weight_gradients(dev, K):
     ops, L = K["ops"], K["L"]
     torch.manual_seed(2)

@@ -754,8 +754,8 @@ def test_model_cfg4_shape_with_channel_weighted_loss(dev, K):
                       step=int(fx["gstep"]), logit_tol=0.05) < 8e-2
 
 
-@pytest.mark.parametrize("Cc,rel_pos,B", [(128, False, 2), (128, True, 2), (192, False, 1), (768, False, 1)],
-                         ids=["cfg2", "cfg2_relpos", "cfg4", "embed768"])
+@pytest.mark.parametrize("Cc,rel_pos,B", [(128, False, 2), (128, True, 2), (192, False, 1), (768, False, 1), (512, False, 1)],
+                         ids=["cfg2", "cfg2_relpos", "cfg4", "embed768", "embed512"])
 def test_full_size_block_forward_backward_against_oracle(dev, K, Cc, rel_pos, B):
     """ONE block at the BASELINE size (180 x 360 tokens, 400 windows of 9 x 18 per sample, 20 of them with the shift mask, 8
     heads) forward AND backward against the bf16-emulating oracle (the 400-window backward -- chunking over
@@ -764,10 +764,11 @@ def test_full_size_block_forward_backward_against_oracle(dev, K, Cc, rel_pos, B)
     cfg 4's width (C = 192, head dim 24 padded to 32: the unfused proj + LN path at 64 800 rows).  "embed768": the reference
     yaml's own width (8 heads of 96 channels in the 128-column layout) on 72 x 360 tokens (160 windows, 25 920 rows): every product
     on the 256 x 256 LDS-DMA kernels (NT, persistent over several tiles; weight gradients with partial matrices, row / column maps,
-    the fp32 cast pre-pass), attention on attn_wide.hip."""
+    the fp32 cast pre-pass), attention on attn_wide.hip.  "embed512": the same wide GEMM kernels with 64-column heads (the head
+    split of the narrow epilogue inside the wide kernels, head-major operands by DMA) and the first-generation attention."""
     N = K["N"]
     torch.manual_seed(11)
-    gh, gw, wh, ww, sh, sw, h = (72 if Cc == 768 else 180), 360, 9, 18, 4, 9, 8
+    gh, gw, wh, ww, sh, sw, h = (72 if Cc >= 512 else 180), 360, 9, 18, 4, 9, 8
     blk = N.SwinTransformerV2CrBlock(dim=Cc, num_heads=h, feat_size=(gh, gw), window_size=(wh, ww), shift_size=(sh, sw),
                                      rel_pos=rel_pos, drop_path=0.0)
     with torch.no_grad():
@@ -794,7 +795,7 @@ def test_full_size_block_forward_backward_against_oracle(dev, K, Cc, rel_pos, B)
     # unfused path stores the proj / fc2 outputs as bf16 before the LayerNorms, one rounding of the branch more than the emulation
     # -- the kernels sit 4.9e-3 and the emulating oracle 4.6e-3 from exact fp32, 4.4e-3 from each other, identically with the 128-tile
     # GEMMs / first-generation attention and with the wide kernels (tools/probe_block768.py): the stated bf16 tolerance, 1e-2
-    assert rel(y, yo) < (1e-2 if Cc == 768 else 1e-3) and rel(xd.grad, xo.grad) < 1.5e-2
+    assert rel(y, yo) < (1e-2 if Cc >= 512 else 1e-3) and rel(xd.grad, xo.grad) < 1.5e-2
     # weight gradients are sums over 129 600 rows: bf16 rounding noise averages out, systematic errors would not
     assert worst_grad(blk, {k[2:]: v.grad for k, v in p.items()}, logit_tol=BLOCK_LOGIT_TOL) < 3e-2
 

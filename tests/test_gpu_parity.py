@@ -489,6 +489,7 @@ def from_heads(xh, Bw, Lw, h, d, parts):
     (9, 18, 2, 16, 1, 2, True, True),   # one window row: every window carries the shift mask
     (9, 18, 2, 96, 2, 2, True, False),   # the reference yaml's head width (768 / 8), 128-column layout: attn_wide.hip's backward
     (9, 18, 2, 80, 1, 2, False, False), (9, 18, 1, 96, 2, 2, True, True),     # 80 channels in the 96-channel kernel; with bias: first generation
+    (8, 20, 2, 96, 2, 2, True, False), (11, 16, 1, 72, 1, 2, True, False),    # other window areas (160, 176 tokens): the run-time-L instantiations of attn_wide.hip
 ])
 def test_attention_core_fwd_bwd(dev, K, wh, ww, h, d, nwh, nww, shifted, use_bias):
     ops, L = K["ops"], K["L"]

@@ -297,10 +297,11 @@ def main():
     from swin_v2_weather_amd.utils.optim import HipAdam
     opt = HipAdam(model.parameters(), lr=1e-3, betas=(0.9, 0.95))        # train.py:176, one swv2_adam_multi launch per step
     net = model
+    from swin_v2_weather_amd.networks.helpers import DDP_BUCKET_CAP_MB, ddp_bucket_plan
     if use_ddp:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev_index], output_device=dev_index,
                                                         broadcast_buffers=False, gradient_as_bucket_view=True,
-                                                        bucket_cap_mb=12)      # the 12.4 MB pos_embed gradient (ready last) alone
+                                                        bucket_cap_mb=DDP_BUCKET_CAP_MB)    # >= 4 block buckets during backward, pos_embed closes its own (helpers.py)
         if os.environ.get("SWV2_DDP_BUCKET_GRADS", "1") != "0":
             from swin_v2_weather_amd.networks.helpers import enable_ddp_bucket_grads
             enable_ddp_bucket_grads(net)
@@ -421,7 +422,8 @@ def main():
             "mfma_frac_end_to_end": value * flops / world / 2.5e15,
             "host_pipeline": host_leg,
             "backend": a.backend if use_ddp else None,
-            "rccl_nranks": dist.get_world_size() if use_ddp else None,   # self-check: ranks in the RCCL group that all-reduced
+            "rccl_nranks": dist.get_world_size() if use_ddp else None,
+            "ddp_buckets_mb": ddp_bucket_plan(model)[0] if use_ddp else None,     # in launch order (gradient arrival), cap DDP_BUCKET_CAP_MB   # self-check: ranks in the RCCL group that all-reduced
             "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)},
             "weak_scaling_local_batch": B,      # fixed per GPU at every N (BASELINE cfg 2's batch; cfg 3's 8 per GPU: --local-batch 8)
             "roofline": main_rf,

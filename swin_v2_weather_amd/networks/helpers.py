@@ -84,6 +84,35 @@ def get_model(params):
     return SingleStepWrapper(params, model)
 
 
+# DDP bucket cap (MB).  The depth-12 / C-128 model has 10.7 MB of block + head + PatchEmbed gradients (0.79 MB per block,
+# all 13 of a block ready at once: one autograd node) and ONE 33.2 MB tensor, pos_embed, whose gradient is ready right after
+# block 0's backward.  With a cap above 10.7 MB everything but the 1 MB first bucket lands in one bucket that closes on
+# pos_embed, i.e. the whole all-reduce starts at the end of backward (round 3 shipped 12: wrong).  At 2 MB the blocks form
+# >= 4 buckets that go out while earlier blocks are still in backward, and pos_embed closes its own bucket the moment it is
+# ready: its all-reduce (~0.2 ms on the xGMI mesh) runs beside the PatchEmbed backward (0.33 ms of kernels).
+DDP_BUCKET_CAP_MB = 2.0
+
+
+def ddp_bucket_plan(model, cap_mb=DDP_BUCKET_CAP_MB):
+    """Bucket sizes (MB, in launch order) DistributedDataParallel forms for `model` at `cap_mb` once it has re-ordered the
+    parameters by gradient arrival (after the first backward): head, blocks last to first, pos_embed, PatchEmbed.  Returns
+    (sizes_mb, index of the bucket that holds pos_embed or -1).  Same routine the reducer uses (`_compute_bucket_assignment_by_size`)."""
+    import torch.distributed as dist
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    order = list(reversed(named))
+    pe = [i for i, (n, _) in enumerate(order) if n.endswith("pos_embed")]
+    if pe:                   # d pos_embed = batch sum of d(embedding): ready before the PatchEmbed LayerNorm / conv gradients
+        item = order.pop(pe[0])
+        first_embed = next((i for i, (n, _) in enumerate(order) if ".patch_embed." in n or n.startswith("patch_embed.")), len(order))
+        order.insert(first_embed, item)
+    tensors = [p for _, p in order]
+    first = getattr(dist, "_DEFAULT_FIRST_BUCKET_BYTES", 1024 * 1024)
+    buckets, _ = dist._compute_bucket_assignment_by_size(tensors, [first, int(cap_mb * 1024 * 1024)])
+    sizes = [round(sum(tensors[i].numel() * tensors[i].element_size() for i in b) / 1e6, 2) for b in buckets]
+    where = next((k for k, b in enumerate(buckets) if any(order[i][0].endswith("pos_embed") for i in b)), -1)
+    return sizes, where
+
+
 def enable_ddp_bucket_grads(ddp_module):
     """Call once right after wrapping the model in DistributedDataParallel(..., gradient_as_bucket_view=True).
 

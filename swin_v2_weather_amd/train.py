@@ -30,7 +30,7 @@ import torch.distributed as dist
 import yaml
 from torch.nn.parallel import DistributedDataParallel
 
-from .networks.helpers import get_model
+from .networks.helpers import DDP_BUCKET_CAP_MB, get_model
 from .utils import get_data_loader_distributed, logging_utils
 from .utils.YParams import YParams
 from .utils.losses import LossHandler
@@ -151,7 +151,7 @@ class Trainer():
 
         if dist.is_initialized():
             ddp_kw = dict(broadcast_buffers=False, gradient_as_bucket_view=True,
-                          bucket_cap_mb=params['ddp_bucket_cap_mb'] if 'ddp_bucket_cap_mb' in params else 12,
+                          bucket_cap_mb=params['ddp_bucket_cap_mb'] if 'ddp_bucket_cap_mb' in params else DDP_BUCKET_CAP_MB,
                           static_graph=bool(params['checkpointing']) if 'checkpointing' in params else False)
             if self.device.type == 'cuda':
                 self.model = DistributedDataParallel(self.model, device_ids=[self.local_rank], output_device=self.local_rank, **ddp_kw)

@@ -10,3 +10,48 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+class _H5StandIn:
+    """Minimal stand-in for the `h5py` module where the image does not ship it (test infrastructure): `File(path, "w")` collects
+    `create_dataset(name, data=...)` calls and writes them as one .npz archive under the given (".h5") name on close; `File(path,
+    "r")` maps dataset names to arrays with `.shape` and `[t]` -- the two things YearArraySource asks of a dataset.  It lets the
+    product's HDF5 branch (host_pipeline.YearArraySource._open) execute in the container and on the GPU box."""
+
+    class File:
+        def __init__(self, path, mode="r"):
+            import numpy as np
+            self.path, self.mode, self._d = str(path), mode, {}
+            if mode == "r":
+                with np.load(self.path) as z:          # (np.load tells .npz by its magic bytes, not by the file name)
+                    self._d = {k: z[k] for k in z.files}
+
+        def create_dataset(self, name, data=None):
+            self._d[name] = data
+            return data
+
+        def __getitem__(self, name):
+            return self._d[name]
+
+        def close(self):
+            if self.mode == "w":
+                import numpy as np
+                with open(self.path, "wb") as f:
+                    np.savez(f, **self._d)
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            self.close()
+
+
+@pytest.fixture
+def h5py_mod(monkeypatch):
+    """the real h5py when importable, else the stand-in above installed as sys.modules['h5py'] for the test's duration"""
+    try:
+        import h5py
+        return h5py
+    except ImportError:
+        monkeypatch.setitem(sys.modules, "h5py", _H5StandIn)
+        return _H5StandIn

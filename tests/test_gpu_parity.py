@@ -1742,8 +1742,8 @@ def test_host_pipeline_reader_failure_reaches_the_training_loop(dev, K):
             pass
 
 
-@pytest.mark.parametrize("pinned", [False, True])
-def test_host_pipeline_end_to_end(dev, K, pinned):
+@pytest.mark.parametrize("pinned", [False, True, "h5"])
+def test_host_pipeline_end_to_end(dev, K, pinned, tmp_path, h5py_mod):
     """every batch of two epochs equals the synchronous host computation (index order, crop, z-score with the INPUT-channel
     statistics on inputs and targets, zenith of input / target times, invariant channels), through the staging ring / the
     zero-copy path, while a consumer keeps the compute stream busy"""
@@ -1754,7 +1754,16 @@ def test_host_pipeline_end_to_end(dev, K, pinned):
     class P(dict):
         __getattr__ = dict.__getitem__
     Craw, Hraw, Wraw, H, W, B, nf = 6, 21, 40, 20, 40, 2, 1
-    src = hp.SyntheticYearSource(n_years=2, n_samples=9, shape=(Craw, Hraw, Wraw), seed=5, pinned=pinned)
+    src = hp.SyntheticYearSource(n_years=2, n_samples=9, shape=(Craw, Hraw, Wraw), seed=5, pinned=pinned is True)
+    if pinned == "h5":          # the reference's storage: one <name>_<year>.h5 per year with a 'fields' dataset (data_loader_era5.py:65-95)
+        arrays = [np.stack([src.slab(y, t).numpy() for t in range(9)]) for y in range(2)]
+        for y, arr in enumerate(arrays):
+            with h5py_mod.File(tmp_path / f"era5_{src.years[y]}.h5", "w") as f:
+                f.create_dataset("fields", data=arr)
+        years = src.years
+        src = hp.YearArraySource(str(tmp_path))
+        assert src.years == years and src.n_samples_year == [9, 9] and src.shape == (Craw, Hraw, Wraw)
+        src.slab = lambda y, t: torch.from_numpy(arrays[y][t])
     tmp = tempfile.mkdtemp()
     means = np.arange(Craw, dtype=np.float32).reshape(1, Craw, 1, 1) * 0.1
     stds = (1.0 + np.arange(Craw, dtype=np.float32)).reshape(1, Craw, 1, 1)

@@ -6,6 +6,11 @@
 // gemm.hip: the wide weight-gradient kernel (partial matrices), launched by gemm_tn.hip
 int swv2_tn_wide_launch(const swv2_operand* y, const swv2_operand* x, float* part, float* dbpart, int M, int N, int K, int S, hipStream_t st);
 
+// gemm_tn_slab.hip: the block's four weight gradients with every operand byte fetched once (LDS-DMA slabs); launch returns 1 when
+// the shape / workspace is not covered (the caller then takes gemm_tn_group_kernel)
+size_t swv2_tn_slab_ws_bytes(int C, int hidden, int heads_dp);
+int swv2_tn_slab_launch(const swv2_wgrad_item* it, void* ws, size_t ws_bytes, hipStream_t st);
+
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;

@@ -559,7 +559,7 @@ int group_slices(int total_tiles, int requested) {
 extern "C" size_t swv2_block_wgrad_ws_bytes(int C, int hidden, int heads_dp, int slices) {
     if (C <= 0 || hidden <= 0 || heads_dp <= 0) return 0;
     const int tt = 2 * cdiv(C, BN) * cdiv(hidden, BN) + cdiv(C, BN) * cdiv(heads_dp, BN) + cdiv(3 * heads_dp, BN) * cdiv(C, BN);
-    return (size_t)group_slices(tt, slices) * tt * BN * BN * sizeof(float);
+    return std::max((size_t)group_slices(tt, slices) * tt * BN * BN * sizeof(float), swv2_tn_slab_ws_bytes(C, hidden, heads_dp));
 }
 
 extern "C" int swv2_block_wgrad(const swv2_wgrad_item* it, int slices, void* ws, size_t ws_bytes, void* stream) {
@@ -582,6 +582,15 @@ extern "C" int swv2_block_wgrad(const swv2_wgrad_item* it, int slices, void* ws,
         tt += cdiv(it[i].dy.cols, BN) * cdiv(it[i].x.cols, BN);
     }
     g.first[4] = tt;
+    // second-generation kernel (gemm_tn_slab.hip: operands fetched once, by LDS-DMA) for the shapes it covers; SWV2_WGRAD_SLAB=0
+    // and an explicit slice count select the 128 x 128 tile kernel below
+    {
+        static const int use_slab = getenv("SWV2_WGRAD_SLAB") ? atoi(getenv("SWV2_WGRAD_SLAB")) : 1;
+        if (use_slab && slices <= 0) {
+            const int rc = swv2_tn_slab_launch(it, ws, ws_bytes, (hipStream_t)stream);
+            if (rc <= 0) return rc;
+        }
+    }
     const int S = group_slices(tt, slices);
     SWV2_CHECK_ARG(ws_bytes >= (size_t)S * tt * BN * BN * sizeof(float), "swv2_block_wgrad: workspace of %zu bytes, %zu needed",
                    ws_bytes, (size_t)S * tt * BN * BN * sizeof(float));

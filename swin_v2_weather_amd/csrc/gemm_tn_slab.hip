@@ -409,17 +409,62 @@ __global__ __launch_bounds__(SL_TH) void gemm_tn_slab_c128_kernel(SlArgs a) {
 // One workgroup per 1 KB chunk (64 lanes x 4 floats in accumulator layout): its S slices are S contiguous KB; the eight 64-thread groups
 // take every eighth slice and are folded through LDS.
 struct SlRed { float* dW; float* db; const int32_t* nmap; const int32_t* kmap; const float* part; const float* dbpart;
-               int ldw, N, K, TN, TK, WGK, IA, JB, ntk, S, first; };
+               int ldw, N, K, TN, TK, WGK, IA, JB, ntk, S, first, dbfirst; };
 struct SlRedArgs { SlRed p[4]; int total; };
 __global__ __launch_bounds__(512) void tn_slab_reduce_kernel(SlRedArgs a) {
     __shared__ f32x4 red[8][64];
     const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    if (b >= a.total) {
+        // ---- bias gradients: workgroup = 64 entries x 8 slice groups (one thread adding all S partial rows of an entry is a chain of
+        // S dependent-latency loads: it alone took 13 us of the first version's 19)
+        const int bb = b - a.total;
+        const int pi = (bb >= a.p[1].dbfirst) + (bb >= a.p[2].dbfirst) + (bb >= a.p[3].dbfirst);
+        const SlRed& p = a.p[pi];
+        const int n = (bb - p.dbfirst) * 64 + lane;
+        float a0 = 0.f, a1 = 0.f;
+        if (p.db && p.dbpart && n < p.N) {
+            int q = sg;
+            for (; q + 8 < p.S; q += 16) { a0 += p.dbpart[(size_t)q * p.N + n]; a1 += p.dbpart[(size_t)(q + 8) * p.N + n]; }
+            if (q < p.S) a0 += p.dbpart[(size_t)q * p.N + n];
+        }
+        float* redf = (float*)red;
+        redf[sg * 64 + lane] = a0 + a1;
+        __syncthreads();
+        if (sg == 0 && p.db && p.dbpart && n < p.N) {
+            const int nn = p.nmap ? p.nmap[n] : n;
+            float t = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t += redf[e * 64 + lane];
+            if (nn >= 0) p.db[nn] += t;
+        }
+        return;
+    }
     const int pi = (b >= a.p[1].first) + (b >= a.p[2].first) + (b >= a.p[3].first);
     const SlRed& p = a.p[pi];
-    const int lane = threadIdx.x & 63, sg = threadIdx.x >> 6, cg = b - p.first;
+    const int cg = b - p.first;
+    // destination of this lane's four values (group 0 only), requested before the partial sums so that the index-map and dW
+    // round trips overlap the slice loads
+    int kk = -1, nn[4] = {-1, -1, -1, -1};
+    float old[4] = {0.f, 0.f, 0.f, 0.f};
+    if (sg == 0) {
+        const int cpt = 8 * p.IA * p.JB, tile = cg / cpt, c = cg - tile * cpt;
+        const int wave = c / (p.IA * p.JB), ij = c - wave * (p.IA * p.JB), i = ij / p.JB, jj = ij - i * p.JB;
+        const int wgn = wave / p.WGK, wgk = wave - wgn * p.WGK, g = lane >> 4, fr = lane & 15;
+        const int n0 = (tile / p.ntk) * p.TN + wgn * p.IA * 16 + 16 * i + 4 * g;
+        const int k = (tile % p.ntk) * p.TK + wgk * p.JB * 16 + 16 * jj + fr;
+        kk = p.kmap ? p.kmap[k] : k;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) nn[r] = p.nmap ? p.nmap[n0 + r] : n0 + r;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) old[r] = p.dW[(long)max(nn[r], 0) * p.ldw + max(kk, 0)];
+    }
     const float* src = p.part + (size_t)cg * p.S * 256 + lane * 4;
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
     int s = sg;
+#if defined(SWV2_SLAB_ABL) && (SWV2_SLAB_ABL & 8)      // timing ablation: one slice only (fixed cost of the reduction launch)
+    s = p.S;
+#endif
     for (; s + 24 < p.S; s += 32) {
         s0 += *(const f32x4*)(src + (size_t)s * 256);
         s1 += *(const f32x4*)(src + (size_t)(s + 8) * 256);
@@ -429,33 +474,11 @@ __global__ __launch_bounds__(512) void tn_slab_reduce_kernel(SlRedArgs a) {
     for (; s < p.S; s += 8) s0 += *(const f32x4*)(src + (size_t)s * 256);
     red[sg][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (sg == 0) {
+    if (sg == 0 && kk >= 0) {
         const f32x4 t = ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) + ((red[4][lane] + red[5][lane]) + (red[6][lane] + red[7][lane]));
-        const int cpt = 8 * p.IA * p.JB, tile = cg / cpt, c = cg - tile * cpt;
-        const int wave = c / (p.IA * p.JB), ij = c - wave * (p.IA * p.JB), i = ij / p.JB, jj = ij - i * p.JB;
-        const int wgn = wave / p.WGK, wgk = wave - wgn * p.WGK, g = lane >> 4, fr = lane & 15;
-        const int n0 = (tile / p.ntk) * p.TN + wgn * p.IA * 16 + 16 * i + 4 * g;
-        int k = (tile % p.ntk) * p.TK + wgk * p.JB * 16 + 16 * jj + fr;
-        if (p.kmap) k = p.kmap[k];
-        if (k >= 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = p.nmap ? p.nmap[n0 + r] : n0 + r;
-                if (n >= 0) p.dW[(long)n * p.ldw + k] += t[r];
-            }
-        }
-    }
-    const int nb = cg * 512 + threadIdx.x;                    // bias gradient: the product's first ceil(N / 512) workgroups
-    if (p.db && p.dbpart && nb < p.N) {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        int q = 0;
-        for (; q + 3 < p.S; q += 4) {
-            a0 += p.dbpart[(size_t)q * p.N + nb]; a1 += p.dbpart[(size_t)(q + 1) * p.N + nb];
-            a2 += p.dbpart[(size_t)(q + 2) * p.N + nb]; a3 += p.dbpart[(size_t)(q + 3) * p.N + nb];
-        }
-        for (; q < p.S; ++q) a0 += p.dbpart[(size_t)q * p.N + nb];
-        const int nn = p.nmap ? p.nmap[nb] : nb;
-        if (nn >= 0) p.db[nn] += (a0 + a1) + (a2 + a3);
+        for (int r = 0; r < 4; ++r)
+            if (nn[r] >= 0) p.dW[(long)nn[r] * p.ldw + kk] = old[r] + t[r];
     }
 }
 
@@ -569,7 +592,7 @@ int swv2_tn_slab_launch(const swv2_wgrad_item* it, void* ws, size_t ws_bytes, hi
     const SlShape& sh = SL_C128;
     SlArgs a = {};
     SlRedArgs r = {};
-    int first = 0, rfirst = 0;
+    int first = 0, rfirst = 0, dbfirst = 0;
     for (int i = 0; i < 4; ++i) {
         SlProd& p = a.p[i];
         p.y = sl_op(it[i].dy); p.x = sl_op(it[i].x);
@@ -583,6 +606,8 @@ int swv2_tn_slab_launch(const swv2_wgrad_item* it, void* ws, size_t ws_bytes, hi
         q.ldw = it[i].ldw; q.N = p.N; q.K = p.K; q.TN = sh.TN[i]; q.TK = sh.TK[i]; q.WGK = sh.WGK[i];
         q.IA = sh.TN[i] / (16 * sh.WGN[i]); q.JB = sh.TK[i] / (16 * sh.WGK[i]); q.ntk = p.K / sh.TK[i]; q.S = pl.S[i]; q.first = rfirst;
         rfirst += p.N * p.K / 256;
+        q.dbfirst = dbfirst;
+        dbfirst += cdiv(p.N, 64);
     }
     r.total = rfirst;
 #ifdef SWV2_SLAB_STAMPS       // the last 64 bytes x workgroups of the workspace receive the phase sums; the split goes to stderr once
@@ -590,7 +615,7 @@ int swv2_tn_slab_launch(const swv2_wgrad_item* it, void* ws, size_t ws_bytes, hi
     { static int once = 0; if (!once++) fprintf(stderr, "slab plan: workgroups %d %d %d %d\n", pl.wgs[0], pl.wgs[1], pl.wgs[2], pl.wgs[3]); }
 #endif
     hipLaunchKernelGGL(gemm_tn_slab_c128_kernel, dim3(first), dim3(SL_TH), 0, st, a);
-    hipLaunchKernelGGL(tn_slab_reduce_kernel, dim3(rfirst), dim3(512), 0, st, r);
+    hipLaunchKernelGGL(tn_slab_reduce_kernel, dim3(rfirst + dbfirst), dim3(512), 0, st, r);
     SWV2_CHECK_LAUNCH("swv2_block_wgrad(slab)");
     return 0;
 }

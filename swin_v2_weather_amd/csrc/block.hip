@@ -164,7 +164,8 @@ extern "C" int swv2_block_bwd(const swv2_block_desc* d, void* st) {
     // the four weight gradients as ONE launch after the data path (needs the operand set of the fused paths)
     const bool defer = fused && fused_pl && d->ln_ws_floats >= swv2_mlp_bwd_ws_floats(BT, C) + swv2_proj_ln_bwd_ws_floats(Mw, C);
     int n_ln1 = 0, n_ln2 = 0;
-    const bool group = d->wgrad_group && fused && fused_pl && d->wgrad_ws && !ss &&
+    // (needs the fused MLP path's operand set: GELU(hpre) on load; the proj + LN1 pair may be fused or not)
+    const bool group = d->wgrad_group && fused && d->wgrad_ws && !ss &&
                        d->wgrad_ws_bytes >= swv2_block_wgrad_ws_bytes(C, hid, h * d->DP, 0);
     if (fused) {
         // 7', 6', 5' data path fused: LN2 backward, dh = (da2 W2) * GELU'(hpre), dx1 = dx2 + dh W1 in one kernel
@@ -232,6 +233,7 @@ extern "C" int swv2_block_bwd(const swv2_block_desc* d, void* st) {
     {
         swv2_operand dy = op(SWV2_OP_BF16, d->da1, Mw, C, C), x = op_heads(d->oh, Bw, h, 1, d->Lp, d->DP);
         if (ss) fork_to(ss, (hipStream_t)st);
+        if (!group)
         LAUNCH(17, swv2_linear_wgrad_ws(&dy, &x, d->d_proj_w, d->d_proj_b, nullptr, d->proj_map, C, sp, d->wgrad_ws, d->wgrad_ws_bytes, ws));
         swv2_epilogue e = epi(SWV2_EPI_HEADS, d->doh, 0);
         e.p[0] = h; e.p[2] = d->Lp; e.p[3] = d->DP; e.p[4] = d->L;

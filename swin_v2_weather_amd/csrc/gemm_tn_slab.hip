@@ -102,7 +102,7 @@ __device__ __forceinline__ int sl_swz(int r, int u) {
     else { static_assert((W * 2) % 128 == 0, "slab width"); return u ^ ((r >> 1) & 3); }
 }
 
-template <int FY, int FX, int TN, int TK, int WGN, int WGK, int SR, int NS>
+template <int FY, int FX, int TN, int TK, int WGN, int WGK, int SR, int NS, bool INPLACE = false>
 __device__ __forceinline__ void slab_job(const SlProd& P, const int j, unsigned char* __restrict__ smem, [[maybe_unused]] unsigned long long* stamps) {
     static_assert(WGN * WGK == 8, "8 waves");
     constexpr int IA = TN / (16 * WGN), JB = TK / (16 * WGK);
@@ -110,15 +110,19 @@ __device__ __forceinline__ void slab_job(const SlProd& P, const int j, unsigned 
     constexpr bool XF32 = FX == F_F32 || FX == F_F32G;
     constexpr int YP = TN * 2, XP = TK * 2;                       // bf16 row pitches (row-major slabs)
     constexpr int YB = SR * TN * 2, XB = SR * TK * (XF32 ? 4 : 2), STG = YB + XB;
-    constexpr int NY = YB / 1024, NX = XB / 1024;
-    static_assert(NY % 8 == 0 && NX % 8 == 0 && YB % 1024 == 0 && XB % 1024 == 0, "DMA instructions per wave");
-    constexpr int NYW = NY / 8, NXW = NX / 8, NIW = NYW + NXW, D = NS - 1;
+    constexpr int NY = YB / 1024, NX = XB / 1024, NTOT = NY + NX;
+    static_assert(YB % 1024 == 0 && XB % 1024 == 0, "whole DMA instructions");
+    // instruction ii = wave + 8 q of a stage (q < NIW): the dY slab's NY instructions first, then the X slab's; when NTOT is not a
+    // multiple of 8 the waves below NTOT % 8 issue one more than the others (two counted-vmcnt variants, selected per wave)
+    constexpr int NIW = (NTOT + 7) / 8, NREM = NTOT % 8, D = NS - 1;
     // LDS: [GELU table (address 0: see sl_gelu8_tab)] [gather index table] [NS stage slots] [bf16 slab of the current fp32 stage]
     constexpr int OFF_TAB = 0, TABB = FX == F_ROWG ? (GT_N * 2 + 1023) / 1024 * 1024 : 0;
     constexpr int OFF_IDX = OFF_TAB + TABB, IDXB = FX == F_F32G ? SL_IDX_CAP * 4 : 0;
     constexpr int OFF_SLOT = OFF_IDX + IDXB;
-    constexpr int OFF_XB = OFF_SLOT + NS * STG, XBB = XF32 ? SR * TK * 2 : 0;
+    // INPLACE: the bf16 copy of an fp32 stage overwrites the head of its own fp32 slab (one more barrier per stage) where the budget is short
+    constexpr int OFF_XB = OFF_SLOT + NS * STG, XBB = (XF32 && !INPLACE) ? SR * TK * 2 : 0;
     static_assert(OFF_XB + XBB <= SL_SMEM, "LDS budget");
+    static_assert(!INPLACE || XF32, "in-place conversion: fp32 operands only");
     constexpr int KS = SR / 32;                                   // MFMA k-steps per stage
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -151,70 +155,71 @@ __device__ __forceinline__ void slab_job(const SlProd& P, const int j, unsigned 
     }
     if constexpr (FX == F_ROWG || FX == F_F32G) __syncthreads();
 
-    // ---- DMA geometry.  Instruction q of this wave is instruction ii = 8 q + wave of its operand's slab: LDS bytes ii * 1024 .. + 1023
-    int yrow[NYW], xrow[NXW];                 // row inside the stage
-    uint32_t ycol[NYW], xcol[NXW];            // row-major: element column (incl. n0 / k0); head-major: element offset of the column part
+    // ---- DMA geometry.  Instruction q of this wave is instruction ii = 8 q + wave of the stage: LDS bytes ii * 1024 .. + 1023 of (dY | X)
+    int orow[NIW];                            // row inside the stage
+    uint32_t ocol[NIW];                       // row-major: element column (incl. n0 / k0); head-major: element offset of the column part
 #pragma unroll
-    for (int q = 0; q < NYW; ++q) {
-        const int o = (8 * q + wave) * 1024 + lane * 16;
-        if constexpr (FY == F_ROW) {
-            const int row = o / YP, rem = o - row * YP, pu = rem >> 5, u = sl_swz<TN>(row, pu);
-            yrow[q] = row; ycol[q] = (uint32_t)(n0 + u * 16 + ((rem >> 4) & 1) * 8);
+    for (int q = 0; q < NIW; ++q) {
+        const int ii = 8 * q + wave;          // (wave-uniform)
+        if (ii < NY) {
+            const int o = ii * 1024 + lane * 16;
+            if constexpr (FY == F_ROW) {
+                const int row = o / YP, rem = o - row * YP, pu = rem >> 5, u = sl_swz<TN>(row, pu);
+                orow[q] = row; ocol[q] = (uint32_t)(n0 + u * 16 + ((rem >> 4) & 1) * 8);
+            } else {
+                static_assert(FY == F_HEAD, "dY kinds");
+                const int blk = o / (SR * 32), rem = o - blk * (SR * 32), row = rem >> 5, col = n0 + blk * 16 + ((rem >> 4) & 1) * 8;
+                const int ph = fdiv(col, P.y.DP, P.y.mgDP), jj = col - ph * P.y.DP, part = fdiv(ph, P.y.heads, P.y.mgH), hd = ph - part * P.y.heads;
+                orow[q] = row; ocol[q] = (uint32_t)(((hd * P.y.parts + part) * P.y.Lp) * P.y.DP + jj);
+            }
         } else {
-            static_assert(FY == F_HEAD, "dY kinds");
-            const int blk = o / (SR * 32), rem = o - blk * (SR * 32), row = rem >> 5, col = n0 + blk * 16 + ((rem >> 4) & 1) * 8;
-            const int ph = fdiv(col, P.y.DP, P.y.mgDP), jj = col - ph * P.y.DP, part = fdiv(ph, P.y.heads, P.y.mgH), hd = ph - part * P.y.heads;
-            yrow[q] = row; ycol[q] = (uint32_t)(((hd * P.y.parts + part) * P.y.Lp) * P.y.DP + jj);
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < NXW; ++q) {
-        const int o = (8 * q + wave) * 1024 + lane * 16;
-        if constexpr (FX == F_ROW || FX == F_ROWG) {
-            const int row = o / XP, rem = o - row * XP, pu = rem >> 5, u = sl_swz<TK>(row, pu);
-            xrow[q] = row; xcol[q] = (uint32_t)(k0 + u * 16 + ((rem >> 4) & 1) * 8);
-        } else if constexpr (XF32) {
-            const int row = o / (TK * 4), rem = o - row * (TK * 4);
-            xrow[q] = row; xcol[q] = (uint32_t)(k0 + (rem >> 2));
-        } else {
-            const int blk = o / (SR * 32), rem = o - blk * (SR * 32), row = rem >> 5, col = k0 + blk * 16 + ((rem >> 4) & 1) * 8;
-            const int ph = fdiv(col, P.x.DP, P.x.mgDP), jj = col - ph * P.x.DP, part = fdiv(ph, P.x.heads, P.x.mgH), hd = ph - part * P.x.heads;
-            xrow[q] = row; xcol[q] = (uint32_t)(((hd * P.x.parts + part) * P.x.Lp) * P.x.DP + jj);
+            const int o = (ii - NY) * 1024 + lane * 16;
+            if constexpr (FX == F_ROW || FX == F_ROWG) {
+                const int row = o / XP, rem = o - row * XP, pu = rem >> 5, u = sl_swz<TK>(row, pu);
+                orow[q] = row; ocol[q] = (uint32_t)(k0 + u * 16 + ((rem >> 4) & 1) * 8);
+            } else if constexpr (XF32) {
+                const int row = o / (TK * 4), rem = o - row * (TK * 4);
+                orow[q] = row; ocol[q] = (uint32_t)(k0 + (rem >> 2));
+            } else {
+                const int blk = o / (SR * 32), rem = o - blk * (SR * 32), row = rem >> 5, col = k0 + blk * 16 + ((rem >> 4) & 1) * 8;
+                const int ph = fdiv(col, P.x.DP, P.x.mgDP), jj = col - ph * P.x.DP, part = fdiv(ph, P.x.heads, P.x.mgH), hd = ph - part * P.x.heads;
+                orow[q] = row; ocol[q] = (uint32_t)(((hd * P.x.parts + part) * P.x.Lp) * P.x.DP + jj);
+            }
         }
     }
     const uint32_t ywst = FY == F_HEAD ? (uint32_t)(P.y.heads * P.y.parts * P.y.Lp * P.y.DP) : 0u;     // elements per window
     const uint32_t xwst = FX == F_HEAD ? (uint32_t)(P.x.heads * P.x.parts * P.x.Lp * P.x.DP) : 0u;
-    // DMA instruction q (0 .. NIW - 1: first the dY slab's, then the X slab's) of stage index ti of this job into `slot`
+    // DMA instruction q of this wave for stage index ti of this job into `slot`
     auto issue_q = [&](int ti, int slot, auto qtag) {    // rows past M repeat row M - 1 (dY rows there are zeroed below)
-        constexpr int qq = decltype(qtag)::value;
+        constexpr int q = decltype(qtag)::value;
+        const int ii = 8 * q + wave;
+        if (NREM != 0 && q == NIW - 1 && ii >= NTOT) return;        // (only the last instruction of a wave can be missing)
         const int t = stage_of(ti);
-        const uint32_t ly = lds0 + (uint32_t)(slot * STG) + (uint32_t)(wave * 1024), lx = ly + YB;
-        if constexpr (qq < NYW) {
-            constexpr int q = qq;
-            const int m = min(t * SR + yrow[q], M - 1);
+        const uint32_t lslot = lds0 + (uint32_t)(slot * STG) + (uint32_t)(ii * 1024);     // (the X slab follows the dY slab: ii * 1024 covers both)
+        if (ii < NY) {
+            const int m = min(t * SR + orow[q], M - 1);
             uint32_t off;
-            if constexpr (FY == F_ROW) off = 2u * ((uint32_t)m * (uint32_t)P.y.ld + ycol[q]);
+            if constexpr (FY == F_ROW) off = 2u * ((uint32_t)m * (uint32_t)P.y.ld + ocol[q]);
             else {
                 const int bw = fdiv(m, P.y.Lp, P.y.mgLp), tt = m - bw * P.y.Lp;
-                off = 2u * ((uint32_t)bw * ywst + (uint32_t)(tt * P.y.DP) + ycol[q]);
+                off = 2u * ((uint32_t)bw * ywst + (uint32_t)(tt * P.y.DP) + ocol[q]);
             }
-            sl_dma(P.y.ptr, off, ly + 8192 * q);
+            sl_dma(P.y.ptr, off, lslot);
         } else {
-            constexpr int q = qq - NYW;
             uint32_t off;
             if constexpr (FX == F_F32G) {
-                const int r = max(idxs[ti * SR + xrow[q]], 0);
-                off = 4u * ((uint32_t)r * (uint32_t)P.x.ld + xcol[q]);
+                const int r = max(idxs[ti * SR + orow[q]], 0);
+                off = 4u * ((uint32_t)r * (uint32_t)P.x.ld + ocol[q]);
             } else {
-                const int m = min(t * SR + xrow[q], M - 1);
-                if constexpr (FX == F_ROW || FX == F_ROWG) off = 2u * ((uint32_t)m * (uint32_t)P.x.ld + xcol[q]);
-                else if constexpr (FX == F_F32) off = 4u * ((uint32_t)m * (uint32_t)P.x.ld + xcol[q]);
+                const int m = min(t * SR + orow[q], M - 1);
+                if constexpr (FX == F_ROW || FX == F_ROWG) off = 2u * ((uint32_t)m * (uint32_t)P.x.ld + ocol[q]);
+                else if constexpr (FX == F_F32) off = 4u * ((uint32_t)m * (uint32_t)P.x.ld + ocol[q]);
                 else {
                     const int bw = fdiv(m, P.x.Lp, P.x.mgLp), tt = m - bw * P.x.Lp;
-                    off = 2u * ((uint32_t)bw * xwst + (uint32_t)(tt * P.x.DP) + xcol[q]);
+                    off = 2u * ((uint32_t)bw * xwst + (uint32_t)(tt * P.x.DP) + ocol[q]);
                 }
             }
-            sl_dma(P.x.ptr, off, lx + 8192 * q);
+            sl_dma(P.x.ptr, off, lslot);
         }
     };
     // instructions [lo, hi) of a stage: the issue of a stage is spread over the compute of the previous one (insertion points below),
@@ -264,8 +269,9 @@ __device__ __forceinline__ void slab_job(const SlProd& P, const int j, unsigned 
         for (int d = 0; d < D; ++d) issue(min(d, nst - 1), d);
         SSTAMP(7);
         for (int t = 0; t < nst; ++t) {
-            if constexpr (D == 2) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NIW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" : : "n"((D - 1) * NIW) : "memory");
+            // all but the (D - 1) youngest stages of this wave have landed
+            if (NREM == 0 || wave < NREM) asm volatile("s_waitcnt vmcnt(%0)" : : "n"((D - 1) * NIW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" : : "n"((D - 1) * (NIW - 1)) : "memory");
             SSTAMP(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();             // stage t has landed (every wave's part); every wave is done with stage t - 1
@@ -288,25 +294,35 @@ __device__ __forceinline__ void slab_job(const SlProd& P, const int j, unsigned 
             continue;
 #endif
             if constexpr (XF32) {                     // fp32 slab -> bf16 slab (row-major, swizzled), 8 elements per thread and pass
-                for (int c = tid; c < SR * TK / 8; c += SL_TH) {
-                    const int row = c / (TK / 8), ch = c - row * (TK / 8);
+                constexpr int NCH = SR * TK / 8, NPASS = (NCH + SL_TH - 1) / SL_TH;
+                uint16_t* const xdst = INPLACE ? (uint16_t*)(sb + YB) : xbs;
+                uint4 cv[NPASS];
+#pragma unroll
+                for (int ps = 0; ps < NPASS; ++ps) {
+                    const int c = min(tid + ps * SL_TH, NCH - 1), row = c / (TK / 8), ch = c - row * (TK / 8);
                     const float* src = (const float*)(sb + YB) + row * TK + ch * 8;
                     RawF32 v = {*(const f32x4*)src, *(const f32x4*)(src + 4)};
-                    uint4 o = cvt_f32x8(v);
+                    cv[ps] = cvt_f32x8(v);
                     if constexpr (FX == F_F32G) {
-                        if (idxs[t * SR + row] < 0) o = make_uint4(0, 0, 0, 0);
+                        if (idxs[t * SR + row] < 0) cv[ps] = make_uint4(0, 0, 0, 0);
                     }
-                    *(uint4*)(xbs + row * TK + (sl_swz<TK>(row, ch >> 1) << 4) + (ch & 1) * 8) = o;
+                }
+                if constexpr (INPLACE) __syncthreads();          // every thread has read its fp32 chunks before the slab's head is overwritten
+#pragma unroll
+                for (int ps = 0; ps < NPASS; ++ps) {
+                    const int c = tid + ps * SL_TH, row = c / (TK / 8), ch = c - row * (TK / 8);
+                    if (c < NCH) *(uint4*)(xdst + row * TK + (sl_swz<TK>(row, ch >> 1) << 4) + (ch & 1) * 8) = cv[ps];
                 }
                 __syncthreads();
-                Xs = xbs;
+                Xs = xdst;
             }
             SSTAMP(3);
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) {
-                bf16x8 af[IA], bf[JB];
-#pragma unroll
-                for (int i = 0; i < IA; ++i) {
+                // Fragments in chunks of at most four along the longer side of the wave tile (the other side, <= 4 fragments, stays in
+                // registers for the k-step): with all IA + JB fragments live beside 144 accumulator registers the C = 192 shapes spilled,
+                // and a scratch access is a VMEM operation that would break the counted vmcnt waits of the DMA pipeline.
+                auto read_a = [&](int i) -> bf16x8 {
                     bf16x4 a0, a1;
                     if constexpr (FY == F_ROW) {
                         a0 = tr_row(Ys, std::integral_constant<int, TN>{}, 32 * kk, n_w + 16 * i);
@@ -315,10 +331,10 @@ __device__ __forceinline__ void slab_job(const SlProd& P, const int j, unsigned 
                         a0 = tr_head(Ys, 32 * kk, n_w + 16 * i);
                         a1 = tr_head(Ys, 32 * kk + 16, n_w + 16 * i);
                     }
-                    af[i] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
-                }
-                if (kk == 0) issue_point(ti_n, slot_n, std::integral_constant<int, 0>{});
-                [&]<int... JJ>(std::integer_sequence<int, JJ...>) { ([&] { constexpr int jj = JJ;
+                    return __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                };
+                auto read_b = [&](auto jtag) -> bf16x8 {            // + GELU, + this fragment's share of the next stage's DMA issue
+                    constexpr int jj = decltype(jtag)::value;
                     bf16x4 b0, b1;
                     if constexpr (FX == F_HEAD) {
                         b0 = tr_head(Xs, 32 * kk, k_w + 16 * jj);
@@ -327,29 +343,61 @@ __device__ __forceinline__ void slab_job(const SlProd& P, const int j, unsigned 
                         b0 = tr_row(Xs, std::integral_constant<int, TK>{}, 32 * kk, k_w + 16 * jj);
                         b1 = tr_row(Xs, std::integral_constant<int, TK>{}, 32 * kk + 16, k_w + 16 * jj);
                     }
-                    bf[jj] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    bf16x8 b = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
 #if !defined(SWV2_SLAB_ABL) || !(SWV2_SLAB_ABL & 2)    // (& 2: timing ablation without the GELU lookups, wrong results)
                     if constexpr (FX == F_ROWG) {
-                        const uint4 raw = __builtin_bit_cast(uint4, bf[jj]);
+                        const uint4 raw = __builtin_bit_cast(uint4, b);
                         bool bad;
                         uint4 gv = sl_gelu8_tab(raw, smem + OFF_TAB, bad);
                         if (__builtin_expect(__any((int)bad), 0)) gv = glf.cvt(raw);       // formula (no table set on glf)
-                        bf[jj] = __builtin_bit_cast(bf16x8, gv);
+                        b = __builtin_bit_cast(bf16x8, gv);
                     }
 #endif
                     [&]<int... KK>(std::integer_sequence<int, KK...>) {          // (kk is a run-time loop variable of an unrolled loop)
                         ((kk == KK ? issue_point(ti_n, slot_n, std::integral_constant<int, 1 + KK * JB + jj>{}) : (void)0), ...);
                     }(std::make_integer_sequence<int, KS>{});
-                }(), ...); }(std::make_integer_sequence<int, JB>{});
-                SSTAMP(4);
+                    return b;
+                };
+                if (kk == 0) issue_point(ti_n, slot_n, std::integral_constant<int, 0>{});
+                if constexpr (JB <= 4) {
+                    bf16x8 bf[JB];
+                    [&]<int... JJ>(std::integer_sequence<int, JJ...>) { ((bf[JJ] = read_b(std::integral_constant<int, JJ>{})), ...); }
+                    (std::make_integer_sequence<int, JB>{});
+                    SSTAMP(4);
 #pragma unroll
-                for (int i = 0; i < IA; ++i)
+                    for (int i0 = 0; i0 < IA; i0 += 4) {
+                        bf16x8 af[4];
 #pragma unroll
-                    for (int jj = 0; jj < JB; ++jj) acc[i][jj] = mfma32(af[i], bf[jj], acc[i][jj]);
-                if (want_db) {
+                        for (int i = i0; i < i0 + 4 && i < IA; ++i) af[i - i0] = read_a(i);
 #pragma unroll
-                    for (int i = 0; i < IA; ++i)
-                        if (i % WGK == wgk) accdb[i / WGK] = mfma32(af[i], ones, accdb[i / WGK]);
+                        for (int i = i0; i < i0 + 4 && i < IA; ++i) {
+#pragma unroll
+                            for (int jj = 0; jj < JB; ++jj) acc[i][jj] = mfma32(af[i - i0], bf[jj], acc[i][jj]);
+                            if (want_db && i % WGK == wgk) accdb[i / WGK] = mfma32(af[i - i0], ones, accdb[i / WGK]);
+                        }
+                    }
+                } else {
+                    static_assert(IA <= 4, "one side of the wave tile has at most four fragments");
+                    bf16x8 af[IA];
+#pragma unroll
+                    for (int i = 0; i < IA; ++i) af[i] = read_a(i);
+                    if (want_db) {
+#pragma unroll
+                        for (int i = 0; i < IA; ++i)
+                            if (i % WGK == wgk) accdb[i / WGK] = mfma32(af[i], ones, accdb[i / WGK]);
+                    }
+                    [&]<int... J0>(std::integer_sequence<int, J0...>) { ([&] {
+                        constexpr int j0 = 4 * J0;
+                        bf16x8 bf[4];
+                        [&]<int... JJ>(std::integer_sequence<int, JJ...>) {
+                            (((j0 + JJ < JB) ? (void)(bf[JJ] = read_b(std::integral_constant<int, (j0 + JJ < JB ? j0 + JJ : 0)>{})) : (void)0), ...);
+                        }(std::make_integer_sequence<int, 4>{});
+#pragma unroll
+                        for (int jj = j0; jj < j0 + 4 && jj < JB; ++jj)
+#pragma unroll
+                            for (int i = 0; i < IA; ++i) acc[i][jj] = mfma32(af[i], bf[jj - j0], acc[i][jj]);
+                    }(), ...); }(std::make_integer_sequence<int, (JB + 3) / 4>{});
+                    SSTAMP(4);
                 }
 #ifdef SWV2_SLAB_STAMPS
                 asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[IA - 1][JB - 1][3]));
@@ -393,16 +441,26 @@ __device__ __forceinline__ void slab_job(const SlProd& P, const int j, unsigned 
 }
 
 // shape set 0: C = 128, hidden = 512, 8 heads x 16 columns (the BASELINE cfg 2 / 3 / 5 block)
-__global__ __launch_bounds__(SL_TH) void gemm_tn_slab_c128_kernel(SlArgs a) {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[SL_SMEM];
-    const int b = blockIdx.x;
 #ifndef SWV2_SLAB_NS
 #define SWV2_SLAB_NS 3
 #endif
+__global__ __launch_bounds__(SL_TH) void gemm_tn_slab_c128_kernel(SlArgs a) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SL_SMEM];
+    const int b = blockIdx.x;
     if (b < a.p[1].first) slab_job<F_ROW, F_ROWG, 128, 512, 1, 8, 32, SWV2_SLAB_NS>(a.p[0], b - a.p[0].first, smem, a.stamps);          // fc2: d(a2)^T GELU(hpre)
     else if (b < a.p[2].first) slab_job<F_ROW, F_F32, 512, 128, 8, 1, 32, SWV2_SLAB_NS>(a.p[1], b - a.p[1].first, smem, a.stamps);      // fc1: d(h)^T x1
-    else if (b < a.p[3].first) slab_job<F_ROW, F_HEAD, 128, 128, 2, 4, 64, SWV2_SLAB_NS + 1>(a.p[2], b - a.p[2].first, smem, a.stamps);     // proj: d(a1)^T merge(oh)
+    else if (b < a.p[3].first) slab_job<F_ROW, F_HEAD, 128, 128, 2, 4, 64, SWV2_SLAB_NS + 1>(a.p[2], b - a.p[2].first, smem, a.stamps); // proj: d(a1)^T merge(oh)
     else slab_job<F_HEAD, F_F32G, 384, 128, 8, 1, 32, SWV2_SLAB_NS>(a.p[3], b - a.p[3].first, smem, a.stamps);                          // qkv: d(qkv)^T gather(x)
+}
+// shape set 1: C = 192, hidden = 768, 8 heads x 32 columns (head dim 24 padded: the BASELINE cfg 4 block).  The outputs of fc2 / fc1 /
+// qkv (192 x 768) do not fit one workgroup's registers: two column tiles each (the narrow operand is read twice).
+__global__ __launch_bounds__(SL_TH) void gemm_tn_slab_c192_kernel(SlArgs a) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SL_SMEM];
+    const int b = blockIdx.x;
+    if (b < a.p[1].first) slab_job<F_ROW, F_ROWG, 192, 384, 1, 8, 32, 3>(a.p[0], b - a.p[0].first, smem, a.stamps);
+    else if (b < a.p[2].first) slab_job<F_ROW, F_F32, 384, 192, 8, 1, 32, 3>(a.p[1], b - a.p[1].first, smem, a.stamps);
+    else if (b < a.p[3].first) slab_job<F_ROW, F_HEAD, 192, 256, 2, 4, 32, 4>(a.p[2], b - a.p[2].first, smem, a.stamps);
+    else slab_job<F_HEAD, F_F32G, 384, 192, 8, 1, 32, 3, true>(a.p[3], b - a.p[3].first, smem, a.stamps);
 }
 
 // dW[nmap(n)][kmap(k)] += sum over the slices of a product's partial chunks; db[nmap(n)] += sum of the partial rows (fixed order).
@@ -483,7 +541,15 @@ __global__ __launch_bounds__(512) void tn_slab_reduce_kernel(SlRedArgs a) {
 }
 
 struct SlShape { int TN[4], TK[4], SR[4], WGN[4], WGK[4]; };       // (the template arguments of the kernel's four instantiations)
-const SlShape SL_C128 = {{128, 512, 128, 384}, {512, 128, 128, 128}, {32, 32, 64, 32}, {1, 8, 2, 8}, {8, 1, 4, 1}};
+const SlShape SL_SETS[2] = {{{128, 512, 128, 384}, {512, 128, 128, 128}, {32, 32, 64, 32}, {1, 8, 2, 8}, {8, 1, 4, 1}},
+                            {{192, 384, 192, 384}, {384, 192, 256, 192}, {32, 32, 32, 32}, {1, 8, 2, 8}, {8, 1, 4, 1}}};
+// block shapes: {C, hidden, heads, head columns}
+const int SL_BLOCKS[2][4] = {{128, 512, 8, 16}, {192, 768, 8, 32}};
+int sl_set(int C, int hidden, int heads_dp) {
+    for (int i = 0; i < 2; ++i)
+        if (C == SL_BLOCKS[i][0] && hidden == SL_BLOCKS[i][1] && heads_dp == SL_BLOCKS[i][2] * SL_BLOCKS[i][3]) return i;
+    return -1;
+}
 
 int sl_cus() {
     static thread_local int cus[16] = {};
@@ -497,17 +563,20 @@ int sl_cus() {
     return cus[dev];
 }
 
-struct SlPlan { bool ok; int wgs[4], ntile[4], S[4]; size_t part_off[4], db_off[4], total; };
+struct SlPlan { bool ok; int set; int wgs[4], ntile[4], S[4]; size_t part_off[4], db_off[4], total; };
 
 // it: the four items of swv2_block_wgrad (kinds already checked by the caller)
 SlPlan sl_plan(const swv2_wgrad_item* it, int cus) {
     SlPlan p = {};
-    const SlShape& sh = SL_C128;
     const int N[4] = {it[0].dy.cols, it[1].dy.cols, it[2].dy.cols, it[3].dy.cols};
     const int K[4] = {it[0].x.cols, it[1].x.cols, it[2].x.cols, it[3].x.cols};
     const int C = N[0], hid = K[0];
-    if (!(C == 128 && hid == 512 && N[1] == hid && K[1] == C && N[2] == C && K[2] == 128 && N[3] == 384 && K[3] == C)) return p;
-    if (!(it[2].x.p[3] == 16 && it[3].dy.p[3] == 16 && it[2].x.p[0] == 8 && it[3].dy.p[0] == 8)) return p;       // 8 heads x 16 columns
+    p.set = sl_set(C, hid, K[2]);
+    if (p.set < 0) return p;
+    const SlShape& sh = SL_SETS[p.set];
+    if (!(N[1] == hid && K[1] == C && N[2] == C && N[3] == 3 * K[2] && K[3] == C)) return p;
+    if (!(it[2].x.p[3] == SL_BLOCKS[p.set][3] && it[3].dy.p[3] == SL_BLOCKS[p.set][3] && it[2].x.p[0] == SL_BLOCKS[p.set][2] &&
+          it[3].dy.p[0] == SL_BLOCKS[p.set][2])) return p;
     if (!(it[0].dy.ld == C && it[0].x.ld == hid && it[1].dy.ld == hid && it[1].x.ld == C && it[2].dy.ld == C && it[3].x.ld == C)) return p;
     if (cus < 16 || cus > 1024) return p;
     // bytes per row of each product; rows in proportion so that every workgroup streams about the same number of bytes
@@ -525,11 +594,11 @@ SlPlan sl_plan(const swv2_wgrad_item* it, int cus) {
     int used = 0;
     for (int i = 0; i < 4; ++i) {
         const int T = cdiv(it[i].dy.rows, sh.SR[i]);
-        int w = (int)(cus * cost[i] / tot + 0.5);
-        w = std::max(1, std::min(w, T)) * p.ntile[i];
-        p.S[i] = w / p.ntile[i];
-        p.wgs[i] = w;
-        used += w;
+        int sl = (int)(cus * cost[i] / tot / p.ntile[i] + 0.5);          // row slices; every slice runs ntile workgroups
+        sl = std::max(1, std::min(sl, T));
+        p.S[i] = sl;
+        p.wgs[i] = sl * p.ntile[i];
+        used += p.wgs[i];
     }
     // hand the rounding remainder to / take it from the products with the most rows per slice (one tile each in this shape set)
     for (int guard = 0; used != cus && guard < 64; ++guard) {
@@ -537,7 +606,7 @@ SlPlan sl_plan(const swv2_wgrad_item* it, int cus) {
         double br = 0;
         for (int i = 0; i < 4; ++i) {
             const int T = cdiv(it[i].dy.rows, sh.SR[i]);
-            if (used < cus ? p.S[i] >= T : p.S[i] <= 1) continue;
+            if (used < cus ? (p.S[i] >= T || used + p.ntile[i] > cus) : p.S[i] <= 1) continue;
             const double r = cost[i] / p.S[i];
             if (best < 0 || (used < cus ? r > br : r < br)) { best = i; br = r; }
         }
@@ -576,9 +645,10 @@ SlOp sl_op(const swv2_operand& o) {
 // upper bound of the slab path's workspace for this block shape on this device (0: shape not covered): the workgroups of all four
 // products together number at most one per CU, each with at most the largest partial tile, + the partial bias rows
 size_t swv2_tn_slab_ws_bytes(int C, int hidden, int heads_dp) {
-    if (!(C == 128 && hidden == 512 && heads_dp == 128)) return 0;
+    const int set = sl_set(C, hidden, heads_dp);
+    if (set < 0) return 0;
     const int cus = sl_cus();
-    const SlShape& sh = SL_C128;
+    const SlShape& sh = SL_SETS[set];
     size_t tile = 0;
     for (int i = 0; i < 4; ++i) tile = std::max(tile, (size_t)sh.TN[i] * sh.TK[i] * 4);
     return (size_t)cus * tile + (size_t)cus * std::max(hidden, 3 * heads_dp) * 4 + 4 * 256;
@@ -589,7 +659,7 @@ int swv2_tn_slab_launch(const swv2_wgrad_item* it, void* ws, size_t ws_bytes, hi
     const int cus = sl_cus();
     const SlPlan pl = sl_plan(it, cus);
     if (!pl.ok || ws_bytes < pl.total) return 1;
-    const SlShape& sh = SL_C128;
+    const SlShape& sh = SL_SETS[pl.set];
     SlArgs a = {};
     SlRedArgs r = {};
     int first = 0, rfirst = 0, dbfirst = 0;
@@ -614,7 +684,8 @@ int swv2_tn_slab_launch(const swv2_wgrad_item* it, void* ws, size_t ws_bytes, hi
     if (ws_bytes >= pl.total + (size_t)first * 64) a.stamps = (unsigned long long*)((char*)ws + ws_bytes - (size_t)first * 64);
     { static int once = 0; if (!once++) fprintf(stderr, "slab plan: workgroups %d %d %d %d\n", pl.wgs[0], pl.wgs[1], pl.wgs[2], pl.wgs[3]); }
 #endif
-    hipLaunchKernelGGL(gemm_tn_slab_c128_kernel, dim3(first), dim3(SL_TH), 0, st, a);
+    if (pl.set == 0) hipLaunchKernelGGL(gemm_tn_slab_c128_kernel, dim3(first), dim3(SL_TH), 0, st, a);
+    else hipLaunchKernelGGL(gemm_tn_slab_c192_kernel, dim3(first), dim3(SL_TH), 0, st, a);
     hipLaunchKernelGGL(tn_slab_reduce_kernel, dim3(rfirst + dbfirst), dim3(512), 0, st, r);
     SWV2_CHECK_LAUNCH("swv2_block_wgrad(slab)");
     return 0;

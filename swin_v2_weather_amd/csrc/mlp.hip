@@ -741,7 +741,7 @@ extern "C" int swv2_mlp_fwd(const swv2_mlp_args* a, void* stream) {
         case 64: mt2 ? launch_mlp_fwd<64, 2>(k, st) : launch_mlp_fwd<64, 1>(k, st); break;
         case 96: mt2 ? launch_mlp_fwd<96, 2>(k, st) : launch_mlp_fwd<96, 1>(k, st); break;
         case 128: mt2 ? launch_mlp_fwd<128, 2>(k, st) : launch_mlp_fwd<128, 1>(k, st); break;
-        case 192: launch_mlp_fwd<192, 1>(k, st); break;
+        case 192: mt2 ? launch_mlp_fwd<192, 2>(k, st) : launch_mlp_fwd<192, 1>(k, st); break;      // (<192, 2>: 94 KB of LDS, one workgroup per CU; cfg 4: 47.8 -> 45.7 ms/step)
         case 256: launch_mlp_fwd<256, 1>(k, st); break;
     }
     SWV2_CHECK_LAUNCH("swv2_mlp_fwd");

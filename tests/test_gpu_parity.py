@@ -1549,11 +1549,14 @@ def test_block_wide_heads_against_oracle(dev, K, gh, gw, wh, ww, sh, sw, Cc, h, 
     assert worst_grad(blk, {k[2:]: v.grad for k, v in p.items() if v.requires_grad}, logit_tol=BLOCK_LOGIT_TOL) < 4e-2
 
 
-@pytest.mark.parametrize("gh,gw,wh,ww,sh,sw,Cc,h", [(36, 72, 9, 18, 4, 9, 128, 8), (12, 27, 6, 9, 3, 4, 64, 4), (12, 18, 6, 9, 0, 0, 96, 8)])
+@pytest.mark.parametrize("gh,gw,wh,ww,sh,sw,Cc,h", [(36, 72, 9, 18, 4, 9, 128, 8), (36, 72, 9, 18, 4, 9, 192, 8), (27, 54, 9, 18, 4, 9, 128, 8),
+                                                    (12, 27, 6, 9, 3, 4, 64, 4), (12, 18, 6, 9, 0, 0, 96, 8)])
 def test_grouped_weight_gradients_match_separate_launches(dev, K, monkeypatch, gh, gw, wh, ww, sh, sw, Cc, h):
-    """swv2_block_wgrad (the block's four weight gradients + bias gradients as one launch over 12 output tiles at C = 128)
-    against the four swv2_linear_wgrad_ws launches on the same block backward: same products, only the order in which the
-    row slices are summed differs (fp32) -> 2e-5 of each gradient's largest element."""
+    """swv2_block_wgrad (the block's four weight gradients + bias gradients as one launch) against the four swv2_linear_wgrad_ws
+    launches on the same block backward: same products, only the order in which the row slices are summed differs (fp32) -> 2e-5
+    of each gradient's largest element.  C = 128 / 8 heads and C = 192 / 8 heads (BASELINE cfg 2 and cfg 4 blocks) run the slab kernel
+    (gemm_tn_slab.hip: operands by LDS-DMA; the 27 x 54 grid has a row count that is not a multiple of the 32-row stage: ragged last
+    stage), the other shapes the 128 x 128 tile kernel."""
     N = K["N"]
     B = 3
     x0 = torch.randn(B, gh, gw, Cc, generator=torch.Generator().manual_seed(5))

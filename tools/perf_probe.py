@@ -54,7 +54,7 @@ def probe_attn(B=2, rel_pos=False):
         a.dbg = dbg
         say(f"attn_fwd  {gen} B={B} bias={rel_pos}: {timeit(lambda: ops.attn_fwd(a), n=20):.1f} us")
         a = ops.attn_args(qkvh, ls, bias, oh, lse, Bw, h, Lw, 16, plan.nwh, plan.nww, plan.mask_thr, doh=doh, rnorm=rnorm,
-                          dqkvh=dq, dlogit=dls, dbias=dbias, max_chunks=32 if rel_pos else 64, bias_pack=pk)
+                          dqkvh=dq, dlogit=dls, dbias=dbias, max_chunks=32 if rel_pos else 256 // h, bias_pack=pk)     # (as swv2_block_bwd)
         a.dbg = dbg
         say(f"attn_bwd  {gen} B={B} bias={rel_pos}: {timeit(lambda: ops.attn_bwd(a), n=20):.1f} us")
 

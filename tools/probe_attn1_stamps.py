@@ -4,11 +4,15 @@ wave 0 of the workgroups of head 0 sums s_memtime deltas per phase -- GPU box, d
 import ctypes, os, subprocess, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from swin_v2_weather_amd import _lib as L
-so = "/tmp/libswv2_a1stamps.so"
-srcs = [os.path.join(L.CSRC, s) for s in L.SOURCES]
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DSWV2_ATTN1_STAMPS", "-o", so] + srcs,
-                      stderr=subprocess.DEVNULL)
+# a prebuilt stamp library (tools/build_variant_all.sh stamps "-DSWV2_ATTN1_STAMPS -DSWV2_ATTN2_STAMPS") or a build on the box
+so = os.path.join(ROOT, "swin_v2_weather_amd", "libswv2_stamps.so")
+if not os.path.exists(so):
+    so = "/tmp/libswv2_a1stamps.so"
+    srcs = [os.path.join(L.CSRC, s) for s in L.SOURCES]
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DSWV2_ATTN1_STAMPS",
+                           "-DSWV2_ATTN2_STAMPS", "-o", so] + srcs, stderr=subprocess.DEVNULL)
 L.LIB_PATH = so
+DMA = os.environ.get("SWV2_ATTN_BWD_DMA", "1") != "0" and not (len(sys.argv) > 1 and sys.argv[1] == "bias")
 from swin_v2_weather_amd import ops
 dev = torch.device("cuda:0"); BF = torch.bfloat16
 B = int(os.environ.get("PROBE_B", "2"))
@@ -26,7 +30,7 @@ ops.attn_fwd(a)
 doh = torch.randn(Bw, h, Lp, DP, device=dev).to(BF); rnorm = torch.rand(Bw, h, 2, Lp, device=dev) + 0.5
 dq, dls = torch.empty_like(qkvh), torch.zeros(h, device=dev)
 a = ops.attn_args(qkvh, ls, bias, oh, lse, Bw, h, Lw, 16, plan.nwh, plan.nww, plan.mask_thr, doh=doh, rnorm=rnorm, dqkvh=dq, dlogit=dls,
-                  dbias=dbias, max_chunks=32 if rel_pos else 64, bias_pack=pk)
+                  dbias=dbias, max_chunks=32 if rel_pos else 256 // h, bias_pack=pk)
 for _ in range(3):
     ops.attn_bwd(a)
 torch.cuda.synchronize()
@@ -36,11 +40,13 @@ for _ in range(10):
     ops.attn_bwd(a)
 e1.record(); torch.cuda.synchronize()
 buf = torch.zeros(512 * 8, dtype=torch.int64)
-assert ctypes.CDLL(so).swv2_debug_attn1_stamps(ctypes.c_void_p(buf.data_ptr())) == 0
+assert getattr(ctypes.CDLL(so), "swv2_debug_attn2_stamps" if DMA else "swv2_debug_attn1_stamps")(ctypes.c_void_p(buf.data_ptr())) == 0
 allw = buf.view(512, 8).double()
 nwg = 512 // 11
 perwave = allw[:nwg * 11].view(nwg, 11, 8)
 st = perwave[:, 0, :]
+if DMA:
+    print("DMA-staged kernel (attn_bwd2.hip): 'commit' = wait for the next window's DMA, 'barrier 3' = its statistics")
 names = ["issue next window's prefetch", "phase 1 (S, dP, softmax bwd, dV, dK)", "dK / dV normalisation + stores", "barrier 1",
          "phase 2 (dQ) + stores", "barrier 2", "commit (prefetch wait, LDS, delta)", "barrier 3"]
 tot = st.sum(1)

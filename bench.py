@@ -117,9 +117,9 @@ ROOFLINE_KERNELS = {
     "attn_fwd": ("attn_fwd3_kernel", "hbm", 8.0, 4.0),      # bf16 q, k, v in; o out
     "mlp_bwd": ("mlp_bwd_kernel", "hbm", 28.0, 0.0),        # dx2, x-stats, a2, hpre in; da2, dh, dx1 out
     "mlp_fwd": ("mlp_fwd_kernel", "hbm", 18.0, 0.0),
-    # the block's four weight gradients in one launch: dY + X streams of fc2 (2 + 8), fc1 (8 + 4), proj (2 + 2), qkv (6 + 4)
-    # bytes per token-channel; the event bracket also covers the ~10 us partial-tile reduction that follows it
-    "wgrad_group": ("gemm_tn_group_kernel", "hbm", 36.0, 0.0),
+    # the block's four weight gradients in one launch (gemm_tn_slab.hip): dY + X streams of fc2 (2 + 8), fc1 (8 + 4), proj (2 + 2),
+    # qkv (6 + 4) bytes per token-channel; the event bracket also covers the ~12 us reduction of the partial outputs that follows it
+    "wgrad_group": ("gemm_tn_slab_c128_kernel", "hbm", 36.0, 0.0),
     # the rest of the attention module: gather + qkv + head split + normalise; proj + LN1 (+ residual, scatter) and
     # its backward; d(qkv) -> dx.  Padded window rows (176 / 162) are in the per-token-channel figures.
     "qkv": ("gemm_rw_kernel<0, 2", "hbm", 10.0, 0.0),

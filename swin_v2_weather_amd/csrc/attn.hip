@@ -1075,9 +1075,6 @@ extern "C" int swv2_attn_fwd(const swv2_attn_args* a, void* stream) {
     SWV2_ATTN_DISPATCH(launch_fwd)
 }
 
-// the DMA-staged backward of attn_bwd2.hip (16-wide heads, no bias, 176-row windows): 0 / negative = handled, 1 = shape not covered
-int swv2_attn_bwd_dma(const swv2_attn_args* a, int Lp, int DP, void* stream);
-
 extern "C" int swv2_attn_bwd(const swv2_attn_args* a, void* stream) {
     int rc0 = check_args(a, true);
     if (rc0) return rc0;
@@ -1086,8 +1083,6 @@ extern "C" int swv2_attn_bwd(const swv2_attn_args* a, void* stream) {
         int rc2 = swv2_attn_geometry(a->L, a->head_dim, &Lp2, &DP2);
         if (rc2) return rc2;
         rc2 = swv2_attn_bwd_wide(a, Lp2, DP2, stream);
-        if (rc2 <= 0) return rc2;
-        rc2 = swv2_attn_bwd_dma(a, Lp2, DP2, stream);
         if (rc2 <= 0) return rc2;
     }
     SWV2_ATTN_DISPATCH(launch_bwd)

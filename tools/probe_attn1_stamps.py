@@ -12,7 +12,8 @@ if not os.path.exists(so):
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DSWV2_ATTN1_STAMPS",
                            "-DSWV2_ATTN2_STAMPS", "-o", so] + srcs, stderr=subprocess.DEVNULL)
 L.LIB_PATH = so
-DMA = os.environ.get("SWV2_ATTN_BWD_DMA", "1") != "0" and not (len(sys.argv) > 1 and sys.argv[1] == "bias")
+# (the DMA-staged variant, tools/experiments/attn_bwd_dma.hip, is not in the library: DMA = 1 needs a build that links it)
+DMA = os.environ.get("SWV2_ATTN_BWD_DMA", "0") != "0" and not (len(sys.argv) > 1 and sys.argv[1] == "bias")
 from swin_v2_weather_amd import ops
 dev = torch.device("cuda:0"); BF = torch.bfloat16
 B = int(os.environ.get("PROBE_B", "2"))

@@ -39,11 +39,21 @@ Tensor = torch.Tensor
 # path stores a value as bf16 (GEMM operands, normalised q/k, v, softmax probabilities, branch outputs).  The default
 # (None) is the exact fp32/fp64 restatement of the reference.  Gradients pass straight through the rounding.
 _ROUND = None
+_SOFTMAX = "row_max"
 
 
-def set_rounding(fn) -> None:
-    global _ROUND
+def set_rounding(fn, softmax: str = "row_max") -> None:
+    """fn: rounding applied at the HIP path's bf16 storage points (None: exact arithmetic).  softmax: the forward softmax regime of
+    the rounding mode, DECLARED by the caller (the tests state it per geometry and check the library's kernel choice against it with
+    swv2_attn_fwd_regime; the oracle never infers it from shapes):
+      "row_max"        exponent reference = the row maximum, normaliser = sum of the exact exponentials (csrc/attn.hip forward);
+      "operand_folded" csrc/attn2.hip (attn_fwd3_kernel): reference = sigma itself while sigma log2(e) <= 40 in windows without a
+                       shift mask (cosines are bounded), the row maximum otherwise; normaliser = sum of the bf16-ROUNDED exponentials
+                       (an all-ones MFMA operand)."""
+    global _ROUND, _SOFTMAX
+    assert softmax in ("row_max", "operand_folded")
     _ROUND = fn
+    _SOFTMAX = softmax if fn is not None else "row_max"
 
 
 def bf16_round(x: Tensor) -> Tensor:
@@ -265,10 +275,7 @@ def attention_core_normed(qn: Tensor, kn: Tensor, v: Tensor, logit_scale: Tensor
     # cancellation -- to a tight bar instead of the 12 - 15 % that exact autograd of this forward leaves.
     rowmax = S.detach().max(dim=-1, keepdim=True).values
     ref, rounded_sum = rowmax, False
-    if bias is None and 64 < L <= 176 and d <= 16:
-        # third-form forward kernel (csrc/attn2.hip, attn_fwd3_kernel): the exponent's reference point is sigma itself
-        # ("fixed maximum", cosines are bounded) while sigma log2(e) <= 40 and the window carries no shift mask, the row
-        # maximum otherwise; the normaliser is the sum of the bf16-ROUNDED exponentials (an all-ones MFMA operand)
+    if _SOFTMAX == "operand_folded":          # declared by the caller (set_rounding), never inferred from the shapes
         sig = torch.exp(torch.clamp(logit_scale.detach(), max=LOGIT_MAX))
         fixed = (sig * math.log2(math.e) <= 40.0).view(1, heads, 1, 1)
         if mask is not None:

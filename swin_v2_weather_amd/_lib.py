@@ -157,6 +157,7 @@ SYMBOLS = {
     "swv2_version": (_I, []),
     "swv2_last_error": (C.c_char_p, []),
     "swv2_attn_geometry": (_I, [_I, _I, C.POINTER(_I), C.POINTER(_I)]),
+    "swv2_attn_fwd_regime": (_I, [_I, _I, _I, _I]),
     "swv2_attn_pack_bias_bytes": (C.c_size_t, [_I, _I]),
     "swv2_attn_dbias_ws_bytes": (C.c_size_t, [_I, _I, _I]),
     "swv2_attn_pack_bias": (_I, [_P, _I, _I, _P, _P]),

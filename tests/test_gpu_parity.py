@@ -468,6 +468,16 @@ def test_layernorm_residual(dev, K, Cc):
     assert rel(y, ref) < 1e-6 and rel(da.float(), ad.grad) < 4e-3 and rel(dg, gd.grad) < 1e-5 and rel(db, bd.grad) < 1e-5
 
 
+def emulate_kernels(K, Lw, d, has_bias, softmax):
+    """Switch the oracle to the HIP path's rounding mode.  `softmax` is the forward softmax regime the TEST declares for this
+    geometry ("operand_folded": csrc/attn2.hip, 16-wide heads without a CPB table at the 65 .. 176-token windows; "row_max": every
+    other kernel) -- an explicit argument, the oracle does not look at shapes -- and the library's own kernel choice for the
+    geometry (swv2_attn_fwd_regime) must be the same one.  Undo with O.set_rounding(None)."""
+    got = K["L"].load().swv2_attn_fwd_regime(int(Lw), int(d), int(bool(has_bias)), 0)
+    assert got == {"row_max": 0, "operand_folded": 1}[softmax], f"test declares '{softmax}' for L={Lw} d={d} bias={has_bias}, the library reports {got}"
+    O.set_rounding(O.bf16_round, softmax=softmax)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # attention core
 # ---------------------------------------------------------------------------------------------------------------
@@ -482,16 +492,19 @@ def from_heads(xh, Bw, Lw, h, d, parts):
     return xh[:, :, :, :Lw, :d].permute(0, 3, 2, 1, 4).reshape(Bw, Lw, parts * h * d)
 
 
-@pytest.mark.parametrize("wh,ww,h,d,nwh,nww,shifted,use_bias", [
-    (6, 9, 4, 12, 2, 2, False, False), (6, 9, 4, 12, 2, 2, True, True), (6, 9, 3, 32, 2, 2, True, True),
-    (9, 18, 8, 16, 2, 3, False, False), (9, 18, 8, 16, 2, 3, True, True), (9, 18, 2, 24, 2, 2, True, False),
-    (9, 18, 8, 16, 2, 3, True, False),   # shifted, no bias: the masked branch of the second-generation kernels
-    (9, 18, 2, 16, 1, 2, True, True),   # one window row: every window carries the shift mask
-    (9, 18, 2, 96, 2, 2, True, False),   # the reference yaml's head width (768 / 8), 128-column layout: attn_wide.hip's backward
-    (9, 18, 2, 80, 1, 2, False, False), (9, 18, 1, 96, 2, 2, True, True),     # 80 channels in the 96-channel kernel; with bias: first generation
-    (8, 20, 2, 96, 2, 2, True, False), (11, 16, 1, 72, 1, 2, True, False),    # other window areas (160, 176 tokens): the run-time-L instantiations of attn_wide.hip
+RM, OF = "row_max", "operand_folded"        # forward softmax regimes (oracle.set_rounding): declared per case, checked against the library
+
+
+@pytest.mark.parametrize("wh,ww,h,d,nwh,nww,shifted,use_bias,softmax", [
+    (6, 9, 4, 12, 2, 2, False, False, RM), (6, 9, 4, 12, 2, 2, True, True, RM), (6, 9, 3, 32, 2, 2, True, True, RM),
+    (9, 18, 8, 16, 2, 3, False, False, OF), (9, 18, 8, 16, 2, 3, True, True, RM), (9, 18, 2, 24, 2, 2, True, False, RM),
+    (9, 18, 8, 16, 2, 3, True, False, OF),   # shifted, no bias: the masked branch of the second-generation kernels
+    (9, 18, 2, 16, 1, 2, True, True, RM),   # one window row: every window carries the shift mask
+    (9, 18, 2, 96, 2, 2, True, False, RM),   # the reference yaml's head width (768 / 8), 128-column layout: attn_wide.hip's backward
+    (9, 18, 2, 80, 1, 2, False, False, RM), (9, 18, 1, 96, 2, 2, True, True, RM),     # 80 channels in the 96-channel kernel; with bias: first generation
+    (8, 20, 2, 96, 2, 2, True, False, RM), (11, 16, 1, 72, 1, 2, True, False, RM),    # other window areas (160, 176 tokens): the run-time-L instantiations of attn_wide.hip
 ])
-def test_attention_core_fwd_bwd(dev, K, wh, ww, h, d, nwh, nww, shifted, use_bias):
+def test_attention_core_fwd_bwd(dev, K, wh, ww, h, d, nwh, nww, shifted, use_bias, softmax):
     ops, L = K["ops"], K["L"]
     torch.manual_seed(0)
     B, Lw, nW, Cc = 2, wh * ww, nwh * nww, h * d
@@ -558,7 +571,7 @@ def test_attention_core_fwd_bwd(dev, K, wh, ww, h, d, nwh, nww, shifted, use_bia
     # rounding of the stored O (delta = rowsum(dO O)) and of dS: 15 % bar; against the oracle in the kernels' rounding mode, which
     # follows the same data flow (oracle._AttnCoreEmu), the tight one.
     assert float(dls[-1]) == 0.0 and rel(dls, ls_ref.grad) < 0.15       # clamp gate
-    O.set_rounding(O.bf16_round)
+    emulate_kernels(K, Lw, d, use_bias, softmax)
     try:
         ls_e = ls.clone().requires_grad_(True)
         b_e = bias.clone() if use_bias else None
@@ -674,7 +687,7 @@ def test_block_against_reference_fixture(dev, K, tag):
     # (1) kernel correctness: oracle with bf16 rounding emulated
     p = {"b." + k[2:]: torch.from_numpy(fx[k]).clone().requires_grad_(True) for k in fx.files if k.startswith("p:")}
     xo = torch.from_numpy(fx["x"]).clone().requires_grad_(True)
-    O.set_rounding(O.bf16_round)
+    emulate_kernels(K, wh * ww, Cc // h, "relpos" in tag, {"nopos_noshift_eval": OF, "nopos_shift_3x3_eval": RM, "relpos_shift_eval": RM}[tag])
     try:
         yo = O.block_forward(xo, p, "b.", block_cfg(gh, gw, wh, ww, sh, sw, Cc, h, "relpos" in tag), 1, training=False)
         yo.backward(torch.from_numpy(fx["gy"]))
@@ -711,7 +724,7 @@ def test_block_at_baseline_head_geometry(dev, K, tag):
     # kernel correctness against the bf16-emulating oracle
     p = {"b." + k[2:]: torch.from_numpy(fx[k]).clone().requires_grad_(True) for k in fx.files if k.startswith("p:")}
     xo = torch.from_numpy(fx["x"]).clone().requires_grad_(True)
-    O.set_rounding(O.bf16_round)
+    emulate_kernels(K, wh * ww, Cc // h, relpos, RM)                # (cfg 4: 24-wide heads; cfg 2 with the CPB table)
     try:
         yo = O.block_forward(xo, p, "b.", block_cfg(gh, gw, wh, ww, sh, sw, Cc, h, relpos), 1, training=False)
         yo.backward(torch.from_numpy(fx["gy"]))
@@ -786,7 +799,7 @@ def test_full_size_block_forward_backward_against_oracle(dev, K, Cc, rel_pos, B)
     y = blk(xd)
     y.backward(gy.to(dev))
     xo = x.clone().requires_grad_(True)
-    O.set_rounding(O.bf16_round)
+    emulate_kernels(K, wh * ww, Cc // h, rel_pos, OF if (Cc, rel_pos) == (128, False) else RM)      # cfg 2 without a table: attn2.hip
     try:
         yo = O.block_forward(xo, p, "b.", block_cfg(gh, gw, wh, ww, sh, sw, Cc, h, rel_pos), 1, training=False)
         yo.backward(gy)
@@ -821,7 +834,7 @@ def test_block_train_mode_replays_droppath_and_cpb_dropout(dev, K):
         s1, s2 = blk.drop_path1.scale(x).cpu(), blk.drop_path2.scale(x).cpu()
         assert set(s1.tolist()) <= {0.0, 1.0 / (1.0 - dp)} or abs(max(s1.tolist()) - 1 / (1 - dp)) < 1e-6
         p = {"b." + k[2:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("p:")}
-        O.set_rounding(O.bf16_round)
+        emulate_kernels(K, wh * ww, Cc // h, True, RM)
         try:
             yo = O.block_forward(torch.from_numpy(fx["x"]), p, "b.", block_cfg(gh, gw, wh, ww, sh, sw, Cc, h, True), 1,
                                  training=True, bias_override=bias, dp_override=(s1, s2))
@@ -875,7 +888,7 @@ def test_whole_model_against_reference_fixture(dev, K, tag):
                     window_ratio=ratio, rel_pos=bool(relpos), residual=bool(residual))
     p = {k[2:]: torch.from_numpy(fx[k]).clone().requires_grad_(True) for k in fx.files if k.startswith("p:")}
     xo = torch.from_numpy(fx["x"]).clone().requires_grad_(True)
-    O.set_rounding(O.bf16_round)
+    emulate_kernels(K, (H // ratio) * (W // ratio), Cc // h, bool(relpos), {"nopos": OF, "relpos_residual": RM}[tag])     # 9 x 18 windows, 16-wide heads
     try:
         yo = O.model_forward(xo, p, cfg, training=False)
         yo.backward(torch.from_numpy(fx["gy"]))
@@ -917,7 +930,7 @@ def test_model_at_yaml_default_width(dev, K):
                     window_ratio=ratio, rel_pos=False, residual=True)
     p = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
     xo = x0.clone().requires_grad_(True)
-    O.set_rounding(O.bf16_round)
+    emulate_kernels(K, (H // ratio) * (W // ratio), Cc // h, False, RM)
     try:
         yo = O.model_forward(xo, p, cfg, training=False)
         yo.backward(gy0)
@@ -988,6 +1001,46 @@ def test_rollout_inplace_and_selective_checkpointing(dev, K, monkeypatch):
     monkeypatch.setenv("SWV2_CKPT_TORCH", "1")                 # the stock torch.utils.checkpoint wrapper still works through the nodes
     y4, gx4, _ = run()
     assert torch.equal(y4, y1) and rel(gx4, gx1) < 1e-5
+
+
+def test_full_size_two_step_rollout_properties(dev, K, monkeypatch):
+    """BASELINE cfg 5 at FULL size (73 + zenith + 3 invariant channels in, 73 out, 720 x 1440, depth 12, C 128, one future step:
+    the 2-step autoregressive finetune, helpers.py:26-41) on size-independent properties (cfg 5 at full size was only ever
+    run by tools/run_cfg.py, unchecked): (1) the in-place rollout -- dual-destination head epilogue, gradients of the fed-back
+    prediction added on load -- equals the reference-shaped torch.cat rollout, outputs bit for bit and gradients to summation order;
+    (2) a sample's two predictions do not depend on its batch mate; (3) no NaN leaks from padded rows / masked windows."""
+    from types import SimpleNamespace
+    H, W = 720, 1440
+    params = SimpleNamespace(img_size=(H, W), patch_size=4, depth=12, num_heads=8, n_in_channels=77, n_out_channels=73, embed_dim=128,
+                             window_ratio=80, drop_path_rate=0.0, full_pos_embed=True, rel_pos=False, mlp_ratio=4, activation_ckpt=False,
+                             residual=True, nettype="swin", n_future=1, add_orography=True, add_landmask=True)
+    torch.manual_seed(23)
+    m = K["helpers"].get_model(params)
+    with torch.no_grad():
+        for n_, p_ in m.named_parameters():
+            if n_.endswith("norm1.weight") or n_.endswith("norm2.weight"):
+                p_.uniform_(0.5, 1.0)
+    m = m.to(dev).eval()
+    inp0 = torch.randn(2, 77, H, W, device=dev)
+    cz = torch.rand(2, 2, H, W, device=dev) * 2 - 1
+    gy = torch.randn(2, 146, H, W, device=dev) * 1e-3
+
+    def run(x0, cz_, gy_):
+        m.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        y = m(x, coszen=cz_)
+        y.backward(gy_)
+        return y.detach().clone(), x.grad.clone(), {n_: p_.grad.clone() for n_, p_ in m.named_parameters()}
+    monkeypatch.setenv("SWV2_ROLLOUT_INPLACE", "0")
+    y0, gx0, gp0 = run(inp0, cz, gy)
+    monkeypatch.setenv("SWV2_ROLLOUT_INPLACE", "1")
+    y1, gx1, gp1 = run(inp0, cz, gy)
+    assert y1.shape == (2, 146, H, W) and not torch.isnan(y1).any() and not torch.isnan(gx1).any()
+    assert torch.equal(y1, y0) and rel(gx1, gx0) < 1e-5
+    assert max(rel(gp1[k], gp0[k]) for k in gp0 if float(gp0[k].abs().max()) > 0) < 2e-3
+    del y0, gx0, gp0
+    ys, gxs, _ = run(inp0[1:2].contiguous(), cz[1:2].contiguous(), gy[1:2].contiguous())
+    assert rel(y1[1:2], ys) < 1e-6 and rel(gx1[1:2], gxs) < 1e-5
 
 
 @pytest.mark.parametrize("fused", ["1", "0"])
@@ -1310,6 +1363,70 @@ def test_full_size_model_batch_independence(dev, K):
     assert rel(y2[1:2], y1) < 1e-6
 
 
+def test_full_size_training_trajectory_against_oracle(dev, K):
+    """Five optimisation steps of BASELINE cfg 2 at FULL size (73 x 720 x 1440, depth 12, C 128, 8 heads, local batch 1, drop_path 0)
+    on the product path -- model + LossHandler (loss fused into the head epilogue) + HipAdam, as train.py / bench.py run it -- against
+    the fp32 oracle on the host cores with torch's Adam from the same initial state and the same batches (the loss-curve
+    pins were at C = 96 / depth 2 only).  LayerNorm weights are randomised so the blocks are not the identity at step 0.  Loss per
+    step within 1e-3 relative (the north star's trajectory bar).  ~3 minutes, almost all of it the oracle (27 s per pass)."""
+    from types import SimpleNamespace
+    import psutil
+    from swin_v2_weather_amd.networks.helpers import get_model
+    from swin_v2_weather_amd.utils.losses import LossHandler
+    from swin_v2_weather_amd.utils.optim import HipAdam
+    if psutil.virtual_memory().available < 64 * 2 ** 30:
+        pytest.skip("the full-size oracle pass keeps ~31 GB of activations: needs 64 GiB of free host memory")
+    H, W, steps, lr = 720, 1440, 5, 1e-3
+    pr = SimpleNamespace(nettype="swin", img_size=[H, W], patch_size=4, depth=12, num_heads=8, n_in_channels=73, n_out_channels=73,
+                         embed_dim=128, window_ratio=80, drop_path_rate=0.0, full_pos_embed=True, rel_pos=False, mlp_ratio=4,
+                         activation_ckpt=False, residual=False, n_future=0, add_orography=False, add_landmask=False)
+    torch.manual_seed(77)
+    model = get_model(pr)
+    with torch.no_grad():
+        for n_, p_ in model.named_parameters():
+            if n_.endswith("norm1.weight") or n_.endswith("norm2.weight"):
+                p_.uniform_(0.5, 1.0)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(78)
+    batches = [(torch.randn(1, 73, H, W, generator=g), torch.randn(1, 73, H, W, generator=g)) for _ in range(2)]
+    # ---- product path
+    model = model.to(dev).train()
+    lh = LossHandler(SimpleNamespace(n_future=0, img_shape_x=H, img_shape_y=W, loss="l2", channel_weights="none", n_out_channels=73,
+                                     model_grid_type="equiangular")).to(dev)
+    opt = HipAdam(model.parameters(), lr=lr, betas=(0.9, 0.95))
+    gpu = []
+    for it in range(steps):
+        x, t = (b.to(dev) for b in batches[it % 2])
+        model.zero_grad()
+        with lh.fused_with(model, t):
+            y = model(x)
+        loss = lh(y, t, x)
+        loss.backward()
+        opt.step()
+        gpu.append(float(loss.detach()))
+    del model, opt, y, loss
+    torch.cuda.empty_cache()
+    # ---- oracle (fp32, exact arithmetic) + torch.optim.Adam on the host
+    cfg = O.SwinCfg.from_params(pr)
+    net = O.OracleNet(cfg, sd).train()
+    chw = O.loss_channel_weights("l2", 73, 0)
+    opt_c = torch.optim.Adam(net.parameters(), lr=lr, betas=(0.9, 0.95))
+    cpu = []
+    for it in range(steps):
+        x, t = batches[it % 2]
+        opt_c.zero_grad()
+        loss_c = O.geometric_l2_loss(net(x), t, chw, "l2")
+        loss_c.backward()
+        opt_c.step()
+        cpu.append(float(loss_c))
+        del loss_c
+    err = [abs(a - b) / abs(b) for a, b in zip(gpu, cpu)]
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump({"gpu": gpu, "oracle": cpu, "rel_err": err}, open(os.path.join(ROOT, "gpurun_out", "trajectory_full_size.json"), "w"))
+    assert cpu[-1] < cpu[0], cpu                                    # the trajectory moves
+    assert max(err) < 1e-3, (gpu, cpu)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # the trainer end to end on the GPU (train.py surface: build, epochs, validation, checkpoint save / resume)
 # ---------------------------------------------------------------------------------------------------------------
@@ -1499,7 +1616,7 @@ def test_block_fused_and_unfused_paths(dev, K, monkeypatch, knob, value):
     assert {"SWV2_FUSE_MLP": desc.fuse_mlp, "SWV2_FUSE_PROJ_LN": desc.fuse_proj_ln, "SWV2_WGRAD_GROUP": desc.wgrad_group}[knob] == int(value)
     p = {"b." + k[2:]: torch.from_numpy(fx[k]).clone().requires_grad_(True) for k in fx.files if k.startswith("p:")}
     xo = torch.from_numpy(fx["x"]).clone().requires_grad_(True)
-    O.set_rounding(O.bf16_round)
+    emulate_kernels(K, wh * ww, Cc // h, False, OF)
     try:
         yo = O.block_forward(xo, p, "b.", block_cfg(gh, gw, wh, ww, sh, sw, Cc, h, False), 1, training=False)
         yo.backward(torch.from_numpy(fx["gy"]))
@@ -1537,7 +1654,7 @@ def test_block_wide_heads_against_oracle(dev, K, gh, gw, wh, ww, sh, sw, Cc, h, 
     assert blk._runner(B, x.device).plan.DP == (64 if Cc // h <= 64 else 96 if Cc // h <= 96 else 128)
     p = {"b." + k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
     xo = x0.clone().requires_grad_(True)
-    O.set_rounding(O.bf16_round)
+    emulate_kernels(K, wh * ww, Cc // h, relpos, RM)
     try:
         yo = O.block_forward(xo, p, "b.", block_cfg(gh, gw, wh, ww, sh, sw, Cc, h, relpos), 1, training=False)
         yo.backward(gy0)

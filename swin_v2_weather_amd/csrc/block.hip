@@ -266,9 +266,17 @@ extern "C" int swv2_block_bwd(const swv2_block_desc* d, void* st) {
         swv2_epilogue e = epi(SWV2_EPI_F32, d->dx, C, nullptr, d->dx1, nullptr, d->rowidx);
         LAUNCH(21, swv2_linear(&dy, d->w_qkvt, &e, C, st));
     }
-    if (defer)       // d gamma / d beta of both LayerNorms: one reduction launch instead of one behind each kernel
-        swv2_launch_ln_partials_reduce2(d->ln_ws, d->d_n2_w, d->d_n2_b, n_ln2, d->ln_ws + swv2_mlp_bwd_ws_floats(BT, C), d->d_n1_w,
-                                        d->d_n1_b, n_ln1, C, (hipStream_t)st);
+    // d gamma / d beta of both LayerNorms: one reduction for both -- riding on the weight-gradient reduction launch when the grouped
+    // products run (swv2_block_wgrad_ln), a launch of its own otherwise
+    swv2_ln_partials lnp = {};
+    if (defer) {
+        lnp.ws[0] = d->ln_ws; lnp.dgamma[0] = d->d_n2_w; lnp.dbeta[0] = d->d_n2_b; lnp.n[0] = n_ln2;
+        lnp.ws[1] = d->ln_ws + swv2_mlp_bwd_ws_floats(BT, C); lnp.dgamma[1] = d->d_n1_w; lnp.dbeta[1] = d->d_n1_b; lnp.n[1] = n_ln1;
+        lnp.C = C;
+        if (!group)
+            swv2_launch_ln_partials_reduce2(lnp.ws[0], lnp.dgamma[0], lnp.dbeta[0], n_ln2, lnp.ws[1], lnp.dgamma[1], lnp.dbeta[1], n_ln1, C,
+                                            (hipStream_t)st);
+    }
     if (group) {
         swv2_wgrad_item it[4] = {};
         it[0].dy = op(SWV2_OP_BF16, d->da2, BT, C, C); it[0].x = op(SWV2_OP_BF16_GELU, d->hpre, BT, hid, hid);
@@ -279,7 +287,7 @@ extern "C" int swv2_block_bwd(const swv2_block_desc* d, void* st) {
         it[2].dW = d->d_proj_w; it[2].db = d->d_proj_b; it[2].kmap = d->proj_map; it[2].ldw = C;
         it[3].dy = op_heads(d->dqkvh, Bw, h, 3, d->Lp, d->DP); it[3].x = op(SWV2_OP_F32, d->x, Mw, C, C, d->rowidx);
         it[3].dW = d->d_qkv_w; it[3].db = d->d_qkv_b; it[3].nmap = d->qkv_map; it[3].ldw = C;
-        LAUNCH(22, swv2_block_wgrad(it, 0, d->wgrad_ws, d->wgrad_ws_bytes, st));
+        LAUNCH(22, swv2_block_wgrad_ln(it, 0, d->wgrad_ws, d->wgrad_ws_bytes, defer ? &lnp : nullptr, st));
     }
     if (ss) join_from(ss, (hipStream_t)st);
     return SWV2_OK;

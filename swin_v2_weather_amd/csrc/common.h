@@ -99,4 +99,10 @@ void swv2_launch_ln_partials_reduce2(const float* ws1, float* dg1, float* db1, i
 int swv2_mlp_bwd_impl(const swv2_mlp_bwd_args* a, void* stream, int* deferred, float* zero, long zero_n);
 int swv2_proj_ln_bwd_impl(const swv2_proj_ln_bwd_args* a, void* stream, int* deferred);
 
+// swv2_block_wgrad with a rider (block.hip -> gemm_tn.hip): the partial rows of the block's two LayerNorm backward kernels are folded
+// into d gamma / d beta by the weight-gradient reduction launch instead of a launch of their own (the 128 x 128 tile path launches
+// swv2_launch_ln_partials_reduce2 itself).  ln == nullptr: plain swv2_block_wgrad.
+struct swv2_ln_partials { const float* ws[2]; float* dgamma[2]; float* dbeta[2]; int n[2]; int C; };
+int swv2_block_wgrad_ln(const swv2_wgrad_item* items4, int slices, void* ws, size_t ws_bytes, const swv2_ln_partials* ln, void* stream);
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -9,7 +9,7 @@ int swv2_tn_wide_launch(const swv2_operand* y, const swv2_operand* x, float* par
 // gemm_tn_slab.hip: the block's four weight gradients with every operand byte fetched once (LDS-DMA slabs); launch returns 1 when
 // the shape / workspace is not covered (the caller then takes gemm_tn_group_kernel)
 size_t swv2_tn_slab_ws_bytes(int C, int hidden, int heads_dp);
-int swv2_tn_slab_launch(const swv2_wgrad_item* it, void* ws, size_t ws_bytes, hipStream_t st);
+int swv2_tn_slab_launch(const swv2_wgrad_item* it, void* ws, size_t ws_bytes, const swv2_ln_partials* ln, hipStream_t st);
 
 namespace {
 

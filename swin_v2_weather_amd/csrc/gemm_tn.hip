@@ -563,6 +563,10 @@ extern "C" size_t swv2_block_wgrad_ws_bytes(int C, int hidden, int heads_dp, int
 }
 
 extern "C" int swv2_block_wgrad(const swv2_wgrad_item* it, int slices, void* ws, size_t ws_bytes, void* stream) {
+    return swv2_block_wgrad_ln(it, slices, ws, ws_bytes, nullptr, stream);
+}
+
+int swv2_block_wgrad_ln(const swv2_wgrad_item* it, int slices, void* ws, size_t ws_bytes, const swv2_ln_partials* ln, void* stream) {
     SWV2_CHECK_ARG(it && ws, "swv2_block_wgrad: null items or workspace");
     static const int want[4][2] = {{SWV2_OP_BF16, SWV2_OP_BF16_GELU}, {SWV2_OP_BF16, SWV2_OP_F32}, {SWV2_OP_BF16, SWV2_OP_HEADS},
                                    {SWV2_OP_HEADS, SWV2_OP_F32}};
@@ -587,10 +591,13 @@ extern "C" int swv2_block_wgrad(const swv2_wgrad_item* it, int slices, void* ws,
     {
         static const int use_slab = getenv("SWV2_WGRAD_SLAB") ? atoi(getenv("SWV2_WGRAD_SLAB")) : 1;
         if (use_slab && slices <= 0) {
-            const int rc = swv2_tn_slab_launch(it, ws, ws_bytes, (hipStream_t)stream);
+            const int rc = swv2_tn_slab_launch(it, ws, ws_bytes, ln, (hipStream_t)stream);
             if (rc <= 0) return rc;
         }
     }
+    if (ln && ln->C > 0)        // (the tile kernel's reduction carries no rider)
+        swv2_launch_ln_partials_reduce2(ln->ws[0], ln->dgamma[0], ln->dbeta[0], ln->n[0], ln->ws[1], ln->dgamma[1], ln->dbeta[1], ln->n[1], ln->C,
+                                        (hipStream_t)stream);
     const int S = group_slices(tt, slices);
     SWV2_CHECK_ARG(ws_bytes >= (size_t)S * tt * BN * BN * sizeof(float), "swv2_block_wgrad: workspace of %zu bytes, %zu needed",
                    ws_bytes, (size_t)S * tt * BN * BN * sizeof(float));

@@ -466,13 +466,39 @@ __global__ __launch_bounds__(SL_TH) void gemm_tn_slab_c192_kernel(SlArgs a) {
 // dW[nmap(n)][kmap(k)] += sum over the slices of a product's partial chunks; db[nmap(n)] += sum of the partial rows (fixed order).
 // One workgroup per 1 KB chunk (64 lanes x 4 floats in accumulator layout): its S slices are S contiguous KB; the eight 64-thread groups
 // take every eighth slice and are folded through LDS.
+// optional rider of the reduction launch: d gamma / d beta of the block's two LayerNorms from the partial rows their backward kernels
+// left (rowops.hip: ln_partials_reduce_kernel as its own launch otherwise): [nblocks][2][C] per set
+struct SlLnRed { const float* ws[2]; float* dg[2]; float* db[2]; int n[2]; int C; };
 struct SlRed { float* dW; float* db; const int32_t* nmap; const int32_t* kmap; const float* part; const float* dbpart;
                int ldw, N, K, TN, TK, WGK, IA, JB, ntk, S, first, dbfirst; };
-struct SlRedArgs { SlRed p[4]; int total; };
+struct SlRedArgs { SlRed p[4]; int total, dbtotal; SlLnRed ln; };
 __global__ __launch_bounds__(512) void tn_slab_reduce_kernel(SlRedArgs a) {
     __shared__ f32x4 red[8][64];
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    if (b >= a.total + a.dbtotal) {
+        // ---- LayerNorm d gamma / d beta: workgroup = 16 columns x 32 slices of partial rows, fixed-order fold (deterministic)
+        const int bb = b - a.total - a.dbtotal, per_set = (2 * a.ln.C + 15) / 16;
+        const int set = bb / per_set, col = threadIdx.x & 15, sl = threadIdx.x >> 4;
+        const int jc = (bb - set * per_set) * 16 + col;
+        float sum = 0.f;
+        if (jc < 2 * a.ln.C) {
+            const float* w = a.ln.ws[set];
+#pragma unroll 4
+            for (int r = sl; r < a.ln.n[set]; r += 32) sum += w[(size_t)r * 2 * a.ln.C + jc];
+        }
+        float* redf = (float*)red;
+        redf[sl * 16 + col] = sum;
+        __syncthreads();
+        for (int hh = 16; hh > 0; hh >>= 1) {
+            if (sl < hh) redf[sl * 16 + col] += redf[(sl + hh) * 16 + col];
+            __syncthreads();
+        }
+        if (sl == 0 && jc < 2 * a.ln.C) {
+            if (jc < a.ln.C) a.ln.dg[set][jc] += redf[col]; else a.ln.db[set][jc - a.ln.C] += redf[col];
+        }
+        return;
+    }
     if (b >= a.total) {
         // ---- bias gradients: workgroup = 64 entries x 8 slice groups (one thread adding all S partial rows of an entry is a chain of
         // S dependent-latency loads: it alone took 13 us of the first version's 19)
@@ -655,7 +681,7 @@ size_t swv2_tn_slab_ws_bytes(int C, int hidden, int heads_dp) {
 }
 
 // 0: launched; 1: shape / workspace not covered (the caller takes the 128 x 128 tile kernel); < 0: error code
-int swv2_tn_slab_launch(const swv2_wgrad_item* it, void* ws, size_t ws_bytes, hipStream_t st) {
+int swv2_tn_slab_launch(const swv2_wgrad_item* it, void* ws, size_t ws_bytes, const swv2_ln_partials* ln, hipStream_t st) {
     const int cus = sl_cus();
     const SlPlan pl = sl_plan(it, cus);
     if (!pl.ok || ws_bytes < pl.total) return 1;
@@ -680,13 +706,20 @@ int swv2_tn_slab_launch(const swv2_wgrad_item* it, void* ws, size_t ws_bytes, hi
         dbfirst += cdiv(p.N, 64);
     }
     r.total = rfirst;
+    r.dbtotal = dbfirst;
+    int lnblocks = 0;
+    if (ln && ln->C > 0) {
+        for (int i = 0; i < 2; ++i) { r.ln.ws[i] = ln->ws[i]; r.ln.dg[i] = ln->dgamma[i]; r.ln.db[i] = ln->dbeta[i]; r.ln.n[i] = ln->n[i]; }
+        r.ln.C = ln->C;
+        lnblocks = 2 * cdiv(2 * ln->C, 16);
+    }
 #ifdef SWV2_SLAB_STAMPS       // the last 64 bytes x workgroups of the workspace receive the phase sums; the split goes to stderr once
     if (ws_bytes >= pl.total + (size_t)first * 64) a.stamps = (unsigned long long*)((char*)ws + ws_bytes - (size_t)first * 64);
     { static int once = 0; if (!once++) fprintf(stderr, "slab plan: workgroups %d %d %d %d\n", pl.wgs[0], pl.wgs[1], pl.wgs[2], pl.wgs[3]); }
 #endif
     if (pl.set == 0) hipLaunchKernelGGL(gemm_tn_slab_c128_kernel, dim3(first), dim3(SL_TH), 0, st, a);
     else hipLaunchKernelGGL(gemm_tn_slab_c192_kernel, dim3(first), dim3(SL_TH), 0, st, a);
-    hipLaunchKernelGGL(tn_slab_reduce_kernel, dim3(rfirst + dbfirst), dim3(512), 0, st, r);
+    hipLaunchKernelGGL(tn_slab_reduce_kernel, dim3(rfirst + dbfirst + lnblocks), dim3(512), 0, st, r);
     SWV2_CHECK_LAUNCH("swv2_block_wgrad(slab)");
     return 0;
 }

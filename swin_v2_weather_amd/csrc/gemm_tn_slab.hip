@@ -32,7 +32,7 @@ namespace {
 
 constexpr int SL_TH = 512;
 constexpr int SL_SMEM = 160 * 1024;           // the whole LDS of a CU: one workgroup per CU
-constexpr int SL_IDX_CAP = 4096;              // gathered rows per workgroup (index table in LDS)
+constexpr int SL_IDX_CAP = 4096;              // gather index table in LDS: a ring of two halves (2 x 2048 rows), refilled while the other half is in use
 enum { F_ROW = 0, F_ROWG = 1, F_F32 = 2, F_F32G = 3, F_HEAD = 4 };
 
 __device__ __forceinline__ void sl_dma(const void* base, uint32_t byte_off, uint32_t lds_addr) {
@@ -147,12 +147,16 @@ __device__ __forceinline__ void slab_job(const SlProd& P, const int j, unsigned 
     if constexpr (FX == F_ROWG) {
         for (int i = tid; i < GT_N; i += SL_TH) tab[i] = f2bf(gelu_f(bf2f(gelu_tab_arg(i))));
     }
-    if constexpr (FX == F_F32G) {
-        for (int i = tid; i < nst * SR; i += SL_TH) {
-            const int m = stage_of(i / SR) * SR + (i % SR);
-            idxs[i] = m < M ? P.x.rowidx[m] : -1;
+    // gather table: stage index ti lives at ring position ti % (2 HS); fill_idx(h0) loads the HS stages h0 .. h0 + HS - 1
+    constexpr int HS = SL_IDX_CAP / 2 / SR, RING = 2 * HS;
+    auto fill_idx = [&](int h0) {
+        for (int i = tid; i < HS * SR; i += SL_TH) {
+            const int ti = h0 + i / SR;
+            const int m = stage_of(ti) * SR + (i % SR);
+            idxs[(ti % RING) * SR + (i % SR)] = (ti < nst && m < M) ? P.x.rowidx[m] : -1;
         }
-    }
+    };
+    if constexpr (FX == F_F32G) { fill_idx(0); fill_idx(HS); }
     if constexpr (FX == F_ROWG || FX == F_F32G) __syncthreads();
 
     // ---- DMA geometry.  Instruction q of this wave is instruction ii = 8 q + wave of the stage: LDS bytes ii * 1024 .. + 1023 of (dY | X)
@@ -208,7 +212,7 @@ __device__ __forceinline__ void slab_job(const SlProd& P, const int j, unsigned 
         } else {
             uint32_t off;
             if constexpr (FX == F_F32G) {
-                const int r = max(idxs[ti * SR + orow[q]], 0);
+                const int r = max(idxs[(ti % RING) * SR + orow[q]], 0);
                 off = 4u * ((uint32_t)r * (uint32_t)P.x.ld + ocol[q]);
             } else {
                 const int m = min(t * SR + orow[q], M - 1);
@@ -278,6 +282,12 @@ __device__ __forceinline__ void slab_job(const SlProd& P, const int j, unsigned 
             __builtin_amdgcn_sched_barrier(0);
             SSTAMP(1);
             const int ti_n = min(t + D, nst - 1), slot_n = (t + D) % NS;
+            if constexpr (FX == F_F32G) {
+                // every HS stages: the half of the gather table that held stages t - HS .. t - 1 (all consumed: issue and conversion of
+                // stage t - 1 lie before this stage's barrier) receives stages t + HS ..; first read HS - D stages (barriers) from now.
+                // (plain loads: the compiler waits for them -- and with them, in order, for the DMA in flight -- once per HS stages)
+                if (t > 0 && t % HS == 0 && t + HS < nst) fill_idx(t + HS);
+            }
             const int slot = t % NS;
             unsigned char* const sb = smem + OFF_SLOT + slot * STG;
             const uint16_t* Ys = (const uint16_t*)sb;
@@ -304,7 +314,7 @@ __device__ __forceinline__ void slab_job(const SlProd& P, const int j, unsigned 
                     RawF32 v = {*(const f32x4*)src, *(const f32x4*)(src + 4)};
                     cv[ps] = cvt_f32x8(v);
                     if constexpr (FX == F_F32G) {
-                        if (idxs[t * SR + row] < 0) cv[ps] = make_uint4(0, 0, 0, 0);
+                        if (idxs[(t % RING) * SR + row] < 0) cv[ps] = make_uint4(0, 0, 0, 0);
                     }
                 }
                 if constexpr (INPLACE) __syncthreads();          // every thread has read its fp32 chunks before the slab's head is overwritten
@@ -643,7 +653,6 @@ SlPlan sl_plan(const swv2_wgrad_item* it, int cus) {
     size_t off = 0;
     for (int i = 0; i < 4; ++i) {
         const int T = cdiv(it[i].dy.rows, sh.SR[i]);
-        if (it[i].x.rowidx && cdiv(T, p.S[i]) * sh.SR[i] > SL_IDX_CAP) return p;       // index table of a gathered operand
         if ((double)it[i].dy.rows * std::max(N[i], K[i]) * 4.0 >= 4.29e9) return p;         // 32-bit byte offsets
         p.part_off[i] = off;
         off += (size_t)p.wgs[i] * sh.TN[i] * sh.TK[i] * sizeof(float);

@@ -49,9 +49,12 @@ def set_rounding(fn, softmax: str = "row_max") -> None:
       "row_max"        exponent reference = the row maximum, normaliser = sum of the exact exponentials (csrc/attn.hip forward);
       "operand_folded" csrc/attn2.hip (attn_fwd3_kernel): reference = sigma itself while sigma log2(e) <= 40 in windows without a
                        shift mask (cosines are bounded), the row maximum otherwise; normaliser = sum of the bf16-ROUNDED exponentials
-                       (an all-ones MFMA operand)."""
+                       (an all-ones MFMA operand);
+      "operand_folded_zero_ref" csrc/attn4.hip (attn_fwd4_kernel, 32 x 32 tiles): NO reference point while sigma log2(e) <= 40 (2^40
+                       is far inside the fp32 / bf16 range; windows with a shift mask included: the mask is one more MFMA term), the
+                       row maximum otherwise; normaliser = sum of the bf16-rounded exponentials (a ones row in the V operand)."""
     global _ROUND, _SOFTMAX
-    assert softmax in ("row_max", "operand_folded")
+    assert softmax in ("row_max", "operand_folded", "operand_folded_zero_ref")
     _ROUND = fn
     _SOFTMAX = softmax if fn is not None else "row_max"
 
@@ -275,14 +278,17 @@ def attention_core_normed(qn: Tensor, kn: Tensor, v: Tensor, logit_scale: Tensor
     # cancellation -- to a tight bar instead of the 12 - 15 % that exact autograd of this forward leaves.
     rowmax = S.detach().max(dim=-1, keepdim=True).values
     ref, rounded_sum = rowmax, False
-    if _SOFTMAX == "operand_folded":          # declared by the caller (set_rounding), never inferred from the shapes
+    if _SOFTMAX in ("operand_folded", "operand_folded_zero_ref"):          # declared by the caller (set_rounding), never inferred from the shapes
         sig = torch.exp(torch.clamp(logit_scale.detach(), max=LOGIT_MAX))
         fixed = (sig * math.log2(math.e) <= 40.0).view(1, heads, 1, 1)
-        if mask is not None:
-            nW = mask.shape[0]
-            masked_w = (mask != 0).flatten(1).any(1).repeat(Bw // nW).view(Bw, 1, 1, 1)
-            fixed = fixed & ~masked_w
-        ref = torch.where(fixed, sig.view(1, heads, 1, 1).to(S.dtype).expand_as(rowmax), rowmax)
+        if _SOFTMAX == "operand_folded":
+            if mask is not None:
+                nW = mask.shape[0]
+                masked_w = (mask != 0).flatten(1).any(1).repeat(Bw // nW).view(Bw, 1, 1, 1)
+                fixed = fixed & ~masked_w
+            ref = torch.where(fixed, sig.view(1, heads, 1, 1).to(S.dtype).expand_as(rowmax), rowmax)
+        else:
+            ref = torch.where(fixed.expand_as(rowmax), torch.zeros_like(rowmax), rowmax)
         rounded_sum = True
     sigma = torch.exp(torch.clamp(logit_scale, max=LOGIT_MAX))
     mfull = None

@@ -1,0 +1,331 @@
+// Cosine window attention core, forward at the benchmark head geometry (16-wide heads, no CPB bias, 161 .. 176-token windows) on 32 x 32
+// MFMA tiles (v_mfma_f32_32x32x16_bf16: K = 16 is the head dim, no wasted k-half).  Fourth form of the forward; semantics, data layout
+// and softmax regimes are those of attn_fwd3_kernel (attn2.hip; reference networks/swinv2_global.py:298-318):
+//   S = sigma_h qn kn^T + Mask ; P = softmax(S) ; O = P v
+//
+// Why.  attn_fwd3 spends, per 16-query tile, 33 MFMA instructions of 16 cycles (11 S^T tiles as K = 32 products against a doubled key
+// image, 10 + 1 P V products, as many all-ones row-sum products) beside ~510 cycles of vector work (44 v_exp + the bf16 packs): the
+// matrix instructions cost a third of the vector work in issue cycles and their operands 22 LDS instructions per tile.  Here
+//   * S^T of 32 keys x 32 queries is ONE 32x32x16 MFMA per part of the scale split (sigma' q^ = hi + lo in bf16, exact to 2^-17: two
+//     chained MFMAs on the same key fragment; the accumulator starts at -sigma', the "fixed maximum" of attn_fwd3);
+//   * the accumulator tile IS the next MFMA's B operand (column = query on the lane, rows = keys in the registers: the
+//     accumulator-as-operand idiom of the 32 x 32 tile): P V^T and the row sum are ONE 32x32x16 MFMA per 16 keys against an A operand
+//     [32 rows][16 keys] whose rows 0 .. 15 are V^T, row 16 all ones and the rest zero.  Lanes 0 - 15 / 32 - 47 of its transposed reads
+//     (ds_read_b64_tr_b16) address the V slab, lanes 16 - 31 / 48 - 63 a constant 4 x 16 block [1 0 .. 0] (two copies, on the bank half
+//     the V rows of that lane half do not use);
+//   * per 32 queries: 12 + 11 MFMAs of 32 cycles (8 of them blocking vector issue) instead of 66 of 16, and 6 + 22 + 2 LDS reads
+//     instead of 44;
+//   * a workgroup is 3 waves, 2 query blocks each (6 blocks of 32 cover 176 rows); four workgroups share a CU (<= 168 registers), each on
+//     its own (window, head) item.  K | V of the NEXT item reach the other LDS buffer by LDS-DMA (global_load_lds_dwordx4, 4 instructions
+//     per wave and item, counted vmcnt): K lands as two planes [half][key][8 channels] (the 16-byte A-operand reads of 32 consecutive
+//     keys are contiguous) through per-lane source addresses, V as it is; Q goes from global memory straight into the B-operand
+//     registers (one 16-byte load per lane and block, one item ahead).
+// Masked windows and scales with sigma log2 e > 40 take two passes over the key blocks (row maximum first), as the general path of
+// attn_fwd3 -- 5 % of the windows at the benchmark shape.
+#include "attn_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x16 mfma32x32(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ void a4_dma(const void* base, uint32_t byte_off, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(byte_off), "s"(base), "s"(lds_addr) : "memory");
+}
+
+template <int LFIX>
+__global__ __launch_bounds__(192, 3) void attn_fwd4_kernel(const uint16_t* __restrict__ qkvh, const float* __restrict__ logit_scale,
+                                                           uint16_t* __restrict__ oh, float* __restrict__ lse, int Bw, int h, int L, int nW,
+                                                           int nww, int nwh, int mask_thr) {
+    constexpr int Lp = 176, DP = 16, SLAB = Lp * DP, QPW = 2;      // 6 query blocks of 32 (the last one half inside the slab): 2 per wave
+    static_assert(LFIX == 0 || (LFIX > 160 && LFIX <= 176), "six key blocks: blocks 0 .. 4 full, block 5 the tail");
+    // one buffer (bytes): K planes [2][176][8] bf16 (5632, padded to six DMA instructions) | V [176][16] bf16 (ditto)
+    // + ONE constant image with the V slab's geometry ([176 rows][32 bytes], every row 1, 0, .., 0), 128 bytes off the V slabs' bank
+    // phase: the A-operand lanes that hold rows 16 .. 31 (ones row | zeros) read it with the SAME immediate offsets as the V lanes
+    constexpr int KPLB = Lp * 16, VOFFB = 6144, BUFB = 2 * 6144, OFF_CONST = 2 * BUFB + 128;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[OFF_CONST + Lp * 32 + 128];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r32 = lane & 31, hh = lane >> 5, i16 = lane & 15, G = lane >> 4;
+    const int hd = blockIdx.y;
+    const int Lc = LFIX > 0 ? LFIX : L;
+    const float sc2 = __expf(fminf(logit_scale[hd], SWV2_LN100)) * SWV2_LOG2E;
+    const bool bounded = sc2 <= 40.f;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+
+    for (int i = tid; i < Lp * 8; i += 192) ((uint32_t*)(smem + OFF_CONST))[i] = (i & 7) == 0 ? 0x3F80u : 0u;
+
+    // ---- DMA of an item into buffer b: 12 instructions, instruction ii = wave + 3 j (j = 0 .. 3); ii < 6: K planes, else V
+    uint32_t dsrc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ii = wave + 3 * j, o = (ii % 6) * 1024 + lane * 16;            // byte offset inside the K-plane / V region
+        if (ii < 6) {
+            const int oc = min(o, 2 * KPLB - 16), half = oc / KPLB, key = (oc - half * KPLB) >> 4;
+            dsrc[j] = (uint32_t)(SLAB * 2 + (key * 2 + half) * 16);              // chunk (key, half) of the K slab
+        } else {
+            dsrc[j] = (uint32_t)(2 * SLAB * 2 + min(o, SLAB * 2 - 16));
+        }
+    }
+    auto issue_dma = [&](int bw, int b) {
+        const unsigned char* base = (const unsigned char*)(qkvh + ((size_t)bw * h + hd) * 3 * SLAB);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ii = wave + 3 * j;
+            a4_dma(base, dsrc[j], lds0 + (uint32_t)(b * BUFB + (ii < 6 ? ii * 1024 : VOFFB + (ii - 6) * 1024)));
+        }
+    };
+    // this lane's Q chunks: query block 2 wave + i, row r32, channels 8 hh .. (rows past the slab repeat its last row: discarded)
+    unsigned qoff[QPW];
+#pragma unroll
+    for (int i = 0; i < QPW; ++i) qoff[i] = (unsigned)(min(32 * (QPW * wave + i) + r32, Lp - 1) * DP + 8 * hh);
+    u32x4 qn[QPW], qc[QPW];
+    auto load_q = [&](int bw) {
+        const uint16_t* base = qkvh + ((size_t)bw * h + hd) * 3 * SLAB;
+#pragma unroll
+        for (int i = 0; i < QPW; ++i) qn[i] = *(const u32x4*)(base + qoff[i]);
+    };
+
+    int bw = blockIdx.x;
+    if (bw >= Bw) return;
+    issue_dma(bw, 0);
+    load_q(bw);
+#pragma unroll
+    for (int i = 0; i < QPW; ++i) qc[i] = qn[i];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // transposed-read addresses of the V' A operand (bytes): lanes with G & 1 = 0 read the V slab, the others the constant block
+    const bool vlane = (G & 1) == 0;
+    const uint32_t v_lane_off = (uint32_t)((4 * hh + (i16 >> 2)) * 32 + (i16 & 3) * 8);
+
+    for (int it = 0; bw < Bw; bw += gridDim.x, ++it) {
+        const int buf = it & 1;
+        const int bw_next = bw + gridDim.x;
+#ifdef SWV2_FWD4_NOLOAD
+        const unsigned char* Kp = smem;
+#else
+        const unsigned char* Kp = smem + buf * BUFB;
+#endif
+        const unsigned char* Vp = Kp + VOFFB;
+#ifdef SWV2_FWD4_NOLOAD            // timing ablation (tools/build_variant.sh): every item computes on the first item's data, wrong results
+        if (false)
+#endif
+        if (bw_next < Bw) { issue_dma(bw_next, buf ^ 1); load_q(bw_next); }
+        const bool do_mask = (mask_thr > 0) && (((bw % nW) / nww) == nwh - 1);
+        const size_t item = (size_t)bw * h + hd;
+        // this lane's image of the V' A operand: the V slab (rows 0 .. 15 of the operand) or the constant image (rows 16 .. 31)
+        const unsigned char* const vimg = (vlane ? Vp : (const unsigned char*)smem + OFF_CONST) + v_lane_off;
+        const unsigned char* const kimg = Kp + hh * KPLB + r32 * 16;
+
+#pragma unroll 1
+        for (int qi = 0; qi < QPW; ++qi) {
+            const int qb = QPW * wave + qi, q = 32 * qb + r32;
+            // B operands of S^T: hi | lo bf16 split of sigma' q^[8 hh .. 8 hh + 7]
+            bf16x8 qhi, qlo;
+            {
+                const u32x4 raw = qi == 0 ? qc[0] : qc[1];
+                uint32_t wh_[4], wl_[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float x0 = __uint_as_float(raw[j] << 16) * sc2, x1 = __uint_as_float(raw[j] & 0xffff0000u) * sc2;
+                    wh_[j] = f2bf2(x0, x1);
+                    wl_[j] = f2bf2(x0 - __uint_as_float(wh_[j] << 16), x1 - __uint_as_float(wh_[j] & 0xffff0000u));
+                }
+                qhi = __builtin_bit_cast(bf16x8, wh_);
+                qlo = __builtin_bit_cast(bf16x8, wl_);
+            }
+            const bool qid = q >= mask_thr;
+            const int ntail = Lc - 160;                            // keys in the tail block (compile time with LFIX)
+            // S'^T of key block kb: rows = keys 32 kb + 8 (r >> 2) + 4 hh + (r & 3) in register r, column = query r32.  ZERO: the accumulator
+            // starts at the inline constant 0 (fixed regime: with s <= sigma' <= 40 the exponentials need no reference point -- 2^40 is far
+            // inside the fp32 / bf16 range, the common factor cancels in P V / sum P and lse = log2 sum -- and a register tile of 16
+            // copies of -sigma' is 16 registers the 168-register budget of three waves per SIMD does not have)
+            auto scores = [&](int kb, float c0, auto zero_c) -> f32x16 {
+                constexpr bool ZERO = decltype(zero_c)::value;
+                const bf16x8 ka = *(const bf16x8*)(Kp + hh * KPLB + (32 * kb + r32) * 16);
+                f32x16 c;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c[r] = ZERO ? 0.f : c0;
+                c = mfma32x32(ka, qhi, c);
+                return mfma32x32(ka, qlo, c);
+            };
+            f32x16 o;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = 0.f;
+            float mx = sc2;
+            // exponentials of one block's scores, then O'^T += V'^T P^T (incl. the all-ones row: row sums) for its 16-key groups
+            auto consume = [&](f32x16 sv, int kb, auto masked_c, auto tail_c) {
+                constexpr bool MASKED = decltype(masked_c)::value, TAIL = decltype(tail_c)::value;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key0 = 8 * (r >> 2) + (r & 3);          // key offset in the block for hh = 0 (hh = 1: + 4)
+                    if (TAIL && LFIX > 0 && key0 >= ntail) { sv[r] = 0.f; continue; }       // (compile time: no real key in either half)
+                    float v = sv[r];
+                    if constexpr (MASKED) v += (((32 * kb + key0 + 4 * hh >= mask_thr) != qid) ? (-100.f * SWV2_LOG2E) : 0.f);
+                    v = __builtin_amdgcn_exp2f(v);
+                    // tail block: registers that straddle the window's end keep the exponential only in the lane half with a real key
+                    if (TAIL && !(LFIX > 0 && key0 + 4 < ntail)) v = (key0 + 4 * hh < ntail) ? v : 0.f;
+                    sv[r] = v;
+                }
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp) {
+                    if (TAIL && (sp == 1 || (LFIX > 0 && 16 * sp >= ntail))) break;         // (the tail's second group lies past the slab)
+                    // P^T as the B operand: registers 8 sp .. 8 sp + 7 -> k-step sp (16 keys)
+                    const uint32_t pw[4] = {f2bf2(sv[8 * sp], sv[8 * sp + 1]), f2bf2(sv[8 * sp + 2], sv[8 * sp + 3]),
+                                            f2bf2(sv[8 * sp + 4], sv[8 * sp + 5]), f2bf2(sv[8 * sp + 6], sv[8 * sp + 7])};
+                    // A operand: row m = 16 (G & 1) + i16 of V' (channels | 1 | 0), k = keys 4 hh + {0..3}, 8 + 4 hh + {0..3} of the 16-key group
+                    const unsigned char* va = vimg + (32 * kb + 16 * sp) * 32;
+                    const bf16x4 v0 = lds_tr_read((const uint16_t*)va), v1 = lds_tr_read((const uint16_t*)(va + 8 * 32));
+                    o = mfma32x32(__builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7), __builtin_bit_cast(bf16x8, pw), o);
+                }
+            };
+            auto run = [&](auto fixed_c, auto masked_c) {
+                constexpr bool FIXED = decltype(fixed_c)::value, MASKED = decltype(masked_c)::value;
+                if constexpr (FIXED) {
+                    mx = 0.f;
+                    // Software pipeline placed by hand (the rolled loop keeps the compiler from moving loads across iterations): per block kb
+                    //   S^T MFMAs of block kb + 1 from the key fragment read one iteration earlier | key fragment of block kb + 2 and the
+                    //   V' fragments of block kb requested | exponentials + packs of block kb (the requests land meanwhile) | P V MFMAs
+                    // shift mask (-100 where the query's and the key's regions differ, swinv2_global.py:403-424; log2 domain): bilinear in the
+                    // two region flags, so it is a THIRD K = 16 product on the same accumulator -- A = (key in region 1, key in region 0, 0 ..)
+                    // per key, B = (-c if the query is in region 0, -c if in region 1, 0 ..) per query, c = 100 log2 e -- in masked
+                    // windows only; no per-element select on the vector ALU.  The masked scores stay representable without a reference
+                    // point (2^(s - 144) >= 2^-184 flushes to 0 at worst: the limit)
+                    bf16x8 qmask = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if constexpr (MASKED) {
+                        const short mc = (short)f2bf(-100.f * SWV2_LOG2E);
+                        if (hh == 0) { qmask[0] = qid ? (short)0 : mc; qmask[1] = qid ? mc : (short)0; }
+                    }
+                    int kblk = 0;
+                    auto smfma = [&](bf16x8 ka) -> f32x16 {
+                        f32x16 c;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) c[r] = 0.f;
+                        c = mfma32x32(ka, qhi, c);
+                        c = mfma32x32(ka, qlo, c);
+                        if constexpr (MASKED) {
+                            const bool kreg = 32 * kblk + r32 >= mask_thr;
+                            bf16x8 kmask = {0, 0, 0, 0, 0, 0, 0, 0};
+                            if (hh == 0) { kmask[0] = kreg ? (short)0x3F80 : (short)0; kmask[1] = kreg ? (short)0 : (short)0x3F80; }
+                            c = mfma32x32(kmask, qmask, c);
+                        }
+                        ++kblk;
+                        return c;
+                    };
+                    auto expo = [&](f32x16& sv, auto tail_c) {
+                        constexpr bool TAIL = decltype(tail_c)::value;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int key0 = 8 * (r >> 2) + (r & 3);
+                            if (TAIL && LFIX > 0 && key0 >= ntail) { sv[r] = 0.f; continue; }
+#ifdef SWV2_FWD4_NOEXP             // timing ablation: no exponentials, wrong results
+                            float v = sv[r] * 0.001f;
+#else
+                            float v = __builtin_amdgcn_exp2f(sv[r]);
+#endif
+                            if (TAIL && !(LFIX > 0 && key0 + 4 < ntail)) v = (key0 + 4 * hh < ntail) ? v : 0.f;
+                            sv[r] = v;
+                        }
+                    };
+                    auto pfrag = [&](const f32x16& sv, int sp) -> bf16x8 {
+                        const uint32_t pw[4] = {f2bf2(sv[8 * sp], sv[8 * sp + 1]), f2bf2(sv[8 * sp + 2], sv[8 * sp + 3]),
+                                                f2bf2(sv[8 * sp + 4], sv[8 * sp + 5]), f2bf2(sv[8 * sp + 6], sv[8 * sp + 7])};
+                        return __builtin_bit_cast(bf16x8, pw);
+                    };
+                    // (counters, tools/pmc_attn_probe.sh: the kernel is bound by vector-instruction issue -- three waves, each active 37 % of
+                    // its cycles -- so the loop is unrolled by two with named accumulator tiles: as `sv = sn` the hand-over was 8 v_mov_b64
+                    // per block, a quarter of the block's vector issue cycles; addresses advance by per-lane strides, no selects)
+                    auto readk2 = [&](int kb) -> bf16x8 { return *(const bf16x8*)(kimg + kb * 512); };      // (compile-time kb: immediate offsets)
+                    auto readv2 = [&](int grp) -> bf16x8 {
+                        const bf16x4 v0 = lds_tr_read((const uint16_t*)(vimg + grp * 512)), v1 = lds_tr_read((const uint16_t*)(vimg + grp * 512 + 256));
+                        return __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    };
+                    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    auto step = [&](f32x16& cur, f32x16& nxt, bf16x8& ka, int kb, bool first) {        // consume `cur` (block kb), produce `nxt` (block kb + 1)
+                        nxt = smfma(ka);
+                        ka = readk2(kb + 2 < 6 ? kb + 2 : 5);
+                        const bf16x8 va0 = readv2(2 * kb), va1 = readv2(2 * kb + 1);
+                        expo(cur, std::false_type{});
+                        o = mfma32x32(va0, pfrag(cur, 0), first ? zero16 : o);
+                        o = mfma32x32(va1, pfrag(cur, 1), o);
+                    };
+                    bf16x8 ka = readk2(0);
+                    f32x16 sa = smfma(ka), sb;
+                    ka = readk2(1);
+                    step(sa, sb, ka, 0, true);
+                    step(sb, sa, ka, 1, false);
+                    step(sa, sb, ka, 2, false);
+                    step(sb, sa, ka, 3, false);
+                    step(sa, sb, ka, 4, false);           // (block 5 = the tail's scores)
+                    {
+                        const bf16x8 va0 = readv2(10);
+                        expo(sb, std::true_type{});
+                        o = mfma32x32(va0, pfrag(sb, 0), o);          // (the tail's second 16-key group lies past the slab)
+                    }
+                } else {
+                    // two passes, block by block (5 % of the windows: no pipelining, the register budget goes to the path above)
+                    mx = SWV2_NEG_BIG;
+#pragma unroll 1
+                    for (int kb = 0; kb < 6; ++kb) {
+                        const f32x16 sv = scores(kb, 0.f, std::true_type{});
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int key = 32 * kb + 8 * (r >> 2) + (r & 3) + 4 * hh;
+                            float v = sv[r];
+                            if constexpr (MASKED) v += (((key >= mask_thr) != qid) ? (-100.f * SWV2_LOG2E) : 0.f);
+                            mx = fmaxf(mx, key < Lc ? v : SWV2_NEG_BIG);
+                        }
+                    }
+                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+#pragma unroll 1
+                    for (int kb = 0; kb < 5; ++kb) consume(scores(kb, -mx, std::false_type{}), kb, masked_c, std::false_type{});
+                    consume(scores(5, -mx, std::false_type{}), 5, masked_c, std::true_type{});
+                }
+            };
+            if (bounded) { if (do_mask) run(std::true_type{}, std::true_type{}); else run(std::true_type{}, std::false_type{}); }
+            else if (do_mask) run(std::false_type{}, std::true_type{});
+            else run(std::false_type{}, std::false_type{});
+            // row 16 of O' (register 8 of the lanes with hh = 0) = sum of the bf16-rounded P of query r32
+            const float sum = __shfl(o[8], r32);
+            const float inv = (q < L) ? __builtin_amdgcn_rcpf(sum) : 0.f;
+            // three store instructions per block (lanes of rows past the slab -- the upper half of block 5 -- masked off: an exec-masked
+            // store is still one VMEM instruction, which is what the counted wait below relies on)
+            if (q < Lp) {
+                uint16_t* orow = oh + item * SLAB + (size_t)q * DP;
+                f32x4 a = {o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv}, b = {o[4] * inv, o[5] * inv, o[6] * inv, o[7] * inv};
+                *(bf16x4*)(orow + 4 * hh) = f2bf4(a);                 // channels 4 hh .. + 3
+                *(bf16x4*)(orow + 8 + 4 * hh) = f2bf4(b);             // channels 8 + 4 hh ..
+                if (hh == 0) lse[item * Lp + q] = (q < L) ? mx + __log2f(sum) : 0.f;
+            }
+        }
+        // the next item's DMA (4 instructions at the top of this item, older than its Q loads and this item's stores) has landed for
+        // this wave: everything but the youngest 2 + 6 VMEM operations
+#pragma unroll
+        for (int i = 0; i < QPW; ++i) qc[i] = qn[i];
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+// called by swv2_attn2_fwd's dispatcher (attn2.hip): 0 / negative = handled, 1 = shape not covered
+int swv2_attn4_fwd(const swv2_attn_args* a, int Lp, int DP, void* stream) {
+    if (a->bias || Lp != 176 || DP != 16 || a->L <= 160) return 1;      // (six key blocks: windows of 161 .. 176 tokens)
+    static const int use = getenv("SWV2_ATTN_FWD4") ? atoi(getenv("SWV2_ATTN_FWD4")) : 1;
+    if (!use) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    int nchunk = (4 * 256 + a->heads - 1) / a->heads;                    // four workgroups per CU on 256 CUs
+    if (nchunk > a->Bw) nchunk = a->Bw;
+    dim3 grid(nchunk, a->heads), block(192);
+#define SWV2_FWD4_ARGS (const uint16_t*)a->qkvh, a->logit_scale, (uint16_t*)a->oh, a->lse, a->Bw, a->heads, a->L, a->nwh * a->nww, a->nww, a->nwh, a->mask_thr
+    if (a->L == 162) hipLaunchKernelGGL((attn_fwd4_kernel<162>), grid, block, 0, st, SWV2_FWD4_ARGS);
+    else hipLaunchKernelGGL((attn_fwd4_kernel<0>), grid, block, 0, st, SWV2_FWD4_ARGS);
+#undef SWV2_FWD4_ARGS
+    SWV2_CHECK_LAUNCH("swv2_attn_fwd");
+    return SWV2_OK;
+}

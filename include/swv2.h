@@ -48,11 +48,9 @@ const char* swv2_last_error(void);
  * ------------------------------------------------------------------------------------------------------------ */
 int swv2_attn_geometry(int L, int head_dim, int* Lp, int* DP);
 
-/* Which forward softmax regime serves window area L / head_dim (with / without a CPB bias table; dbg as in swv2_attn_args): 2 = the
- * 32 x 32-tile forward of csrc/attn4.hip (161 .. 176-token windows of 16-wide heads: no exponent reference while sigma log2(e) <= 40,
- * shifted windows included), 1 = the operand-folded softmax of csrc/attn2.hip (exponent reference sigma itself where sigma log2(e) <= 40
- * in unmasked windows; both: normaliser = sum of the bf16-rounded exponentials), 0 = row maximum + exact sum (csrc/attn.hip,
- * attn_wide.hip); negative: unsupported geometry.
+/* Which forward softmax regime serves window area L / head_dim (with / without a CPB bias table; dbg as in swv2_attn_args): 1 = the
+ * operand-folded softmax of csrc/attn2.hip (exponent reference sigma itself where sigma log2(e) <= 40 in unmasked windows, normaliser =
+ * sum of the bf16-rounded exponentials), 0 = row maximum + exact sum (csrc/attn.hip, attn_wide.hip); negative: unsupported geometry.
  * Pure host function.  The parity tests declare the regime their oracle emulates and check it against this (reference: the softmax of
  * swinv2_global.py:309-314, one function in both regimes up to rounding). */
 int swv2_attn_fwd_regime(int L, int head_dim, int has_bias, int dbg);

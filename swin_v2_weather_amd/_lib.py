@@ -13,7 +13,7 @@ import threading
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("SWV2_LIB") or os.path.join(HERE, "libswv2.so")     # SWV2_LIB: a privately built variant (tools/ab_macro.sh)
-SOURCES = ["capi.hip", "attn.hip", "attn2.hip", "attn4.hip", "attn_wide.hip", "gemm.hip", "gemm_tn.hip", "gemm_tn_slab.hip", "rowops.hip", "block.hip", "cpb.hip", "mlp.hip", "proj_ln.hip", "dataio.hip"]
+SOURCES = ["capi.hip", "attn.hip", "attn2.hip", "attn_wide.hip", "gemm.hip", "gemm_tn.hip", "gemm_tn_slab.hip", "rowops.hip", "block.hip", "cpb.hip", "mlp.hip", "proj_ln.hip", "dataio.hip"]
 
 _lib = None
 _lock = threading.Lock()

@@ -1060,17 +1060,14 @@ int swv2_attn2_fwd(const swv2_attn_args* a, int Lp, int DP, void* stream);
 int swv2_attn_fwd_wide(const swv2_attn_args* a, int Lp, int DP, void* stream);
 int swv2_attn_bwd_wide(const swv2_attn_args* a, int Lp, int DP, void* stream);
 
-// which forward kernel family serves a geometry (pure host function, no launch): 2 = the 32 x 32-tile forward of attn4.hip (no
-// reference point in the exponent while sigma log2 e <= 40), 1 = the operand-folded softmax of attn2.hip (reference sigma), 0 = row
+// which forward kernel family serves a geometry (pure host function, no launch): 1 = the operand-folded softmax of attn2.hip, 0 = row
 // maximum + exact sum (attn.hip, attn_wide.hip); negative: geometry not covered.  The parity tests declare the regime their oracle
-// emulates and check it against this.
+// emulates and check it against this.  (2 = the 32 x 32-tile forward, oracle regime "operand_folded_zero_ref": tools/experiments/.)
 extern "C" int swv2_attn_fwd_regime(int L, int head_dim, int has_bias, int dbg) {
     int Lp, DP;
     const int rc = swv2_attn_geometry(L, head_dim, &Lp, &DP);
     if (rc) return rc;
-    if (has_bias || Lp != 176 || DP != 16 || (dbg & SWV2_ATTN_FIRST_GEN)) return 0;
-    static const int use4 = getenv("SWV2_ATTN_FWD4") ? atoi(getenv("SWV2_ATTN_FWD4")) : 1;
-    return (use4 && L > 160) ? 2 : 1;
+    return (!has_bias && Lp == 176 && DP == 16 && !(dbg & SWV2_ATTN_FIRST_GEN)) ? 1 : 0;
 }
 
 extern "C" int swv2_attn_fwd(const swv2_attn_args* a, void* stream) {

@@ -300,15 +300,9 @@ int launch_fwd3(const swv2_attn_args* a, hipStream_t st) {
 
 // called by swv2_attn_fwd (attn.hip); returns 1 when this kernel does not cover the shape (the caller then runs the
 // first-generation kernel)
-int swv2_attn4_fwd(const swv2_attn_args* a, int Lp, int DP, void* stream);       // attn4.hip: the 32 x 32-tile forward
-
 int swv2_attn2_fwd(const swv2_attn_args* a, int Lp, int DP, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (a->bias || Lp != 176 || DP != 16) return 1;
-    {
-        const int rc4 = swv2_attn4_fwd(a, Lp, DP, stream);
-        if (rc4 <= 0) return rc4;
-    }
     if (a->L == 162) return launch_fwd3<11, 162, 4, 3, false>(a, st);          // measured best: 49 us at B = 2 (first generation: 72)
     return launch_fwd3<11, 0, 4, 3, false>(a, st);
 }

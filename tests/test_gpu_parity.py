@@ -470,8 +470,8 @@ def test_layernorm_residual(dev, K, Cc):
 
 def emulate_kernels(K, Lw, d, has_bias, softmax):
     """Switch the oracle to the HIP path's rounding mode.  `softmax` is the forward softmax regime the TEST declares for this
-    geometry ("operand_folded_zero_ref": csrc/attn4.hip, 16-wide heads without a CPB table at the 161 .. 176-token windows;
-    "operand_folded": csrc/attn2.hip, the same at 65 .. 160 tokens; "row_max": every other kernel) -- an explicit argument, the oracle does not look at shapes -- and the library's own kernel choice for the
+    geometry ("operand_folded": csrc/attn2.hip, 16-wide heads without a CPB table at the 65 .. 176-token windows; "row_max": every
+    other kernel; "operand_folded_zero_ref": the 32 x 32-tile forward of tools/experiments/, not in the library) -- an explicit argument, the oracle does not look at shapes -- and the library's own kernel choice for the
     geometry (swv2_attn_fwd_regime) must be the same one.  Undo with O.set_rounding(None)."""
     got = K["L"].load().swv2_attn_fwd_regime(int(Lw), int(d), int(bool(has_bias)), 0)
     assert got == {"row_max": 0, "operand_folded": 1, "operand_folded_zero_ref": 2}[softmax], f"test declares '{softmax}' for L={Lw} d={d} bias={has_bias}, the library reports {got}"
@@ -497,9 +497,9 @@ RM, OF, OFZ = "row_max", "operand_folded", "operand_folded_zero_ref"    # forwar
 
 @pytest.mark.parametrize("wh,ww,h,d,nwh,nww,shifted,use_bias,softmax", [
     (6, 9, 4, 12, 2, 2, False, False, RM), (6, 9, 4, 12, 2, 2, True, True, RM), (6, 9, 3, 32, 2, 2, True, True, RM),
-    (9, 18, 8, 16, 2, 3, False, False, OFZ), (9, 18, 8, 16, 2, 3, True, True, RM), (9, 18, 2, 24, 2, 2, True, False, RM),
-    (9, 18, 8, 16, 2, 3, True, False, OFZ),   # shifted, no bias: the shift mask as an MFMA term (attn4.hip)
-    (8, 20, 8, 16, 2, 2, True, False, OF), (10, 17, 8, 16, 2, 2, True, False, OFZ),   # 160 tokens: attn2.hip (masked branch); 170 tokens: attn4.hip's run-time-L instantiation
+    (9, 18, 8, 16, 2, 3, False, False, OF), (9, 18, 8, 16, 2, 3, True, True, RM), (9, 18, 2, 24, 2, 2, True, False, RM),
+    (9, 18, 8, 16, 2, 3, True, False, OF),   # shifted, no bias: the masked branch of the second-generation kernels
+    (8, 20, 8, 16, 2, 2, True, False, OF), (10, 17, 8, 16, 2, 2, True, False, OF),   # 160 / 170 tokens: attn2.hip's run-time-L instantiation (masked branch)
     (9, 18, 2, 16, 1, 2, True, True, RM),   # one window row: every window carries the shift mask
     (9, 18, 2, 96, 2, 2, True, False, RM),   # the reference yaml's head width (768 / 8), 128-column layout: attn_wide.hip's backward
     (9, 18, 2, 80, 1, 2, False, False, RM), (9, 18, 1, 96, 2, 2, True, True, RM),     # 80 channels in the 96-channel kernel; with bias: first generation
@@ -688,7 +688,7 @@ def test_block_against_reference_fixture(dev, K, tag):
     # (1) kernel correctness: oracle with bf16 rounding emulated
     p = {"b." + k[2:]: torch.from_numpy(fx[k]).clone().requires_grad_(True) for k in fx.files if k.startswith("p:")}
     xo = torch.from_numpy(fx["x"]).clone().requires_grad_(True)
-    emulate_kernels(K, wh * ww, Cc // h, "relpos" in tag, {"nopos_noshift_eval": OFZ, "nopos_shift_3x3_eval": RM, "relpos_shift_eval": RM}[tag])
+    emulate_kernels(K, wh * ww, Cc // h, "relpos" in tag, {"nopos_noshift_eval": OF, "nopos_shift_3x3_eval": RM, "relpos_shift_eval": RM}[tag])
     try:
         yo = O.block_forward(xo, p, "b.", block_cfg(gh, gw, wh, ww, sh, sw, Cc, h, "relpos" in tag), 1, training=False)
         yo.backward(torch.from_numpy(fx["gy"]))
@@ -800,7 +800,7 @@ def test_full_size_block_forward_backward_against_oracle(dev, K, Cc, rel_pos, B)
     y = blk(xd)
     y.backward(gy.to(dev))
     xo = x.clone().requires_grad_(True)
-    emulate_kernels(K, wh * ww, Cc // h, rel_pos, OFZ if (Cc, rel_pos) == (128, False) else RM)      # cfg 2 without a table: attn4.hip
+    emulate_kernels(K, wh * ww, Cc // h, rel_pos, OF if (Cc, rel_pos) == (128, False) else RM)      # cfg 2 without a table: attn2.hip
     try:
         yo = O.block_forward(xo, p, "b.", block_cfg(gh, gw, wh, ww, sh, sw, Cc, h, rel_pos), 1, training=False)
         yo.backward(gy)
@@ -889,7 +889,7 @@ def test_whole_model_against_reference_fixture(dev, K, tag):
                     window_ratio=ratio, rel_pos=bool(relpos), residual=bool(residual))
     p = {k[2:]: torch.from_numpy(fx[k]).clone().requires_grad_(True) for k in fx.files if k.startswith("p:")}
     xo = torch.from_numpy(fx["x"]).clone().requires_grad_(True)
-    emulate_kernels(K, (H // ratio) * (W // ratio), Cc // h, bool(relpos), {"nopos": OFZ, "relpos_residual": RM}[tag])     # 9 x 18 windows, 16-wide heads
+    emulate_kernels(K, (H // ratio) * (W // ratio), Cc // h, bool(relpos), {"nopos": OF, "relpos_residual": RM}[tag])     # 9 x 18 windows, 16-wide heads
     try:
         yo = O.model_forward(xo, p, cfg, training=False)
         yo.backward(torch.from_numpy(fx["gy"]))
@@ -1617,7 +1617,7 @@ def test_block_fused_and_unfused_paths(dev, K, monkeypatch, knob, value):
     assert {"SWV2_FUSE_MLP": desc.fuse_mlp, "SWV2_FUSE_PROJ_LN": desc.fuse_proj_ln, "SWV2_WGRAD_GROUP": desc.wgrad_group}[knob] == int(value)
     p = {"b." + k[2:]: torch.from_numpy(fx[k]).clone().requires_grad_(True) for k in fx.files if k.startswith("p:")}
     xo = torch.from_numpy(fx["x"]).clone().requires_grad_(True)
-    emulate_kernels(K, wh * ww, Cc // h, False, OFZ)
+    emulate_kernels(K, wh * ww, Cc // h, False, OF)
     try:
         yo = O.block_forward(xo, p, "b.", block_cfg(gh, gw, wh, ww, sh, sw, Cc, h, False), 1, training=False)
         yo.backward(torch.from_numpy(fx["gy"]))

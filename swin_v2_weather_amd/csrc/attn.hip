@@ -279,7 +279,7 @@ __device__ unsigned long long attn1_stamps[512 * 8];
 // fragments of a step are read once for both key tiles, and the dcos image is kept compact ([L rounded up to 4 (+ one
 // zero block)][Lp + 4]) so that TWO workgroups fit one CU's LDS (2 x 77 KB): 12 waves = 3 per SIMD, and one workgroup's
 // barriers / staging overlap the other's MFMA + softmax work.  TPW = 1 is the one-tile-per-wave layout (11 waves).
-// AUGP (16-wide heads, no bias, one key tile per wave): the softmax statistics, the padded-key flag and the shift mask ride in
+// AUGP (16- and 32-wide heads, no bias, one key tile per wave; described for 16, the 32-wide variant at `QP` below): the softmax statistics, the padded-key flag and the shift mask ride in
 // the unused half of K = 32 MFMA operands, so phase 1 reads no lse / delta rows and has no per-element selects: two LDS reads and
 // ~6 vector instructions less per 16 x 16 tile in the kernel's LDS-bound phase.  Construction (head dim 16 fills k = 0 .. 15 of
 // the K = 32 operand, the same 16 issue cycles as K = 16):
@@ -324,10 +324,13 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
     // 4 x 45 KB + 63 KB) -- their fragments are then read from global memory / L2 (the slab layout in memory is the LDS
     // image), the transposed ones as four 2-byte loads.  A coverage path for wide heads, not a tuned one.
     constexpr bool QG = (4 * SLAB * 2 + IROWS * DSP * 2 + Lp * 8 + 256 > 160 * 1024);
-    constexpr bool AUG = AUGP && DK == 1 && !HAS_BIAS && TPW == 1 && !QG;
+    constexpr bool AUG = AUGP && DK <= 2 && !HAS_BIAS && TPW == 1 && !QG;
     // row pitch of the q / dO slabs: AUG rows carry 16 more operand slots, padded to 80 bytes (at 64 bytes the 16-byte operand
-    // reads of 16 consecutive rows fall on 4 bank groups: conflict cycles 39 % of the LDS index cycles)
+    // reads of 16 consecutive rows fall on 4 bank groups: conflict cycles 39 % of the LDS index cycles).  32-wide heads (DK = 2):
+    // the 32 channels fill the K = 32 operand, the 8 statistics slots follow them in the same 80-byte row and go through a second
+    // MFMA (operand = the row's slots 32 .. 39 in every lane group, against a key-side operand that is zero outside k = 0 .. 7).
     constexpr int QP = AUG ? 40 : DP;
+    constexpr int QSTAT = AUG ? (DK == 1 ? 16 : 32) : 0;       // first statistics slot of a row
     constexpr int OFF_Q = 0, OFF_DO = OFF_Q + (QG ? 0 : Lp * QP * 2), OFF_LSE = OFF_DO + (QG ? 0 : Lp * QP * 2), OFF_DL = OFF_LSE + Lp * 4,
                   OFF_K = OFF_DL + Lp * 4, OFF_V = OFF_K + SLAB * 2, OFF_DS = OFF_V + SLAB * 2,
                   OFF_BIAS = OFF_DS + IROWS * DSP * 2, OFF_RED = OFF_BIAS + (BIAS_LDS ? Lp * DSP * 2 : 16),
@@ -443,9 +446,9 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
         for (int j = 0; j < CPT; ++j) {
             const int c = tid + j * NT;
             if (c < CH) {
-                if constexpr (AUG) {          // rows of 32 slots: the 16 channels, then the statistics slots written below
-                    *(uint4*)((uint16_t*)(lds + OFF_Q) + (c >> 1) * QP + (c & 1) * 8) = sq[j];
-                    *(uint4*)((uint16_t*)(lds + OFF_DO) + (c >> 1) * QP + (c & 1) * 8) = sdo[j];
+                if constexpr (AUG) {          // rows of 32 / 40 slots: the channels, then the statistics slots written below
+                    *(uint4*)((uint16_t*)(lds + OFF_Q) + (c / CPR) * QP + (c % CPR) * 8) = sq[j];
+                    *(uint4*)((uint16_t*)(lds + OFF_DO) + (c / CPR) * QP + (c % CPR) * 8) = sdo[j];
                 } else {
                     if (!QG) *(uint4*)((uint16_t*)(lds + OFF_Q) + c * 8) = sq[j];
                     if (!QG) *(uint4*)((uint16_t*)(lds + OFF_DO) + c * 8) = sdo[j];
@@ -474,9 +477,9 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
                 // bf16 parts, a constant 1 (padded-key flag), the query's mask-region flags -- and delta in three parts for the dO
                 // slab; slots 24..31 (the odd chunk's thread): zeros.  The B-operand side (-1, -1, -1, flags) is built per wave.
                 if (c < CH) {
-                    const int row = c >> 1;
+                    const int row = c / CPR;
                     uint4 aq = make_uint4(0, 0, 0, 0), ad = make_uint4(0, 0, 0, 0);
-                    if (!(c & 1)) {
+                    if ((c % CPR) == 0) {
                         const bool q_ok = row < L;
                         const float lq = q_ok ? slse_row * inv_sc2 : 1.0e30f;            // padded query rows: P = 0
                         uint16_t l0 = f2bf(lq);
@@ -490,8 +493,10 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
                         aq = make_uint4(l0 | ((uint32_t)l1 << 16), l2 | (one << 16), rqf | ((one - rqf) << 16), 0);
                         ad = make_uint4(d0 | ((uint32_t)d1 << 16), d2, 0, 0);
                     }
-                    *(uint4*)((uint16_t*)(lds + OFF_Q) + row * QP + 16 + (c & 1) * 8) = aq;
-                    *(uint4*)((uint16_t*)(lds + OFF_DO) + row * QP + 16 + (c & 1) * 8) = ad;
+                    if (DK == 1 || (c % CPR) == 0) {          // (DK = 1: the odd chunk's thread writes the zero slots 24 .. 31)
+                        *(uint4*)((uint16_t*)(lds + OFF_Q) + row * QP + QSTAT + (DK == 1 ? (c & 1) * 8 : 0)) = aq;
+                        *(uint4*)((uint16_t*)(lds + OFF_DO) + row * QP + QSTAT + (DK == 1 ? (c & 1) * 8 : 0)) = ad;
+                    }
                 }
             } else if constexpr (CPR_P2) {
                 if (c < CH && (c % CPR) == 0) DLs[c / CPR] = dl;
@@ -631,10 +636,11 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
             // statistics, padded keys and the shift mask inside the K = 32 operands (construction: the comment above the kernel); the
             // same two-stage software pipeline as below, with two 16-byte operand reads per step instead of two 8-byte fragment
             // reads + two 16-byte statistics reads, and  p = exp2(s * sc2), ds = p * dp  as the whole softmax backward
-            struct St { f32x4 s, dp; bf16x4 tq, td; };
+            struct St { f32x4 s, dp; bf16x4 tq[DK], td[DK]; };
             const int key = 16 * tw + fr;
             const float cmask = do_mask ? fmaxf(-100.f * SWV2_LOG2E * inv_sc2, -1.0e30f) : 0.f;
             bf16x8 kf8, vf8;
+            [[maybe_unused]] bf16x8 kx8, vx8;                                      // DK = 2: key side of the statistics product
             {
                 const uint32_t m1 = 0xbf80u;                                       // -1
                 const uint32_t padk = (key < Lc) ? 0u : (uint32_t)f2bf(-1.0e30f);
@@ -642,20 +648,38 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
                 const uint32_t mk0 = f2bf(kreg ? 0.f : cmask), mk1 = f2bf(kreg ? cmask : 0.f);
                 const uint4 augk = make_uint4(m1 | (m1 << 16), m1 | (padk << 16), mk0 | (mk1 << 16), 0);
                 const uint4 augv = make_uint4(m1 | (m1 << 16), m1, 0, 0);
-                const uint4 rk = *(const uint4*)(Ks + key * DP + (g & 1) * 8), rv = *(const uint4*)(Vs + key * DP + (g & 1) * 8);
                 const uint4 z = make_uint4(0, 0, 0, 0);
-                kf8 = __builtin_bit_cast(bf16x8, g < 2 ? rk : (g == 2 ? augk : z));
-                vf8 = __builtin_bit_cast(bf16x8, g < 2 ? rv : (g == 2 ? augv : z));
+                if constexpr (DK == 1) {
+                    const uint4 rk = *(const uint4*)(Ks + key * DP + (g & 1) * 8), rv = *(const uint4*)(Vs + key * DP + (g & 1) * 8);
+                    kf8 = __builtin_bit_cast(bf16x8, g < 2 ? rk : (g == 2 ? augk : z));
+                    vf8 = __builtin_bit_cast(bf16x8, g < 2 ? rv : (g == 2 ? augv : z));
+                } else {
+                    kf8 = *(const bf16x8*)(Ks + key * DP + 8 * g);
+                    vf8 = *(const bf16x8*)(Vs + key * DP + 8 * g);
+                    kx8 = __builtin_bit_cast(bf16x8, g == 0 ? augk : z);
+                    vx8 = __builtin_bit_cast(bf16x8, g == 0 ? augv : z);
+                }
             }
             const uint16_t* const Qa = (const uint16_t*)(lds + OFF_Q);
             const uint16_t* const Da = (const uint16_t*)(lds + OFF_DO);
             auto stageA = [&](const int qt, St& o) {
                 const bf16x8 qa = *(const bf16x8*)(Qa + (16 * qt + fr) * QP + 8 * g);
                 const bf16x8 da = *(const bf16x8*)(Da + (16 * qt + fr) * QP + 8 * g);
-                o.td = lds_tr_read(Da + (16 * qt + 4 * g + (fr >> 2)) * QP + (fr & 3) * 4);
-                o.tq = lds_tr_read(Qa + (16 * qt + 4 * g + (fr >> 2)) * QP + (fr & 3) * 4);
-                o.s = mfma32(qa, kf8, (f32x4){0.f, 0.f, 0.f, 0.f});
-                o.dp = mfma32(da, vf8, (f32x4){0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                for (int dt = 0; dt < DK; ++dt) {
+                    o.td[dt] = lds_tr_read(Da + (16 * qt + 4 * g + (fr >> 2)) * QP + 16 * dt + (fr & 3) * 4);
+                    o.tq[dt] = lds_tr_read(Qa + (16 * qt + 4 * g + (fr >> 2)) * QP + 16 * dt + (fr & 3) * 4);
+                }
+                if constexpr (DK == 1) {
+                    o.s = mfma32(qa, kf8, (f32x4){0.f, 0.f, 0.f, 0.f});
+                    o.dp = mfma32(da, vf8, (f32x4){0.f, 0.f, 0.f, 0.f});
+                } else {
+                    // the row's statistics slots in every lane group (one address per row: no bank conflict); the key side is zero for k >= 8
+                    const bf16x8 qx = *(const bf16x8*)(Qa + (16 * qt + fr) * QP + QSTAT);
+                    const bf16x8 dx = *(const bf16x8*)(Da + (16 * qt + fr) * QP + QSTAT);
+                    o.s = mfma32(qa, kf8, mfma32(qx, kx8, (f32x4){0.f, 0.f, 0.f, 0.f}));
+                    o.dp = mfma32(da, vf8, mfma32(dx, vx8, (f32x4){0.f, 0.f, 0.f, 0.f}));
+                }
             };
             auto stageB = [&](const int qt, const St& in) {
                 f32x4 p, ds;
@@ -666,8 +690,11 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
                 }
                 const bf16x4 pb = f2bf4(p), dsb = f2bf4(ds);
                 *(bf16x4*)(dSb + key * DSP + 16 * qt + 4 * g) = dsb;
-                dv[0][0] = mfma16(in.td, pb, dv[0][0]);
-                dk[0][0] = mfma16(in.tq, dsb, dk[0][0]);
+#pragma unroll
+                for (int dt = 0; dt < DK; ++dt) {
+                    dv[0][dt] = mfma16(in.td[dt], pb, dv[0][dt]);
+                    dk[0][dt] = mfma16(in.tq[dt], dsb, dk[0][dt]);
+                }
             };
             St sa, sb;
             stageA(0, sa);
@@ -958,7 +985,7 @@ int launch_bwd(const swv2_attn_args* a, hipStream_t st) {
         constexpr int TPW = 1;
         dim3 grid(nchunk, a->heads), block(64 * ((LT + TPW - 1) / TPW));
         // 16-wide heads: statistics / mask inside the MFMA operands (SWV2_ATTN_PLAIN_STATS keeps the kernel that reads them from LDS)
-        if (DK == 1 && !(a->dbg & SWV2_ATTN_PLAIN_STATS))
+        if (DK <= 2 && !(a->dbg & SWV2_ATTN_PLAIN_STATS))
             hipLaunchKernelGGL((attn_bwd_kernel<LT, DK, false, LFIX, TPW, true>), grid, block, 0, st, (const uint16_t*)a->qkvh,
                                a->logit_scale, a->bias, (const uint16_t*)nullptr, (const uint16_t*)a->oh, (const uint16_t*)a->doh, a->lse,
                                a->rnorm, (uint16_t*)a->dqkvh, a->dlogit_scale, a->dbias, a->Bw, a->heads, a->L, nW, a->nww, a->nwh,
@@ -1014,6 +1041,7 @@ extern "C" int swv2_attn_geometry(int L, int head_dim, int* Lp, int* DP) {
     if (Lp == 64 && DP == 16) return FN<4, 1, 0>(a, st);                               \
     if (Lp == 64 && DP == 32) return FN<4, 2, 0>(a, st);                               \
     if (Lp == 176 && DP == 16) return FN<11, 1, 0>(a, st);                             \
+    if (Lp == 176 && DP == 32 && a->L == 162) return FN<11, 2, 162>(a, st);            \
     if (Lp == 176 && DP == 32) return FN<11, 2, 0>(a, st);                             \
     if (Lp == 64 && DP == 64) return FN<4, 4, 0>(a, st);                               \
     if (Lp == 64 && DP == 96) return FN<4, 6, 0>(a, st);                               \
@@ -1067,7 +1095,7 @@ extern "C" int swv2_attn_fwd_regime(int L, int head_dim, int has_bias, int dbg) 
     int Lp, DP;
     const int rc = swv2_attn_geometry(L, head_dim, &Lp, &DP);
     if (rc) return rc;
-    return (!has_bias && Lp == 176 && DP == 16 && !(dbg & SWV2_ATTN_FIRST_GEN)) ? 1 : 0;
+    return (!has_bias && Lp == 176 && (DP == 16 || DP == 32) && !(dbg & SWV2_ATTN_FIRST_GEN)) ? 1 : 0;
 }
 
 extern "C" int swv2_attn_fwd(const swv2_attn_args* a, void* stream) {

@@ -284,6 +284,175 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn_fwd3_kernel(
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// the same forward for 32-wide head slots (head_dim 17 .. 32; BASELINE configs[4]: 192 channels, 8 heads of 24): the K = 32
+// operand is filled by the head itself, so the (hi | lo) split of sigma' q^ takes TWO MFMAs per key tile against the same K
+// fragment (the matrix pipe has the room: ~40 MFMAs = 640 cycles per 16-query row against ~1500 cycles of vector work), the K
+// image needs no duplication (one 16-byte read per lane from the slab as it lies in memory), and O^T has two 16-row tiles.
+// The item's q | k | v slabs are one contiguous 3 x Lp x 32 block in memory and are staged as such.  NBUF = 2: the next item's
+// slabs go to the other LDS buffer during the wave's last row (one barrier per item, 2 x 33 KB: two workgroups per CU);
+// NBUF = 1: one buffer, rewritten between two barriers (three workgroups per CU).
+// ------------------------------------------------------------------------------------------------
+template <int LT, int LFIX, int WAVES, int OCC, int NBUF>
+__global__ __launch_bounds__(64 * WAVES, OCC) void attn_fwd3w_kernel(
+    const uint16_t* __restrict__ qkvh, const float* __restrict__ logit_scale, uint16_t* __restrict__ oh, float* __restrict__ lse,
+    int Bw, int h, int L, int nW, int nww, int nwh, int mask_thr) {
+    constexpr int DP = 32, Lp = 16 * LT, SLAB = Lp * DP;
+    constexpr int NT = 64 * WAVES;
+    constexpr int CH = 3 * SLAB / 8;                  // 16-byte chunks of the q | k | v slabs
+    constexpr int CPT = (CH + NT - 1) / NT;
+    constexpr int BUF = 3 * SLAB;
+    __shared__ __attribute__((aligned(16))) uint16_t smem[NBUF * BUF];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, g = lane >> 4;
+    const int hd = blockIdx.y;
+    const bool last_chunk_ok = (wave * 64 + (CPT - 1) * NT) < CH;          // wave-uniform (CH is a multiple of 64)
+    const int Lc = LFIX > 0 ? LFIX : L;
+
+    const float sc2 = __expf(fminf(logit_scale[hd], SWV2_LN100)) * SWV2_LOG2E;
+    const bool bounded = sc2 <= 40.f;
+
+    u32x4 stage[CPT];
+    unsigned soff[CPT];                               // 32-bit lane offsets against a wave-uniform base (see attn_fwd3_kernel)
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) soff[j] = (unsigned)(min(tid + j * NT, CH - 1) * 8);
+    auto issue_loads = [&](int bw) {
+        const uint16_t* base = qkvh + ((size_t)bw * h + hd) * 3 * SLAB;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) stage[j] = *(const u32x4*)(base + soff[j]);
+    };
+    auto write_stage = [&](int buf) {
+        uint16_t* dst = smem + buf * BUF;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j)
+            if (j < CPT - 1 || last_chunk_ok) *(u32x4*)(dst + (size_t)(tid + j * NT) * 8) = stage[j];
+    };
+
+    int bw = blockIdx.x;
+    if (bw >= Bw) return;
+    issue_loads(bw);
+    write_stage(0);
+    __syncthreads();
+
+    const bf16x8 ones8 = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    const bf16x4 ones4 = {0x3F80, 0x3F80, 0x3F80, 0x3F80};
+
+    for (int it = 0; bw < Bw; bw += gridDim.x, ++it) {
+        const int buf = NBUF == 2 ? (it & 1) : 0;
+        const int bw_next = bw + gridDim.x;
+        const uint16_t* Qs = smem + buf * BUF;
+        const uint16_t* Ks = Qs + SLAB;
+        const uint16_t* Vs = Ks + SLAB;
+        if (bw_next < Bw) issue_loads(bw_next);
+        const bool do_mask = (mask_thr > 0) && (((bw % nW) / nww) == nwh - 1);
+        const bool fixed = bounded && !do_mask;                       // wave-uniform
+        const float c0 = fixed ? -sc2 : 0.f;
+        f32x4 cpad;                                                   // padded keys start at -1e30: P = 0 there
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cpad[r] = (16 * (LT - 1) + 4 * g + r < Lc) ? c0 : SWV2_NEG_BIG;
+
+#pragma unroll 1
+        for (int qt = wave; qt < LT; qt += WAVES) {                   // wave-uniform trip count
+            const int q = 16 * qt + fr;
+            if (NBUF == 2 && qt + WAVES >= LT && bw_next < Bw) write_stage(buf ^ 1);
+            const bf16x8 qraw = *(const bf16x8*)(Qs + (size_t)q * DP + 8 * g);
+            // B operands of S^T = K Q^T: hi and lo bf16 parts of sigma' q^[8g .. 8g + 7] (sum exact to ~2^-17)
+            bf16x8 qhi, qlo;
+            {
+                uint32_t wh[4], wl[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float x0 = bf2f(qraw[2 * j]) * sc2, x1 = bf2f(qraw[2 * j + 1]) * sc2;
+                    wh[j] = f2bf2(x0, x1);
+                    wl[j] = f2bf2(x0 - __uint_as_float(wh[j] << 16), x1 - __uint_as_float(wh[j] & 0xffff0000u));
+                }
+                qhi = __builtin_bit_cast(bf16x8, wh);
+                qlo = __builtin_bit_cast(bf16x8, wl);
+            }
+            f32x4 acc[LT];
+#pragma unroll
+            for (int t = 0; t < LT; ++t) {
+                const bf16x8 kA = *(const bf16x8*)(Ks + (16 * t + fr) * DP + 8 * g);
+                const f32x4 c = (t == LT - 1) ? cpad : (f32x4){c0, c0, c0, c0};
+                acc[t] = mfma32(kA, qlo, c);
+                acc[t] = mfma32(kA, qhi, acc[t]);
+            }
+            float mx = sc2;
+            if (!fixed) {
+                mx = SWV2_NEG_BIG;
+                const bool qid = q >= mask_thr;
+#pragma unroll
+                for (int t = 0; t < LT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (do_mask) acc[t][r] += (((16 * t + 4 * g + r) >= mask_thr) != qid) ? (-100.f * SWV2_LOG2E) : 0.f;
+                        mx = fmaxf(mx, acc[t][r]);
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+#pragma unroll
+                for (int t = 0; t < LT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[t][r] -= mx;
+            }
+#pragma unroll
+            for (int t = 0; t < LT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (LFIX > 0 && 16 * t + r >= LFIX && t == LT - 1) acc[t][r] = 0.f;      // registers that only hold padded keys
+                    else acc[t][r] = __builtin_amdgcn_exp2f(acc[t][r]);
+                }
+            // O^T[d][q] (two 16-row tiles of d) and the row sums, pairs of key tiles per K = 32
+            f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0, rs = o0;
+            auto vfrag = [&](int t, int dt) { return lds_tr_read(Vs + (16 * t + 4 * g + (fr >> 2)) * DP + 16 * dt + (fr & 3) * 4); };
+#pragma unroll
+            for (int t = 0; t + 1 < LT; t += 2) {
+                const bf16x4 p0 = f2bf4(acc[t]), p1 = f2bf4(acc[t + 1]);
+                const bf16x8 pb = __builtin_shufflevector(p0, p1, 0, 1, 2, 3, 4, 5, 6, 7);
+                const bf16x8 vA0 = __builtin_shufflevector(vfrag(t, 0), vfrag(t + 1, 0), 0, 1, 2, 3, 4, 5, 6, 7);
+                const bf16x8 vA1 = __builtin_shufflevector(vfrag(t, 1), vfrag(t + 1, 1), 0, 1, 2, 3, 4, 5, 6, 7);
+                o0 = mfma32(vA0, pb, o0);
+                o1 = mfma32(vA1, pb, o1);
+                rs = mfma32(ones8, pb, rs);
+            }
+            if (LT & 1) {
+                const bf16x4 pb = f2bf4(acc[LT - 1]);
+                // own accumulators for the K = 16 tail (see attn.hip)
+                o0 += mfma16(vfrag(LT - 1, 0), pb, (f32x4){0.f, 0.f, 0.f, 0.f});
+                o1 += mfma16(vfrag(LT - 1, 1), pb, (f32x4){0.f, 0.f, 0.f, 0.f});
+                rs += mfma16(ones4, pb, (f32x4){0.f, 0.f, 0.f, 0.f});
+            }
+            const float sum = rs[0];                                  // every row of the ones product holds the column sums
+            const float inv = (q < L) ? __builtin_amdgcn_rcpf(sum) : 0.f;
+            uint16_t* orow = oh + ((size_t)bw * h + hd) * SLAB + (size_t)q * DP;
+            o0[0] *= inv; o0[1] *= inv; o0[2] *= inv; o0[3] *= inv;
+            o1[0] *= inv; o1[1] *= inv; o1[2] *= inv; o1[3] *= inv;
+            *(bf16x4*)(orow + 4 * g) = f2bf4(o0);
+            *(bf16x4*)(orow + 16 + 4 * g) = f2bf4(o1);
+            if (g == 0) lse[((size_t)bw * h + hd) * Lp + q] = (q < L) ? mx + __log2f(sum) : 0.f;
+        }
+        __syncthreads();
+        if (NBUF == 1 && bw_next < Bw) {
+            write_stage(0);
+            __syncthreads();
+        }
+    }
+}
+
+template <int LT, int LFIX, int WAVES, int OCC, int NBUF>
+int launch_fwd3w(const swv2_attn_args* a, hipStream_t st) {
+    int nchunk = (OCC * 256 + a->heads - 1) / a->heads;
+    if (nchunk > a->Bw) nchunk = a->Bw;
+    dim3 grid(nchunk, a->heads), block(64 * WAVES);
+    hipLaunchKernelGGL((attn_fwd3w_kernel<LT, LFIX, WAVES, OCC, NBUF>), grid, block, 0, st, (const uint16_t*)a->qkvh, a->logit_scale,
+                       (uint16_t*)a->oh, a->lse, a->Bw, a->heads, a->L, a->nwh * a->nww, a->nww, a->nwh, a->mask_thr);
+    SWV2_CHECK_LAUNCH("swv2_attn_fwd");
+    return SWV2_OK;
+}
+
 template <int LT, int LFIX, int WAVES, int OCC, bool KREG>
 int launch_fwd3(const swv2_attn_args* a, hipStream_t st) {
     // OCC workgroups per CU on 256 CUs, every workgroup loops over windows
@@ -302,7 +471,13 @@ int launch_fwd3(const swv2_attn_args* a, hipStream_t st) {
 // first-generation kernel)
 int swv2_attn2_fwd(const swv2_attn_args* a, int Lp, int DP, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    if (a->bias || Lp != 176 || DP != 16) return 1;
+    if (a->bias || Lp != 176 || (DP != 16 && DP != 32)) return 1;
+    if (DP == 32) {
+        static const int var = getenv("SWV2_ATTN_FWD3W") ? atoi(getenv("SWV2_ATTN_FWD3W")) : 1;
+        if (var == 2) return a->L == 162 ? launch_fwd3w<11, 162, 6, 2, 2>(a, st) : launch_fwd3w<11, 0, 6, 2, 2>(a, st);
+        if (var == 0) return a->L == 162 ? launch_fwd3w<11, 162, 4, 3, 1>(a, st) : launch_fwd3w<11, 0, 4, 3, 1>(a, st);
+        return a->L == 162 ? launch_fwd3w<11, 162, 4, 2, 2>(a, st) : launch_fwd3w<11, 0, 4, 2, 2>(a, st);      // measured: 85 us (0: 99, 2: 112; first generation 203)
+    }
     if (a->L == 162) return launch_fwd3<11, 162, 4, 3, false>(a, st);          // measured best: 49 us at B = 2 (first generation: 72)
     return launch_fwd3<11, 0, 4, 3, false>(a, st);
 }

@@ -1137,7 +1137,7 @@ __device__ unsigned long long rw_stamps[256 * 8];
 #endif
 __device__ __forceinline__ int swzk(int r, int kc, int K) { return r * K + ((kc ^ ((r >> 1) & 7)) << 3); }
 
-template <int AK, int EK, int N, int K, int BMT>
+template <int AK, int EK, int N, int K, int BMT, int HS = 16>
 __global__ __launch_bounds__(512) void gemm_rw_kernel(ALoad<AK> al, const uint16_t* __restrict__ Wb, Epi<EK> ep, int M) {
     constexpr int NTH = 512, KC = K / 8;                    // 16-byte chunks per row
     constexpr int ACH = BMT * KC / NTH;                     // A chunks per thread per tile
@@ -1281,12 +1281,15 @@ __global__ __launch_bounds__(512) void gemm_rw_kernel(ALoad<AK> al, const uint16
                     for (int r = 0; r < 4; ++r) st[(4 * g + r) * EP + 16 * j + fr] = acc[i][j0 + j][r];
                 const int m0 = t * BMT + wr * 16 * RT + i * 16, n0 = wc * (N / 2) + j0 * 16;
                 if constexpr (EK == E_QKV_HEADS) {
-                    // heads_item<16, true> with the bias from LDS: lane = (row r, 16-column head slot)
+                    // heads_item<HS, true> with the bias from LDS: lane = (row r, 16-column slot); HS = 32: a head is two slots
+                    // (adjacent lane groups share the squared norm).  d.p1 = first q / k / v part of this launch's columns (a
+                    // launch over one part of a split weight: BASELINE configs[4], see launch_nt2)
                     const EpiDesc& d = ep.d;
                     const int h = d.p0, Lp = d.p2, L = d.p4;
                     const int r = lane & 15, slot = lane >> 4, nb = n0 + slot * 16, m = m0 + r;
                     if (m < d.M) {
-                        const int ph = nb >> 4, part = (h == 1) ? ph : fdiv(ph, h, d.mg1), hd = ph - part * h;
+                        const int ph = HS == 16 ? nb >> 4 : nb >> 5, lp = (h == 1) ? ph : fdiv(ph, h, d.mg1), hd = ph - lp * h;
+                        const int part = lp + d.p1;
                         const int bw = fdiv(m, Lp, d.mg0), tt = m - bw * Lp;
                         const bool valid = tt < L;
                         float v[16];
@@ -1300,12 +1303,13 @@ __global__ __launch_bounds__(512) void gemm_rw_kernel(ALoad<AK> al, const uint16
                                 ss = fmaf(v[j + e], v[j + e], ss);
                             }
                         }
+                        if constexpr (HS == 32) ss += __shfl_xor(ss, 16);      // (rows m and m past d.M differ only in lane bits 0 .. 3)
                         float rn = 1.f;
                         if (part < 2) {
                             rn = 1.f / fmaxf(sqrtf(ss), 1e-12f);
-                            d.aux_out[(((long)bw * h + hd) * 2 + part) * Lp + tt] = valid ? rn : 0.f;
+                            if (HS == 16 || !(slot & 1)) d.aux_out[(((long)bw * h + hd) * 2 + part) * Lp + tt] = valid ? rn : 0.f;
                         }
-                        uint16_t* o = (uint16_t*)d.out + ((((long)bw * h + hd) * 3 + part) * Lp + tt) * 16;
+                        uint16_t* o = (uint16_t*)d.out + ((((long)bw * h + hd) * 3 + part) * Lp + tt) * HS + (HS == 32 ? (slot & 1) * 16 : 0);
                         float w8[8];
 #pragma unroll
                         for (int e = 0; e < 8; ++e) w8[e] = v[e] * rn;
@@ -1369,8 +1373,25 @@ int launch_nt2(const swv2_operand* a, const void* w, const swv2_epilogue* e, int
     static const int rw = getenv("SWV2_GEMM_RW") ? atoi(getenv("SWV2_GEMM_RW")) : 1;
     if constexpr (AK == A_F32 && EK == E_QKV_HEADS) {
         if (rw && N == 384 && K == 128 && M >= 256 * 128 && e->p[3] == 16 && a->rowidx) {
+            Epi<EK> ep1 = ep;
+            ep1.d.p1 = 0;                                 // (first part of the launch's columns; p[1] is not a parameter of this epilogue)
             hipLaunchKernelGGL((gemm_rw_kernel<AK, EK, 384, 128, 128>), dim3(256), dim3(512), 0, st, make_loader<AK>(a),
-                               (const uint16_t*)w, ep, M);
+                               (const uint16_t*)w, ep1, M);
+            SWV2_CHECK_LAUNCH("swv2_linear");
+            return SWV2_OK;
+        }
+        // BASELINE configs[4] (192 channels, 8 heads in 32-wide slots): the 768 x 192 weight does not fit LDS beside an A tile, one
+        // of its q / k / v parts (256 x 192 = 96 KB) does: three launches, each over all rows (the gathered fp32 rows are read three
+        // times, 3 x 108 MB, against the generic kernel's re-read of the weight per 64-row tile: 207 -> 3 x ~45 us)
+        if (rw && N == 768 && K == 192 && M >= 256 * 128 && e->p[3] == 32 && e->p[0] == 8 && a->rowidx) {
+            for (int part = 0; part < 3; ++part) {
+                Epi<EK> ep2 = ep;
+                ep2.d.N = 256;
+                ep2.d.p1 = part;
+                ep2.d.bias = e->bias ? e->bias + 256 * part : nullptr;
+                hipLaunchKernelGGL((gemm_rw_kernel<AK, EK, 256, 192, 128, 32>), dim3(256), dim3(512), 0, st, make_loader<AK>(a),
+                                   (const uint16_t*)w + (size_t)part * 256 * 192, ep2, M);
+            }
             SWV2_CHECK_LAUNCH("swv2_linear");
             return SWV2_OK;
         }

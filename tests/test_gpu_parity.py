@@ -497,7 +497,8 @@ RM, OF, OFZ = "row_max", "operand_folded", "operand_folded_zero_ref"    # forwar
 
 @pytest.mark.parametrize("wh,ww,h,d,nwh,nww,shifted,use_bias,softmax", [
     (6, 9, 4, 12, 2, 2, False, False, RM), (6, 9, 4, 12, 2, 2, True, True, RM), (6, 9, 3, 32, 2, 2, True, True, RM),
-    (9, 18, 8, 16, 2, 3, False, False, OF), (9, 18, 8, 16, 2, 3, True, True, RM), (9, 18, 2, 24, 2, 2, True, False, RM),
+    (9, 18, 8, 16, 2, 3, False, False, OF), (9, 18, 8, 16, 2, 3, True, True, RM), (9, 18, 2, 24, 2, 2, True, False, OF),
+    (9, 18, 8, 24, 2, 3, False, False, OF), (8, 20, 3, 32, 2, 2, True, False, OF),   # BASELINE configs[4]'s heads (24 wide in 32-wide slots): attn2.hip's wide-slot forward, compile-time and run-time window area
     (9, 18, 8, 16, 2, 3, True, False, OF),   # shifted, no bias: the masked branch of the second-generation kernels
     (8, 20, 8, 16, 2, 2, True, False, OF), (10, 17, 8, 16, 2, 2, True, False, OF),   # 160 / 170 tokens: attn2.hip's run-time-L instantiation (masked branch)
     (9, 18, 2, 16, 1, 2, True, True, RM),   # one window row: every window carries the shift mask
@@ -725,7 +726,7 @@ def test_block_at_baseline_head_geometry(dev, K, tag):
     # kernel correctness against the bf16-emulating oracle
     p = {"b." + k[2:]: torch.from_numpy(fx[k]).clone().requires_grad_(True) for k in fx.files if k.startswith("p:")}
     xo = torch.from_numpy(fx["x"]).clone().requires_grad_(True)
-    emulate_kernels(K, wh * ww, Cc // h, relpos, RM)                # (cfg 4: 24-wide heads; cfg 2 with the CPB table)
+    emulate_kernels(K, wh * ww, Cc // h, relpos, RM if relpos else OF)      # (cfg 4: 24-wide heads, attn2.hip forward; cfg 2 with the CPB table: first generation)
     try:
         yo = O.block_forward(xo, p, "b.", block_cfg(gh, gw, wh, ww, sh, sw, Cc, h, relpos), 1, training=False)
         yo.backward(torch.from_numpy(fx["gy"]))
@@ -800,7 +801,7 @@ def test_full_size_block_forward_backward_against_oracle(dev, K, Cc, rel_pos, B)
     y = blk(xd)
     y.backward(gy.to(dev))
     xo = x.clone().requires_grad_(True)
-    emulate_kernels(K, wh * ww, Cc // h, rel_pos, OF if (Cc, rel_pos) == (128, False) else RM)      # cfg 2 without a table: attn2.hip
+    emulate_kernels(K, wh * ww, Cc // h, rel_pos, OF if (Cc, rel_pos) in ((128, False), (192, False)) else RM)      # cfg 2 / cfg 4 without a table: attn2.hip
     try:
         yo = O.block_forward(xo, p, "b.", block_cfg(gh, gw, wh, ww, sh, sw, Cc, h, rel_pos), 1, training=False)
         yo.backward(gy)
@@ -810,7 +811,10 @@ def test_full_size_block_forward_backward_against_oracle(dev, K, Cc, rel_pos, B)
     # unfused path stores the proj / fc2 outputs as bf16 before the LayerNorms, one rounding of the branch more than the emulation
     # -- the kernels sit 4.9e-3 and the emulating oracle 4.6e-3 from exact fp32, 4.4e-3 from each other, identically with the 128-tile
     # GEMMs / first-generation attention and with the wide kernels (tools/probe_block768.py): the stated bf16 tolerance, 1e-2
-    assert rel(y, yo) < (1e-2 if Cc >= 512 else 1e-3) and rel(xd.grad, xo.grad) < 1.5e-2
+    # Width 192 (cfg 4) also runs proj and LayerNorm1 as two launches (no fused instantiation: swv2_proj_ln_supported) with the same
+    # extra bf16 store; measured 1.01e-3 with the attn2.hip forward (operand-folded softmax), below 1e-3 with the first-generation one:
+    # bar 1.5e-3 there
+    assert rel(y, yo) < (1e-2 if Cc >= 512 else 1.5e-3 if Cc == 192 else 1e-3) and rel(xd.grad, xo.grad) < 1.5e-2
     # weight gradients are sums over 129 600 rows: bf16 rounding noise averages out, systematic errors would not
     assert worst_grad(blk, {k[2:]: v.grad for k, v in p.items()}, logit_tol=BLOCK_LOGIT_TOL) < 3e-2
 

@@ -35,7 +35,8 @@ def timeit(fn, n=10, warm=3):
 
 
 def probe_attn(B=2, rel_pos=False):
-    plan = ops.window_plan(B, 180, 360, 9, 18, 4, 9, 8, 16, 0)
+    HD = int(os.environ.get("PROBE_HD", "16"))             # head width (24: BASELINE configs[4], 32-wide slots)
+    plan = ops.window_plan(B, 180, 360, 9, 18, 4, 9, 8, HD, 0)
     Bw, h, Lp, DP, Lw = plan.Bw, 8, plan.Lp, plan.DP, plan.L
     qkvh = (torch.randn(Bw, h, 3, Lp, DP, device=dev) * 0.25).to(BF)
     qkvh[:, :, :, Lw:] = 0
@@ -50,10 +51,10 @@ def probe_attn(B=2, rel_pos=False):
     dbias = torch.zeros(h, Lw, Lw, device=dev) if rel_pos else None
     pk = ops.attn_pack_bias(bias) if rel_pos else None
     for gen, dbg in (("first generation (csrc/attn.hip)", L.ATTN_FIRST_GEN), ("default", 0), ("statistics from LDS (backward)", L.ATTN_PLAIN_STATS)):
-        a = ops.attn_args(qkvh, ls, bias, oh, lse, Bw, h, Lw, 16, plan.nwh, plan.nww, plan.mask_thr, max_chunks=32 if rel_pos else 64, bias_pack=pk)
+        a = ops.attn_args(qkvh, ls, bias, oh, lse, Bw, h, Lw, HD, plan.nwh, plan.nww, plan.mask_thr, max_chunks=32 if rel_pos else 64, bias_pack=pk)
         a.dbg = dbg
         say(f"attn_fwd  {gen} B={B} bias={rel_pos}: {timeit(lambda: ops.attn_fwd(a), n=20):.1f} us")
-        a = ops.attn_args(qkvh, ls, bias, oh, lse, Bw, h, Lw, 16, plan.nwh, plan.nww, plan.mask_thr, doh=doh, rnorm=rnorm,
+        a = ops.attn_args(qkvh, ls, bias, oh, lse, Bw, h, Lw, HD, plan.nwh, plan.nww, plan.mask_thr, doh=doh, rnorm=rnorm,
                           dqkvh=dq, dlogit=dls, dbias=dbias, max_chunks=32 if rel_pos else 256 // h, bias_pack=pk)     # (as swv2_block_bwd)
         a.dbg = dbg
         say(f"attn_bwd  {gen} B={B} bias={rel_pos}: {timeit(lambda: ops.attn_bwd(a), n=20):.1f} us")

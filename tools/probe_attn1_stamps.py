@@ -17,7 +17,8 @@ DMA = os.environ.get("SWV2_ATTN_BWD_DMA", "0") != "0" and not (len(sys.argv) > 1
 from swin_v2_weather_amd import ops
 dev = torch.device("cuda:0"); BF = torch.bfloat16
 B = int(os.environ.get("PROBE_B", "2"))
-plan = ops.window_plan(B, 180, 360, 9, 18, 4, 9, 8, 16, 0)
+HD = int(os.environ.get("PROBE_HD", "16"))            # head width (24: BASELINE configs[4])
+plan = ops.window_plan(B, 180, 360, 9, 18, 4, 9, 8, HD, 0)
 Bw, h, Lp, DP, Lw = plan.Bw, 8, plan.Lp, plan.DP, plan.L
 qkvh = (torch.randn(Bw, h, 3, Lp, DP, device=dev) * 0.25).to(BF); qkvh[:, :, :, Lw:] = 0
 oh = torch.empty(Bw, h, Lp, DP, dtype=BF, device=dev); lse = torch.zeros(Bw, h, Lp, device=dev)
@@ -26,11 +27,11 @@ rel_pos = len(sys.argv) > 1 and sys.argv[1] == "bias"          # CPB bias varian
 bias = torch.randn(h, Lw, Lw, device=dev) if rel_pos else None
 dbias = torch.zeros(h, Lw, Lw, device=dev) if rel_pos else None
 pk = ops.attn_pack_bias(bias) if rel_pos else None
-a = ops.attn_args(qkvh, ls, bias, oh, lse, Bw, h, Lw, 16, plan.nwh, plan.nww, plan.mask_thr, max_chunks=32 if rel_pos else 64, bias_pack=pk)
+a = ops.attn_args(qkvh, ls, bias, oh, lse, Bw, h, Lw, HD, plan.nwh, plan.nww, plan.mask_thr, max_chunks=32 if rel_pos else 64, bias_pack=pk)
 ops.attn_fwd(a)
 doh = torch.randn(Bw, h, Lp, DP, device=dev).to(BF); rnorm = torch.rand(Bw, h, 2, Lp, device=dev) + 0.5
 dq, dls = torch.empty_like(qkvh), torch.zeros(h, device=dev)
-a = ops.attn_args(qkvh, ls, bias, oh, lse, Bw, h, Lw, 16, plan.nwh, plan.nww, plan.mask_thr, doh=doh, rnorm=rnorm, dqkvh=dq, dlogit=dls,
+a = ops.attn_args(qkvh, ls, bias, oh, lse, Bw, h, Lw, HD, plan.nwh, plan.nww, plan.mask_thr, doh=doh, rnorm=rnorm, dqkvh=dq, dlogit=dls,
                   dbias=dbias, max_chunks=32 if rel_pos else 256 // h, bias_pack=pk)
 for _ in range(3):
     ops.attn_bwd(a)

@@ -47,7 +47,9 @@ def set_rounding(fn, softmax: str = "row_max") -> None:
     the rounding mode, DECLARED by the caller (the tests state it per geometry and check the library's kernel choice against it with
     swv2_attn_fwd_regime; the oracle never infers it from shapes):
       "row_max"        exponent reference = the row maximum, normaliser = sum of the exact exponentials (csrc/attn.hip forward);
-      "operand_folded" csrc/attn2.hip (attn_fwd3_kernel): reference = sigma itself while sigma log2(e) <= 40 in windows without a
+      "operand_folded" csrc/attn2.hip (attn_fwd3_kernel, attn_fwd3w_kernel): the scale enters the QK^T product inside the query operand,
+                       sigma log2(e) q^ as TWO bf16 parts hi + lo (hi = bf16(x), lo = bf16(x - hi): the scaled query is
+                       exact to ~2^-17 instead of fp32); reference = sigma itself while sigma log2(e) <= 40 in windows without a
                        shift mask (cosines are bounded), the row maximum otherwise; normaliser = sum of the bf16-ROUNDED exponentials
                        (an all-ones MFMA operand);
       "operand_folded_zero_ref" csrc/attn4.hip (attn_fwd4_kernel, 32 x 32 tiles): NO reference point while sigma log2(e) <= 40 (2^40
@@ -295,7 +297,7 @@ def attention_core_normed(qn: Tensor, kn: Tensor, v: Tensor, logit_scale: Tensor
     if mask is not None:
         nW = mask.shape[0]
         mfull = mask.view(1, nW, 1, L, L).expand(Bw // nW, nW, 1, L, L).reshape(Bw, 1, L, L)
-    O = _AttnCoreEmu.apply(qn, kn, v, sigma, bias, mfull, ref.detach(), rounded_sum)
+    O = _AttnCoreEmu.apply(qn, kn, v, sigma, bias, mfull, ref.detach(), rounded_sum, rounded_sum)      # (both regimes with a rounded sum fold the scale)
     return O.permute(0, 2, 1, 3).reshape(Bw, L, C)
 
 
@@ -307,8 +309,16 @@ class _AttnCoreEmu(torch.autograd.Function):
     bf16(dS), d bias from the un-rounded dS."""
 
     @staticmethod
-    def forward(ctx, qn, kn, v, sigma, bias, mask, ref, rounded_sum):
-        S = torch.einsum("bhqd,bhkd->bhqk", qn, kn) * sigma.view(1, -1, 1, 1)
+    def forward(ctx, qn, kn, v, sigma, bias, mask, ref, rounded_sum, folded_scale=False):
+        if folded_scale:
+            # sigma log2(e) q^ as the kernel's two-part operand: hi = round(x), lo = round(x - hi) (the fp32 rounding of the product
+            # itself, 2^-24, is not modelled; with an identity rounding function hi = x, lo = 0: the exact logits)
+            x = qn * (sigma * math.log2(math.e)).view(1, -1, 1, 1)
+            hi = _r(x)
+            lo = _r(x - hi)
+            S = torch.einsum("bhqd,bhkd->bhqk", hi + lo, kn) / math.log2(math.e)
+        else:
+            S = torch.einsum("bhqd,bhkd->bhqk", qn, kn) * sigma.view(1, -1, 1, 1)
         if bias is not None:
             S = S + bias.unsqueeze(0)
         if mask is not None:
@@ -341,7 +351,7 @@ class _AttnCoreEmu(torch.autograd.Function):
         dkn = sg * torch.einsum("bhqk,bhqd->bhkd", dSr, qn)
         dsigma = (dSr * cos).sum((0, 2, 3))
         dbias = dS.sum(0) if bias is not None else None
-        return dqn, dkn, dV, dsigma, dbias, None, None, None
+        return dqn, dkn, dV, dsigma, dbias, None, None, None, None
 
 
 def window_attention(xw: Tensor, p: Dict[str, Tensor], pre: str, heads: int,

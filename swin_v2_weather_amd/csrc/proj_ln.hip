@@ -21,20 +21,24 @@ struct ProjLnFwd {
     int Mw, Lp, h, rows_per_sample; float eps;
 };
 
-template <int C, int MT>
-__global__ __launch_bounds__(256, 2) void proj_ln_fwd_kernel(const ProjLnFwd a) {
-    constexpr int NTC = C / 16;
-    constexpr int PWP = PL_MAX_HDP + 8, PA = C + 8;
+// HS = head slot width (16, or 32: BASELINE configs[4], 192 channels in 8 heads of 24), NW = waves per workgroup: with the 192 x 256
+// weight (101 KB) one workgroup fits a CU, so it is 8 waves instead of 2 x 4.
+template <int C, int MT, int HS = 16, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void proj_ln_fwd_kernel(const ProjLnFwd a) {
+    constexpr int NTC = C / 16, NT = 64 * NW;
+    constexpr int HDPM = 8 * HS;                             // at most 8 heads
+    constexpr int PWP = HDPM + 8, PA = C + 8;
     constexpr int EWAVE = 16 * PA * 2 + 16 * 2 * 4;
-    constexpr int KSM = PL_MAX_HDP / 32;
+    constexpr int KSM = HDPM / 32;
+    static_assert(C * PWP * 2 + NW * EWAVE + 3 * C * 4 <= 160 * 1024, "LDS budget");
     __shared__ __attribute__((aligned(16))) uint16_t Wps[C * PWP];
-    __shared__ __attribute__((aligned(16))) unsigned char epi[4 * EWAVE];
+    __shared__ __attribute__((aligned(16))) unsigned char epi[NW * EWAVE];
     __shared__ __attribute__((aligned(16))) float cs[3 * C];
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4;
-    const int hdp = a.h * 16, ksn = hdp / 32;
-    const int row0 = blockIdx.x * (64 * MT) + wave * (16 * MT);
+    const int hdp = a.h * HS, ksn = hdp / 32;
+    const int row0 = blockIdx.x * (16 * NW * MT) + wave * (16 * MT);
 
     // The scatter rows (window reverse + un-roll table) and the residual rows of the EPILOGUE are fetched first: as loads
     // inside the epilogue they were two dependent memory round trips per row tile with nothing to overlap them (a
@@ -54,7 +58,7 @@ __global__ __launch_bounds__(256, 2) void proj_ln_fwd_kernel(const ProjLnFwd a) 
             dstv[mt][p] = a.rowidx ? a.rowidx[m] : m;
         }
     // A^T fragments straight from the head-major attention output: lane (m = fr, g) holds k = 32 ks + 8 g .. + 7,
-    // i.e. 8 channels of head 2 ks + (g >> 1)
+    // i.e. 8 channels of head 2 ks + (g >> 1) (HS = 16) resp. of head ks (HS = 32)
     bf16x8 xf[MT][KSM];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -62,14 +66,14 @@ __global__ __launch_bounds__(256, 2) void proj_ln_fwd_kernel(const ProjLnFwd a) 
 #pragma unroll
         for (int ks = 0; ks < KSM; ++ks) {
             const int k0 = 32 * ks + 8 * g, kc = min(k0, hdp - 8);
-            xf[mt][ks] = *(const bf16x8*)(a.oh + (((size_t)w * a.h + (kc >> 4)) * a.Lp + t) * 16 + (kc & 15));
+            xf[mt][ks] = *(const bf16x8*)(a.oh + (((size_t)w * a.h + kc / HS) * a.Lp + t) * HS + (kc & (HS - 1)));
         }
     }
-    for (int i = tid; i < C * (hdp / 8); i += 256) {
+    for (int i = tid; i < C * (hdp / 8); i += NT) {
         const int r = i / (hdp / 8), c8 = i % (hdp / 8);
         *(u32x4*)(Wps + r * PWP + 8 * c8) = *(const u32x4*)(a.wp + (size_t)r * hdp + 8 * c8);
     }
-    for (int i = tid; i < C; i += 256) { cs[i] = a.bp[i]; cs[C + i] = a.gamma[i]; cs[2 * C + i] = a.beta[i]; }
+    for (int i = tid; i < C; i += NT) { cs[i] = a.bp[i]; cs[C + i] = a.gamma[i]; cs[2 * C + i] = a.beta[i]; }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -168,25 +172,30 @@ struct ProjLnBwd {
     int Mw, Lp, h, rows_per_sample;
 };
 
-template <int C, int MT>
-__global__ __launch_bounds__(256, 2) void proj_ln_bwd_kernel(const ProjLnBwd a) {
-    constexpr int KS = C / 32;
-    constexpr int ROWS = 64 * MT, PX = C + 8, PW = C + 8;
+template <int C, int MT, int HS = 16, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void proj_ln_bwd_kernel(const ProjLnBwd a) {
+    constexpr int KS = C / 32, NT = 64 * NW, HDPM = 8 * HS;
+    constexpr int ROWS = 16 * NW * MT, PX = C + 8, PW = C + 8;
     constexpr int LPR = C <= 32 ? 8 : C <= 64 ? 16 : C <= 128 ? 32 : 64;
-    constexpr int RPP = 256 / LPR, NPASS = ROWS / RPP;
+    constexpr int RPP = NT / LPR, NPASS = ROWS / RPP;
     constexpr int BATCH = NPASS < 4 ? NPASS : 4;
     static_assert(NPASS % BATCH == 0, "row passes must come in whole batches");
-    __shared__ __attribute__((aligned(16))) uint16_t Wts[PL_MAX_HDP * PW];        // Wp^T rows: [heads * 16][C]
+    // d gamma / d beta partials of the RPP row groups: summed through LDS -- in two rounds (upper half of the row groups onto the
+    // lower half, then across the lower half) where the one-round table would not fit beside the 102 KB weight (NW = 8)
+    constexpr bool TWO_ROUNDS = NW == 8;
+    constexpr int GROWS = TWO_ROUNDS ? RPP / 2 : RPP;
+    static_assert(HDPM * PW * 2 + ROWS * PX * 2 + GROWS * 2 * C * 4 <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(16))) uint16_t Wts[HDPM * PW];              // Wp^T rows: [heads * HS][C]
     __shared__ __attribute__((aligned(16))) uint16_t Xs[ROWS * PX];               // da1 tile
-    __shared__ __attribute__((aligned(16))) float gs[RPP * 2 * C];
+    __shared__ __attribute__((aligned(16))) float gs[GROWS * 2 * C];
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4;
-    const int hdp = a.h * 16;
+    const int hdp = a.h * HS;
     const int wg_row0 = blockIdx.x * ROWS;
 
-    for (int i = tid; i < hdp * (C / 8); i += 256) {
+    for (int i = tid; i < hdp * (C / 8); i += NT) {
         const int r = i / (C / 8), c8 = i % (C / 8);
         *(u32x4*)(Wts + r * PW + 8 * c8) = *(const u32x4*)(a.wpt + (size_t)r * C + 8 * c8);
     }
@@ -276,15 +285,27 @@ __global__ __launch_bounds__(256, 2) void proj_ln_bwd_kernel(const ProjLnBwd a) 
                 }
             }
         }
-        if (act) {
+        if constexpr (TWO_ROUNDS) {
+            if (act && rg >= GROWS) {
+                *(f32x4*)(gs + ((rg - GROWS) * 2 + 0) * C + c0) = dgm;
+                *(f32x4*)(gs + ((rg - GROWS) * 2 + 1) * C + c0) = dbt;
+            }
+            __syncthreads();
+            if (act && rg < GROWS) {
+                dgm += *(const f32x4*)(gs + (rg * 2 + 0) * C + c0);
+                dbt += *(const f32x4*)(gs + (rg * 2 + 1) * C + c0);
+            }
+            __syncthreads();
+        }
+        if (act && rg < GROWS) {
             *(f32x4*)(gs + (rg * 2 + 0) * C + c0) = dgm;
             *(f32x4*)(gs + (rg * 2 + 1) * C + c0) = dbt;
         }
         __syncthreads();
-        for (int i = tid; i < 2 * C; i += 256) {
+        for (int i = tid; i < 2 * C; i += NT) {
             float t = 0.f;
 #pragma unroll
-            for (int r = 0; r < RPP; ++r) t += gs[r * 2 * C + i];
+            for (int r = 0; r < GROWS; ++r) t += gs[r * 2 * C + i];
             a.ws[(size_t)blockIdx.x * 2 * C + i] = t;
         }
     }
@@ -295,14 +316,14 @@ __global__ __launch_bounds__(256, 2) void proj_ln_bwd_kernel(const ProjLnBwd a) 
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) xf[ks] = *(const bf16x8*)(Xs + (wave * 16 * MT + 16 * mt + fr) * PX + 32 * ks + 8 * g);
         const int m = min(wg_row0 + wave * 16 * MT + 16 * mt + fr, a.Mw - 1), w = m / a.Lp, t = m - w * a.Lp;
-        for (int hd = 0; hd < a.h; ++hd) {
+        for (int kt = 0; kt < a.h * (HS / 16); ++kt) {              // 16-channel tile kt of the head-major columns
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 wf = *(const bf16x8*)(Wts + (16 * hd + fr) * PW + 32 * ks + 8 * g);
+                const bf16x8 wf = *(const bf16x8*)(Wts + (16 * kt + fr) * PW + 32 * ks + 8 * g);
                 acc = mfma32(wf, xf[ks], acc);
             }
-            *(bf16x4*)(a.doh + (((size_t)w * a.h + hd) * a.Lp + t) * 16 + 4 * g) = f2bf4(acc);
+            *(bf16x4*)(a.doh + (((size_t)w * a.h + kt / (HS / 16)) * a.Lp + t) * HS + 16 * (kt % (HS / 16)) + 4 * g) = f2bf4(acc);
         }
     }
 }
@@ -310,6 +331,7 @@ __global__ __launch_bounds__(256, 2) void proj_ln_bwd_kernel(const ProjLnBwd a) 
 }  // namespace
 
 extern "C" int swv2_proj_ln_supported(int C, int heads, int head_pad) {
+    if (C == 192) return head_pad == 32 && heads >= 1 && heads <= 8;             // (32-wide slots: a K = 32 step is one head)
     return (C == 32 || C == 64 || C == 96 || C == 128) && head_pad == 16 && heads >= 2 && heads % 2 == 0 && heads * 16 <= PL_MAX_HDP;
 }
 
@@ -319,7 +341,7 @@ extern "C" int swv2_proj_ln_fwd(const swv2_proj_ln_args* a, void* stream) {
     SWV2_CHECK_ARG(a && a->oh && a->wp && a->bp && a->gamma && a->beta && a->x && a->a1 && a->mean && a->rstd && a->y,
                    "swv2_proj_ln_fwd: null pointer");
     SWV2_CHECK_ARG(a->Bw > 0 && a->Lp > 0 && a->Lp % 16 == 0 && a->rows_per_sample > 0, "swv2_proj_ln_fwd: bad geometry");
-    if (!swv2_proj_ln_supported(a->C, a->heads, 16)) {
+    if (!swv2_proj_ln_supported(a->C, a->heads, a->C == 192 ? 32 : 16)) {
         swv2_set_error("swv2_proj_ln_fwd: C=%d heads=%d not instantiated; use swv2_linear + swv2_ln_residual_fwd", a->C, a->heads);
         return SWV2_ERR_UNSUPPORTED;
     }
@@ -334,7 +356,10 @@ extern "C" int swv2_proj_ln_fwd(const swv2_proj_ln_args* a, void* stream) {
         if (mt2) hipLaunchKernelGGL((proj_ln_fwd_kernel<CC, 2>), dim3(cdiv(Mw, 128)), dim3(256), 0, st, k);          \
         else hipLaunchKernelGGL((proj_ln_fwd_kernel<CC, 1>), dim3(cdiv(Mw, 64)), dim3(256), 0, st, k);               \
         break;
-    switch (a->C) { PL_CASE(32) PL_CASE(64) PL_CASE(96) PL_CASE(128) }
+    switch (a->C) {
+        PL_CASE(32) PL_CASE(64) PL_CASE(96) PL_CASE(128)
+        case 192: hipLaunchKernelGGL((proj_ln_fwd_kernel<192, 1, 32, 8>), dim3(cdiv(Mw, 128)), dim3(512), 0, st, k); break;
+    }
 #undef PL_CASE
     SWV2_CHECK_LAUNCH("swv2_proj_ln_fwd");
     return SWV2_OK;
@@ -346,7 +371,7 @@ int swv2_proj_ln_bwd_impl(const swv2_proj_ln_bwd_args* a, void* stream, int* def
     SWV2_CHECK_ARG(a && a->dy && a->a1 && a->mean && a->rstd && a->gamma && a->wpt && a->da1 && a->doh && a->dgamma && a->dbeta &&
                        a->ws, "swv2_proj_ln_bwd: null pointer");
     SWV2_CHECK_ARG(a->Bw > 0 && a->Lp > 0 && a->Lp % 16 == 0 && a->rows_per_sample > 0, "swv2_proj_ln_bwd: bad geometry");
-    if (!swv2_proj_ln_supported(a->C, a->heads, 16)) {
+    if (!swv2_proj_ln_supported(a->C, a->heads, a->C == 192 ? 32 : 16)) {
         swv2_set_error("swv2_proj_ln_bwd: C=%d heads=%d not instantiated; use swv2_ln_residual_bwd + swv2_linear", a->C, a->heads);
         return SWV2_ERR_UNSUPPORTED;
     }
@@ -361,10 +386,14 @@ int swv2_proj_ln_bwd_impl(const swv2_proj_ln_bwd_args* a, void* stream, int* def
         if (mt2) hipLaunchKernelGGL((proj_ln_bwd_kernel<CC, 2>), dim3(cdiv(Mw, 128)), dim3(256), 0, st, k);          \
         else hipLaunchKernelGGL((proj_ln_bwd_kernel<CC, 1>), dim3(cdiv(Mw, 64)), dim3(256), 0, st, k);               \
         break;
-    switch (a->C) { PL_CASE(32) PL_CASE(64) PL_CASE(96) PL_CASE(128) }
+    int nblk = cdiv(Mw, mt2 ? 128 : 64);
+    switch (a->C) {
+        PL_CASE(32) PL_CASE(64) PL_CASE(96) PL_CASE(128)
+        case 192: nblk = cdiv(Mw, 128); hipLaunchKernelGGL((proj_ln_bwd_kernel<192, 1, 32, 8>), dim3(nblk), dim3(512), 0, st, k); break;
+    }
 #undef PL_CASE
-    if (deferred) *deferred = cdiv(Mw, mt2 ? 128 : 64);
-    else swv2_launch_ln_partials_reduce(a->ws, a->dgamma, a->dbeta, cdiv(Mw, mt2 ? 128 : 64), a->C, st);
+    if (deferred) *deferred = nblk;
+    else swv2_launch_ln_partials_reduce(a->ws, a->dgamma, a->dbeta, nblk, a->C, st);
     SWV2_CHECK_LAUNCH("swv2_proj_ln_bwd");
     return SWV2_OK;
 }

@@ -785,7 +785,7 @@ __global__ __launch_bounds__(WTH) void gemm_nt_wide_dma_kernel(ALoad<AK> al, con
             t.boff[i] = 2u * (uint32_t)(row * K + dkc[i] * 8);
             t.aoff[i] = AK == A_BF16 ? 2u * (uint32_t)(row * (int)al.d.ld + dkc[i] * 8) : 0u;
 #else
-            t.boff[i] = 2u * (uint32_t)((t.n_base + row) * K + dkc[i] * 8);
+            t.boff[i] = 2u * (uint32_t)(min(t.n_base + row, N - 1) * K + dkc[i] * 8);      // (N = 192, one partial column tile: rows past N re-read the last one, their columns are never stored)
             t.aoff[i] = AK == A_BF16 ? 2u * (uint32_t)(min(t.m_base + row, M - 1) * (int)al.d.ld + dkc[i] * 8) : 0u;
 #endif
         }
@@ -863,7 +863,7 @@ __global__ __launch_bounds__(WTH) void gemm_nt_wide_dma_kernel(ALoad<AK> al, con
         {
             float* st = (float*)(smem + 3 * WSTG) + wave * 16 * EP;
 #ifndef SWV2_WIDE_NO_EPI            // (timing ablation)
-            wide_epilogue<EK>(ep, acc, st, cur.m_base + wr * 128, cur.n_base + wc * 64, lane);
+            if (cur.n_base + wc * 64 < N) wide_epilogue<EK>(ep, acc, st, cur.m_base + wr * 128, cur.n_base + wc * 64, lane);      // (N: a multiple of 64)
 #else
             for (int i = 0; i < 8; ++i) asm volatile("" :: "v"(acc[i][0]), "v"(acc[i][1]), "v"(acc[i][2]), "v"(acc[i][3]));
 #endif
@@ -1408,8 +1408,13 @@ int launch_nt2(const swv2_operand* a, const void* w, const swv2_epilogue* e, int
     if constexpr ((AK == A_F32 || AK == A_BF16 || AK == A_HEADS) &&
                   (EK == E_BF16 || EK == E_F32 || EK == E_F32_ACC || EK == E_QKV_HEADS || EK == E_HEADS || EK == E_GELU_GRAD || EK == E_BF16_GELU)) {
         const int wide = getenv("SWV2_GEMM_WIDE") ? atoi(getenv("SWV2_GEMM_WIDE")) : 1;      // (read per call: the tests toggle it)
-        if (wide && N % WBN == 0 && K % BK == 0 && N >= 512 && K >= 512 && M >= 16 * WBM) {
-            const int mtiles = cdiv(M, WBM), ntn = N / WBN, groups = cdiv(mtiles, 8);
+        // BASELINE configs[4]'s d(qkv) -> dx product (N = 192, K = 768, head-major operand): one partial column tile of the DMA kernel --
+        // the operand is read exactly once, the weight's 192 rows stream from L2; a quarter of the MFMAs multiply clamped rows
+        // (the 64-row tile kernel re-reads the weight per tile behind a barrier per 64 k: 165 us)
+        const bool part192 = AK == A_HEADS && EK == E_F32 && N == 192 && K == 768 && !a->rowidx && M >= 64 * WBM &&
+                             (double)a->rows * a->cols * 2 < 4.29e9;                  // (only the DMA kernel clamps the weight rows)
+        if (wide && (N % WBN == 0 || part192) && K % BK == 0 && (N >= 512 || part192) && K >= 512 && M >= 16 * WBM) {
+            const int mtiles = cdiv(M, WBM), ntn = cdiv(N, WBN), groups = cdiv(mtiles, 8);
             const int grid = 8 * cdiv(groups, 8) * 8 * ntn;
             // 32-bit byte offsets in the DMA addressing: weights and operand below 4 GB (the operand: checked for its kind below)
             SWV2_CHECK_ARG((double)N * K * 2 < 4.29e9, "swv2_linear: weight too large for the wide kernel's 32-bit offsets");

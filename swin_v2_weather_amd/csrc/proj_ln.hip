@@ -15,6 +15,29 @@ namespace {
 
 constexpr int PL_MAX_HDP = 128;
 
+// The weight into LDS with a compile-time trip count and the loads in batches of up to 6 before their LDS writes.  (As a loop over
+// the run-time chunk count, `dst[i] = src[i]`, every iteration was a memory round trip of its own: 8 in series per workgroup at 128
+// channels, 12 at 192.)  ROWS x COLS = the largest shape; rows >= `rows` / columns >= `cols` are skipped; source rows are `cols` wide.
+template <int ROWS, int COLS, int PITCH, int NT>
+__device__ __forceinline__ void stage_weight(uint16_t* dst, const uint16_t* __restrict__ src, int rows, int cols, int tid) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int CPRW = COLS / 8, CHUNKS = ROWS * CPRW, PER = (CHUNKS + NT - 1) / NT, B = PER < 6 ? PER : 6;
+#pragma unroll
+    for (int j0 = 0; j0 < PER; j0 += B) {
+        u32x4 v[B];
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+            const int i = tid + (j0 + u) * NT, r = i / CPRW, c8 = i % CPRW;
+            v[u] = *(const u32x4*)(src + (size_t)min(r, rows - 1) * cols + min(8 * c8, cols - 8));        // unconditional (clamped)
+        }
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+            const int i = tid + (j0 + u) * NT, r = i / CPRW, c8 = i % CPRW;
+            if (j0 + u < PER && r < rows && 8 * c8 < cols) *(u32x4*)(dst + r * PITCH + 8 * c8) = v[u];
+        }
+    }
+}
+
 struct ProjLnFwd {
     const uint16_t* oh; const uint16_t* wp; const float* bp; const float* gamma; const float* beta; const float* scale;
     const int32_t* rowidx; const float* x; uint16_t* a1; float* mean; float* rstd; float* y;
@@ -69,10 +92,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void proj_ln_fwd_kernel(c
             xf[mt][ks] = *(const bf16x8*)(a.oh + (((size_t)w * a.h + kc / HS) * a.Lp + t) * HS + (kc & (HS - 1)));
         }
     }
-    for (int i = tid; i < C * (hdp / 8); i += NT) {
-        const int r = i / (hdp / 8), c8 = i % (hdp / 8);
-        *(u32x4*)(Wps + r * PWP + 8 * c8) = *(const u32x4*)(a.wp + (size_t)r * hdp + 8 * c8);
-    }
+    stage_weight<C, HDPM, PWP, NT>(Wps, a.wp, C, hdp, tid);
     for (int i = tid; i < C; i += NT) { cs[i] = a.bp[i]; cs[C + i] = a.gamma[i]; cs[2 * C + i] = a.beta[i]; }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -195,10 +215,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void proj_ln_bwd_kernel(c
     const int hdp = a.h * HS;
     const int wg_row0 = blockIdx.x * ROWS;
 
-    for (int i = tid; i < hdp * (C / 8); i += NT) {
-        const int r = i / (C / 8), c8 = i % (C / 8);
-        *(u32x4*)(Wts + r * PW + 8 * c8) = *(const u32x4*)(a.wpt + (size_t)r * C + 8 * c8);
-    }
+    stage_weight<HDPM, C, PW, NT>(Wts, a.wpt, hdp, C, tid);
     // ---- LayerNorm backward in row layout (see mlp_bwd_kernel), dy rows gathered through the row table; padded rows
     // (table < 0) give da1 = 0 and count nothing
     {

@@ -293,7 +293,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn_fwd3_kernel(
 // slabs go to the other LDS buffer during the wave's last row (one barrier per item, 2 x 33 KB: two workgroups per CU);
 // NBUF = 1: one buffer, rewritten between two barriers (three workgroups per CU).
 // ------------------------------------------------------------------------------------------------
-template <int LT, int LFIX, int WAVES, int OCC, int NBUF>
+template <int LT, int LFIX, int WAVES, int OCC, int NBUF, bool KREG = false>
 __global__ __launch_bounds__(64 * WAVES, OCC) void attn_fwd3w_kernel(
     const uint16_t* __restrict__ qkvh, const float* __restrict__ logit_scale, uint16_t* __restrict__ oh, float* __restrict__ lse,
     int Bw, int h, int L, int nW, int nww, int nwh, int mask_thr) {
@@ -353,6 +353,24 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn_fwd3w_kernel(
         f32x4 cpad;                                                   // padded keys start at -1e30: P = 0 there
 #pragma unroll
         for (int r = 0; r < 4; ++r) cpad[r] = (16 * (LT - 1) + 4 * g + r < Lc) ? c0 : SWV2_NEG_BIG;
+        auto vfrag = [&](int t, int dt) { return lds_tr_read(Vs + (16 * t + 4 * g + (fr >> 2)) * DP + 16 * dt + (fr & 3) * 4); };
+        // KREG: the item's K and V^T fragments in registers, read once per item and wave and pinned (see attn_fwd3_kernel)
+        bf16x8 kreg[KREG ? LT : 1], vreg[KREG ? LT / 2 : 1][2];
+        bf16x4 vtail[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+        if constexpr (KREG) {
+#pragma unroll
+            for (int t = 0; t < LT; ++t) kreg[t] = *(const bf16x8*)(Ks + (16 * t + fr) * DP + 8 * g);
+#pragma unroll
+            for (int t = 0; t + 1 < LT; t += 2)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) vreg[t / 2][dt] = __builtin_shufflevector(vfrag(t, dt), vfrag(t + 1, dt), 0, 1, 2, 3, 4, 5, 6, 7);
+            if (LT & 1) { vtail[0] = vfrag(LT - 1, 0); vtail[1] = vfrag(LT - 1, 1); }
+#pragma unroll
+            for (int t = 0; t < LT; ++t) asm volatile("" : "+v"(kreg[t]));
+#pragma unroll
+            for (int t = 0; t < LT / 2; ++t) asm volatile("" : "+v"(vreg[t][0]), "+v"(vreg[t][1]));
+            asm volatile("" : "+v"(vtail[0]), "+v"(vtail[1]));
+        }
 
 #pragma unroll 1
         for (int qt = wave; qt < LT; qt += WAVES) {                   // wave-uniform trip count
@@ -375,7 +393,9 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn_fwd3w_kernel(
             f32x4 acc[LT];
 #pragma unroll
             for (int t = 0; t < LT; ++t) {
-                const bf16x8 kA = *(const bf16x8*)(Ks + (16 * t + fr) * DP + 8 * g);
+                bf16x8 kA;
+                if constexpr (KREG) kA = kreg[t];
+                else kA = *(const bf16x8*)(Ks + (16 * t + fr) * DP + 8 * g);
                 const f32x4 c = (t == LT - 1) ? cpad : (f32x4){c0, c0, c0, c0};
                 acc[t] = mfma32(kA, qlo, c);
                 acc[t] = mfma32(kA, qhi, acc[t]);
@@ -407,13 +427,16 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn_fwd3w_kernel(
                 }
             // O^T[d][q] (two 16-row tiles of d) and the row sums, pairs of key tiles per K = 32
             f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0, rs = o0;
-            auto vfrag = [&](int t, int dt) { return lds_tr_read(Vs + (16 * t + 4 * g + (fr >> 2)) * DP + 16 * dt + (fr & 3) * 4); };
 #pragma unroll
             for (int t = 0; t + 1 < LT; t += 2) {
                 const bf16x4 p0 = f2bf4(acc[t]), p1 = f2bf4(acc[t + 1]);
                 const bf16x8 pb = __builtin_shufflevector(p0, p1, 0, 1, 2, 3, 4, 5, 6, 7);
-                const bf16x8 vA0 = __builtin_shufflevector(vfrag(t, 0), vfrag(t + 1, 0), 0, 1, 2, 3, 4, 5, 6, 7);
-                const bf16x8 vA1 = __builtin_shufflevector(vfrag(t, 1), vfrag(t + 1, 1), 0, 1, 2, 3, 4, 5, 6, 7);
+                bf16x8 vA0, vA1;
+                if constexpr (KREG) { vA0 = vreg[t / 2][0]; vA1 = vreg[t / 2][1]; }
+                else {
+                    vA0 = __builtin_shufflevector(vfrag(t, 0), vfrag(t + 1, 0), 0, 1, 2, 3, 4, 5, 6, 7);
+                    vA1 = __builtin_shufflevector(vfrag(t, 1), vfrag(t + 1, 1), 0, 1, 2, 3, 4, 5, 6, 7);
+                }
                 o0 = mfma32(vA0, pb, o0);
                 o1 = mfma32(vA1, pb, o1);
                 rs = mfma32(ones8, pb, rs);
@@ -421,8 +444,8 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn_fwd3w_kernel(
             if (LT & 1) {
                 const bf16x4 pb = f2bf4(acc[LT - 1]);
                 // own accumulators for the K = 16 tail (see attn.hip)
-                o0 += mfma16(vfrag(LT - 1, 0), pb, (f32x4){0.f, 0.f, 0.f, 0.f});
-                o1 += mfma16(vfrag(LT - 1, 1), pb, (f32x4){0.f, 0.f, 0.f, 0.f});
+                o0 += mfma16(KREG ? vtail[0] : vfrag(LT - 1, 0), pb, (f32x4){0.f, 0.f, 0.f, 0.f});
+                o1 += mfma16(KREG ? vtail[1] : vfrag(LT - 1, 1), pb, (f32x4){0.f, 0.f, 0.f, 0.f});
                 rs += mfma16(ones4, pb, (f32x4){0.f, 0.f, 0.f, 0.f});
             }
             const float sum = rs[0];                                  // every row of the ones product holds the column sums
@@ -442,12 +465,12 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn_fwd3w_kernel(
     }
 }
 
-template <int LT, int LFIX, int WAVES, int OCC, int NBUF>
+template <int LT, int LFIX, int WAVES, int OCC, int NBUF, bool KREG = false>
 int launch_fwd3w(const swv2_attn_args* a, hipStream_t st) {
     int nchunk = (OCC * 256 + a->heads - 1) / a->heads;
     if (nchunk > a->Bw) nchunk = a->Bw;
     dim3 grid(nchunk, a->heads), block(64 * WAVES);
-    hipLaunchKernelGGL((attn_fwd3w_kernel<LT, LFIX, WAVES, OCC, NBUF>), grid, block, 0, st, (const uint16_t*)a->qkvh, a->logit_scale,
+    hipLaunchKernelGGL((attn_fwd3w_kernel<LT, LFIX, WAVES, OCC, NBUF, KREG>), grid, block, 0, st, (const uint16_t*)a->qkvh, a->logit_scale,
                        (uint16_t*)a->oh, a->lse, a->Bw, a->heads, a->L, a->nwh * a->nww, a->nww, a->nwh, a->mask_thr);
     SWV2_CHECK_LAUNCH("swv2_attn_fwd");
     return SWV2_OK;
@@ -473,10 +496,12 @@ int swv2_attn2_fwd(const swv2_attn_args* a, int Lp, int DP, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (a->bias || Lp != 176 || (DP != 16 && DP != 32)) return 1;
     if (DP == 32) {
-        static const int var = getenv("SWV2_ATTN_FWD3W") ? atoi(getenv("SWV2_ATTN_FWD3W")) : 1;
-        if (var == 2) return a->L == 162 ? launch_fwd3w<11, 162, 6, 2, 2>(a, st) : launch_fwd3w<11, 0, 6, 2, 2>(a, st);
-        if (var == 0) return a->L == 162 ? launch_fwd3w<11, 162, 4, 3, 1>(a, st) : launch_fwd3w<11, 0, 4, 3, 1>(a, st);
-        return a->L == 162 ? launch_fwd3w<11, 162, 4, 2, 2>(a, st) : launch_fwd3w<11, 0, 4, 2, 2>(a, st);      // measured: 85 us (0: 99, 2: 112; first generation 203)
+        // measured at B = 2 (800 windows x 8 heads, 24-wide heads): 4 waves x 2 workgroups per CU, two LDS buffers: 90 us with the K / V^T
+        // fragments read per row, 80 us with them in registers (227 VGPRs); one buffer at 3 workgroups per CU (spills): 99; 6 waves x 2
+        // workgroups (SIMDs loaded 4 / 4 / 2 / 2): 112; first generation: 203
+        static const int kreg = getenv("SWV2_ATTN_FWD3W_KREG") ? atoi(getenv("SWV2_ATTN_FWD3W_KREG")) : 1;
+        if (!kreg) return a->L == 162 ? launch_fwd3w<11, 162, 4, 2, 2, false>(a, st) : launch_fwd3w<11, 0, 4, 2, 2, false>(a, st);
+        return a->L == 162 ? launch_fwd3w<11, 162, 4, 2, 2, true>(a, st) : launch_fwd3w<11, 0, 4, 2, 2, true>(a, st);
     }
     if (a->L == 162) return launch_fwd3<11, 162, 4, 3, false>(a, st);          // measured best: 49 us at B = 2 (first generation: 72)
     return launch_fwd3<11, 0, 4, 3, false>(a, st);

@@ -342,7 +342,7 @@ struct MlpBwd {
 // fc1 weight then serves BOTH products that need it from ONE row-major LDS chunk: as A operand of the recompute (row reads)
 // and, through transposed LDS reads, as A operand of dx^T = W1^T dH^T; the separately staged W1^T chunk goes away.
 template <int C, int MT, bool RECOMP>
-__global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const MlpBwd a) {
+__global__ __launch_bounds__(256, (C >= 192 && MT == 2) ? 1 : 2) void mlp_bwd_kernel(const MlpBwd a) {
     // swv2_block_bwd: this is the FIRST kernel of a block's backward, and everything that accumulates into the block's 13
     // parameter gradients runs behind it on the stream -- so it zeroes them (16 bytes per thread and pass, spread over all
     // workgroups) and the separate 3 us fill launch in front of every block's backward goes away.
@@ -379,8 +379,11 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const MlpBwd a) {
     constexpr int PHS = 72;                                           // pitch (bf16) of the wave-private dh staging tile
     __shared__ __attribute__((aligned(16))) uint16_t hst_all[4 * 16 * MT * PHS];
     uint16_t* const Hst = hst_all + wave * (16 * MT * PHS);
-    // GELU'(x) for every bf16 x in the table range (18 KB) -- only where two workgroups per CU still fit beside it
-    constexpr bool GTAB = SBYTES + 4 * 16 * MT * PHS * 2 + GT_N * 4 <= 80 * 1024;
+    // GELU'(x) for every bf16 x in the table range (18 KB) -- where two workgroups per CU still fit beside it, or where only one fits
+    // a CU anyway (192 channels, two row tiles per wave)
+    constexpr int LBASE = SBYTES + 4 * 16 * MT * PHS * 2;
+    constexpr bool ONE_WG = C >= 192 && MT == 2;          // (the launch bounds of that shape: one wave per SIMD, > 256 registers)
+    constexpr bool GTAB = LBASE + GT_N * 4 <= (ONE_WG ? 156 : 80) * 1024;
     __shared__ __attribute__((aligned(16))) float ggtab[GTAB ? GT_N : 4];
     if (GTAB)
         for (int i = tid; i < GT_N; i += 256) ggtab[i] = gelu_grad_f(bf2f(gelu_tab_arg(i)));
@@ -672,17 +675,24 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const MlpBwd a) {
     float* Ys = (float*)smem_raw + wave * 16 * PY;
     // the dy rows of ALL passes first: written as  dx[off] = dy[off] + ...  per pass, every load had to wait behind the previous
     // pass's store (dx and dy may alias as far as the compiler knows) -- 16 serial memory round trips per workgroup
+    // (192 channels x 2 row tiles: 96 registers of dy beside 96 of accumulators -- there the rows of one tile at a time)
     constexpr int EPASS = 16 * (C / 4) / 64;
-    f32x4 dyv[MT][EPASS];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    constexpr bool DY_ALL = MT * EPASS <= 16;
+    f32x4 dyv[DY_ALL ? MT : 1][EPASS];
+    auto load_dy = [&](int mt) {
 #pragma unroll
         for (int p = 0; p < EPASS; ++p) {
             const int u = lane + 64 * p, row = u / (C / 4), c4 = u % (C / 4);
-            dyv[mt][p] = *(const f32x4*)(a.dy + (size_t)min(row0 + 16 * mt + row, a.M - 1) * C + 4 * c4);
+            dyv[DY_ALL ? mt : 0][p] = *(const f32x4*)(a.dy + (size_t)min(row0 + 16 * mt + row, a.M - 1) * C + 4 * c4);
         }
+    };
+    if constexpr (DY_ALL) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) load_dy(mt);
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
+        if constexpr (!DY_ALL) load_dy(mt);
 #pragma unroll
         for (int t = 0; t < NT; ++t) *(f32x4*)(Ys + fr * PY + 16 * t + 4 * g) = yacc[mt][t];
         __syncthreads();
@@ -691,7 +701,7 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const MlpBwd a) {
         for (int p = 0; p < EPASS; ++p) {
             const int u = lane + 64 * p, row = u / (C / 4), c4 = u % (C / 4);
             const size_t off = (size_t)min(rbase + row, a.M - 1) * C + 4 * c4;
-            *(f32x4*)(a.dx + off) = dyv[mt][p] + *(const f32x4*)(Ys + row * PY + 4 * c4);
+            *(f32x4*)(a.dx + off) = dyv[DY_ALL ? mt : 0][p] + *(const f32x4*)(Ys + row * PY + 4 * c4);
         }
         if (mt + 1 < MT) __syncthreads();
     }
@@ -770,15 +780,25 @@ int swv2_mlp_bwd_impl(const swv2_mlp_bwd_args* a, void* stream, int* deferred, f
     hipStream_t st = (hipStream_t)stream;
     static const int force_mt = getenv("SWV2_MLP_MT") ? atoi(getenv("SWV2_MLP_MT")) : 0;
     const bool mt2 = force_mt ? force_mt == 2 : a->M >= 128 * 256;      // measured at C = 128, M = 129600: 170 us vs 185 us
+    bool two192 = false;
     switch (a->C) {
         case 32: mt2 ? launch_mlp_bwd<32, 2>(k, st) : launch_mlp_bwd<32, 1>(k, st); break;
         case 64: mt2 ? launch_mlp_bwd<64, 2>(k, st) : launch_mlp_bwd<64, 1>(k, st); break;
         case 96: mt2 ? launch_mlp_bwd<96, 2>(k, st) : launch_mlp_bwd<96, 1>(k, st); break;
         case 128: mt2 ? launch_mlp_bwd<128, 2>(k, st) : launch_mlp_bwd<128, 1>(k, st); break;
-        case 192: launch_mlp_bwd<192, 1>(k, st); break;
+        case 192: {
+            // measured on BASELINE configs[4] (B = 2, ms per step): one row tile per wave, two workgroups per CU, GELU' by formula (the
+            // table does not fit beside two workgroups): 35.5; the same with the table and one workgroup per CU: 38.3; two row tiles
+            // per wave (302 registers, one workgroup per CU, table; SWV2_MLP_BWD192=2): 37.2
+            static const int v192 = getenv("SWV2_MLP_BWD192") ? atoi(getenv("SWV2_MLP_BWD192")) : 0;
+            two192 = k.hpre && mt2 && v192 == 2;
+            if (two192) hipLaunchKernelGGL((mlp_bwd_kernel<192, 2, false>), dim3(cdiv(k.M, 128)), dim3(256), 0, st, k);
+            else launch_mlp_bwd<192, 1>(k, st);
+            break;
+        }
         case 256: launch_mlp_bwd<256, 1>(k, st); break;
     }
-    const bool two = (a->C <= 128) && mt2;
+    const bool two = ((a->C <= 128) && mt2) || two192;
     if (deferred) *deferred = cdiv(a->M, two ? 128 : 64);
     else swv2_launch_ln_partials_reduce(a->ws, a->dgamma, a->dbeta, cdiv(a->M, two ? 128 : 64), a->C, st);
     SWV2_CHECK_LAUNCH("swv2_mlp_bwd");

@@ -49,7 +49,7 @@ const char* swv2_last_error(void);
 int swv2_attn_geometry(int L, int head_dim, int* Lp, int* DP);
 
 /* Which forward softmax regime serves window area L / head_dim (with / without a CPB bias table; dbg as in swv2_attn_args): 1 = the
- * operand-folded softmax of csrc/attn2.hip (exponent reference sigma itself where sigma log2(e) <= 40 in unmasked windows, normaliser =
+ * operand-folded softmax of csrc/attn2.hip (16- and 32-wide head slots without a CPB table at the 176-row window; exponent reference sigma itself where sigma log2(e) <= 40 in unmasked windows, normaliser =
  * sum of the bf16-rounded exponentials), 0 = row maximum + exact sum (csrc/attn.hip, attn_wide.hip); negative: unsupported geometry.
  * Pure host function.  The parity tests declare the regime their oracle emulates and check it against this (reference: the softmax of
  * swinv2_global.py:309-314, one function in both regimes up to rounding). */
@@ -352,7 +352,8 @@ int swv2_era5_static(const float* stat, float* out, int B, int Cs, int H, int W,
  *             saves a1 = bf16(proj output) [Bw*Lp][C] (window order), mean, rstd            (replaces swv2_linear + swv2_ln_residual_fwd)
  *   backward: da1 = LN backward of scale * dy[dst] (zeros for padded rows), d(oh) = split_heads(da1 Wp), head-major;
  *             dgamma / dbeta ACCUMULATED; ws >= swv2_proj_ln_bwd_ws_floats(Bw*Lp, C) floats   (replaces swv2_ln_residual_bwd + swv2_linear)
- * C in {32,64,96,128}, head dim padded to 16, an even number of heads with heads * 16 <= 128 (swv2_proj_ln_supported). */
+ * C in {32,64,96,128}, head dim padded to 16, an even number of heads with heads * 16 <= 128; or C = 192 with up to 8 heads in
+ * 32-wide slots (oh / doh [Bw][heads][Lp][32], wp [192][heads*32], wpt [heads*32][192]: BASELINE configs[4])  (swv2_proj_ln_supported). */
 typedef struct {
     const void* oh;        /* bf16 [Bw][heads][Lp][16] */
     const void* wp;        /* bf16 [C][heads*16] (swv2_prep_weight with the head-padding column map) */

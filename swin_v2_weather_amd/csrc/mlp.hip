@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(const MlpFwd a) {
     commit(0);
     __syncthreads();
     STAMP(0);
-    for (int ch = 0; ch < nch; ++ch) {
+    auto chunk = [&](const int ch) {
         if (ch + 1 < nch) issue(ch + 1);
         const uint16_t* W1s = smem + (ch & 1) * (W1E + W2E);
         const uint16_t* W2s = W1s + W1E;
@@ -218,7 +218,32 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(const MlpFwd a) {
         STAMP(5);
         __syncthreads();
         STAMP(6);
-    }
+    };
+    // residual rows and drop-path scales of ALL row passes, unconditionally: loaded inside the pass loop each one was a
+    // memory round trip of its own (the ISA read  load, s_waitcnt vmcnt(0), store  per pass; 19 % of the kernel in the
+    // epilogue).  The first row tile's are requested BEFORE the last weight chunk (they land while its MFMAs run), the others behind
+    // it (in flight while the first tile's LayerNorm statistics are computed): requested at the top of the epilogue they were one
+    // bare memory round trip per workgroup with nothing in front of them.
+    constexpr int UNITS = 16 * (C / 8), NP = (UNITS + 63) / 64;
+    f32x4 xres[MT][NP][2];
+    float scv[MT][NP];
+    auto load_res = [&](const int mt) {
+        const float* scp = a.scale ? a.scale : a.gamma;         // any valid address: the value is ignored without a scale
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int u = min(lane + 64 * p, UNITS - 1), row = u / (C / 8), c8 = u % (C / 8);
+            const int rc = min(row0 + 16 * mt + row, a.M - 1);
+            const size_t off = (size_t)rc * C + 8 * c8;
+            xres[mt][p][0] = *(const f32x4*)(a.x + off);
+            xres[mt][p][1] = *(const f32x4*)(a.x + off + 4);
+            scv[mt][p] = scp[a.scale ? rc / a.rows_per_sample : 0];
+        }
+    };
+    for (int ch = 0; ch + 1 < nch; ++ch) chunk(ch);
+    load_res(0);                      // (measured 91.8 - 96.0 us against 96.1 - 97.0 with the request behind the last chunk: ~1 %)
+    chunk(nch - 1);
+#pragma unroll
+    for (int mt = 1; mt < MT; ++mt) load_res(mt);
 
     // ---- epilogue.  Accumulator layout (lane (m = fr, g) holds n = 16 t + 4 g + r; a row is spread over the 4 lanes
     // with equal fr): + b2, bf16 round (the saved fc2 output), row mean / rstd (2 shuffle steps each).  The bf16 tile
@@ -226,26 +251,6 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(const MlpFwd a) {
     // layout (a lane owns 8 consecutive columns), so the residual read and both stores are whole rows per instruction.
     uint16_t* As = (uint16_t*)(smem_raw + wave * EWAVE);
     float* St = (float*)(As + 16 * PA);                       // [16 rows][mean, rstd]
-    // residual rows and drop-path scales of ALL row passes first, unconditionally: loaded inside the pass loop each one was a
-    // memory round trip of its own (the ISA read  load, s_waitcnt vmcnt(0), store  per pass; 19 % of the kernel in the
-    // epilogue), now they are in flight together while the LayerNorm statistics are computed
-    constexpr int UNITS = 16 * (C / 8), NP = (UNITS + 63) / 64;
-    f32x4 xres[MT][NP][2];
-    float scv[MT][NP];
-    {
-        const float* scp = a.scale ? a.scale : a.gamma;         // any valid address: the value is ignored without a scale
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                const int u = min(lane + 64 * p, UNITS - 1), row = u / (C / 8), c8 = u % (C / 8);
-                const int rc = min(row0 + 16 * mt + row, a.M - 1);
-                const size_t off = (size_t)rc * C + 8 * c8;
-                xres[mt][p][0] = *(const f32x4*)(a.x + off);
-                xres[mt][p][1] = *(const f32x4*)(a.x + off + 4);
-                scv[mt][p] = scp[a.scale ? rc / a.rows_per_sample : 0];
-            }
-    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         float s = 0.f;

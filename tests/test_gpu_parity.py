@@ -498,6 +498,7 @@ RM, OF, OFZ = "row_max", "operand_folded", "operand_folded_zero_ref"    # forwar
 @pytest.mark.parametrize("wh,ww,h,d,nwh,nww,shifted,use_bias,softmax", [
     (6, 9, 4, 12, 2, 2, False, False, RM), (6, 9, 4, 12, 2, 2, True, True, RM), (6, 9, 3, 32, 2, 2, True, True, RM),
     (9, 18, 8, 16, 2, 3, False, False, OF), (9, 18, 8, 16, 2, 3, True, True, RM), (9, 18, 2, 24, 2, 2, True, False, OF),
+    (6, 9, 2, 24, 2, 2, True, False, RM), (6, 9, 3, 32, 2, 2, False, False, RM),   # 32-wide slots at the 64-row window: first-generation forward, operand-carried statistics in the backward (LT = 4)
     (9, 18, 8, 24, 2, 3, False, False, OF), (8, 20, 3, 32, 2, 2, True, False, OF),   # BASELINE configs[4]'s heads (24 wide in 32-wide slots): attn2.hip's wide-slot forward, compile-time and run-time window area
     (9, 18, 8, 16, 2, 3, True, False, OF),   # shifted, no bias: the masked branch of the second-generation kernels
     (8, 20, 8, 16, 2, 2, True, False, OF), (10, 17, 8, 16, 2, 2, True, False, OF),   # 160 / 170 tokens: attn2.hip's run-time-L instantiation (masked branch)

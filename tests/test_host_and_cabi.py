@@ -430,3 +430,28 @@ def test_ddp_bucket_plan_overlaps_backward_and_isolates_pos_embed():
     import inspect
     from swin_v2_weather_amd import train as T
     assert "DDP_BUCKET_CAP_MB" in inspect.getsource(T.Trainer.__init__) or "DDP_BUCKET_CAP_MB" in inspect.getsource(T)
+
+
+def test_dma_kernels_with_hand_counted_waits_use_no_scratch(tmp_path):
+    """csrc/gemm_tn_slab.hip retires its LDS-DMA loads with hand-counted `s_waitcnt vmcnt(N)`: a register spill is a VMEM operation
+    the count does not know about (a reload would be waited for too early or too late).  The compiler's own resource report must
+    show 0 bytes of scratch and 0 spilled VGPRs for both slab kernels (cross-compiled for gfx950, no GPU needed)."""
+    import subprocess
+    src = os.path.join(L.CSRC, "gemm_tn_slab.hip")
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Rpass-analysis=kernel-resource-usage",
+                        "-c", src, "-o", str(tmp_path / "slab.o")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    seen = {}
+    name = None
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            continue
+        m = re.search(r"(ScratchSize \[bytes/lane\]|VGPRs Spill): (\d+)", line)
+        if m and name:
+            seen.setdefault(name, {})[m.group(1)] = int(m.group(2))
+    slab = {k: v for k, v in seen.items() if "gemm_tn_slab_c" in k}
+    assert len(slab) == 2, sorted(seen)
+    for k, v in slab.items():
+        assert v.get("ScratchSize [bytes/lane]") == 0 and v.get("VGPRs Spill") == 0, (k, v)

@@ -216,7 +216,9 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(const MlpFwd a) {
             }
         }
         STAMP(5);
+#ifndef SWV2_MLP_ABL_NO_BARRIER      // (timing ablation, wrong results: tools/build_variant.sh)
         __syncthreads();
+#endif
         STAMP(6);
     };
     // residual rows and drop-path scales of ALL row passes, unconditionally: loaded inside the pass loop each one was a

@@ -481,7 +481,7 @@ __global__ __launch_bounds__(SL_TH) void gemm_tn_slab_c192_kernel(SlArgs a) {
 struct SlLnRed { const float* ws[2]; float* dg[2]; float* db[2]; int n[2]; int C; };
 struct SlRed { float* dW; float* db; const int32_t* nmap; const int32_t* kmap; const float* part; const float* dbpart;
                int ldw, N, K, TN, TK, WGK, IA, JB, ntk, S, first, dbfirst; };
-struct SlRedArgs { SlRed p[4]; int total, dbtotal; SlLnRed ln; };
+struct SlRedArgs { SlRed p[4]; int total, dbtotal; SlLnRed ln; int cpw; };      // cpw: 1 KB chunks per workgroup (1: 8 slice groups per chunk; 2: 4 each)
 __global__ __launch_bounds__(512) void tn_slab_reduce_kernel(SlRedArgs a) {
     __shared__ f32x4 red[8][64];
     const int b = blockIdx.x;
@@ -534,14 +534,17 @@ __global__ __launch_bounds__(512) void tn_slab_reduce_kernel(SlRedArgs a) {
         }
         return;
     }
+    // cpw = 2 (few slices per chunk: the C = 192 shape set, ~32): two chunks per workgroup, four slice groups each -- half the
+    // workgroups, each with the same number of loads in flight per thread (24 -> 16 us for that shape)
     const int pi = (b >= a.p[1].first) + (b >= a.p[2].first) + (b >= a.p[3].first);
     const SlRed& p = a.p[pi];
-    const int cg = b - p.first;
+    const int NG = 8 / a.cpw;                                   // slice groups per chunk
+    const int cg = (b - p.first) * a.cpw + sg / NG, sl0 = sg % NG;
     // destination of this lane's four values (group 0 only), requested before the partial sums so that the index-map and dW
     // round trips overlap the slice loads
     int kk = -1, nn[4] = {-1, -1, -1, -1};
     float old[4] = {0.f, 0.f, 0.f, 0.f};
-    if (sg == 0) {
+    if (sl0 == 0) {
         const int cpt = 8 * p.IA * p.JB, tile = cg / cpt, c = cg - tile * cpt;
         const int wave = c / (p.IA * p.JB), ij = c - wave * (p.IA * p.JB), i = ij / p.JB, jj = ij - i * p.JB;
         const int wgn = wave / p.WGK, wgk = wave - wgn * p.WGK, g = lane >> 4, fr = lane & 15;
@@ -555,21 +558,23 @@ __global__ __launch_bounds__(512) void tn_slab_reduce_kernel(SlRedArgs a) {
     }
     const float* src = p.part + (size_t)cg * p.S * 256 + lane * 4;
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
-    int s = sg;
+    int s = sl0;
 #if defined(SWV2_SLAB_ABL) && (SWV2_SLAB_ABL & 8)      // timing ablation: one slice only (fixed cost of the reduction launch)
     s = p.S;
 #endif
-    for (; s + 24 < p.S; s += 32) {
+    for (; s + 3 * NG < p.S; s += 4 * NG) {
         s0 += *(const f32x4*)(src + (size_t)s * 256);
-        s1 += *(const f32x4*)(src + (size_t)(s + 8) * 256);
-        s2 += *(const f32x4*)(src + (size_t)(s + 16) * 256);
-        s3 += *(const f32x4*)(src + (size_t)(s + 24) * 256);
+        s1 += *(const f32x4*)(src + (size_t)(s + NG) * 256);
+        s2 += *(const f32x4*)(src + (size_t)(s + 2 * NG) * 256);
+        s3 += *(const f32x4*)(src + (size_t)(s + 3 * NG) * 256);
     }
-    for (; s < p.S; s += 8) s0 += *(const f32x4*)(src + (size_t)s * 256);
+    for (; s < p.S; s += NG) s0 += *(const f32x4*)(src + (size_t)s * 256);
     red[sg][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (sg == 0 && kk >= 0) {
-        const f32x4 t = ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) + ((red[4][lane] + red[5][lane]) + (red[6][lane] + red[7][lane]));
+    if (sl0 == 0 && kk >= 0) {
+        f32x4 t;
+        if (a.cpw == 1) t = ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) + ((red[4][lane] + red[5][lane]) + (red[6][lane] + red[7][lane]));
+        else t = (red[sg][lane] + red[sg + 1][lane]) + (red[sg + 2][lane] + red[sg + 3][lane]);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             if (nn[r] >= 0) p.dW[(long)nn[r] * p.ldw + kk] = old[r] + t[r];
@@ -698,6 +703,14 @@ int swv2_tn_slab_launch(const swv2_wgrad_item* it, void* ws, size_t ws_bytes, co
     SlArgs a = {};
     SlRedArgs r = {};
     int first = 0, rfirst = 0, dbfirst = 0;
+    // two 1 KB chunks per reduction workgroup where every product has few slices and an even number of chunks
+    int cpw = 2;
+    for (int i = 0; i < 4; ++i)
+        if (pl.S[i] > 40 || ((it[i].dy.cols * it[i].x.cols / 256) & 1)) cpw = 1;
+    if (const char* e = getenv("SWV2_SLAB_RED_CPW")) cpw = atoi(e) == 2 ? 2 : 1;
+    for (int i = 0; i < 4 && cpw == 2; ++i)
+        if ((it[i].dy.cols * it[i].x.cols / 256) & 1) cpw = 1;
+    r.cpw = cpw;
     for (int i = 0; i < 4; ++i) {
         SlProd& p = a.p[i];
         p.y = sl_op(it[i].dy); p.x = sl_op(it[i].x);
@@ -710,7 +723,7 @@ int swv2_tn_slab_launch(const swv2_wgrad_item* it, void* ws, size_t ws_bytes, co
         q.dW = it[i].dW; q.db = it[i].db; q.nmap = it[i].nmap; q.kmap = it[i].kmap; q.part = p.part; q.dbpart = p.dbpart;
         q.ldw = it[i].ldw; q.N = p.N; q.K = p.K; q.TN = sh.TN[i]; q.TK = sh.TK[i]; q.WGK = sh.WGK[i];
         q.IA = sh.TN[i] / (16 * sh.WGN[i]); q.JB = sh.TK[i] / (16 * sh.WGK[i]); q.ntk = p.K / sh.TK[i]; q.S = pl.S[i]; q.first = rfirst;
-        rfirst += p.N * p.K / 256;
+        rfirst += p.N * p.K / 256 / cpw;
         q.dbfirst = dbfirst;
         dbfirst += cdiv(p.N, 64);
     }

@@ -76,12 +76,17 @@ class PreProcessor(nn.Module):
     def forward(self, data):
         if isinstance(data, AssembledBatch):          # host pipeline: zenith + invariants already written by the assembly kernels
             return tuple(data)
+        # zenith channel and invariants appended in ONE torch.cat (the reference appends them one after the other: two full copies of
+        # the 73-channel input, 0.65 ms per step at local batch 2; same result)
+        parts = None
         if self.params.add_zenith:
             inp, tar, izen, tzen = map(lambda x: x.to(self.device, dtype=torch.float), data)
-            inp = torch.cat([inp, izen], dim=1)
+            parts = [inp, izen]
         else:
             inp, tar = map(lambda x: x.to(self.device, dtype=torch.float), data)
             tzen = None
         if self.do_add_static_features:
-            inp = torch.cat([inp, self.static_features.expand(inp.shape[0], -1, -1, -1)], dim=1)
+            parts = (parts or [inp]) + [self.static_features.expand(inp.shape[0], -1, -1, -1)]
+        if parts is not None:
+            inp = torch.cat(parts, dim=1)
         return inp, tar, tzen

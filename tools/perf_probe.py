@@ -108,9 +108,9 @@ def probe_gemm(B=2):
     say(f"ln_residual_bwd: {t:.1f} us ({M * Cc * (2 + 4 + 2) / t / 1e3:.0f} GB/s)")
 
 
-def probe_mlp(B=2):
+def probe_mlp(B=2, hid=512):
     import ctypes
-    T, Cc, hid = 64800, 128, 512
+    T, Cc = 64800, 128
     M = B * T
     x = torch.randn(M, Cc, device=dev)
     w1, w2 = ops.prep_weight(torch.randn(hid, Cc, device=dev) * 0.1), ops.prep_weight(torch.randn(Cc, hid, device=dev) * 0.1)
@@ -123,7 +123,7 @@ def probe_mlp(B=2):
     a.M, a.C, a.hidden, a.rows_per_sample, a.eps = M, Cc, hid, T, 1e-5
     fn, st = L.load().swv2_mlp_fwd, torch.cuda.current_stream().cuda_stream
     t = timeit(lambda: fn(ctypes.byref(a), st), n=20)
-    say(f"mlp_fwd M={M}: {t:.1f} us ({M * (Cc * 4 * 2 + hid * 2 + Cc * 2) / t / 1e3:.0f} GB/s)")
+    say(f"mlp_fwd M={M} hidden={hid}: {t:.1f} us ({M * (Cc * 4 * 2 + hid * 2 + Cc * 2) / t / 1e3:.0f} GB/s)")
     dy, da2, dh, dx = torch.randn(M, Cc, device=dev), torch.empty(M, Cc, dtype=BF, device=dev), torch.empty(M, hid, dtype=BF, device=dev), torch.empty(M, Cc, device=dev)
     dg, db = torch.zeros(Cc, device=dev), torch.zeros(Cc, device=dev)
     ws = torch.empty(L.load().swv2_mlp_bwd_ws_floats(M, Cc), device=dev)
@@ -135,12 +135,13 @@ def probe_mlp(B=2):
     b.M, b.C, b.hidden, b.rows_per_sample = M, Cc, hid, T
     fb = L.load().swv2_mlp_bwd
     t = timeit(lambda: fb(ctypes.byref(b), st), n=20)
-    say(f"mlp_bwd M={M}: {t:.1f} us ({M * (Cc * 4 * 2 + hid * 2 * 2 + Cc * 2 * 2) / t / 1e3:.0f} GB/s)")
+    say(f"mlp_bwd M={M} hidden={hid}: {t:.1f} us ({M * (Cc * 4 * 2 + hid * 2 * 2 + Cc * 2 * 2) / t / 1e3:.0f} GB/s)")
 
 
 if __name__ == "__main__":
     if "mlp" in (sys.argv[1] if len(sys.argv) > 1 else ""):
-        probe_mlp(2)
+        for hid in ([128, 256, 512, 1024] if "sweep" in sys.argv[1] else [512]):      # (mlp_sweep: cost per 32-unit weight chunk vs fixed cost)
+            probe_mlp(2, hid)
     flt = sys.argv[1] if len(sys.argv) > 1 else ""
     if "attn" in flt or not flt:
         probe_attn(2, False)

@@ -324,7 +324,10 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
     // 4 x 45 KB + 63 KB) -- their fragments are then read from global memory / L2 (the slab layout in memory is the LDS
     // image), the transposed ones as four 2-byte loads.  A coverage path for wide heads, not a tuned one.
     constexpr bool QG = (4 * SLAB * 2 + IROWS * DSP * 2 + Lp * 8 + 256 > 160 * 1024);
-    constexpr bool AUG = AUGP && DK <= 2 && !HAS_BIAS && TPW == 1 && !QG;
+    constexpr bool AUG = AUGP && DK <= 2 && TPW == 1 && !QG && (!HAS_BIAS || (DK == 1 && BIAS_LDS && LFIX > 0));
+    // bias image rows (keys): with AUG the padded keys are switched off inside the operand, so the image ends at the last real key
+    // (rounded up to 4) and the last wave reads a clamped row -- 5 KB that the 80-byte Q / dO rows need
+    constexpr int BROWS = (HAS_BIAS && AUG) ? (LFIX + 3) / 4 * 4 : Lp;
     // row pitch of the q / dO slabs: AUG rows carry 16 more operand slots, padded to 80 bytes (at 64 bytes the 16-byte operand
     // reads of 16 consecutive rows fall on 4 bank groups: conflict cycles 39 % of the LDS index cycles).  32-wide heads (DK = 2):
     // the 32 channels fill the K = 32 operand, the 8 statistics slots follow them in the same 80-byte row and go through a second
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
     constexpr int QSTAT = AUG ? (DK == 1 ? 16 : 32) : 0;       // first statistics slot of a row
     constexpr int OFF_Q = 0, OFF_DO = OFF_Q + (QG ? 0 : Lp * QP * 2), OFF_LSE = OFF_DO + (QG ? 0 : Lp * QP * 2), OFF_DL = OFF_LSE + Lp * 4,
                   OFF_K = OFF_DL + Lp * 4, OFF_V = OFF_K + SLAB * 2, OFF_DS = OFF_V + SLAB * 2,
-                  OFF_BIAS = OFF_DS + IROWS * DSP * 2, OFF_RED = OFF_BIAS + (BIAS_LDS ? Lp * DSP * 2 : 16),
+                  OFF_BIAS = OFF_DS + IROWS * DSP * 2, OFF_RED = OFF_BIAS + (BIAS_LDS ? BROWS * DSP * 2 : 16),
                   OFF_DLP = OFF_RED + ((WAVES * 4 + 15) / 16) * 16,
                   // chunks per row not a power of two (96 columns = 12 chunks): the per-chunk parts of delta go through LDS
                   LDS_BYTES = OFF_DLP + (((CPR & (CPR - 1)) != 0) ? CH * 4 : 0);
@@ -386,7 +389,7 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
         for (int qt = 0; qt < LT; ++qt) dbr[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (BIAS_LDS && bimg) {
             const uint4* src = (const uint4*)(bimg + (size_t)hd * Lp * DSP);       // Lp * DSP * 2 bytes, multiple of 16
-            for (int i = tid; i < Lp * DSP / 8; i += NT) ((uint4*)biasS)[i] = src[i];
+            for (int i = tid; i < BROWS * DSP / 8; i += NT) ((uint4*)biasS)[i] = src[i];
         } else if (BIAS_LDS) {
             // 8 loads in flight per thread (a load -> LDS-write loop exposes one memory round trip per element: 44 trips)
             for (int i0 = 0; i0 < Lp * Lp; i0 += 8 * NT) {
@@ -400,7 +403,7 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int i = i0 + u * NT + tid, q = i / Lp, k = i - q * Lp;
-                    if (i < Lp * Lp) biasS[k * DSP + q] = f2bf((k < L) ? ((q < L) ? v[u] * SWV2_LOG2E : 0.f) : SWV2_NEG_BIG);
+                    if (i < Lp * Lp && k < BROWS) biasS[k * DSP + q] = f2bf((k < L) ? ((q < L) ? v[u] * SWV2_LOG2E : 0.f) : SWV2_NEG_BIG);
                 }
             }
         } else {
@@ -607,7 +610,54 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
                 }
             }
         };
-        if constexpr (HAS_BIAS) {
+        if constexpr (HAS_BIAS && AUG) {
+            // CPB bias with the statistics / padded-key flag / shift mask inside the K = 32 operands (16-wide heads, bias image in LDS):
+            // S' = Q_aug K_aug^T and dP' = dO_aug V_aug^T as in the kernel without bias, p = exp2(fma(S', sigma log2 e, b)), dS = p dP'.
+            // Against the branch below: two 16-byte operand reads instead of four 8-byte + two statistics reads, no subtractions /
+            // selects.  Rolled loop and the scalar switch for the d bias rows as below (44 registers of d bias leave no room for the
+            // two-stage pipeline of the kernel without bias).
+            const int key = 16 * tw + fr;
+            const float cmask = do_mask ? fmaxf(-100.f * SWV2_LOG2E * inv_sc2, -1.0e30f) : 0.f;
+            bf16x8 kf8, vf8;
+            {
+                const uint32_t m1 = 0xbf80u;                                       // -1
+                const uint32_t padk = (key < Lc) ? 0u : (uint32_t)f2bf(-1.0e30f);
+                const bool kreg = key >= mask_thr;
+                const uint32_t mk0 = f2bf(kreg ? 0.f : cmask), mk1 = f2bf(kreg ? cmask : 0.f);
+                const uint4 augk = make_uint4(m1 | (m1 << 16), m1 | (padk << 16), mk0 | (mk1 << 16), 0);
+                const uint4 augv = make_uint4(m1 | (m1 << 16), m1, 0, 0);
+                const uint4 z = make_uint4(0, 0, 0, 0);
+                const uint4 rk = *(const uint4*)(Ks + key * DP + (g & 1) * 8), rv = *(const uint4*)(Vs + key * DP + (g & 1) * 8);
+                kf8 = __builtin_bit_cast(bf16x8, g < 2 ? rk : (g == 2 ? augk : z));
+                vf8 = __builtin_bit_cast(bf16x8, g < 2 ? rv : (g == 2 ? augv : z));
+            }
+            const uint16_t* const Qa = (const uint16_t*)(lds + OFF_Q);
+            const uint16_t* const Da = (const uint16_t*)(lds + OFF_DO);
+#pragma unroll 1
+            for (int qt = 0; qt < LT; ++qt) {
+                const bf16x8 qa = *(const bf16x8*)(Qa + (16 * qt + fr) * QP + 8 * g);
+                const bf16x8 da = *(const bf16x8*)(Da + (16 * qt + fr) * QP + 8 * g);
+                const bf16x4 td = lds_tr_read(Da + (16 * qt + 4 * g + (fr >> 2)) * QP + (fr & 3) * 4);
+                const bf16x4 tq = lds_tr_read(Qa + (16 * qt + 4 * g + (fr >> 2)) * QP + (fr & 3) * 4);
+                const bf16x4 b4 = *(const bf16x4*)(biasS + min(key, BROWS - 1) * DSP + 16 * qt + 4 * g);
+                const f32x4 sv = mfma32(qa, kf8, (f32x4){0.f, 0.f, 0.f, 0.f});
+                const f32x4 dpv = mfma32(da, vf8, (f32x4){0.f, 0.f, 0.f, 0.f});
+                f32x4 p, ds;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    p[r] = __builtin_amdgcn_exp2f(fmaf(sv[r], sc2, bf2f(b4[r])));
+                    ds[r] = p[r] * dpv[r];
+                }
+                const bf16x4 pb = f2bf4(p), dsb = f2bf4(ds);
+                *(bf16x4*)(dSb + key * DSP + 16 * qt + 4 * g) = dsb;
+                dv[0][0] = mfma16(td, pb, dv[0][0]);
+                dk[0][0] = mfma16(tq, dsb, dk[0][0]);
+#define SWV2_CASE(I) case I: if (I < LT) dbr[I < LT ? I : 0] += ds; break;
+                switch (qt) { SWV2_CASE(0) SWV2_CASE(1) SWV2_CASE(2) SWV2_CASE(3) SWV2_CASE(4) SWV2_CASE(5)
+                              SWV2_CASE(6) SWV2_CASE(7) SWV2_CASE(8) SWV2_CASE(9) SWV2_CASE(10) }
+#undef SWV2_CASE
+            }
+        } else if constexpr (HAS_BIAS) {
             const int key = 16 * tw + fr;
             // rolled loop; the bias-gradient rows stay statically indexed registers through a (scalar, wave-uniform)
             // switch on the tile index -- full unrolling costs > 100 extra VGPRs and spills
@@ -971,6 +1021,13 @@ int launch_bwd(const swv2_attn_args* a, hipStream_t st) {
         // benchmark shape)
         const size_t need = (size_t)nchunk * a->heads * a->L * a->L * sizeof(float);
         float* dbws = (a->dbias_ws && a->dbias_ws_bytes >= need) ? (float*)a->dbias_ws : nullptr;
+        // 16-wide heads with the bias image in LDS: statistics / mask inside the MFMA operands here too
+        if (DK == 1 && !(a->dbg & SWV2_ATTN_PLAIN_STATS))
+            hipLaunchKernelGGL((attn_bwd_kernel<LT, DK, true, LFIX, 1, true>), grid, block, 0, st, (const uint16_t*)a->qkvh, a->logit_scale,
+                               a->bias, bimg, (const uint16_t*)a->oh, (const uint16_t*)a->doh, a->lse, a->rnorm,
+                               (uint16_t*)a->dqkvh, a->dlogit_scale, a->dbias, a->Bw, a->heads, a->L, nW, a->nww, a->nwh,
+                               a->mask_thr, dbws);
+        else
         hipLaunchKernelGGL((attn_bwd_kernel<LT, DK, true, LFIX, 1>), grid, block, 0, st, (const uint16_t*)a->qkvh, a->logit_scale,
                            a->bias, bimg, (const uint16_t*)a->oh, (const uint16_t*)a->doh, a->lse, a->rnorm,
                            (uint16_t*)a->dqkvh, a->dlogit_scale, a->dbias, a->Bw, a->heads, a->L, nW, a->nww, a->nwh,

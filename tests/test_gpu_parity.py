@@ -271,6 +271,63 @@ def test_wide_gemm_kernels_equal_the_128_tile_kernel_bit_for_bit(dev, K, persist
             assert rel(g.float(), rows @ rb(wo).T) < 4e-3
 
 
+def test_cfg4_qkv_part_launches_and_dx_partial_tile(dev, K):
+    """BASELINE configs[4]'s two per-block products on their round-4 kernels, at a row count that selects them (Bw * Lp >= 32 768):
+    qkv -- 192 -> 3 x 8 heads in 32-wide slots (head dim 24: the pad rows of the weight / bias are zero) as three resident-weight
+    launches, one per q / k / v part, gathered fp32 rows with zero rows, bias, head split, L2-normalised q and k + rnorm -- against
+    torch; d(qkv) -> dx -- head-major operand, N = 192, K = 768, residual add + scatter -- as one partial column tile of the LDS-DMA
+    kernel, against torch AND bit for bit against the 64-row tile kernel (SWV2_GEMM_WIDE=0: same k order, same epilogue arithmetic)."""
+    ops, L = K["ops"], K["L"]
+    torch.manual_seed(21)
+    h, d, DP, Lp, Lv, Bw, Cc = 8, 24, 32, 176, 162, 190, 192
+    Mw = Bw * Lp                                                  # 33 440 rows
+    T = Bw * Lv
+    x = torch.randn(T, Cc)
+    ri = torch.full((Bw, Lp), -1, dtype=torch.int32)
+    ri[:, :Lv] = torch.randperm(T).to(torch.int32).view(Bw, Lv)   # window order -> image rows; padded rows gather nothing
+    ri = ri.view(-1)
+    real = (torch.arange(DP) < d).repeat(3 * h)                   # real channels of the 32-wide slots
+    wq, bq = torch.randn(3 * h * DP, Cc) * 0.1, torch.randn(3 * h * DP)
+    wq[~real], bq[~real] = 0, 0
+    wqb = ops.prep_weight(wq.to(dev))
+    qkvh = torch.full((Bw, h, 3, Lp, DP), float("nan"), dtype=BF, device=dev)
+    rn = torch.full((Bw, h, 2, Lp), float("nan"), device=dev)
+    ops.linear(ops.op_f32(x.to(dev), rows=Mw, rowidx=ri.to(dev)), wqb,
+               ops.epilogue(L.EPI_QKV_HEADS, qkvh, bias=bq.to(dev), aux_out=rn, p=(h, 0, Lp, DP, Lv)), 3 * h * DP)
+    xg = torch.zeros(Mw, Cc)
+    ok = ri >= 0
+    xg[ok] = x[ri[ok].long()]
+    full = (rb(xg) @ rb(wq).T + bq).view(Bw, Lp, 3, h, DP).permute(0, 3, 2, 1, 4)          # [Bw][h][3][Lp][DP]
+    valid = (torch.arange(Lp) < Lv).view(1, 1, 1, Lp, 1)
+    full = torch.where(valid, full, torch.zeros(()))
+    nrm = full[:, :, :2].norm(dim=-1).clamp_min(1e-12)
+    exp = full.clone()
+    exp[:, :, :2] = full[:, :, :2] / nrm.unsqueeze(-1)
+    got = qkvh.float().cpu()
+    assert not torch.isnan(got).any() and rel(got, exp) < 4e-3
+    assert float(got[..., d:].abs().max()) == 0 and float(got[:, :, :, Lv:].abs().max()) == 0
+    rn_exp = torch.where(valid.view(1, 1, 1, Lp), 1.0 / nrm, torch.zeros(()))
+    assert rel(rn.cpu(), rn_exp) < 1e-4
+    # d(qkv) -> dx: rows scattered back to image order on top of the residual gradient
+    dq = torch.randn(Bw, h, 3, Lp, DP).to(BF)
+    dq[..., d:] = 0
+    dq[:, :, :, Lv:] = 0
+    wt = torch.randn(Cc, 3 * h * DP) * 0.05                       # W_qkv^T rows = output channels, columns in head-major order
+    wtb = ops.prep_weight(wt.to(dev))
+    aux = torch.randn(T, Cc)
+    outs = []
+    for flag in ("0", "1"):
+        dx = torch.full((T, Cc), float("nan"), device=dev)
+        _with_wide(flag, lambda: ops.linear(ops.op_heads(dq.to(dev), Bw, h, 3, Lp, DP), wtb,
+                                            ops.epilogue(L.EPI_F32, dx, ld=Cc, aux=aux.to(dev), rowidx=ri.to(dev)), Cc))
+        outs.append(dx.cpu())
+    assert torch.equal(outs[0], outs[1])
+    rows = dq.float().permute(0, 3, 2, 1, 4).reshape(Mw, 3 * h * DP)
+    exp = aux.clone()
+    exp[ri[ok].long()] += (rows @ rb(wt).T)[ok]
+    assert not torch.isnan(outs[1]).any() and rel(outs[1], exp) < 1e-5
+
+
 def test_wide_weight_gradient_kernel(dev, K):
     """gemm_tn_wide_kernel (256 x 256 tiles by LDS-DMA, transposed fragment reads, partial matrices + reduction) against torch and
     against the 128-tile kernel: every operand pair of the width-768 block -- bf16 x bf16, bf16 x fp32 (cast pre-pass), head-major

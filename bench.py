@@ -234,6 +234,8 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, the measured path); gloo: self-test of the N > 1 code path with all ranks on one GPU "
                          "(tests/test_gpu_parity.py), never a benchmark")
+    ap.add_argument("--time-every", type=int, default=6, help="bracket every N-th launch of the roofline kernel inside the timed region with HIP events")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="diagnostic: no HIP event pairs inside the timed region (the roofline object is then empty)")
     ap.add_argument("--settle", type=int, default=8, help="untimed set-up steps before the W warm-up steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", default="full", choices=["full", "extrapolate"],
@@ -330,14 +332,26 @@ def main():
     for i in range(a.warmup):
         step(i)
     fence()
-    timed_kernels = [a.roofline_kernel] + [k for k in ROOFLINE_KERNELS if k != a.roofline_kernel]
-    ops.start_kernel_timing(timed_kernels)
+    # Inside the timed region only the roofline kernel is bracketed with HIP events, and only on every 6th eligible block call
+    # (2 of its 12 launches per step): an event record between two kernels is a packet the next kernel waits behind -- one pair per
+    # block call (24 per step, what rounds 2 - 3 did to time nine kernels at once) measured 3.3 % of the step (208.5 vs 215.5
+    # samples/s).  The other kernels of `roofline_others` are timed in extra steps AFTER the timed region.
+    ops.prewarm_events(64)
+    fence()
+    ops.start_kernel_timing([] if a.no_kernel_timing else [a.roofline_kernel], every=a.time_every)
     t0 = time.perf_counter()
     for i in range(a.steps):
         loss = step(a.warmup + i)
     fence()
     dt = time.perf_counter() - t0
     ktimes = ops.stop_kernel_timing()
+    others = [k for k in ROOFLINE_KERNELS if k != a.roofline_kernel]
+    if others and not a.no_kernel_timing:          # not part of `value`: three more steps with every block call bracketed
+        ops.start_kernel_timing(others)
+        for i in range(3):
+            step(i)
+        fence()
+        ktimes.update(ops.stop_kernel_timing())
     # after the timed region (not part of `value`): the same kernel without the co-running weight-gradient stream
     alone_ms = None
     if world == 1 and os.environ.get("SWV2_WGRAD_SIDE_STREAM", "0") != "0":
@@ -406,6 +420,7 @@ def main():
             pmc = None
         main_rf = roofline_entry(a.roofline_kernel, ktimes, a, pmc, B)
         main_rf["co_running"] = None
+        main_rf["timed"] = f"HIP event pairs on the launch stream around every {a.time_every}th launch inside the timed region"
         if alone_ms:
             main_rf["avg_ms_alone"] = alone_ms
             main_rf["frac_alone"] = main_rf["algorithmic_bytes_per_launch"] / (alone_ms * 1e-3) / 1e9 / 8000.0
@@ -427,7 +442,8 @@ def main():
             "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)},
             "weak_scaling_local_batch": B,      # fixed per GPU at every N (BASELINE cfg 2's batch; cfg 3's 8 per GPU: --local-batch 8)
             "roofline": main_rf,
-            "roofline_others": [roofline_entry(k, ktimes, a, pmc, B) for k in ROOFLINE_KERNELS if k != a.roofline_kernel],
+            "roofline_others": [dict(roofline_entry(k, ktimes, a, pmc, B), timed="every launch of 3 extra steps AFTER the timed region")
+                                for k in ROOFLINE_KERNELS if k != a.roofline_kernel],
             "attention_module": attention_module(ktimes, a, B),
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -206,8 +206,12 @@ class LossHandler(nn.Module):
         lc, self._fused = self._fused, None
         if (lc is not None and lc.y is not None and lc.tar is tar and self.training and
                 (lc.y is prd or (prd.data_ptr() == lc.y.data_ptr() and prd.shape == lc.y.shape and prd.dtype == lc.y.dtype))):
-            chw = (self.channel_weights * self.multistep_weight).reshape(-1).contiguous().float()
-            return _FusedGeoL2.apply(lc.sums, chw, self.absolute, self.squared)
+            # (the product of two constant buffers: cached, one tiny launch per step less; re-made when a buffer moved or changed)
+            key = (self.channel_weights.data_ptr(), self.channel_weights._version, self.multistep_weight.data_ptr(), self.multistep_weight._version)
+            if getattr(self, "_chw_key", None) != key:
+                self._chw_flat = (self.channel_weights * self.multistep_weight).reshape(-1).contiguous().float()
+                self._chw_key = key
+            return _FusedGeoL2.apply(lc.sums, self._chw_flat, self.absolute, self.squared)
         chw = self.channel_weights
         if self.training:
             chw = (chw * self.multistep_weight).reshape(1, -1)

@@ -446,6 +446,13 @@ int swv2_cpb_fwd(const float* w1, const float* b1, const float* w2, const float*
                  int wh, int ww, int heads, int hidden, float drop_p, void* stream);
 int swv2_cpb_bwd(const float* dbias, const float* w1, const float* b1, const float* w2, const void* keep_bf16, float* dw1,
                  float* db1, float* dw2, float* db2, int wh, int ww, int heads, int hidden, float drop_p, void* stream);
+/* The same with a caller workspace of swv2_cpb_bwd_ws_bytes(wh, ww, heads, hidden) bytes: every workgroup leaves one partial row,
+ * a second launch adds them in a fixed order -- no float atomics (bit-reproducible gradients).  ws = NULL or too small: the atomics
+ * path of swv2_cpb_bwd.  Outputs ACCUMULATED as above. */
+size_t swv2_cpb_bwd_ws_bytes(int wh, int ww, int heads, int hidden);
+int swv2_cpb_bwd_ws(const float* dbias, const float* w1, const float* b1, const float* w2, const void* keep_bf16, float* dw1,
+                    float* db1, float* dw2, float* db2, int wh, int ww, int heads, int hidden, float drop_p, void* ws,
+                    size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Whole-block orchestration: one host call enqueues the 7 forward / 13 backward launches of a Swin block

@@ -200,6 +200,8 @@ SYMBOLS = {
     "swv2_mlp_bwd": (_I, [C.POINTER(MlpBwdArgs), _P]),
     "swv2_cpb_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "swv2_cpb_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "swv2_cpb_bwd_ws": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, C.c_size_t, _P]),
+    "swv2_cpb_bwd_ws_bytes": (C.c_size_t, [_I, _I, _I, _I]),
     "swv2_block_fwd": (_I, [C.POINTER(BlockDesc), _P]),
     "swv2_block_bwd": (_I, [C.POINTER(BlockDesc), _P]),
 }

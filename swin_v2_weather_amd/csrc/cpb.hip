@@ -83,7 +83,7 @@ __global__ __launch_bounds__(512) void cpb_bwd_kernel(const float* __restrict__ 
                                                       const uint16_t* __restrict__ keep, float* __restrict__ dw1,
                                                       float* __restrict__ db1, float* __restrict__ dw2,
                                                       float* __restrict__ db2, int L, int ww, int heads, int Hd,
-                                                      float scale, int pairs_per_block) {
+                                                      float scale, int pairs_per_block, float* __restrict__ part) {
     __shared__ __attribute__((aligned(16))) float dbs[64][HEADS_MAX + 4];   // [pair][d bias of head 0.., r0, r1]
     const int j = threadIdx.x;
     const bool act = j < Hd;
@@ -140,6 +140,22 @@ __global__ __launch_bounds__(512) void cpb_bwd_kernel(const float* __restrict__ 
         if (j < heads)
             for (int pp = 0; pp < 64; ++pp) gb2 += dbs[pp][j];
     }
+    if (part) {
+        // one partial row per workgroup, laid out like the four gradients one after the other: [dw1 (2 Hd) | db1 (Hd) | dw2 (heads Hd) |
+        // db2 (heads)]; cpb_fold_kernel adds the rows in a fixed order (no atomics: the gradient is bit-reproducible, and 205 workgroups
+        // no longer queue on the same 4 232 addresses)
+        float* row = part + (size_t)blockIdx.x * (3 * Hd + heads * Hd + heads);
+        if (act) {
+            row[2 * j] = ga;
+            row[2 * j + 1] = gb;
+            row[2 * Hd + j] = gbias;
+#pragma unroll
+            for (int h = 0; h < HEADS_MAX; ++h)
+                if (h < heads) row[3 * Hd + h * Hd + j] = g2[h];
+        }
+        if (j < heads) row[3 * Hd + heads * Hd + j] = gb2;
+        return;
+    }
     if (act) {
         atomicAdd(dw1 + 2 * j, ga);
         atomicAdd(dw1 + 2 * j + 1, gb);
@@ -149,6 +165,32 @@ __global__ __launch_bounds__(512) void cpb_bwd_kernel(const float* __restrict__ 
             if (h < heads) atomicAdd(dw2 + h * Hd + j, g2[h]);
     }
     if (j < heads) atomicAdd(db2 + j, gb2);
+}
+
+// out[i] += sum over the workgroups' partial rows (fixed order); 64 entries x 8 row groups per workgroup, four loads in flight per thread
+__global__ __launch_bounds__(512) void cpb_fold_kernel(const float* __restrict__ part, int rows, int n, float* __restrict__ dw1,
+                                                        float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2,
+                                                        int Hd, int heads) {
+    __shared__ float red[8][64];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6, i = blockIdx.x * 64 + lane;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (i < n) {
+        int r = rg;
+        for (; r + 24 < rows; r += 32) {
+            a0 += part[(size_t)r * n + i];
+            a1 += part[(size_t)(r + 8) * n + i];
+            a2 += part[(size_t)(r + 16) * n + i];
+            a3 += part[(size_t)(r + 24) * n + i];
+        }
+        for (; r < rows; r += 8) a0 += part[(size_t)r * n + i];
+    }
+    red[rg][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (rg == 0 && i < n) {
+        const float t = ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) + ((red[4][lane] + red[5][lane]) + (red[6][lane] + red[7][lane]));
+        float* dst = i < 2 * Hd ? dw1 + i : i < 3 * Hd ? db1 + (i - 2 * Hd) : i < 3 * Hd + heads * Hd ? dw2 + (i - 3 * Hd) : db2 + (i - 3 * Hd - heads * Hd);
+        *dst += t;
+    }
 }
 
 }  // namespace
@@ -172,23 +214,46 @@ extern "C" int swv2_cpb_fwd(const float* w1, const float* b1, const float* w2, c
     return SWV2_OK;
 }
 
+extern "C" int swv2_cpb_bwd_ws(const float* dbias, const float* w1, const float* b1, const float* w2, const void* keep_bf16,
+                               float* dw1, float* db1, float* dw2, float* db2, int wh, int ww, int heads, int hidden,
+                               float drop_p, void* ws, size_t ws_bytes, void* stream);
+
+extern "C" size_t swv2_cpb_bwd_ws_bytes(int wh, int ww, int heads, int hidden) {
+    if (wh <= 0 || ww <= 0 || heads <= 0 || hidden <= 0) return 0;
+    const int L2 = wh * ww * wh * ww;
+    return (size_t)cdiv(L2, 128) * (3 * hidden + heads * hidden + heads) * sizeof(float);
+}
+
 extern "C" int swv2_cpb_bwd(const float* dbias, const float* w1, const float* b1, const float* w2, const void* keep_bf16,
                             float* dw1, float* db1, float* dw2, float* db2, int wh, int ww, int heads, int hidden,
                             float drop_p, void* stream) {
+    return swv2_cpb_bwd_ws(dbias, w1, b1, w2, keep_bf16, dw1, db1, dw2, db2, wh, ww, heads, hidden, drop_p, nullptr, 0, stream);
+}
+
+extern "C" int swv2_cpb_bwd_ws(const float* dbias, const float* w1, const float* b1, const float* w2, const void* keep_bf16,
+                               float* dw1, float* db1, float* dw2, float* db2, int wh, int ww, int heads, int hidden,
+                               float drop_p, void* ws, size_t ws_bytes, void* stream) {
     SWV2_CHECK_ARG(dbias && w1 && b1 && w2 && dw1 && db1 && dw2 && db2, "cpb_bwd: null pointer");
     SWV2_CHECK_ARG(heads > 0 && heads <= CPB_MAX_HEADS && hidden > 0 && hidden <= 512 && drop_p >= 0.f && drop_p < 1.f,
                    "cpb_bwd: heads <= %d, hidden <= 512 required", CPB_MAX_HEADS);
     const int L = wh * ww, L2 = L * L, ppb = 128;      // measured: 64 -> 34 us, 128 -> 33 us, 256 -> 46 us (9x18 window)
     const int threads = cdiv(hidden, 64) * 64;
     const float scale = 1.f / (1.f - drop_p);
+    // with a workspace (swv2_cpb_bwd_ws_bytes): partial rows + a fixed-order fold instead of float atomics
+    float* part = (ws && ws_bytes >= swv2_cpb_bwd_ws_bytes(wh, ww, heads, hidden)) ? (float*)ws : nullptr;
 #define CPB_BWD(HM)                                                                                                  \
     hipLaunchKernelGGL((cpb_bwd_kernel<HM>), dim3(cdiv(L2, ppb)), dim3(threads), 0, (hipStream_t)stream, dbias, w1, b1, \
-                       w2, (const uint16_t*)keep_bf16, dw1, db1, dw2, db2, L, ww, heads, hidden, scale, ppb)
+                       w2, (const uint16_t*)keep_bf16, dw1, db1, dw2, db2, L, ww, heads, hidden, scale, ppb, part)
     if (heads <= 4) CPB_BWD(4);
     else if (heads <= 8) CPB_BWD(8);
     else if (heads <= 16) CPB_BWD(16);
     else CPB_BWD(CPB_MAX_HEADS);
 #undef CPB_BWD
+    if (part) {
+        const int n = 3 * hidden + heads * hidden + heads;
+        hipLaunchKernelGGL(cpb_fold_kernel, dim3(cdiv(n, 64)), dim3(512), 0, (hipStream_t)stream, (const float*)part, cdiv(L2, ppb), n, dw1,
+                           db1, dw2, db2, hidden, heads);
+    }
     SWV2_CHECK_LAUNCH("swv2_cpb_bwd");
     return SWV2_OK;
 }

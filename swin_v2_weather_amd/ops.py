@@ -466,9 +466,18 @@ def cpb_fwd(w1, b1, w2, b2, keep, bias, wh, ww, heads, hidden, drop_p):
             "swv2_cpb_fwd")
 
 
-def cpb_bwd(dbias, w1, b1, w2, keep, dw1, db1, dw2, db2, wh, ww, heads, hidden, drop_p):
-    L.check(L.load().swv2_cpb_bwd(_p(dbias), _p(w1), _p(b1), _p(w2), _p(keep), _p(dw1), _p(db1), _p(dw2), _p(db2), wh, ww,
-                                  heads, hidden, drop_p, _stream()), "swv2_cpb_bwd")
+def cpb_bwd(dbias, w1, b1, w2, keep, dw1, db1, dw2, db2, wh, ww, heads, hidden, drop_p, atomics=False):
+    """d(meta MLP) accumulated into dw1 / db1 / dw2 / db2: partial rows in a scratch buffer + a fixed-order fold (default), or the float
+    atomics of swv2_cpb_bwd (`atomics=True`)"""
+    lib = L.load()
+    if atomics:
+        L.check(lib.swv2_cpb_bwd(_p(dbias), _p(w1), _p(b1), _p(w2), _p(keep), _p(dw1), _p(db1), _p(dw2), _p(db2), wh, ww,
+                                 heads, hidden, drop_p, _stream()), "swv2_cpb_bwd")
+        return
+    nb = lib.swv2_cpb_bwd_ws_bytes(wh, ww, heads, hidden)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dbias.device)
+    L.check(lib.swv2_cpb_bwd_ws(_p(dbias), _p(w1), _p(b1), _p(w2), _p(keep), _p(dw1), _p(db1), _p(dw2), _p(db2), wh, ww,
+                                heads, hidden, drop_p, _p(ws), nb, _stream()), "swv2_cpb_bwd_ws")
 
 
 # ---- per-geometry index tables ------------------------------------------------------------------------------

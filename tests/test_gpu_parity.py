@@ -1576,6 +1576,19 @@ def test_cpb_kernels_match_oracle(dev, K, wh, ww, heads, hidden, train):
                 heads, hidden, 0.125)
     for gk, k in zip(gs, ("a.meta_mlp.fc1.weight", "a.meta_mlp.fc1.bias", "a.meta_mlp.fc2.weight", "a.meta_mlp.fc2.bias")):
         assert rel(gk, p[k].grad) < 2e-5, k
+    # the default path (partial rows + fixed-order fold, swv2_cpb_bwd_ws) is bit-reproducible and ACCUMULATES; the float-atomics path
+    # (swv2_cpb_bwd) gives the same sums up to the order of the additions
+    gs2 = [torch.zeros_like(g_) for g_ in gs]
+    ops.cpb_bwd(gy.to(dev), d["a.meta_mlp.fc1.weight"], d["a.meta_mlp.fc1.bias"], d["a.meta_mlp.fc2.weight"], keep_d, *gs2, wh, ww,
+                heads, hidden, 0.125)
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(gs, gs2))
+    ops.cpb_bwd(gy.to(dev), d["a.meta_mlp.fc1.weight"], d["a.meta_mlp.fc1.bias"], d["a.meta_mlp.fc2.weight"], keep_d, *gs2, wh, ww,
+                heads, hidden, 0.125)
+    assert all(rel(b_, 2 * a_) < 1e-6 for a_, b_ in zip(gs, gs2))
+    gs3 = [torch.zeros_like(g_) for g_ in gs]
+    ops.cpb_bwd(gy.to(dev), d["a.meta_mlp.fc1.weight"], d["a.meta_mlp.fc1.bias"], d["a.meta_mlp.fc2.weight"], keep_d, *gs3, wh, ww,
+                heads, hidden, 0.125, atomics=True)
+    assert all(rel(b_, a_) < 1e-5 for a_, b_ in zip(gs, gs3))
 
 
 @pytest.mark.parametrize("M,Cc,hid,T", [(300, 128, 512, 100), (77, 32, 128, 77), (130, 96, 384, 65), (50, 192, 96, 25), (64, 256, 64, 64),

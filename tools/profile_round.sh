@@ -14,7 +14,7 @@ rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o p --output-format csv -- $B > $O/fetch
 rocprofv3 --pmc WRITE_SIZE -d $O/write -o p --output-format csv -- $B > $O/write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -d $O/sq -o p --output-format csv -- $B > $O/sq.log 2>&1
 cd $R
-python3 profiles/summarize.py stats $O/trace 21 $O/${TAG}_kernel_stats.md > /dev/null
+python3 profiles/summarize.py stats $O/trace 24 $O/${TAG}_kernel_stats.md > /dev/null
 python3 profiles/summarize.py pmc $O/fetch $O/write $O/${TAG}_pmc_hbm.json > /dev/null
 python3 profiles/summarize.py counters $O/sq $O/${TAG}_pmc_sq.json > /dev/null
 python3 profiles/summarize.py mfma $O/${TAG}_pmc_sq.json $O/${TAG}_pmc_mfma.json > $O/mfma.txt

@@ -215,6 +215,87 @@ def attention_module(ktimes, a, B):
     return out
 
 
+def secondary_legs(a, dev, rank):
+    """After the timed region (never part of `value`): the other BASELINE.json configurations and the variants VERDICT r4 asked to see
+    in the driver-run line instead of builder-written files -- each 3 settle + 8 timed steps of the same full optimisation step, same
+    process, one GPU: the CPB-bias model (rel_pos=True: the attention the north star describes), configs[2]'s per-GPU load (local batch
+    8), configs[3] (depth 24 / embed 192 / 77 input channels with zenith + invariants / channel-weighted loss, through the Trainer) and
+    configs[4] (2-step autoregressive rollout, through the Trainer).  Returns a list of {"workload", "local_batch", "value",
+    "ms_per_step"} (+ "error" when a leg failed: a broken leg must not cost the headline line)."""
+    import gc
+    import tempfile
+    from swin_v2_weather_amd.networks.helpers import get_model
+    from swin_v2_weather_amd.utils.losses import LossHandler
+    from swin_v2_weather_amd.utils.optim import HipAdam
+    settle, steps = 3, 8
+    out = []
+
+    def timed(step_fn):
+        for i in range(settle):
+            step_fn(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step_fn(settle + i)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    def bench_loop_leg(label, rel_pos, B):
+        torch.manual_seed(333)
+        p = model_params(a)
+        p.rel_pos = bool(rel_pos)
+        model = get_model(p).to(dev)
+        model.train()
+        lp = SimpleNamespace(n_future=0, img_shape_x=a.height, img_shape_y=a.width, loss="l2", channel_weights="none",
+                             n_out_channels=73, model_grid_type="equiangular")
+        loss_obj = LossHandler(lp).to(dev)
+        opt = HipAdam(model.parameters(), lr=1e-3, betas=(0.9, 0.95))
+        g = torch.Generator(device=dev).manual_seed(333 + rank)
+        pool = [(torch.randn(B, 73, a.height, a.width, device=dev, generator=g),
+                 torch.randn(B, 73, a.height, a.width, device=dev, generator=g)) for _ in range(2)]
+
+        def step(i):
+            inp, tar = pool[i % 2]
+            model.zero_grad()
+            with loss_obj.fused_with(model, tar):
+                gen = model(inp)
+            loss = loss_obj(gen, tar, inp)
+            loss.backward()
+            opt.step()
+        dt = timed(step)
+        return {"workload": label, "local_batch": B, "value": B / dt, "ms_per_step": 1e3 * dt, "loop": "bench.py"}
+
+    def trainer_leg(label, cfg_name, B):
+        from swin_v2_weather_amd.train import Trainer
+        from swin_v2_weather_amd.utils.YParams import YParams
+        p = YParams(os.path.join(ROOT, "swin_v2_weather_amd", "config", "swin.yaml"), cfg_name)
+        p["batch_size"], p["max_epochs"] = B, 1
+        p["synthetic_device_pool"], p["synthetic_steps_per_epoch"] = 2, settle + steps
+        p["exp_dir"], p["save_checkpoint"], p["log_to_screen"], p["log_to_wandb"] = tempfile.mkdtemp(prefix="swv2_bench_"), False, False, False
+        tr = Trainer(p, SimpleNamespace(sweep_id=None, config=cfg_name, run_num="00", enable_amp=True))
+        tr.build()
+        tr.model.train()
+        it = iter(tr.train_data_loader)
+        dt = timed(lambda i: tr.train_step(next(it)))
+        return {"workload": label, "local_batch": B, "value": B / dt, "ms_per_step": 1e3 * dt, "loop": "Trainer.train_step", "yaml": cfg_name}
+
+    base = f"swin_73var depth{a.depth} embed{a.embed_dim} heads{a.heads} 73x{a.height}x{a.width}"
+    legs = [
+        (lambda: bench_loop_leg(base + " rel_pos=True (log-spaced CPB bias, meta-MLP dropout on)", 1, a.local_batch)),
+        (lambda: bench_loop_leg(base + " rel_pos=False at configs[2]'s per-GPU load", 0, 8)),
+        (lambda: trainer_leg("configs[3]: swin_73var_geo depth24 embed192 77ch (zenith + orography + landmask) chweight loss", "bench_geo_depth24_e192_invar", 2)),
+        (lambda: trainer_leg("configs[4]: 2-step autoregressive finetune, depth12 embed128 77ch, multi-step loss", "bench_depth12_e128_2step", 2)),
+    ]
+    for leg in legs:
+        try:
+            out.append(leg())
+        except Exception as e:                      # noqa: BLE001
+            out.append({"workload": "leg failed", "error": f"{type(e).__name__}: {e}"[:300]})
+        gc.collect()
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -238,6 +319,7 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true", help="diagnostic: no HIP event pairs inside the timed region (the roofline object is then empty)")
     ap.add_argument("--settle", type=int, default=8, help="untimed set-up steps before the W warm-up steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary legs (rel_pos=True, local batch 8, configs[3], configs[4]) that follow the timed region at N = 1")
     ap.add_argument("--cpu-baseline", default="full", choices=["full", "extrapolate"],
                     help="full: the real depth-D model, 1 warm-up + 2 timed iterations (default); extrapolate: depth 0 and 1 only")
     ap.add_argument("--roofline-kernel", default="attn_bwd")
@@ -338,13 +420,22 @@ def main():
     # samples/s).  The other kernels of `roofline_others` are timed in extra steps AFTER the timed region.
     ops.prewarm_events(64)
     fence()
+    # one HIP event per STEP boundary (K + 1 records on the launch stream, created beforehand): the GPU-side duration of every timed
+    # step, so that a reader can tell box noise from signal (the timed region is 0.2 s)
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
+    for e_ in step_ev:
+        e_.record()
+    fence()
     ops.start_kernel_timing([] if a.no_kernel_timing else [a.roofline_kernel], every=a.time_every)
     t0 = time.perf_counter()
+    step_ev[0].record()
     for i in range(a.steps):
         loss = step(a.warmup + i)
+        step_ev[i + 1].record()
     fence()
     dt = time.perf_counter() - t0
     ktimes = ops.stop_kernel_timing()
+    step_ms = sorted(step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(a.steps))
     others = [k for k in ROOFLINE_KERNELS if k != a.roofline_kernel]
     if others and not a.no_kernel_timing:          # not part of `value`: three more steps with every block call bracketed
         ops.start_kernel_timing(others)
@@ -395,6 +486,19 @@ def main():
             host_leg[label] = {"samples_per_s": world * B * n_done / dth, "ms_per_step": 1e3 * dth / n_done,
                                "h2d_gb_per_s_per_gpu": B * n_done * 2 * 73 * 721 * 1440 * 4 / dth / 1e9}
             del pipe, src
+    final_loss = float(loss.detach())
+    ddp_observed = None
+    if use_ddp:
+        from swin_v2_weather_amd.networks.helpers import ddp_observed_buckets
+        ddp_observed = ddp_observed_buckets(net)
+    secondary = None
+    if world == 1 and not use_ddp and not a.no_secondary:
+        # the main model / pool are no longer needed: free them before the secondary configurations allocate theirs
+        del loss, pool, opt, net, model, loss_obj
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        secondary = secondary_legs(a, dev, rank)
     rank_ms = [1e3 * dt / a.steps]
     if use_ddp:
         if dist.get_world_size() != a.gpus:
@@ -432,14 +536,20 @@ def main():
                                    f"window{a.height // a.window_ratio}x{a.width // a.window_ratio} rel_pos={bool(a.rel_pos)} "
                                    f"full train step (fwd+loss+bwd+Adam)",
                        "local_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                       "final_loss": float(loss.detach())},
+                       "final_loss": final_loss},
             "model_tflops_per_gpu": value * flops / world / 1e12,
             "mfma_frac_end_to_end": value * flops / world / 2.5e15,
             "host_pipeline": host_leg,
             "backend": a.backend if use_ddp else None,
             "rccl_nranks": dist.get_world_size() if use_ddp else None,
-            "ddp_buckets_mb": ddp_bucket_plan(model)[0] if use_ddp else None,     # in launch order (gradient arrival), cap DDP_BUCKET_CAP_MB   # self-check: ranks in the RCCL group that all-reduced
+            # what the reducer REPORTS after its bucket rebuild (launch order = gradient arrival), next to the plan the cap was chosen with
+            "ddp_buckets_mb": ddp_observed if use_ddp else None,
+            "ddp_buckets_mb_planned": ddp_bucket_plan(model)[0] if use_ddp else None,
             "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)},
+            # GPU-side duration of every timed step of rank 0 (HIP events at the step boundaries): spread of the K steps behind `value`
+            "step_ms": {"min": step_ms[0], "p50": step_ms[len(step_ms) // 2], "p90": step_ms[min(len(step_ms) - 1, int(0.9 * len(step_ms)))],
+                        "max": step_ms[-1], "n": len(step_ms)},
+            "secondary": secondary,
             "weak_scaling_local_batch": B,      # fixed per GPU at every N (BASELINE cfg 2's batch; cfg 3's 8 per GPU: --local-batch 8)
             "roofline": main_rf,
             "roofline_others": [dict(roofline_entry(k, ktimes, a, pmc, B), timed="every launch of 3 extra steps AFTER the timed region")

@@ -25,7 +25,11 @@
 extern "C" {
 #endif
 
-#define SWV2_VERSION 100 /* round 1 */
+/* ABI revision: bumped whenever a struct layout or an entry point of this header changes (swv2_version() returns the value the
+ * library was built with; swin_v2_weather_amd/_lib.py refuses a library whose revision differs from the one it mirrors).
+ * 100 rounds 1 - 4; 105 round 5: swv2_attn_args.dbias_partials, swv2_block_desc.bias_prepacked / dbias_part, the *_multi CPB
+ * entry points, swv2_attn_pack_bias_multi / swv2_attn_bias_chunks, a (max, min) part in the packed bias buffer. */
+#define SWV2_VERSION 105
 
 enum {
     SWV2_OK = 0,
@@ -48,9 +52,10 @@ const char* swv2_last_error(void);
  * ------------------------------------------------------------------------------------------------------------ */
 int swv2_attn_geometry(int L, int head_dim, int* Lp, int* DP);
 
-/* Which forward softmax regime serves window area L / head_dim (with / without a CPB bias table; dbg as in swv2_attn_args): 1 = the
- * operand-folded softmax of csrc/attn2.hip (16- and 32-wide head slots without a CPB table at the 176-row window; exponent reference sigma itself where sigma log2(e) <= 40 in unmasked windows, normaliser =
- * sum of the bf16-rounded exponentials), 0 = row maximum + exact sum (csrc/attn.hip, attn_wide.hip); negative: unsupported geometry.
+/* Which forward softmax regime serves window area L / head_dim (with / without a PACKED CPB bias table; dbg as in swv2_attn_args): 1 = the
+ * operand-folded softmax of csrc/attn2.hip (160 .. 176-token windows; 16- and 32-wide head slots without a table, 16-wide ones with
+ * a packed table; exponent reference sigma' (+ the table's maximum) where 2 sigma' + (table max - min) <= 80 in unmasked windows,
+ * normaliser = sum of the bf16-rounded exponentials), 0 = row maximum + exact sum (csrc/attn.hip, attn_wide.hip); negative: unsupported geometry.
  * Pure host function.  The parity tests declare the regime their oracle emulates and check it against this (reference: the softmax of
  * swinv2_global.py:309-314, one function in both regimes up to rounding). */
 int swv2_attn_fwd_regime(int L, int head_dim, int has_bias, int dbg);
@@ -88,14 +93,21 @@ typedef struct swv2_attn_args {
                                  workgroups store their d bias tables there and one more launch sums them into dbias (in a
                                  fixed order); NULL / too small = 31 K float atomics per workgroup instead */
     size_t dbias_ws_bytes;
+    int dbias_partials;       /* bwd, 1 (needs dbias_ws): LEAVE the workgroups' tables in dbias_ws -- [swv2_attn_bias_chunks(Bw)][heads][L][L],
+                                 every entry written -- and do not touch dbias (may be NULL): the caller sums them, e.g. swv2_cpb_bwd_multi */
 } swv2_attn_args;
 
 /* bytes of swv2_attn_args.dbias_ws for swv2_attn_bwd with a bias */
 size_t swv2_attn_dbias_ws_bytes(int heads, int L, int max_chunks);
 
-/* bias table -> the kernels' layouts (bf16, log2 domain); out: swv2_attn_pack_bias_bytes(heads, L) bytes */
+/* workgroups per head of swv2_attn_bwd with a bias table (= tables per head in dbias_ws) when max_chunks is left to swv2_block_bwd */
+int swv2_attn_bias_chunks(int Bw);
+
+/* bias table -> the kernels' layouts (bf16, log2 domain) + the (max, min) of every head's packed values; out:
+ * swv2_attn_pack_bias_bytes(heads, L) bytes.  _multi: ntab tables [ntab][heads][L][L] -> ntab packed buffers, one launch */
 size_t swv2_attn_pack_bias_bytes(int heads, int L);
 int swv2_attn_pack_bias(const float* bias, int heads, int L, void* out, void* stream);
+int swv2_attn_pack_bias_multi(const float* bias, int ntab, int heads, int L, void* out, void* stream);
 
 /* cosine window attention core, forward: swinv2_global.py:304-318 (q,k normalisation is in the QKV epilogue) */
 int swv2_attn_fwd(const swv2_attn_args* a, void* stream);
@@ -454,6 +466,22 @@ int swv2_cpb_bwd_ws(const float* dbias, const float* w1, const float* b1, const 
                     float* db1, float* dw2, float* db2, int wh, int ww, int heads, int hidden, float drop_p, void* ws,
                     size_t ws_bytes, void* stream);
 
+/* The tables of ALL blocks of a stage in one launch each way (nothing in :240-261,274-287 depends on activations, so the model
+ * computes the `nblk` tables before its first block and their parameter gradients after the first block's backward).
+ *   params_dev : DEVICE array [nblk][4] of device pointers: w1 [hidden][2], b1 [hidden], w2 [heads][hidden], b2 [heads] of each block
+ *   keep_bits  : u32 [nblk][L*L][hidden / 8] of uniformly random bits drawn by the caller, or NULL (eval): hidden unit j of a pair is
+ *                DROPPED iff the 3-bit field (word[j / 8] >> 3 (j % 8)) & 7 is < 8 drop_p (drop_p must be a multiple of 1/8; the
+ *                reference's hard-coded Dropout(0.125), :245, is 1/8); kept units are scaled by 1 / (1 - drop_p)
+ *   bias       : out [nblk][heads][L][L]
+ * backward: dbias_tables [nblk][nchunk][heads][L][L] -- d bias of a block = the SUM of its nchunk tables (the per-workgroup tables
+ * swv2_attn_bwd leaves with dbias_partials; nchunk = 1: plain gradients) -- grads [nblk][3 hidden + heads hidden + heads] =
+ * (dw1 | db1 | dw2 | db2) per block, ACCUMULATED; ws: swv2_cpb_bwd_multi_ws_bytes.  hidden % 32 == 0, heads <= 32.  No atomics. */
+int swv2_cpb_fwd_multi(const float* const* params_dev, int nblk, const uint32_t* keep_bits, float* bias, int wh, int ww, int heads,
+                       int hidden, float drop_p, void* stream);
+size_t swv2_cpb_bwd_multi_ws_bytes(int nblk, int wh, int ww, int heads, int hidden);
+int swv2_cpb_bwd_multi(const float* dbias_tables, int nchunk, const float* const* params_dev, int nblk, const uint32_t* keep_bits,
+                       float* grads, int wh, int ww, int heads, int hidden, float drop_p, void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Whole-block orchestration: one host call enqueues the 7 forward / 13 backward launches of a Swin block
  * (reference SwinTransformerV2CrBlock.forward, swinv2_global.py:480-497, and its autograd) from C++, so the per-launch
@@ -516,6 +544,12 @@ typedef struct swv2_block_desc {
     size_t grad_zero_bytes;
     size_t ln_ws_floats;     /* floats available at ln_ws; >= swv2_mlp_bwd_ws_floats + swv2_proj_ln_bwd_ws_floats lets the backward
                                 keep both LayerNorms' d gamma / d beta partial rows and fold them with ONE launch (0: one each) */
+    int bias_prepacked;      /* 1: bias_pack already holds the packed table (swv2_attn_pack_bias_multi: all blocks' tables in one
+                                launch before the first block); 0: swv2_block_fwd packs `bias` into bias_pack itself */
+    float* dbias_part;       /* optional, with bias: swv2_attn_dbias_ws_bytes(heads, L, swv2_attn_bias_chunks(Bw)) bytes.  The backward
+                                LEAVES the attention workgroups' d bias tables there (swv2_attn_args.dbias_partials) and does not
+                                touch d_bias (may be NULL): the caller sums them with swv2_cpb_bwd_multi */
+    size_t dbias_part_bytes;
 } swv2_block_desc;
 
 int swv2_block_fwd(const swv2_block_desc* d, void* stream);

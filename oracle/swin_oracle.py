@@ -47,16 +47,14 @@ def set_rounding(fn, softmax: str = "row_max") -> None:
     the rounding mode, DECLARED by the caller (the tests state it per geometry and check the library's kernel choice against it with
     swv2_attn_fwd_regime; the oracle never infers it from shapes):
       "row_max"        exponent reference = the row maximum, normaliser = sum of the exact exponentials (csrc/attn.hip forward);
-      "operand_folded" csrc/attn2.hip (attn_fwd3_kernel, attn_fwd3w_kernel): the scale enters the QK^T product inside the query operand,
-                       sigma log2(e) q^ as TWO bf16 parts hi + lo (hi = bf16(x), lo = bf16(x - hi): the scaled query is
-                       exact to ~2^-17 instead of fp32); reference = sigma itself while sigma log2(e) <= 40 in windows without a
-                       shift mask (cosines are bounded), the row maximum otherwise; normaliser = sum of the bf16-ROUNDED exponentials
-                       (an all-ones MFMA operand);
-      "operand_folded_zero_ref" csrc/attn4.hip (attn_fwd4_kernel, 32 x 32 tiles): NO reference point while sigma log2(e) <= 40 (2^40
-                       is far inside the fp32 / bf16 range; windows with a shift mask included: the mask is one more MFMA term), the
-                       row maximum otherwise; normaliser = sum of the bf16-rounded exponentials (a ones row in the V operand)."""
+      "operand_folded" csrc/attn2.hip (attn_fwd3_kernel, attn_fwd3w_kernel, attn_fwd3b_kernel): the scale enters the QK^T product inside
+                       the query operand, sigma log2(e) q^ as TWO bf16 parts hi + lo (hi = bf16(x), lo = bf16(x - hi): the scaled query is
+                       exact to ~2^-17 instead of fp32); reference = sigma (+ the largest entry of the head's CPB table, which enters the
+                       scores through an identity MFMA) while 2 sigma log2(e) + (max - min of the table, log2 domain) <= 80 in windows
+                       without a shift mask (cosines are bounded), the row maximum otherwise; normaliser = sum of the bf16-ROUNDED
+                       exponentials (an all-ones MFMA operand)."""
     global _ROUND, _SOFTMAX
-    assert softmax in ("row_max", "operand_folded", "operand_folded_zero_ref")
+    assert softmax in ("row_max", "operand_folded")
     _ROUND = fn
     _SOFTMAX = softmax if fn is not None else "row_max"
 
@@ -280,17 +278,19 @@ def attention_core_normed(qn: Tensor, kn: Tensor, v: Tensor, logit_scale: Tensor
     # cancellation -- to a tight bar instead of the 12 - 15 % that exact autograd of this forward leaves.
     rowmax = S.detach().max(dim=-1, keepdim=True).values
     ref, rounded_sum = rowmax, False
-    if _SOFTMAX in ("operand_folded", "operand_folded_zero_ref"):          # declared by the caller (set_rounding), never inferred from the shapes
+    if _SOFTMAX == "operand_folded":          # declared by the caller (set_rounding), never inferred from the shapes
         sig = torch.exp(torch.clamp(logit_scale.detach(), max=LOGIT_MAX))
-        fixed = (sig * math.log2(math.e) <= 40.0).view(1, heads, 1, 1)
-        if _SOFTMAX == "operand_folded":
-            if mask is not None:
-                nW = mask.shape[0]
-                masked_w = (mask != 0).flatten(1).any(1).repeat(Bw // nW).view(Bw, 1, 1, 1)
-                fixed = fixed & ~masked_w
-            ref = torch.where(fixed, sig.view(1, heads, 1, 1).to(S.dtype).expand_as(rowmax), rowmax)
+        l2e = math.log2(math.e)
+        if bias is not None:                  # (the table as the kernels hold it: bf16 in the log2 domain)
+            bmax, bmin = bias.detach().flatten(1).max(1).values, bias.detach().flatten(1).min(1).values
         else:
-            ref = torch.where(fixed.expand_as(rowmax), torch.zeros_like(rowmax), rowmax)
+            bmax = bmin = torch.zeros_like(sig)
+        fixed = (2.0 * sig * l2e + (bmax - bmin) * l2e <= 80.0).view(1, heads, 1, 1)
+        if mask is not None:
+            nW = mask.shape[0]
+            masked_w = (mask != 0).flatten(1).any(1).repeat(Bw // nW).view(Bw, 1, 1, 1)
+            fixed = fixed & ~masked_w
+        ref = torch.where(fixed, (sig + bmax).view(1, heads, 1, 1).to(S.dtype).expand_as(rowmax), rowmax)
         rounded_sum = True
     sigma = torch.exp(torch.clamp(logit_scale, max=LOGIT_MAX))
     mfull = None

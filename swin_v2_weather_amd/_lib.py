@@ -15,6 +15,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("SWV2_LIB") or os.path.join(HERE, "libswv2.so")     # SWV2_LIB: a privately built variant (tools/ab_macro.sh)
 SOURCES = ["capi.hip", "attn.hip", "attn2.hip", "attn_wide.hip", "gemm.hip", "gemm_tn.hip", "gemm_tn_slab.hip", "rowops.hip", "block.hip", "cpb.hip", "mlp.hip", "proj_ln.hip", "dataio.hip"]
 
+ABI_VERSION = 105          # SWV2_VERSION of the include/swv2.h these ctypes mirrors were written against (checked in load())
+
 _lib = None
 _lock = threading.Lock()
 
@@ -71,7 +73,7 @@ class AttnArgs(C.Structure):
                 ("dlogit_scale", C.c_void_p), ("dbias", C.c_void_p),
                 ("Bw", C.c_int), ("heads", C.c_int), ("L", C.c_int), ("head_dim", C.c_int),
                 ("nwh", C.c_int), ("nww", C.c_int), ("mask_thr", C.c_int), ("max_chunks", C.c_int), ("dbg", C.c_int),
-                ("dbias_ws", C.c_void_p), ("dbias_ws_bytes", C.c_size_t)]
+                ("dbias_ws", C.c_void_p), ("dbias_ws_bytes", C.c_size_t), ("dbias_partials", C.c_int)]
 
 
 class Operand(C.Structure):
@@ -145,7 +147,8 @@ class BlockDesc(C.Structure):
                     "d_fc1_b", "d_fc2_w", "d_fc2_b", "d_n2_w", "d_n2_b")] +
                 [("wgrad_splits", C.c_int), ("ev_kernel", C.c_int), ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p),
                  ("fuse_proj_ln", C.c_int), ("fuse_attn", C.c_int), ("fuse_mlp", C.c_int), ("wgrad_ws", C.c_void_p), ("wgrad_ws_bytes", C.c_size_t), ("wgrad_side_stream", C.c_int), ("wgrad_group", C.c_int), ("grad_zero", C.c_void_p),
-                 ("grad_zero_bytes", C.c_size_t), ("ln_ws_floats", C.c_size_t)])
+                 ("grad_zero_bytes", C.c_size_t), ("ln_ws_floats", C.c_size_t),
+                 ("bias_prepacked", C.c_int), ("dbias_part", C.c_void_p), ("dbias_part_bytes", C.c_size_t)])
 
 
 OP_F32, OP_BF16, OP_BF16_GELU, OP_HEADS, OP_PATCH, OP_MERGE_LN, OP_BF16_CSCALE = range(7)
@@ -161,6 +164,8 @@ SYMBOLS = {
     "swv2_attn_pack_bias_bytes": (C.c_size_t, [_I, _I]),
     "swv2_attn_dbias_ws_bytes": (C.c_size_t, [_I, _I, _I]),
     "swv2_attn_pack_bias": (_I, [_P, _I, _I, _P, _P]),
+    "swv2_attn_pack_bias_multi": (_I, [_P, _I, _I, _I, _P, _P]),
+    "swv2_attn_bias_chunks": (_I, [_I]),
     "swv2_attn_fwd": (_I, [C.POINTER(AttnArgs), _P]),
     "swv2_attn_bwd": (_I, [C.POINTER(AttnArgs), _P]),
     "swv2_linear": (_I, [C.POINTER(Operand), _P, C.POINTER(Epilogue), _I, _P]),
@@ -202,6 +207,9 @@ SYMBOLS = {
     "swv2_cpb_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "swv2_cpb_bwd_ws": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, C.c_size_t, _P]),
     "swv2_cpb_bwd_ws_bytes": (C.c_size_t, [_I, _I, _I, _I]),
+    "swv2_cpb_fwd_multi": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "swv2_cpb_bwd_multi_ws_bytes": (C.c_size_t, [_I, _I, _I, _I, _I]),
+    "swv2_cpb_bwd_multi": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _F, _P, C.c_size_t, _P]),
     "swv2_block_fwd": (_I, [C.POINTER(BlockDesc), _P]),
     "swv2_block_bwd": (_I, [C.POINTER(BlockDesc), _P]),
 }
@@ -221,6 +229,10 @@ def load() -> C.CDLL:
             for name, (res, args) in SYMBOLS.items():
                 fn = getattr(lib, name)            # AttributeError if a declared symbol is missing
                 fn.restype, fn.argtypes = res, args
+            got = lib.swv2_version()
+            if got != ABI_VERSION:         # a stale .so behind newer struct mirrors shifts every later member by one slot
+                raise Swv2Error(f"{LIB_PATH} reports ABI revision {got}, this binding mirrors revision {ABI_VERSION} of include/swv2.h: "
+                                "rebuild the library (python -c 'import __graft_entry__ as g; g.build()')")
             _lib = lib
     return _lib
 

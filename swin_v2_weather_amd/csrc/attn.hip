@@ -45,26 +45,48 @@ struct BiasPack {
     static constexpr int Lp = 16 * LT, DSP = Lp + 4;
     static constexpr size_t FWD_U32 = (size_t)LT * LT * 2 * 64;       // per head
     static constexpr size_t BWD_BF16 = (size_t)Lp * DSP;              // per head
-    static size_t bytes(int heads) { return heads * (FWD_U32 * 4 + BWD_BF16 * 2); }
+    // third part: fp32 [h][2] = (max, min) of the head's packed values over the real (query, key) pairs -- the bound behind the
+    // "fixed maximum" softmax of the bias-capable forward in attn2.hip
+    __host__ __device__ static size_t range_off(int heads) { return heads * (FWD_U32 * 4 + BWD_BF16 * 2); }
+    static size_t bytes(int heads) { return (range_off(heads) + (size_t)heads * 8 + 15) / 16 * 16; }
 };
 
+// one workgroup per (head, table): `nblk` tables [heads][L][L] -> `nblk` packed buffers of `pack_bytes` each
 template <int LT>
-__global__ void attn_pack_bias_kernel(const float* __restrict__ bias, int heads, int L, uint32_t* __restrict__ fwd,
-                                      uint16_t* __restrict__ bwd) {
+__global__ __launch_bounds__(1024) void attn_pack_bias_kernel(const float* __restrict__ bias_all, int heads, int L, unsigned char* __restrict__ out_all,
+                                                              size_t pack_bytes) {
     using P = BiasPack<LT>;
-    const int hd = blockIdx.y;
+    __shared__ float red[2][16];
+    const int hd = blockIdx.y, blk = blockIdx.z;
+    const float* bias = bias_all + (size_t)blk * heads * L * L;
+    unsigned char* out = out_all + (size_t)blk * pack_bytes;
+    uint32_t* fwd = (uint32_t*)out;
+    uint16_t* bwd = (uint16_t*)(out + heads * P::FWD_U32 * 4);
+    float* range = (float*)(out + P::range_off(heads));
     auto val = [&](int q, int key) -> float {
         if (key >= L) return SWV2_NEG_BIG;
         return (q < L) ? bias[((size_t)hd * L + q) * L + key] * SWV2_LOG2E : 0.f;
     };
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < P::FWD_U32; i += (size_t)gridDim.x * blockDim.x) {
+    for (size_t i = threadIdx.x; i < P::FWD_U32; i += blockDim.x) {
         const int lane = i & 63, j = (i >> 6) & 1, t = (int)((i >> 7) % LT), qt = (int)((i >> 7) / LT);
         const int q = 16 * qt + (lane & 15), key = 16 * t + 4 * (lane >> 4) + 2 * j;
         fwd[(size_t)hd * P::FWD_U32 + i] = f2bf2(val(q, key), val(q, key + 1));
     }
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < P::BWD_BF16; i += (size_t)gridDim.x * blockDim.x) {
+    float mx = -3.0e38f, mn = 3.0e38f;
+    for (size_t i = threadIdx.x; i < P::BWD_BF16; i += blockDim.x) {
         const int key = (int)(i / P::DSP), q = (int)(i % P::DSP);
-        bwd[(size_t)hd * P::BWD_BF16 + i] = (q < P::Lp) ? f2bf(val(q, key)) : (uint16_t)0;
+        const uint16_t b = (q < P::Lp) ? f2bf(val(q, key)) : (uint16_t)0;
+        bwd[(size_t)hd * P::BWD_BF16 + i] = b;
+        if (q < L && key < L) { mx = fmaxf(mx, bf2f(b)); mn = fminf(mn, bf2f(b)); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, o)); mn = fminf(mn, __shfl_xor(mn, o)); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = mx; red[1][threadIdx.x >> 6] = mn; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { mx = fmaxf(mx, red[0][w]); mn = fminf(mn, red[1][w]); }
+        range[2 * hd] = mx;
+        range[2 * hd + 1] = mn;
     }
 }
 
@@ -1032,7 +1054,8 @@ int launch_bwd(const swv2_attn_args* a, hipStream_t st) {
                            a->bias, bimg, (const uint16_t*)a->oh, (const uint16_t*)a->doh, a->lse, a->rnorm,
                            (uint16_t*)a->dqkvh, a->dlogit_scale, a->dbias, a->Bw, a->heads, a->L, nW, a->nww, a->nwh,
                            a->mask_thr, dbws);
-        if (dbws) {
+        if (a->dbias_partials) SWV2_CHECK_ARG(dbws != nullptr, "attn_bwd: dbias_partials needs a workspace of %zu bytes", need);
+        if (dbws && !a->dbias_partials) {
             const int n = a->heads * a->L * a->L;
             hipLaunchKernelGGL(dbias_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)dbws, a->dbias, n, nchunk);
         }
@@ -1066,7 +1089,7 @@ int check_args(const swv2_attn_args* a, bool bwd) {
                    "attn: Bw=%d is not a multiple of the %dx%d windows per sample", a->Bw, a->nwh, a->nww);
     SWV2_CHECK_ARG(a->mask_thr >= 0 && a->mask_thr < a->L, "attn: mask_thr out of range");
     SWV2_CHECK_ARG(a->max_chunks > 0, "attn: max_chunks must be positive");
-    if (bwd) SWV2_CHECK_ARG(a->doh && a->rnorm && a->dqkvh && a->dlogit_scale && (!a->bias || a->dbias),
+    if (bwd) SWV2_CHECK_ARG(a->doh && a->rnorm && a->dqkvh && a->dlogit_scale && (!a->bias || a->dbias || (a->dbias_partials && a->dbias_ws)),
                             "attn_bwd: null gradient pointer");
     return SWV2_OK;
 }
@@ -1125,18 +1148,27 @@ extern "C" size_t swv2_attn_pack_bias_bytes(int heads, int L) {
     return L <= 64 ? BiasPack<4>::bytes(heads) : (L <= 176 ? BiasPack<11>::bytes(heads) : 0);
 }
 
-extern "C" int swv2_attn_pack_bias(const float* bias, int heads, int L, void* out, void* stream) {
-    SWV2_CHECK_ARG(bias && out && heads > 0 && L > 0 && L <= 176, "swv2_attn_pack_bias: null pointer or L=%d out of range", L);
+// byte offset of the (max, min) part inside a packed table (attn2.hip's bias forward)
+size_t swv2_attn_bias_range_offset(int heads, int L) { return L <= 64 ? BiasPack<4>::range_off(heads) : BiasPack<11>::range_off(heads); }
+
+extern "C" int swv2_attn_pack_bias_multi(const float* bias, int ntab, int heads, int L, void* out, void* stream) {
+    SWV2_CHECK_ARG(bias && out && heads > 0 && ntab > 0 && L > 0 && L <= 176, "swv2_attn_pack_bias: null pointer or L=%d out of range", L);
     hipStream_t st = (hipStream_t)stream;
+    const size_t pb = swv2_attn_pack_bias_bytes(heads, L);
     if (L <= 64)
-        hipLaunchKernelGGL((attn_pack_bias_kernel<4>), dim3(16, heads), dim3(256), 0, st, bias, heads, L, (uint32_t*)out,
-                           (uint16_t*)((char*)out + heads * BiasPack<4>::FWD_U32 * 4));
+        hipLaunchKernelGGL((attn_pack_bias_kernel<4>), dim3(1, heads, ntab), dim3(1024), 0, st, bias, heads, L, (unsigned char*)out, pb);
     else
-        hipLaunchKernelGGL((attn_pack_bias_kernel<11>), dim3(64, heads), dim3(256), 0, st, bias, heads, L, (uint32_t*)out,
-                           (uint16_t*)((char*)out + heads * BiasPack<11>::FWD_U32 * 4));
+        hipLaunchKernelGGL((attn_pack_bias_kernel<11>), dim3(1, heads, ntab), dim3(1024), 0, st, bias, heads, L, (unsigned char*)out, pb);
     SWV2_CHECK_LAUNCH("swv2_attn_pack_bias");
     return SWV2_OK;
 }
+
+extern "C" int swv2_attn_pack_bias(const float* bias, int heads, int L, void* out, void* stream) {
+    return swv2_attn_pack_bias_multi(bias, 1, heads, L, out, stream);
+}
+
+// workgroups per head of the attention backward with a CPB table (= d bias tables per head it leaves in swv2_attn_args.dbias_ws)
+extern "C" int swv2_attn_bias_chunks(int Bw) { return Bw < 32 ? Bw : 32; }
 
 // the small-workgroup forward of attn2.hip: 0 / negative = handled (ok / error), 1 = shape not covered
 int swv2_attn2_fwd(const swv2_attn_args* a, int Lp, int DP, void* stream);
@@ -1147,12 +1179,15 @@ int swv2_attn_bwd_wide(const swv2_attn_args* a, int Lp, int DP, void* stream);
 
 // which forward kernel family serves a geometry (pure host function, no launch): 1 = the operand-folded softmax of attn2.hip, 0 = row
 // maximum + exact sum (attn.hip, attn_wide.hip); negative: geometry not covered.  The parity tests declare the regime their oracle
-// emulates and check it against this.  (2 = the 32 x 32-tile forward, oracle regime "operand_folded_zero_ref": tools/experiments/.)
+// emulates and check it against this.
 extern "C" int swv2_attn_fwd_regime(int L, int head_dim, int has_bias, int dbg) {
     int Lp, DP;
     const int rc = swv2_attn_geometry(L, head_dim, &Lp, &DP);
     if (rc) return rc;
-    return (!has_bias && Lp == 176 && (DP == 16 || DP == 32) && !(dbg & SWV2_ATTN_FIRST_GEN)) ? 1 : 0;
+    // (has_bias: a table in its PACKED form, as the model always passes it; a raw table without swv2_attn_pack_bias runs attn.hip)
+    static const int fwd3b = getenv("SWV2_ATTN_FWD3B") ? atoi(getenv("SWV2_ATTN_FWD3B")) : 1;
+    const bool shape = Lp == 176 && L >= 160 && !(dbg & SWV2_ATTN_FIRST_GEN);
+    return (shape && (has_bias ? (DP == 16 && fwd3b) : (DP == 16 || DP == 32))) ? 1 : 0;
 }
 
 extern "C" int swv2_attn_fwd(const swv2_attn_args* a, void* stream) {

@@ -465,6 +465,219 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn_fwd3w_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// the same forward WITH the CPB bias table (round 5; the table reference swinv2_global.py:274-287 adds before the softmax, :307).
+// The bias costs no vector instruction: the wave keeps the packed bf16 rows of its (head, q-tiles) in registers for the lifetime of the
+// workgroup (swv2_attn_pack_bias's forward part: exactly the B-operand layout of a 16 x 16 x 16 MFMA, 2 registers per key tile), and
+// every S'^T tile STARTS as  I . B_bias + c0  -- one more MFMA with an identity A operand (exact: 1.0 x bf16 into fp32) whose result
+// is the accumulator of the K = 32 score product.  Padded keys carry -1e30 in the table.  The "fixed maximum" reference becomes
+// sigma' + max(bias') of the head (the (max, min) part of the packed buffer), valid while 2 sigma' + (max - min) <= 80.
+// 66 registers of bias per wave (3 q-tiles) on top of the 145 of the kernel without bias: two workgroups per CU instead of three.
+// ------------------------------------------------------------------------------------------------
+template <int LT, int LFIX, int WAVES, int OCC>
+__global__ __launch_bounds__(64 * WAVES, OCC) void attn_fwd3b_kernel(
+    const uint16_t* __restrict__ qkvh, const float* __restrict__ logit_scale, const uint32_t* __restrict__ bpack,
+    const float* __restrict__ brange, uint16_t* __restrict__ oh, float* __restrict__ lse, int Bw, int h, int L, int nW, int nww, int nwh,
+    int mask_thr) {
+    constexpr int DP = 16, Lp = 16 * LT, SLAB = Lp * DP;
+    constexpr int NT = 64 * WAVES;
+    constexpr int CH = 2 * SLAB / 8;
+    constexpr int CPT = (CH + NT - 1) / NT;
+    constexpr int KIMG = 2 * SLAB, BUF = KIMG + 2 * SLAB;
+    constexpr int QCH = SLAB / 8, QPT = (QCH + NT - 1) / NT;
+    constexpr int NQ = (LT + WAVES - 1) / WAVES;               // q-tiles per wave (the last wave may own one less)
+    static_assert(NQ <= 4, "the bias-set switch has four cases");
+    __shared__ __attribute__((aligned(16))) uint16_t smem[2 * BUF];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, g = lane >> 4;
+    const int hd = blockIdx.y;
+    const bool last_chunk_ok = (wave * 64 + (CPT - 1) * NT) < CH;          // wave-uniform
+
+    const float sc2 = __expf(fminf(logit_scale[hd], SWV2_LN100)) * SWV2_LOG2E;
+    const float bmax = brange[2 * hd], bmin = brange[2 * hd + 1];
+    const bool bounded = 2.f * sc2 + (bmax - bmin) <= 80.f;
+
+    // bias rows of this wave's q-tiles: bq[i][t] = keys 16t + 4g .. + 3 of query 16 (wave + i WAVES) + fr, packed bf16, log2 domain
+    uint32_t bq[NQ][LT][2];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int qt = min(wave + i * WAVES, LT - 1);
+        const uint32_t* src = bpack + (((size_t)hd * LT + qt) * LT) * 128 + lane;
+#pragma unroll
+        for (int t = 0; t < LT; ++t) {
+            bq[i][t][0] = src[t * 128];
+            bq[i][t][1] = src[t * 128 + 64];
+        }
+    }
+    // identity A operand of the 16 x 16 x 16 MFMA: A[i = fr][k = 4g + j]
+    bf16x4 idA;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) idA[j] = (fr == 4 * g + j) ? (short)0x3F80 : (short)0;
+
+    u32x4 stage[CPT], stageq[QPT];
+    unsigned soff[CPT], qoff[QPT];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) soff[j] = (unsigned)(SLAB + min(tid + j * NT, CH - 1) * 8);
+#pragma unroll
+    for (int j = 0; j < QPT; ++j) qoff[j] = (unsigned)(min(tid + j * NT, QCH - 1) * 8);
+    auto issue_loads = [&](int bw) {
+        const uint16_t* base = qkvh + ((size_t)bw * h + hd) * 3 * SLAB;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) stage[j] = *(const u32x4*)(base + soff[j]);
+#pragma unroll
+        for (int j = 0; j < QPT; ++j) stageq[j] = *(const u32x4*)(base + qoff[j]);
+    };
+    auto write_stage = [&](int buf) {
+        uint16_t* dst = smem + buf * BUF;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j)
+            if (j < CPT - 1 || last_chunk_ok) {
+                const int c = tid + j * NT;
+                if (c < CH / 2) {
+                    const u32x4 lo = {stage[j][0], stage[j][1], stage[j][0], stage[j][1]};
+                    const u32x4 hi = {stage[j][2], stage[j][3], stage[j][2], stage[j][3]};
+                    *(u32x4*)(dst + (size_t)c * 16) = lo;
+                    *(u32x4*)(dst + (size_t)c * 16 + 8) = hi;
+                } else {
+                    *(u32x4*)(dst + KIMG + (size_t)(c - CH / 2) * 8) = stage[j];
+                }
+            }
+#pragma unroll
+        for (int j = 0; j < QPT; ++j)
+            if (tid + j * NT < QCH) *(u32x4*)(dst + KIMG + SLAB + (size_t)(tid + j * NT) * 8) = stageq[j];
+    };
+
+    int bw = blockIdx.x;
+    if (bw >= Bw) return;
+    issue_loads(bw);
+    write_stage(0);
+    __syncthreads();
+
+    const bf16x8 ones8 = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    const bf16x4 ones4 = {0x3F80, 0x3F80, 0x3F80, 0x3F80};
+
+    for (int it = 0; bw < Bw; bw += gridDim.x, ++it) {
+        const int buf = it & 1;
+        const int bw_next = bw + gridDim.x;
+        const uint16_t* Ki = smem + buf * BUF;
+        const uint16_t* Vs = Ki + KIMG;
+        const uint16_t* Qs = Vs + SLAB;
+        if (bw_next < Bw) issue_loads(bw_next);
+        const bool do_mask = (mask_thr > 0) && (((bw % nW) / nww) == nwh - 1);
+        const bool fixed = bounded && !do_mask;                       // wave-uniform
+        const float c0 = fixed ? -(sc2 + bmax) : 0.f;
+        const f32x4 cinit = {c0, c0, c0, c0};
+
+        // rolled loop (unrolled, the compiler interleaves the rows and spills: 256 registers + 94 in scratch); the wave's i-th bias
+        // register set is picked by a scalar switch around the identity products only
+#pragma unroll 1
+        for (int i = 0; i < NQ; ++i) {
+            const int qt = wave + i * WAVES;
+            if (qt >= LT) break;                                      // wave-uniform
+            const int q = 16 * qt + fr;
+            if (qt + WAVES >= LT && bw_next < Bw) write_stage(buf ^ 1);
+            const bf16x4 qraw = *(const bf16x4*)(Qs + (size_t)q * DP + 4 * g);
+            bf16x8 qB;
+            {
+                float x[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[j] = bf2f(qraw[j]) * sc2;
+                uint32_t w[4];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    w[j] = f2bf2(x[2 * j], x[2 * j + 1]);
+                    w[2 + j] = f2bf2(x[2 * j] - __uint_as_float(w[j] << 16), x[2 * j + 1] - __uint_as_float(w[j] & 0xffff0000u));
+                }
+                qB = __builtin_bit_cast(bf16x8, w);
+            }
+            // S'^T tiles: bias + c0 through the identity product, then the scaled scores on top
+            f32x4 acc[LT];
+#define SWV2_BIAS_TILES(I)                                                               \
+    case I:                                                                              \
+        if (I < NQ) {                                                                    \
+            _Pragma("unroll") for (int t = 0; t < LT; ++t) {                             \
+                const uint32_t bw2[2] = {bq[I < NQ ? I : 0][t][0], bq[I < NQ ? I : 0][t][1]}; \
+                acc[t] = mfma16(idA, __builtin_bit_cast(bf16x4, bw2), cinit);            \
+            }                                                                            \
+        }                                                                                \
+        break;
+            switch (i) { SWV2_BIAS_TILES(0) SWV2_BIAS_TILES(1) SWV2_BIAS_TILES(2) SWV2_BIAS_TILES(3) default: break; }
+#undef SWV2_BIAS_TILES
+#pragma unroll
+            for (int t = 0; t < LT; ++t) {
+                const bf16x8 kA = *(const bf16x8*)(Ki + (16 * t + fr) * 32 + 8 * g);
+                acc[t] = mfma32(kA, qB, acc[t]);
+            }
+            float mx = sc2 + bmax;
+            if (!fixed) {
+                mx = SWV2_NEG_BIG;
+                const bool qid = q >= mask_thr;
+#pragma unroll
+                for (int t = 0; t < LT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (do_mask) acc[t][r] += (((16 * t + 4 * g + r) >= mask_thr) != qid) ? (-100.f * SWV2_LOG2E) : 0.f;
+                        mx = fmaxf(mx, acc[t][r]);
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+#pragma unroll
+                for (int t = 0; t < LT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[t][r] -= mx;
+            }
+#pragma unroll
+            for (int t = 0; t < LT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (LFIX > 0 && 16 * t + 4 * 0 + r >= LFIX && t == LT - 1) acc[t][r] = 0.f;
+                    else acc[t][r] = __builtin_amdgcn_exp2f(acc[t][r]);
+                }
+            f32x4 o = {0.f, 0.f, 0.f, 0.f}, rs = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t + 1 < LT; t += 2) {
+                const bf16x4 p0 = f2bf4(acc[t]), p1 = f2bf4(acc[t + 1]);
+                const bf16x8 pb = __builtin_shufflevector(p0, p1, 0, 1, 2, 3, 4, 5, 6, 7);
+                const bf16x4 v0 = lds_tr_read(Vs + (16 * t + 4 * g + (fr >> 2)) * DP + (fr & 3) * 4);
+                const bf16x4 v1 = lds_tr_read(Vs + (16 * (t + 1) + 4 * g + (fr >> 2)) * DP + (fr & 3) * 4);
+                const bf16x8 vA = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                o = mfma32(vA, pb, o);
+                rs = mfma32(ones8, pb, rs);
+            }
+            if (LT & 1) {
+                const bf16x4 pb = f2bf4(acc[LT - 1]);
+                const bf16x4 vf = lds_tr_read(Vs + (16 * (LT - 1) + 4 * g + (fr >> 2)) * DP + (fr & 3) * 4);
+                const f32x4 to = mfma16(vf, pb, (f32x4){0.f, 0.f, 0.f, 0.f});
+                const f32x4 ts = mfma16(ones4, pb, (f32x4){0.f, 0.f, 0.f, 0.f});
+                o += to;
+                rs += ts;
+            }
+            const float sum = rs[0];
+            const float inv = (q < L) ? __builtin_amdgcn_rcpf(sum) : 0.f;
+            uint16_t* orow = oh + ((size_t)bw * h + hd) * SLAB + (size_t)q * DP;
+            f32x4 v = o;
+            v[0] *= inv; v[1] *= inv; v[2] *= inv; v[3] *= inv;
+            *(bf16x4*)(orow + 4 * g) = f2bf4(v);
+            if (g == 0) lse[((size_t)bw * h + hd) * Lp + q] = (q < L) ? mx + __log2f(sum) : 0.f;
+        }
+        __syncthreads();
+    }
+}
+
+template <int LT, int LFIX, int WAVES, int OCC>
+int launch_fwd3b(const swv2_attn_args* a, const uint32_t* bpack, const float* brange, hipStream_t st) {
+    int nchunk = (OCC * 256 + a->heads - 1) / a->heads;
+    if (nchunk > a->Bw) nchunk = a->Bw;
+    dim3 grid(nchunk, a->heads), block(64 * WAVES);
+    hipLaunchKernelGGL((attn_fwd3b_kernel<LT, LFIX, WAVES, OCC>), grid, block, 0, st, (const uint16_t*)a->qkvh, a->logit_scale, bpack, brange,
+                       (uint16_t*)a->oh, a->lse, a->Bw, a->heads, a->L, a->nwh * a->nww, a->nww, a->nwh, a->mask_thr);
+    SWV2_CHECK_LAUNCH("swv2_attn_fwd");
+    return SWV2_OK;
+}
+
 template <int LT, int LFIX, int WAVES, int OCC, int NBUF, bool KREG = false>
 int launch_fwd3w(const swv2_attn_args* a, hipStream_t st) {
     int nchunk = (OCC * 256 + a->heads - 1) / a->heads;
@@ -491,10 +704,20 @@ int launch_fwd3(const swv2_attn_args* a, hipStream_t st) {
 }  // namespace
 
 // called by swv2_attn_fwd (attn.hip); returns 1 when this kernel does not cover the shape (the caller then runs the
-// first-generation kernel)
+// first-generation kernel).  Window areas: only the LAST key tile's accumulators start at -1e30 for padded keys, so every other key tile
+// must hold real keys only -- L >= 16 (LT - 1) = 160 (at 65 .. 159 tokens the zero K rows of the padded keys in tiles 4 .. 9
+// entered the row sum with weight exp2(-sigma')); smaller areas run the first-generation kernel.  With a CPB table: the packed form (swv2_attn_pack_bias)
+// is required -- its forward part is the register image, its (max, min) part bounds the fixed-maximum softmax.
 int swv2_attn2_fwd(const swv2_attn_args* a, int Lp, int DP, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    if (a->bias || Lp != 176 || (DP != 16 && DP != 32)) return 1;
+    if (Lp != 176 || a->L < 160 || (DP != 16 && DP != 32)) return 1;
+    if (a->bias) {
+        static const int fwd3b = getenv("SWV2_ATTN_FWD3B") ? atoi(getenv("SWV2_ATTN_FWD3B")) : 1;
+        if (!fwd3b || !a->bias_pack || DP != 16 || a->heads <= 0) return 1;
+        const uint32_t* bpack = (const uint32_t*)a->bias_pack;
+        const float* brange = (const float*)((const char*)a->bias_pack + swv2_attn_bias_range_offset(a->heads, a->L));
+        return a->L == 162 ? launch_fwd3b<11, 162, 4, 2>(a, bpack, brange, st) : launch_fwd3b<11, 0, 4, 2>(a, bpack, brange, st);
+    }
     if (DP == 32) {
         // measured at B = 2 (800 windows x 8 heads, 24-wide heads): 4 waves x 2 workgroups per CU, two LDS buffers: 90 us with the K / V^T
         // fragments read per row, 80 us with them in registers (227 VGPRs); one buffer at 3 workgroups per CU (spills): 99; 6 waves x 2

@@ -3,6 +3,8 @@
 #pragma once
 #include "common.h"
 
+size_t swv2_attn_bias_range_offset(int heads, int L);       // attn.hip: the (max, min) part of a packed CPB table
+
 namespace {
 
 template <int LT, int DK>

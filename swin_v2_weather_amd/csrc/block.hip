@@ -95,7 +95,7 @@ extern "C" int swv2_block_fwd(const swv2_block_desc* d, void* st) {
     }
     // 2. cosine attention core (the CPB table is packed once into the kernels' layouts; the backward reuses it)
     {
-        if (d->bias && d->bias_pack) TRY(swv2_attn_pack_bias(d->bias, h, d->L, d->bias_pack, st));
+        if (d->bias && d->bias_pack && !d->bias_prepacked) TRY(swv2_attn_pack_bias(d->bias, h, d->L, d->bias_pack, st));
         swv2_attn_args a = attn(d);
         if (d->bias) a.max_chunks = 32;          // per-workgroup table load: fewer, longer-lived workgroups
         LAUNCH(2, swv2_attn_fwd(&a, st));
@@ -247,10 +247,12 @@ extern "C" int swv2_block_bwd(const swv2_block_desc* d, void* st) {
         // every workgroup adds its d bias table with atomics: fewer, longer-lived workgroups (end-to-end at depth 12:
         // 16 chunks 89.9, 32 chunks 98.8, 64 chunks 97.0 samples/s)
         if (d->bias) {
-            a.max_chunks = 32;
+            a.max_chunks = swv2_attn_bias_chunks(Bw);
             // the weight-gradient workspace is idle until the grouped launch at the end of the block: the workgroups' d bias
             // tables go there and are summed by one more launch instead of 31 K atomics per workgroup
-            if (!ss) { a.dbias_ws = d->wgrad_ws; a.dbias_ws_bytes = d->wgrad_ws_bytes; }       // (a side stream may still be using it)
+            if (d->dbias_part) {     // the tables stay where they are written: summed for all blocks by swv2_cpb_bwd_multi
+                a.dbias_ws = d->dbias_part; a.dbias_ws_bytes = d->dbias_part_bytes; a.dbias_partials = 1;
+            } else if (!ss) { a.dbias_ws = d->wgrad_ws; a.dbias_ws_bytes = d->wgrad_ws_bytes; }       // (a side stream may still be using it)
         }
         // without bias at the 176-token window one workgroup (11 waves, ~90 KB of LDS) fills a CU: exactly one persistent
         // workgroup per CU (256 / heads chunks) instead of two rounds of 256 (same box: 110.4 vs 116.2 us per launch)

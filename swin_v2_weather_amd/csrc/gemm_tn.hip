@@ -595,12 +595,14 @@ int swv2_block_wgrad_ln(const swv2_wgrad_item* it, int slices, void* ws, size_t 
             if (rc <= 0) return rc;
         }
     }
-    if (ln && ln->C > 0)        // (the tile kernel's reduction carries no rider)
-        swv2_launch_ln_partials_reduce2(ln->ws[0], ln->dgamma[0], ln->dbeta[0], ln->n[0], ln->ws[1], ln->dgamma[1], ln->dbeta[1], ln->n[1], ln->C,
-                                        (hipStream_t)stream);
     const int S = group_slices(tt, slices);
     SWV2_CHECK_ARG(ws_bytes >= (size_t)S * tt * BN * BN * sizeof(float), "swv2_block_wgrad: workspace of %zu bytes, %zu needed",
                    ws_bytes, (size_t)S * tt * BN * BN * sizeof(float));
+    // (the tile kernel's reduction carries no rider.  Launched only after every argument check: an error return must not leave the
+    // LayerNorm gradients accumulated and the weight gradients not -- ADVICE r4)
+    if (ln && ln->C > 0)
+        swv2_launch_ln_partials_reduce2(ln->ws[0], ln->dgamma[0], ln->dbeta[0], ln->n[0], ln->ws[1], ln->dgamma[1], ln->dbeta[1], ln->n[1], ln->C,
+                                        (hipStream_t)stream);
     TnReduce r = {};
     for (int i = 0; i < 4; ++i) {
         const int tiles = cdiv(it[i].dy.cols, BN) * cdiv(it[i].x.cols, BN);

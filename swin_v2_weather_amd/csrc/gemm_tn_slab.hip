@@ -592,6 +592,10 @@ int sl_set(int C, int hidden, int heads_dp) {
     return -1;
 }
 
+// workgroups of the launch = CUs of the current device, at most SL_CU_BOUND: the workspace SIZE (swv2_tn_slab_ws_bytes, a pure host
+// function: no HIP call, no dependence on the thread's current device -- ADVICE r4) is computed for the bound, so a workspace sized on
+// any device / before set_device covers every launch
+constexpr int SL_CU_BOUND = 320;
 int sl_cus() {
     static thread_local int cus[16] = {};
     int dev = 0;
@@ -599,7 +603,7 @@ int sl_cus() {
     if (!cus[dev]) {
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        cus[dev] = v;
+        cus[dev] = v < SL_CU_BOUND ? v : SL_CU_BOUND;
     }
     return cus[dev];
 }
@@ -682,12 +686,12 @@ SlOp sl_op(const swv2_operand& o) {
 
 }  // namespace
 
-// upper bound of the slab path's workspace for this block shape on this device (0: shape not covered): the workgroups of all four
-// products together number at most one per CU, each with at most the largest partial tile, + the partial bias rows
+// upper bound of the slab path's workspace for this block shape on any device (0: shape not covered): the workgroups of all four
+// products together number at most one per CU (<= SL_CU_BOUND), each with at most the largest partial tile, + the partial bias rows
 size_t swv2_tn_slab_ws_bytes(int C, int hidden, int heads_dp) {
     const int set = sl_set(C, hidden, heads_dp);
     if (set < 0) return 0;
-    const int cus = sl_cus();
+    const int cus = SL_CU_BOUND;
     const SlShape& sh = SL_SETS[set];
     size_t tile = 0;
     for (int i = 0; i < 4; ++i) tile = std::max(tile, (size_t)sh.TN[i] * sh.TK[i] * 4);
@@ -698,6 +702,11 @@ size_t swv2_tn_slab_ws_bytes(int C, int hidden, int heads_dp) {
 int swv2_tn_slab_launch(const swv2_wgrad_item* it, void* ws, size_t ws_bytes, const swv2_ln_partials* ln, hipStream_t st) {
     const int cus = sl_cus();
     const SlPlan pl = sl_plan(it, cus);
+    if (pl.ok && ws_bytes < pl.total) {
+        static int once = 0;
+        if (!once++) fprintf(stderr, "swv2: grouped weight gradient declined (workspace %zu bytes, %zu needed): size it with swv2_block_wgrad_ws_bytes; "
+                                     "running the 128 x 128 tile kernels\n", ws_bytes, pl.total);
+    }
     if (!pl.ok || ws_bytes < pl.total) return 1;
     const SlShape& sh = SL_SETS[pl.set];
     SlArgs a = {};

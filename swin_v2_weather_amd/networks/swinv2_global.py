@@ -232,25 +232,31 @@ class _BlockRunner:
 class _BlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, bias, dp1, dp2, logit_scale, qkv_w, qkv_b, proj_w, proj_b, n1_w, n1_b, fc1_w, fc1_b, fc2_w,
-                fc2_b, n2_w, n2_b, blk, ckpt=0):
+                fc2_b, n2_w, n2_b, blk, ckpt=0, cpb=None):
+        """`cpb` = (_CpbStage, index): the block's CPB table comes out of the stage's one-launch pipeline (already packed; `bias` is
+        then the stage's 1-element autograd token, which orders _CpbMultiFn.backward behind every block's backward) and the backward
+        leaves its d bias tables in the stage's buffer instead of returning a gradient"""
         B, gh, gw, Cc = x.shape
         run = blk._runner(B, x.device)
         d = run.desc
         x = x.contiguous()
         keep = run.set_params(blk._wcache, logit_scale, qkv_w, qkv_b, proj_w, proj_b, n1_w, n1_b, fc1_w, fc1_b, fc2_w, fc2_b,
                               n2_w, n2_b, backward=False)
-        bias_c = None if bias is None else bias.detach().float().contiguous()
+        bias_c = None if (bias is None or cpb is not None) else bias.detach().float().contiguous()
         acts = torch.empty(run.act_bytes, dtype=torch.uint8, device=x.device)
         x2 = torch.empty(B, gh, gw, Cc, dtype=torch.float32, device=x.device)
         run.set_acts(acts)
         d.x, d.x2 = x.data_ptr(), x2.data_ptr()
         d.bias = None if bias_c is None else bias_c.data_ptr()
+        d.bias_prepacked, d.dbias_part, d.dbias_part_bytes = 0, None, 0
+        if cpb is not None:
+            cpb[0].point(d, cpb[1])
         d.dp1 = None if dp1 is None else dp1.data_ptr()
         d.dp2 = None if dp2 is None else dp2.data_ptr()
         ops.block_event_pair("fwd", d)
         L.check(ops._timed("block_fwd", L.load().swv2_block_fwd, run.desc, ops._stream()), "swv2_block_fwd")
         del keep
-        ctx.blk, ctx.run, ctx.has_bias, ctx.ckpt = blk, run, bias is not None, int(ckpt)
+        ctx.blk, ctx.run, ctx.has_bias, ctx.ckpt, ctx.cpb = blk, run, bias is not None, int(ckpt), cpb
         e = x.new_empty(0)
         if ckpt:
             # selective activation checkpointing (swinv2_global.py:650-651 / torch.utils.checkpoint in the reference): only the
@@ -261,7 +267,7 @@ class _BlockFn(torch.autograd.Function):
             xs = x.to(BF16) if ckpt == 2 else x
         else:
             xs = x
-        ctx.save_for_backward(xs, bias_c if bias is not None else e, dp1 if dp1 is not None else e, dp2 if dp2 is not None else e,
+        ctx.save_for_backward(xs, bias_c if bias_c is not None else e, dp1 if dp1 is not None else e, dp2 if dp2 is not None else e,
                               acts, logit_scale, qkv_w, qkv_b, proj_w, proj_b, n1_w, n1_b, fc1_w, fc1_b, fc2_w, fc2_b, n2_w, n2_b)
         return x2
 
@@ -269,19 +275,23 @@ class _BlockFn(torch.autograd.Function):
     def backward(ctx, dx2):
         (x, bias_c, dp1, dp2, acts, logit_scale, qkv_w, qkv_b, proj_w, proj_b, n1_w, n1_b, fc1_w, fc1_b, fc2_w, fc2_b, n2_w,
          n2_b) = ctx.saved_tensors
-        blk, run = ctx.blk, ctx.run
+        blk, run, cpb = ctx.blk, ctx.run, ctx.cpb
         d = run.desc
         dev = x.device
         keep = run.set_params(blk._wcache, logit_scale, qkv_w, qkv_b, proj_w, proj_b, n1_w, n1_b, fc1_w, fc1_b, fc2_w, fc2_b,
                               n2_w, n2_b, backward=True)
         dx2 = dx2.contiguous().float()
+        own_bias = ctx.has_bias and cpb is None          # the table is this node's input (and gets a gradient from it)
+        d.bias_prepacked, d.dbias_part, d.dbias_part_bytes = 0, None, 0
         if ctx.ckpt:
             x = x.float() if x.dtype != torch.float32 else x
             acts = torch.empty(run.act_bytes, dtype=torch.uint8, device=dev)
             x2_tmp = torch.empty_like(x)
             run.set_acts(acts)
             d.x, d.x2 = x.data_ptr(), x2_tmp.data_ptr()
-            d.bias = bias_c.data_ptr() if ctx.has_bias else None
+            d.bias = bias_c.data_ptr() if own_bias else None
+            if cpb is not None:
+                cpb[0].point(d, cpb[1])
             d.dp1 = dp1.data_ptr() if dp1.numel() else None
             d.dp2 = dp2.data_ptr() if dp2.numel() else None
             d.ev_kernel = 0
@@ -313,7 +323,7 @@ class _BlockFn(torch.autograd.Function):
                 os.environ.get("SWV2_GRAD_ZERO_IN_KERNEL", "1") != "0"
             nfl = (run.grad_bytes // 4 + 3) // 4 * 4
             # (+ the CPB bias gradient table, zeroed by the same kernel instead of a fill of its own)
-            nb = (bias_c.numel() + 3) // 4 * 4 if ctx.has_bias else 0
+            nb = (bias_c.numel() + 3) // 4 * 4 if own_bias else 0
             grads = (torch.empty if in_kernel else torch.zeros)(nfl + nb, dtype=torch.float32, device=dev)
             gb = grads.data_ptr()
             d.grad_zero, d.grad_zero_bytes = (gb, (nfl + nb) * 4) if in_kernel else (None, 0)
@@ -323,11 +333,13 @@ class _BlockFn(torch.autograd.Function):
                 setattr(d, name, gb + off)
         if blk._ddp_bucket_grads:
             blk._queue_view_refresh(params)
-        dbias = (dbias_view if dbias_view is not None else torch.zeros_like(bias_c)) if ctx.has_bias else None
+        dbias = (dbias_view if dbias_view is not None else torch.zeros_like(bias_c)) if own_bias else None
         dx = torch.empty_like(x)
         d.x, d.dx2, d.dx = x.data_ptr(), dx2.data_ptr(), dx.data_ptr()
-        d.bias = bias_c.data_ptr() if ctx.has_bias else None
-        d.d_bias = dbias.data_ptr() if ctx.has_bias else None
+        d.bias = bias_c.data_ptr() if own_bias else None
+        d.d_bias = dbias.data_ptr() if own_bias else None
+        if cpb is not None:
+            cpb[0].point(d, cpb[1], backward=True)
         d.dp1 = dp1.data_ptr() if dp1.numel() else None
         d.dp2 = dp2.data_ptr() if dp2.numel() else None
         ops.block_event_pair("bwd", d)
@@ -339,7 +351,7 @@ class _BlockFn(torch.autograd.Function):
             g = [grads[o // 4:o // 4 + int(torch.Size(s).numel())].view(*s) for o, s in zip(run.grad_off, run.grad_shapes)]
         (dlogit, dqkvw, dqkvb, dprojw, dprojb, dn1w, dn1b, dfc1w, dfc1b, dfc2w, dfc2b, dn2w, dn2b) = g
         return (dx, dbias, None, None, dlogit, dqkvw, dqkvb, dprojw, dprojb, dn1w, dn1b, dfc1w, dfc1b, dfc2w, dfc2b, dn2w,
-                dn2b, None, None)
+                dn2b, None, None, None)
 
 
 class _CpbFn(torch.autograd.Function):
@@ -368,6 +380,95 @@ class _CpbFn(torch.autograd.Function):
         ops.cpb_bwd(dbias.contiguous().float(), w1c, b1c, w2c, keep if keep.numel() else None, dw1, db1, dw2, db2, wh, ww, heads,
                     hidden, drop_p)
         return dw1, db1, dw2, db2, None, None, None, None
+
+
+class _CpbStage:
+    """The CPB tables of ALL blocks of a stage for one forward pass (round 5): nothing in the meta-MLP pipeline (reference
+    swinv2_global.py:240-261, 274-287) depends on activations, so instead of one dropout draw + table kernel + pack per block and one
+    reduction + meta-MLP backward + fold per block, the stage makes ONE draw (random bits, 3 per hidden unit), ONE table launch and ONE
+    pack launch before its first block, and ONE backward launch (+ its fold) after the first block's backward, which sums the d bias
+    tables the attention backward's workgroups left in `dpart` (no per-block reduction, no zero fills)."""
+
+    def __init__(self, blocks, device):
+        a0 = blocks[0].attn
+        self.nblk, self.heads, self.hidden = len(blocks), a0.num_heads, a0.meta_mlp.fc1.weight.shape[0]
+        self.wh, self.ww = a0.window_size
+        self.L = self.wh * self.ww
+        self.device = device
+        self.params = [t for b in blocks for t in (b.attn.meta_mlp.fc1.weight, b.attn.meta_mlp.fc1.bias, b.attn.meta_mlp.fc2.weight,
+                                                   b.attn.meta_mlp.fc2.bias)]
+        self.bias_all = self.packs = self.keep_bits = self.ptab = self.dpart = None
+        self.pack_bytes = L.load().swv2_attn_pack_bias_bytes(self.heads, self.L)
+        self.nchunk = 0
+
+    _ptabs = {}
+
+    def pointer_table(self):
+        """device int64 [nblk * 4] of the parameters' addresses; cached while they stay where they are"""
+        key = tuple(p.data_ptr() for p in self.params)
+        t = _CpbStage._ptabs.get(key)
+        if t is None:
+            if len(_CpbStage._ptabs) > 16:
+                _CpbStage._ptabs.clear()
+            t = _CpbStage._ptabs[key] = torch.tensor(key, dtype=torch.int64).to(self.device)
+        return t
+
+    def point(self, d, i, backward=False):
+        """block i's launch descriptor -> its table / packed table (and, in the backward, its slice of the d bias buffer)"""
+        d.bias = self.bias_all[i].data_ptr()
+        d.bias_pack = self.packs[i].data_ptr()
+        d.bias_prepacked = 1
+        d.d_bias = None
+        if backward:
+            Bw = d.B * d.nwh * d.nww
+            nchunk = L.load().swv2_attn_bias_chunks(Bw)
+            if self.dpart is None or self.nchunk != nchunk:
+                self.nchunk = nchunk
+                self.dpart = torch.empty(self.nblk, nchunk, self.heads, self.L, self.L, dtype=torch.float32, device=self.device)
+                self.written = [False] * self.nblk
+            if self.written[i]:
+                raise L.Swv2Error("a block's backward ran twice against one CPB stage context (retain_graph): set SWV2_CPB_PER_BLOCK=1")
+            self.written[i] = True
+            d.dbias_part = self.dpart[i].data_ptr()
+            d.dbias_part_bytes = self.dpart[i].numel() * 4
+
+
+class _CpbMultiFn(torch.autograd.Function):
+    """params of every block's meta MLP -> a 1-element token; the tables themselves live in the _CpbStage (the blocks read them by
+    pointer).  Every block node takes the token as an input, so this node's backward runs after all of them."""
+
+    @staticmethod
+    def forward(ctx, st, train, *params):
+        ctx.set_materialize_grads(False)
+        dev = st.device
+        st.ptab = st.pointer_table()
+        st.keep_bits = None
+        if train:
+            # Dropout(0.125) of the meta MLP (:245) for all blocks: uniformly random bits from the torch generator, 3 per hidden unit
+            # (dropped iff all three are zero); SWV2_CPB_PER_BLOCK=1 restores the reference's per-block F.dropout draws
+            st.keep_bits = torch.empty(st.nblk, st.L * st.L, st.hidden // 8, dtype=torch.int32, device=dev).random_()
+        st.bias_all = torch.empty(st.nblk, st.heads, st.L, st.L, dtype=torch.float32, device=dev)
+        ops.cpb_fwd_multi(st.ptab, st.nblk, st.keep_bits, st.bias_all, st.wh, st.ww, st.heads, st.hidden, 0.125)
+        st.packs = ops.attn_pack_bias_multi(st.bias_all)
+        ctx.st = st
+        return params[0].new_zeros(1)
+
+    @staticmethod
+    def backward(ctx, _g):
+        st = ctx.st
+        Hd, h = st.hidden, st.heads
+        n = 3 * Hd + h * Hd + h
+        grads = torch.zeros(st.nblk, n, dtype=torch.float32, device=st.device)
+        if st.dpart is not None:
+            if not all(st.written):
+                raise L.Swv2Error("CPB stage backward: not every block of the stage has run its backward")
+            ops.cpb_bwd_multi(st.dpart, st.nchunk, st.ptab, st.nblk, st.keep_bits, grads, st.wh, st.ww, h, Hd, 0.125)
+            st.dpart = None
+        out = []
+        for i in range(st.nblk):
+            g = grads[i]
+            out += [g[:2 * Hd].view(Hd, 2), g[2 * Hd:3 * Hd], g[3 * Hd:3 * Hd + h * Hd].view(h, Hd), g[3 * Hd + h * Hd:]]
+        return (None, None) + tuple(out)
 
 
 class Mlp(nn.Module):
@@ -582,14 +683,15 @@ class SwinTransformerV2CrBlock(nn.Module):
             r = self._runners[key] = _BlockRunner(self, self._plan(B, device), self.dim, self.mlp.fc1.weight.shape[0], device)
         return r
 
-    def forward(self, x: torch.Tensor, ckpt: int = 0, dp_scales: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, ckpt: int = 0, dp_scales: Optional[torch.Tensor] = None, cpb=None) -> torch.Tensor:
         """x: [B, H, W, C] fp32 -> [B, H, W, C].  ckpt: 0 = keep the activations, 1 / 2 = keep only the fp32 / bf16 block input
         and recompute the forward inside the backward (activation checkpointing).  dp_scales [2, B]: DropPath scales already
-        drawn by the stage for this block's two sites (None: drawn here, one launch per site)."""
+        drawn by the stage for this block's two sites (None: drawn here, one launch per site).  cpb = (_CpbStage, index, token): the
+        CPB table was computed by the stage for all its blocks (None: computed here, the reference's per-block order)."""
         _need_gpu(x, "SwinTransformerV2CrBlock")
         if tuple(x.shape[1:3]) != self.feat_size:
             raise L.Swv2Error(f"block built for feature size {self.feat_size}, got {tuple(x.shape[1:3])}")
-        bias = self.attn.position_bias()
+        bias = self.attn.position_bias() if cpb is None else cpb[2]
         if dp_scales is not None and isinstance(self.drop_path1, DropPath) and self.drop_path1.drop_prob > 0.0:
             dp1, dp2 = dp_scales[0], dp_scales[1]
         else:
@@ -598,7 +700,8 @@ class SwinTransformerV2CrBlock(nn.Module):
         a, m = self.attn, self.mlp
         return _BlockFn.apply(x.float(), bias, dp1, dp2, a.logit_scale, a.qkv.weight, a.qkv.bias, a.proj.weight,
                               a.proj.bias, self.norm1.weight, self.norm1.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight,
-                              m.fc2.bias, self.norm2.weight, self.norm2.bias, self, ckpt if torch.is_grad_enabled() else 0)
+                              m.fc2.bias, self.norm2.weight, self.norm2.bias, self, ckpt if torch.is_grad_enabled() else 0,
+                              None if cpb is None else (cpb[0], cpb[1]))
 
 
 # ================================================================================================
@@ -907,6 +1010,7 @@ class SwinTransformerV2CrStage(nn.Module):
             for index in range(depth)])
 
     _dp_keep = None
+    _last_cpb = None
 
     def update_input_size(self, new_window_size, new_feat_size: Tuple[int, int]) -> None:
         self.feat_size = (new_feat_size[0] // 2, new_feat_size[1] // 2) if self.downscale else tuple(new_feat_size)
@@ -934,12 +1038,33 @@ class SwinTransformerV2CrStage(nn.Module):
                     keep = torch.tensor([[1.0 - r] * 2 for r in rates], dtype=torch.float32, device=x.device)
                     self._dp_keep = keep.unsqueeze(-1).expand(len(rates), 2, x.shape[0]).contiguous()
                 scales = torch.bernoulli(self._dp_keep).div_(self._dp_keep)            # [depth, 2, B]
+        cpb = None if torch_ckpt else self._cpb_stage(x)
         for i, block in enumerate(self.blocks):
             if torch_ckpt:
                 x = checkpoint(block, x, use_reentrant=False)
             else:
-                x = block(x, mode, None if scales is None else scales[i])
+                x = block(x, mode, None if scales is None else scales[i], None if cpb is None else (cpb[0], i, cpb[1]))
         return x
+
+    def _cpb_stage(self, x):
+        """(stage context, token) when the CPB tables of all blocks are computed here in one launch; None: every block computes its
+        own (blocks without CPB, SWV2_CPB_PER_BLOCK=1 = the reference's per-block draw order, or a geometry the multi kernels do
+        not cover)"""
+        blocks = list(self.blocks)
+        if not blocks or not all(getattr(b.attn, "rel_pos", False) for b in blocks) or os.environ.get("SWV2_CPB_PER_BLOCK", "0") == "1":
+            return None
+        a0 = blocks[0].attn
+        hid = a0.meta_mlp.fc1.weight.shape[0]
+        flags = {b.attn.meta_mlp.drop1.training for b in blocks}
+        same = all(b.attn.window_size == a0.window_size and b.attn.num_heads == a0.num_heads and
+                   b.attn.meta_mlp.fc1.weight.shape[0] == hid for b in blocks)
+        st_params_ok = all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for b in blocks for p in b.attn.meta_mlp.parameters())
+        if not same or len(flags) != 1 or not st_params_ok or not ops.cpb_multi_supported(a0.num_heads, hid, 0.125):
+            return None
+        st = _CpbStage(blocks, x.device)
+        tok = _CpbMultiFn.apply(st, flags.pop(), *st.params)
+        self._last_cpb = st                   # (inspection / tests: the tables and the drawn bits of the last forward)
+        return st, tok
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return bhwc_to_bchw(self.forward_bhwc(bchw_to_bhwc(x)))

@@ -466,6 +466,19 @@ def cpb_fwd(w1, b1, w2, b2, keep, bias, wh, ww, heads, hidden, drop_p):
             "swv2_cpb_fwd")
 
 
+_SCRATCH = {}
+
+
+def _scratch(nbytes: int, device, tag: str) -> torch.Tensor:
+    """a cached uint8 workspace per (device, tag), grown on demand: kernels that only need scratch for the duration of their own
+    launches on the current stream share it instead of a torch.empty per call in the training step"""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), tag, _stream())
+    t = _SCRATCH.get(key)
+    if t is None or t.numel() < nbytes:
+        t = _SCRATCH[key] = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
+    return t
+
+
 def cpb_bwd(dbias, w1, b1, w2, keep, dw1, db1, dw2, db2, wh, ww, heads, hidden, drop_p, atomics=False):
     """d(meta MLP) accumulated into dw1 / db1 / dw2 / db2: partial rows in a scratch buffer + a fixed-order fold (default), or the float
     atomics of swv2_cpb_bwd (`atomics=True`)"""
@@ -475,9 +488,44 @@ def cpb_bwd(dbias, w1, b1, w2, keep, dw1, db1, dw2, db2, wh, ww, heads, hidden, 
                                  heads, hidden, drop_p, _stream()), "swv2_cpb_bwd")
         return
     nb = lib.swv2_cpb_bwd_ws_bytes(wh, ww, heads, hidden)
-    ws = torch.empty(nb, dtype=torch.uint8, device=dbias.device)
+    ws = _scratch(nb, dbias.device, "cpb_bwd")
     L.check(lib.swv2_cpb_bwd_ws(_p(dbias), _p(w1), _p(b1), _p(w2), _p(keep), _p(dw1), _p(db1), _p(dw2), _p(db2), wh, ww,
                                 heads, hidden, drop_p, _p(ws), nb, _stream()), "swv2_cpb_bwd_ws")
+
+
+def cpb_multi_supported(heads: int, hidden: int, drop_p: float) -> bool:
+    """shapes the one-launch-per-stage CPB kernels cover (swv2_cpb_fwd_multi): 3-bit keep fields, 8 hidden units per word"""
+    return 0 < heads <= 32 and 0 < hidden <= 512 and hidden % 32 == 0 and abs(drop_p * 8 - round(drop_p * 8)) < 1e-6 and drop_p < 1.0
+
+
+def cpb_fwd_multi(ptab, nblk, keep_bits, bias_all, wh, ww, heads, hidden, drop_p):
+    """bias_all [nblk][heads][L][L] from the blocks' meta MLPs (device pointer table ptab [nblk][4]); keep_bits int32 [nblk][L^2][hidden / 8]
+    of random bits or None (eval)"""
+    _chk(bias_all, torch.float32, "cpb_fwd_multi bias")
+    if keep_bits is not None:
+        _chk(keep_bits, torch.int32, "cpb_fwd_multi keep_bits")
+    L.check(L.load().swv2_cpb_fwd_multi(_p(ptab), nblk, _p(keep_bits), _p(bias_all), wh, ww, heads, hidden, drop_p, _stream()),
+            "swv2_cpb_fwd_multi")
+
+
+def cpb_bwd_multi(dtables, nchunk, ptab, nblk, keep_bits, grads, wh, ww, heads, hidden, drop_p):
+    """grads [nblk][3 hidden + heads hidden + heads] += d(meta MLP) of every block from dtables [nblk][nchunk][heads][L][L] (summed over nchunk)"""
+    lib = L.load()
+    _chk(dtables, torch.float32, "cpb_bwd_multi tables"); _chk(grads, torch.float32, "cpb_bwd_multi grads")
+    nb = lib.swv2_cpb_bwd_multi_ws_bytes(nblk, wh, ww, heads, hidden)
+    ws = _scratch(nb, grads.device, "cpb_bwd_multi")
+    L.check(lib.swv2_cpb_bwd_multi(_p(dtables), nchunk, _p(ptab), nblk, _p(keep_bits), _p(grads), wh, ww, heads, hidden, drop_p,
+                                   _p(ws), nb, _stream()), "swv2_cpb_bwd_multi")
+
+
+def attn_pack_bias_multi(bias_all: torch.Tensor) -> torch.Tensor:
+    """[ntab][heads][L][L] fp32 CPB tables -> [ntab][swv2_attn_pack_bias_bytes] uint8, one launch"""
+    _chk(bias_all, torch.float32, "attn_pack_bias_multi")
+    ntab, heads, Lw = bias_all.shape[0], bias_all.shape[1], bias_all.shape[2]
+    nb = L.load().swv2_attn_pack_bias_bytes(heads, Lw)
+    out = torch.empty(ntab, nb, dtype=torch.uint8, device=bias_all.device)
+    L.check(L.load().swv2_attn_pack_bias_multi(_p(bias_all), ntab, heads, Lw, _p(out), _stream()), "swv2_attn_pack_bias_multi")
+    return out
 
 
 # ---- per-geometry index tables ------------------------------------------------------------------------------

@@ -10,7 +10,11 @@ Differences that are deliberate (reference quirks):
     raises; hyperparams.yaml is written with PyYAML;
   * --enable_amp is accepted for CLI compatibility.  The HIP path always computes its GEMMs and attention on bf16 MFMA
     with fp32 accumulation, fp32 LayerNorm / softmax / residual stream (what autocast does in the reference), and bf16
-    needs no GradScaler, so the flag only sets params.enable_amp;
+    needs no GradScaler, so the flag only sets params.enable_amp.  WITHOUT the flag the reference computes in fp32
+    (train.py:277): that mode has no counterpart here, and the trainer says so once with a WARNING at build time;
+  * `log_every_n_steps` (yaml key, default 1 = the reference: all_reduce(loss) + .item() every step, train.py:292-294):
+    with N > 1 the step losses are accumulated on the device and all-reduced / read back every N steps and at the end
+    of the epoch -- the epoch mean is the same number, the step loop has no host synchronisation in between;
   * DDP: broadcast_buffers=False (the model has no persistent buffers; the reference re-broadcasts ~250 MB of constant
     masks every forward), gradient_as_bucket_view=True; backend nccl (= RCCL over xGMI) on GPUs.
 """
@@ -134,6 +138,11 @@ class Trainer():
             with open(os.path.join(params['experiment_dir'], 'hyperparams.yaml'), 'w') as hpfile:
                 yaml.safe_dump(hparams, hpfile)
 
+        if not params.enable_amp and self.device.type == 'cuda' and self.world_rank == 0:
+            logging.warning("--enable_amp is not set: the reference would compute in fp32 (train.py:277); this build computes every GEMM "
+                            "and the attention products on bf16 MFMA with fp32 accumulation regardless (fp32 residual stream, LayerNorm, "
+                            "softmax statistics, gradients and optimizer state).  Stated tolerance against the fp32 reference: outputs "
+                            "1.5e-2, input gradients 4e-2, weight gradients 8e-2 relative l2; loss curves within 1e-3 over 100 steps.")
         self.loss_obj = self._loss_factory(params).to(self.device)
         self.model = self._model_factory(params).to(self.device)
         self.preprocessor = PreProcessor(params, self.device).to(self.device)
@@ -236,23 +245,48 @@ class Trainer():
         self.epoch += 1
         tr_time = 0
         data_time = 0
-        tr_loss = []
         self.model.train()
         n_samples = 0
         world = dist.get_world_size() if dist.is_initialized() else 1
+        # reference: all_reduce(loss) + loss.item() after EVERY step (train.py:292-294) -- one host synchronisation per step.
+        # log_every_n_steps = N > 1 keeps the running sum on the device and synchronises every N steps (and at the epoch's end)
+        every = max(1, int(self.params['log_every_n_steps'])) if 'log_every_n_steps' in self.params else 1
+        loss_sum = torch.zeros((), dtype=torch.float64, device=self.device)      # sum over steps of the all-rank loss sum
+        n_steps, last = 0, None
         for i, data in enumerate(self.train_data_loader, 0):
             tr_start = time.time()
             loss = self.train_step(data)
-            if dist.is_initialized():
-                dist.all_reduce(loss)
-            tr_loss.append(loss.item() / world)        # host sync per step, as the reference (train.py:294)
+            loss_sum += loss.double()
+            n_steps += 1
+            if n_steps % every == 0:
+                last = self._sync_loss(loss if every == 1 else None)
             self.iters += 1
             n_samples += self.params.local_batch_size * world
             tr_time += time.time() - tr_start
-        logs = {'loss': np.mean(tr_loss), 'samples_per_sec': n_samples / max(tr_time, 1e-9)}
+        t0 = time.time()
+        if dist.is_initialized():
+            dist.all_reduce(loss_sum)
+        mean_loss = float(loss_sum.item()) / world / max(n_steps, 1)            # == np.mean of the per-step all-rank means
+        tr_time += time.time() - t0
+        logs = {'loss': mean_loss, 'samples_per_sec': n_samples / max(tr_time, 1e-9)}
+        if last is not None:
+            logs['last_step_loss'] = last
         if self.log_to_wandb:
             wandb.log(logs, step=self.epoch)
         return tr_time, data_time, logs
+
+    def _sync_loss(self, loss):
+        """the reference's per-step logging point: with a step loss, its all-rank mean (all_reduce + .item()); without (N > 1), only
+        the host waits for the device queue to drain so that the step loop cannot run arbitrarily far ahead"""
+        if loss is None:
+            if self.device.type == 'cuda':
+                torch.cuda.current_stream().synchronize()
+            return None
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        if dist.is_initialized():
+            loss = loss.clone()
+            dist.all_reduce(loss)
+        return loss.item() / world
 
     def validate_one_epoch(self):
         self.model.eval()

@@ -19,7 +19,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from swin_v2_weather_amd.networks import swinv2_global as N          # noqa: E402
-from swin_v2_weather_amd.networks.helpers import enable_ddp_bucket_grads, get_model   # noqa: E402
+from swin_v2_weather_amd.networks.helpers import ddp_bucket_plan, ddp_observed_buckets, enable_ddp_bucket_grads, get_model   # noqa: E402
 
 rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 backend = os.environ.get("SWV2_DDP_BACKEND", "nccl")
@@ -43,7 +43,8 @@ with torch.no_grad():                                                 # LN weigh
             p.uniform_(0.5, 1.0)
 net = m
 if mode != "plain":
-    net = torch.nn.parallel.DistributedDataParallel(m, device_ids=[0], broadcast_buffers=False, gradient_as_bucket_view=True)
+    cap_mb = float(os.environ.get("SWV2_DDP_CAP_MB", "25"))
+    net = torch.nn.parallel.DistributedDataParallel(m, device_ids=[0], broadcast_buffers=False, gradient_as_bucket_view=True, bucket_cap_mb=cap_mb)
     if mode == "alias":
         enable_ddp_bucket_grads(net)
 # plain SGD: the parameter difference is then linear in the gradient difference (Adam turns a rounding-level difference of a
@@ -78,7 +79,10 @@ used = sum(1 for b in blocks if all(hasattr(p, "_swv2_bv") for p in b.mlp.parame
 stuck = sum(1 for b in blocks if b._bv_in_use)
 if rank == 0:
     torch.save({"losses": losses, "params": [p.detach().cpu() for p in m.parameters()], "used": used, "stuck": stuck,
-                "nranks": dist.get_world_size() if mode != "plain" else 1}, os.environ["SWV2_DDP_OUT"])
+                "nranks": dist.get_world_size() if mode != "plain" else 1,
+                # what the reducer reports after its bucket rebuild vs the plan the cap was chosen with (helpers.ddp_bucket_plan)
+                "buckets_observed": ddp_observed_buckets(net) if mode != "plain" else None,
+                "buckets_planned": ddp_bucket_plan(m, cap_mb)[0] if mode != "plain" else None}, os.environ["SWV2_DDP_OUT"])
     print(f"rank 0 of {world} ({backend}, {mode}, n_future={n_future}): losses {losses} bucket-view blocks {used}")
 if mode != "plain":
     dist.barrier()

@@ -87,8 +87,20 @@ def _worker(rank, world, port, tmp, out):
     loss = tr.train_step(_batch(rank, 2))
     dist.all_reduce(loss)
     grads = {n: p.grad.clone() for n, p in tr.model.module.named_parameters()}
+    # the epoch loop with the reference's per-step loss synchronisation (log_every_n_steps = 1: all_reduce + .item() every step,
+    # train.py:292-294) and with it taken out of the step loop (N = 2: device-side running sum, one all-reduce at the end of the epoch):
+    # the same epoch-mean loss from the same start (lr = 0: the parameters stay put)
+    for g_ in tr.optimizer.param_groups:
+        g_["lr"] = 0.0
+    epoch = {}
+    for every in (1, 2):
+        tr.params["log_every_n_steps"] = every
+        if tr.train_sampler is not None:
+            tr.train_sampler.set_epoch(0)
+        _, _, logs = tr.train_one_epoch()
+        epoch[every] = logs
     if rank == 0:
-        torch.save({"grads": grads, "loss": float(loss)}, out)
+        torch.save({"grads": grads, "loss": float(loss), "epoch": epoch}, out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -108,6 +120,9 @@ def test_two_rank_ddp_matches_single_rank():
     loss = loss_obj(model(torch.cat(xs)), torch.cat(ts))
     loss.backward()
     assert abs(got["loss"] - float(loss)) <= 1e-5 * abs(float(loss))           # all-reduced sum of local (sum) losses
+    e1, e2 = got["epoch"][1], got["epoch"][2]
+    assert e1["loss"] > 0 and abs(e1["loss"] - e2["loss"]) <= 1e-6 * abs(e1["loss"])
+    assert "last_step_loss" in e1 and "last_step_loss" not in e2               # the per-step value exists only where a step was read back
     for n, prm in model.named_parameters():
         # the loss is a SUM over the local batch and DDP averages over ranks: grad_ddp = grad_global_sum / world
         torch.testing.assert_close(got["grads"][n], prm.grad / 2, rtol=1e-4, atol=1e-6)

@@ -411,20 +411,22 @@ def main():
 
     for i in range(a.settle):          # untimed set-up: the caching allocator grows to its steady-state footprint and the
         step(i)                        # clocks settle during the first ~10 steps (one of them stalls for ~80 ms)
-    for i in range(a.warmup):
-        step(i)
-    fence()
-    # Inside the timed region only the roofline kernel is bracketed with HIP events, and only on every 6th eligible block call
-    # (2 of its 12 launches per step): an event record between two kernels is a packet the next kernel waits behind -- one pair per
-    # block call (24 per step, what rounds 2 - 3 did to time nine kernels at once) measured 3.3 % of the step (208.5 vs 215.5
-    # samples/s).  The other kernels of `roofline_others` are timed in extra steps AFTER the timed region.
+    # Every HIP event the timed region uses is created (and recorded once: that is what materialises its handle) BEFORE the warm-up
+    # steps, so that nothing but the barrier + synchronize the contract asks for sits between the last warm-up step and the first timed
+    # one: a GPU left idle for a few milliseconds re-ramps its clocks, and the first timed step (10.4 - 14.7 ms against 9.1, round 5
+    # measurements) is already the one that cannot overlap its host-side launch work with a previous step's kernels.
+    #   * one event per STEP boundary (K + 1 records on the launch stream): the GPU-side duration of every timed step, so that a
+    #     reader can tell box noise from signal (the timed region is 0.2 s);
+    #   * inside the timed region only the roofline kernel is bracketed with HIP events, and only on every 6th eligible block call
+    #     (2 of its 12 launches per step): an event record between two kernels is a packet the next kernel waits behind -- one pair per
+    #     block call (24 per step, what rounds 2 - 3 did to time nine kernels at once) measured 3.3 % of the step (208.5 vs 215.5
+    #     samples/s).  The other kernels of `roofline_others` are timed in extra steps AFTER the timed region.
     ops.prewarm_events(64)
-    fence()
-    # one HIP event per STEP boundary (K + 1 records on the launch stream, created beforehand): the GPU-side duration of every timed
-    # step, so that a reader can tell box noise from signal (the timed region is 0.2 s)
     step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     for e_ in step_ev:
         e_.record()
+    for i in range(a.warmup):
+        step(i)
     fence()
     ops.start_kernel_timing([] if a.no_kernel_timing else [a.roofline_kernel], every=a.time_every)
     t0 = time.perf_counter()
@@ -435,7 +437,8 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     ktimes = ops.stop_kernel_timing()
-    step_ms = sorted(step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(a.steps))
+    step_seq = [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(a.steps)]
+    step_ms = sorted(step_seq)
     others = [k for k in ROOFLINE_KERNELS if k != a.roofline_kernel]
     if others and not a.no_kernel_timing:          # not part of `value`: three more steps with every block call bracketed
         ops.start_kernel_timing(others)
@@ -548,7 +551,7 @@ def main():
             "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)},
             # GPU-side duration of every timed step of rank 0 (HIP events at the step boundaries): spread of the K steps behind `value`
             "step_ms": {"min": step_ms[0], "p50": step_ms[len(step_ms) // 2], "p90": step_ms[min(len(step_ms) - 1, int(0.9 * len(step_ms)))],
-                        "max": step_ms[-1], "n": len(step_ms)},
+                        "max": step_ms[-1], "n": len(step_ms), "sequence": [round(v, 3) for v in step_seq]},
             "secondary": secondary,
             "weak_scaling_local_batch": B,      # fixed per GPU at every N (BASELINE cfg 2's batch; cfg 3's 8 per GPU: --local-batch 8)
             "roofline": main_rf,

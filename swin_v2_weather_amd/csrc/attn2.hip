@@ -474,7 +474,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn_fwd3w_kernel(
 // sigma' + max(bias') of the head (the (max, min) part of the packed buffer), valid while 2 sigma' + (max - min) <= 80.
 // 66 registers of bias per wave (3 q-tiles) on top of the 145 of the kernel without bias: two workgroups per CU instead of three.
 // ------------------------------------------------------------------------------------------------
-template <int LT, int LFIX, int WAVES, int OCC>
+template <int LT, int LFIX, int WAVES, int OCC, bool KREG>
 __global__ __launch_bounds__(64 * WAVES, OCC) void attn_fwd3b_kernel(
     const uint16_t* __restrict__ qkvh, const float* __restrict__ logit_scale, const uint32_t* __restrict__ bpack,
     const float* __restrict__ brange, uint16_t* __restrict__ oh, float* __restrict__ lse, int Bw, int h, int L, int nW, int nww, int nwh,
@@ -570,6 +570,14 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn_fwd3b_kernel(
         const bool fixed = bounded && !do_mask;                       // wave-uniform
         const float c0 = fixed ? -(sc2 + bmax) : 0.f;
         const f32x4 cinit = {c0, c0, c0, c0};
+        // KREG: the item's K fragments (A operands of S^T) in registers, read once per item and wave and pinned (see attn_fwd3_kernel)
+        bf16x8 kreg[KREG ? LT : 1];
+        if constexpr (KREG) {
+#pragma unroll
+            for (int t = 0; t < LT; ++t) kreg[t] = *(const bf16x8*)(Ki + (16 * t + fr) * 32 + 8 * g);
+#pragma unroll
+            for (int t = 0; t < LT; ++t) asm volatile("" : "+v"(kreg[t]));
+        }
 
         // rolled loop (unrolled, the compiler interleaves the rows and spills: 256 registers + 94 in scratch); the wave's i-th bias
         // register set is picked by a scalar switch around the identity products only
@@ -608,7 +616,9 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn_fwd3b_kernel(
 #undef SWV2_BIAS_TILES
 #pragma unroll
             for (int t = 0; t < LT; ++t) {
-                const bf16x8 kA = *(const bf16x8*)(Ki + (16 * t + fr) * 32 + 8 * g);
+                bf16x8 kA;
+                if constexpr (KREG) kA = kreg[t];
+                else kA = *(const bf16x8*)(Ki + (16 * t + fr) * 32 + 8 * g);
                 acc[t] = mfma32(kA, qB, acc[t]);
             }
             float mx = sc2 + bmax;
@@ -667,12 +677,12 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn_fwd3b_kernel(
     }
 }
 
-template <int LT, int LFIX, int WAVES, int OCC>
+template <int LT, int LFIX, int WAVES, int OCC, bool KREG>
 int launch_fwd3b(const swv2_attn_args* a, const uint32_t* bpack, const float* brange, hipStream_t st) {
     int nchunk = (OCC * 256 + a->heads - 1) / a->heads;
     if (nchunk > a->Bw) nchunk = a->Bw;
     dim3 grid(nchunk, a->heads), block(64 * WAVES);
-    hipLaunchKernelGGL((attn_fwd3b_kernel<LT, LFIX, WAVES, OCC>), grid, block, 0, st, (const uint16_t*)a->qkvh, a->logit_scale, bpack, brange,
+    hipLaunchKernelGGL((attn_fwd3b_kernel<LT, LFIX, WAVES, OCC, KREG>), grid, block, 0, st, (const uint16_t*)a->qkvh, a->logit_scale, bpack, brange,
                        (uint16_t*)a->oh, a->lse, a->Bw, a->heads, a->L, a->nwh * a->nww, a->nww, a->nwh, a->mask_thr);
     SWV2_CHECK_LAUNCH("swv2_attn_fwd");
     return SWV2_OK;
@@ -716,7 +726,9 @@ int swv2_attn2_fwd(const swv2_attn_args* a, int Lp, int DP, void* stream) {
         if (!fwd3b || !a->bias_pack || DP != 16 || a->heads <= 0) return 1;
         const uint32_t* bpack = (const uint32_t*)a->bias_pack;
         const float* brange = (const float*)((const char*)a->bias_pack + swv2_attn_bias_range_offset(a->heads, a->L));
-        return a->L == 162 ? launch_fwd3b<11, 162, 4, 2>(a, bpack, brange, st) : launch_fwd3b<11, 0, 4, 2>(a, bpack, brange, st);
+        static const int kreg = getenv("SWV2_ATTN_FWD3B_KREG") ? atoi(getenv("SWV2_ATTN_FWD3B_KREG")) : 0;
+        if (kreg) return a->L == 162 ? launch_fwd3b<11, 162, 4, 2, true>(a, bpack, brange, st) : launch_fwd3b<11, 0, 4, 2, true>(a, bpack, brange, st);
+        return a->L == 162 ? launch_fwd3b<11, 162, 4, 2, false>(a, bpack, brange, st) : launch_fwd3b<11, 0, 4, 2, false>(a, bpack, brange, st);
     }
     if (DP == 32) {
         // measured at B = 2 (800 windows x 8 heads, 24-wide heads): 4 waves x 2 workgroups per CU, two LDS buffers: 90 us with the K / V^T

@@ -255,12 +255,15 @@ __global__ __launch_bounds__(256) void cpb_fwd_multi_kernel(const float* const* 
 
 // backward of all blocks: d bias of block b = the sum of `nchunk` tables [heads][L^2] (the per-workgroup tables the attention
 // backward leaves, summed here while they are staged -- no reduction launch, no zero fill; nchunk = 1: a plain d bias table);
-// one partial row per workgroup + cpb_fold_multi_kernel (fixed order, bit-reproducible)
-template <int HEADS_MAX>
+// one partial row per workgroup + cpb_fold_multi_kernel (fixed order, bit-reproducible).
+// The staging is the kernel's cost (nchunk = 32 at the benchmark shape: 27 MB per block, 324 MB per step): all CPB_PPB = 128 pairs of the
+// workgroup in ONE round, 16-byte loads (4 consecutive pairs of one (chunk, head) row), 8 chunk loads in flight per thread -- the first
+// version (64 pairs per round, 4-byte loads, 4 in flight: 6 KB in flight per workgroup) ran at 1.16 TB/s, 281 us per step.
+template <int HEADS_MAX, bool VEC4>
 __global__ __launch_bounds__(512) void cpb_bwd_multi_kernel(const float* __restrict__ dpart, int nchunk, const float* const* __restrict__ ptab,
                                                             const uint32_t* __restrict__ keep_bits, int L, int ww, int heads, int Hd,
                                                             float scale, uint32_t thr, float* __restrict__ part) {
-    __shared__ __attribute__((aligned(16))) float dbs[64][HEADS_MAX + 4];   // [pair][d bias of head 0.., r0, r1]
+    __shared__ __attribute__((aligned(16))) float dbs[HEADS_MAX + 2][CPB_PPB];   // [d bias of head 0.., r0, r1][pair]
     const int blk = blockIdx.y;
     const gfloat* __restrict__ w1 = (const gfloat*)ptab[blk * 4 + 0];
     const gfloat* __restrict__ b1 = (const gfloat*)ptab[blk * 4 + 1];
@@ -277,26 +280,31 @@ __global__ __launch_bounds__(512) void cpb_bwd_multi_kernel(const float* __restr
     const int p0 = blockIdx.x * CPB_PPB, p1 = min(L2, p0 + CPB_PPB);
     const float* dsrc = dpart + (size_t)blk * nchunk * heads * L2;
     const size_t cstride = (size_t)heads * L2;
-    for (int pc = p0; pc < p1; pc += 64) {
-        uint32_t kbits[2] = {~0u, ~0u};        // the chunk's keep flags of this hidden unit, in flight during the staging
-        if (keep_bits) {
-            const uint32_t* kw = keep_bits + (size_t)blk * L2 * (Hd >> 3) + (jc >> 3);
-            const int sh = 3 * (jc & 7);
+    // ---- stage: dbs[h][pp] = sum over the chunks' tables, + the pairs' two coordinates
+    if constexpr (VEC4) {                      // L2 % 4 == 0: every (chunk, head) row segment is 16-byte aligned
+        for (int i = threadIdx.x; i < heads * (CPB_PPB / 4); i += blockDim.x) {
+            const int h = i / (CPB_PPB / 4), q4 = i % (CPB_PPB / 4), pp = 4 * q4;
+            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+            if (p0 + pp < p1) {                // (p1 - p0 is a multiple of 4)
+                const float* src = dsrc + (size_t)h * L2 + p0 + pp;
+                int c = 0;
+                for (; c + 7 < nchunk; c += 8) {
+                    f32x4 v[8];
 #pragma unroll
-            for (int w = 0; w < 2; ++w) {
-                uint32_t b = 0;
+                    for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)(src + (size_t)(c + u) * cstride);
 #pragma unroll
-                for (int u = 0; u < 32; ++u)
-                    b |= (uint32_t)(((kw[(size_t)min(pc + 32 * w + u, L2 - 1) * (Hd >> 3)] >> sh) & 7u) >= thr) << u;
-                kbits[w] = b;
+                    for (int u = 0; u < 8; u += 2) { s0 += v[u]; s1 += v[u + 1]; }
+                }
+                for (; c < nchunk; ++c) s0 += *(const f32x4*)(src + (size_t)c * cstride);
             }
+            *(f32x4*)&dbs[h][pp] = s0 + s1;
         }
-        __syncthreads();
-        for (int i = threadIdx.x; i < 64 * HEADS_MAX; i += blockDim.x) {
-            const int h = i >> 6, pp = i & 63;
+    } else {
+        for (int i = threadIdx.x; i < heads * CPB_PPB; i += blockDim.x) {
+            const int h = i / CPB_PPB, pp = i % CPB_PPB;
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-            if (h < heads && pc + pp < p1) {
-                const float* src = dsrc + (size_t)h * L2 + pc + pp;
+            if (p0 + pp < p1) {
+                const float* src = dsrc + (size_t)h * L2 + p0 + pp;
                 int c = 0;
                 for (; c + 3 < nchunk; c += 4) {
                     s0 += src[(size_t)c * cstride];
@@ -306,36 +314,52 @@ __global__ __launch_bounds__(512) void cpb_bwd_multi_kernel(const float* __restr
                 }
                 for (; c < nchunk; ++c) s0 += src[(size_t)c * cstride];
             }
-            dbs[pp][h] = (s0 + s1) + (s2 + s3);
+            dbs[h][pp] = (s0 + s1) + (s2 + s3);
         }
-        if (threadIdx.x < 64) {
-            float r0, r1;
-            rel_coord(min(pc + (int)threadIdx.x, L2 - 1), L, ww, r0, r1);
-            dbs[threadIdx.x][HEADS_MAX] = r0;
-            dbs[threadIdx.x][HEADS_MAX + 1] = r1;
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (int pp = 0; pp < 64; ++pp) {          // rows past p1 hold d bias = 0 and contribute nothing
-            const float r0 = dbs[pp][HEADS_MAX], r1 = dbs[pp][HEADS_MAX + 1];
-            const float pre = fmaf(wa, r0, fmaf(wb, r1, bb));
-            const float m = keep_bits ? (((kbits[pp >> 5] >> (pp & 31)) & 1u) ? scale : 0.f) : 1.f;
-            const float hdn = fmaxf(pre, 0.f) * m;
-            float dh = 0.f;
-#pragma unroll
-            for (int h = 0; h < HEADS_MAX; ++h) {
-                const float d = dbs[pp][h];
-                g2[h] = fmaf(d, hdn, g2[h]);
-                dh = fmaf(d, w2r[h], dh);
-            }
-            dh = (pre > 0.f) ? dh * m : 0.f;
-            ga = fmaf(dh, r0, ga);
-            gb = fmaf(dh, r1, gb);
-            gbias += dh;
-        }
-        if (j < heads)
-            for (int pp = 0; pp < 64; ++pp) gb2 += dbs[pp][j];
     }
+    if (threadIdx.x < CPB_PPB) {
+        float r0, r1;
+        rel_coord(min(p0 + (int)threadIdx.x, L2 - 1), L, ww, r0, r1);
+        dbs[HEADS_MAX][threadIdx.x] = r0;
+        dbs[HEADS_MAX + 1][threadIdx.x] = r1;
+    }
+    // the pairs' keep flags of this hidden unit (in flight during the staging)
+    uint32_t kbits[CPB_PPB / 32];
+#pragma unroll
+    for (int w = 0; w < CPB_PPB / 32; ++w) kbits[w] = ~0u;
+    if (keep_bits) {
+        const uint32_t* kw = keep_bits + (size_t)blk * L2 * (Hd >> 3) + (jc >> 3);
+        const int sh = 3 * (jc & 7);
+#pragma unroll
+        for (int w = 0; w < CPB_PPB / 32; ++w) {
+            uint32_t b = 0;
+#pragma unroll
+            for (int u = 0; u < 32; ++u)
+                b |= (uint32_t)(((kw[(size_t)min(p0 + 32 * w + u, L2 - 1) * (Hd >> 3)] >> sh) & 7u) >= thr) << u;
+            kbits[w] = b;
+        }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int pp = 0; pp < CPB_PPB; ++pp) {          // pairs past p1 hold d bias = 0 and contribute nothing
+        const float r0 = dbs[HEADS_MAX][pp], r1 = dbs[HEADS_MAX + 1][pp];
+        const float pre = fmaf(wa, r0, fmaf(wb, r1, bb));
+        const float m = keep_bits ? (((kbits[pp >> 5] >> (pp & 31)) & 1u) ? scale : 0.f) : 1.f;
+        const float hdn = fmaxf(pre, 0.f) * m;
+        float dh = 0.f;
+#pragma unroll
+        for (int h = 0; h < HEADS_MAX; ++h) {
+            const float d = (h < heads) ? dbs[h][pp] : 0.f;
+            g2[h] = fmaf(d, hdn, g2[h]);
+            dh = fmaf(d, w2r[h], dh);
+        }
+        dh = (pre > 0.f) ? dh * m : 0.f;
+        ga = fmaf(dh, r0, ga);
+        gb = fmaf(dh, r1, gb);
+        gbias += dh;
+    }
+    if (j < heads)
+        for (int pp = 0; pp < CPB_PPB; ++pp) gb2 += dbs[j][pp];
     const int n = 3 * Hd + heads * Hd + heads;
     float* row = part + ((size_t)blk * gridDim.x + blockIdx.x) * n;
     if (act) {
@@ -492,13 +516,20 @@ extern "C" int swv2_cpb_bwd_multi(const float* dbias_tables, int nchunk, const f
     const int threads = cdiv(hidden, 64) * 64;
     const float scale = 1.f / (1.f - drop_p);
 #define CPB_BWDM(HM)                                                                                                        \
-    hipLaunchKernelGGL((cpb_bwd_multi_kernel<HM>), dim3(rows, nblk), dim3(threads), 0, (hipStream_t)stream, dbias_tables, nchunk, \
-                       params_dev, keep_bits, L, ww, heads, hidden, scale, thr, (float*)ws)
+    do {                                                                                                                    \
+        if ((L2 & 3) == 0)                                                                                                  \
+            hipLaunchKernelGGL((cpb_bwd_multi_kernel<HM, true>), dim3(rows, nblk), dim3(threads), 0, (hipStream_t)stream, dbias_tables, \
+                               nchunk, params_dev, keep_bits, L, ww, heads, hidden, scale, thr, (float*)ws);               \
+        else                                                                                                                \
+            hipLaunchKernelGGL((cpb_bwd_multi_kernel<HM, false>), dim3(rows, nblk), dim3(threads), 0, (hipStream_t)stream, dbias_tables, \
+                               nchunk, params_dev, keep_bits, L, ww, heads, hidden, scale, thr, (float*)ws);               \
+    } while (0)
     if (heads <= 4) CPB_BWDM(4);
     else if (heads <= 8) CPB_BWDM(8);
     else if (heads <= 16) CPB_BWDM(16);
     else CPB_BWDM(CPB_MAX_HEADS);
 #undef CPB_BWDM
+    static_assert(CPB_PPB % 32 == 0 && CPB_PPB <= 512, "pairs per workgroup");
     hipLaunchKernelGGL(cpb_fold_multi_kernel, dim3(cdiv(n, 64), nblk), dim3(512), 0, (hipStream_t)stream, (const float*)ws, rows, n, grads);
     SWV2_CHECK_LAUNCH("swv2_cpb_bwd_multi");
     return SWV2_OK;

@@ -106,8 +106,11 @@ def ddp_bucket_plan(model, cap_mb=DDP_BUCKET_CAP_MB):
         first_embed = next((i for i, (n, _) in enumerate(order) if ".patch_embed." in n or n.startswith("patch_embed.")), len(order))
         order.insert(first_embed, item)
     tensors = [p for _, p in order]
-    first = getattr(dist, "_DEFAULT_FIRST_BUCKET_BYTES", 1024 * 1024)
-    buckets, _ = dist._compute_bucket_assignment_by_size(tensors, [first, int(cap_mb * 1024 * 1024)])
+    # an EXPLICIT bucket_cap_mb (every caller here passes one) also caps the first bucket: torch applies
+    # dist._DEFAULT_FIRST_BUCKET_BYTES (1 MB) only with the default 25 MB cap (DistributedDataParallel.__init__: `bucket_bytes_cap_default`).
+    # Rounds 3 - 4 planned with the 1 MB first bucket and printed [1.13, 2.12, ...]; the reducer's own report (ddp_observed_buckets,
+    # compared in tests/test_gpu_parity.py::test_ddp_two_ranks_hip_model since round 5) showed the difference.
+    buckets, _ = dist._compute_bucket_assignment_by_size(tensors, [int(cap_mb * 1024 * 1024)])
     sizes = [round(sum(tensors[i].numel() * tensors[i].element_size() for i in b) / 1e6, 2) for b in buckets]
     where = next((k for k, b in enumerate(buckets) if any(order[i][0].endswith("pos_embed") for i in b)), -1)
     return sizes, where

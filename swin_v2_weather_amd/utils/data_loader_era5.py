@@ -126,21 +126,36 @@ class GetDataset(Dataset):
 
 
 class DevicePoolLoader:
-    """K device-resident batches, generated once with the device RNG (seed = base seed + rank) and cycled."""
+    """K device-resident batches, generated once with the device RNG (seed = base seed + rank) and cycled.  With a zenith channel /
+    static features (configs with `add_zenith`, `add_orography`, `add_landmask`) the pool holds the batches as the host pipeline delivers
+    them: the model's input already ASSEMBLED in one buffer -- [data channels | cos zenith | land mask (2) | orography] in the
+    reference's order (preprocess_utils.py:50-68) -- so the PreProcessor passes them through instead of concatenating 319 MB per sample
+    in every step (the 375 us CatArrayBatchedCopy of round 4's cfg-4 profile); `assemble=False` keeps the raw tuples."""
 
-    def __init__(self, params, dataset, device, train, pool, steps_per_epoch):
+    def __init__(self, params, dataset, device, train, pool, steps_per_epoch, assemble=True):
         self.dataset, self.steps, self.batches = dataset, steps_per_epoch, []
         B, H, W = int(params.local_batch_size), dataset.img_shape_x, dataset.img_shape_y
         n_in = len(dataset.in_channels)
         n_tar = dataset.n_out_channels * (dataset.n_future + 1)
         g = torch.Generator(device=device).manual_seed(dataset.seed + 7919 * _get(params, 'data_shard_id', 0) + (0 if train else 1))
+        stat = None
+        if assemble and (_get(params, 'add_orography', False) or _get(params, 'add_landmask', False)):
+            from .preprocess_utils import build_static_features
+            stat = build_static_features(params)
+            stat = None if stat is None else stat.to(device)
         for k in range(pool):
             inp = torch.randn(B, n_in, H, W, device=device, generator=g)
             tar = torch.randn(B, n_tar, H, W, device=device, generator=g)
+            zi = zt = None
             if params.add_zenith:
                 zi = cos_zenith(dataset.years[0], 6.0 * k, H, W).to(device).expand(B, 1, H, W).contiguous()
                 zt = torch.stack([cos_zenith(dataset.years[0], 6.0 * (k + 1 + s), H, W) for s in range(dataset.n_future + 1)],
                                  0).to(device).unsqueeze(0).expand(B, -1, H, W).contiguous()
+            if assemble and (zi is not None or stat is not None):
+                from .host_pipeline import AssembledBatch
+                parts = [inp] + ([zi] if zi is not None else []) + ([stat.expand(B, -1, -1, -1)] if stat is not None else [])
+                self.batches.append(AssembledBatch((torch.cat(parts, dim=1).contiguous(), tar, zt)))       # once, at pool creation
+            elif zi is not None:
                 self.batches.append((inp, tar, zi, zt))
             else:
                 self.batches.append((inp, tar))

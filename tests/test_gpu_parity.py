@@ -1565,6 +1565,31 @@ def test_full_size_training_trajectory_against_oracle(dev, K):
 # ---------------------------------------------------------------------------------------------------------------
 # the trainer end to end on the GPU (train.py surface: build, epochs, validation, checkpoint save / resume)
 # ---------------------------------------------------------------------------------------------------------------
+def test_device_pool_batches_are_assembled_like_the_preprocessor(dev, K):
+    """The synthetic device pool hands the model's input already assembled ([data | cos zenith | land mask (2) | orography], as the
+    host pipeline does) so that no 319 MB-per-sample torch.cat sits in the step: identical tensors to the reference's
+    PreProcessor (preprocess_utils.py:50-68) applied to the raw tuples of the same pool."""
+    from swin_v2_weather_amd.utils.YParams import YParams
+    from swin_v2_weather_amd.utils.data_loader_era5 import DevicePoolLoader, GetDataset
+    from swin_v2_weather_amd.utils.host_pipeline import AssembledBatch
+    from swin_v2_weather_amd.utils.preprocess_utils import PreProcessor
+    p = YParams(os.path.join(ROOT, "swin_v2_weather_amd", "config", "swin.yaml"), "bench_depth12_e128_2step")
+    p["img_size"] = [48, 72]
+    p["local_batch_size"] = 2
+    p["n_in_channels"], p["n_out_channels"] = 73, 73
+    assert p.add_zenith and p.add_orography and p.add_landmask and p.n_future == 1
+    ds = GetDataset(p, None, True)
+    a = DevicePoolLoader(p, ds, dev, True, 2, 2)
+    b = DevicePoolLoader(p, ds, dev, True, 2, 2, assemble=False)
+    pre = PreProcessor(p, dev).to(dev)
+    for ba, bb in zip(a.batches, b.batches):
+        assert isinstance(ba, AssembledBatch) and not isinstance(bb, AssembledBatch) and len(bb) == 4
+        ia, ta, za = pre(ba)
+        ib, tb, zb = pre(bb)
+        assert ia.shape == (2, 77, 48, 72) and torch.equal(ia, ib) and torch.equal(ta, tb) and torch.equal(za, zb)
+        assert ia.data_ptr() == ba[0].data_ptr()                      # passed through, not copied
+
+
 def test_trainer_end_to_end_with_checkpoint_resume(dev, K, tmp_path):
     from types import SimpleNamespace
     from swin_v2_weather_amd.train import Trainer
@@ -1718,10 +1743,12 @@ def test_cpb_multi_kernels_match_oracle(dev, K, wh, ww, heads, hidden, train, nc
     assert rel(g2, 2 * grads) < 1e-6
     # the packed tables of all blocks in one launch == block by block, incl. the (max, min) part
     pk = ops.attn_pack_bias_multi(bias_all)
+    LT = 4 if Lw <= 64 else 11
+    off = heads * (LT * LT * 2 * 64 * 4 + 16 * LT * (16 * LT + 4) * 2)          # forward part + backward image; then (max, min) per head
+    assert off + heads * 8 <= pk.shape[1] < off + heads * 8 + 16
     for i in range(nblk):
-        assert torch.equal(pk[i], ops.attn_pack_bias(bias_all[i].contiguous()))
-    nb = pk.shape[1]
-    rng = pk[0, nb - (heads * 8 + 15) // 16 * 16:][:heads * 8].view(torch.float32).view(heads, 2).cpu()
+        assert torch.equal(pk[i, :off + heads * 8], ops.attn_pack_bias(bias_all[i].contiguous())[:off + heads * 8])
+    rng = pk[0, off:off + heads * 8].clone().view(torch.float32).view(heads, 2).cpu()
     b2 = (bias_all[0].cpu() * 1.4426950408889634).to(BF).float()
     assert torch.equal(rng[:, 0], b2.flatten(1).max(1).values) and torch.equal(rng[:, 1], b2.flatten(1).min(1).values)
 
@@ -2022,8 +2049,13 @@ def test_ddp_two_ranks_hip_model(dev, K, tmp_path):
     # against what the REAL 2-rank reducer reports after its rebuild: same buckets, with a cap that splits the model
     capped = _ddp_run(tmp_path, "capped", 2, "gloo", "alias", 0, 29555, cap_mb=0.12)
     print("DDP buckets observed", capped["buckets_observed"], "planned", capped["buckets_planned"])
-    assert capped["buckets_observed"] is not None and len(capped["buckets_observed"]) >= 4
-    assert capped["buckets_observed"] == capped["buckets_planned"], (capped["buckets_observed"], capped["buckets_planned"])
+    obs, plan = capped["buckets_observed"], capped["buckets_planned"]
+    assert obs is not None and len(obs) >= 4
+    # same number of buckets, same bytes, every bucket the planned size up to the parameters that straddle a boundary (the plan knows
+    # the order of the autograd NODES -- head, blocks last to first, pos_embed / PatchEmbed -- not the order in which the engine
+    # marks the gradients of ONE node ready; the block's largest parameter here is 0.07 MB)
+    assert len(obs) == len(plan) and abs(sum(obs) - sum(plan)) < 0.03, (obs, plan)
+    assert all(abs(a_ - b_) <= 0.08 for a_, b_ in zip(obs, plan)), (obs, plan)
     _ddp_close(capped, ref)
     # the optimizer the trainer / bench use under DDP: HipAdam on the reducer's bucket-view gradients against torch's Adam on
     # the same two-rank run (identical gradients, so the updates must agree to rounding)

@@ -207,11 +207,14 @@ __global__ __launch_bounds__(512) void cpb_fold_kernel(const float* __restrict__
 //               random bits drawn by the caller (ONE torch `random_()` launch); dropped iff field < thr, i.e. with probability
 //               thr / 8 (Dropout(0.125): thr = 1); kept units are scaled by 1 / (1 - drop_p).  NULL: eval mode.
 // ------------------------------------------------------------------------------------------------
-template <int HEADS_MAX>
+// PPL pairs per lane: the uniform weight values (88 scalar loads per 8 hidden units) serve PPL x 64 pairs per wave, so their latency is
+// amortised over PPL times the vector work (PPL = 1: 88 us per step at depth 12 -- every trip waited for its scalar loads)
+template <int HEADS_MAX, int PPL>
 __global__ __launch_bounds__(256) void cpb_fwd_multi_kernel(const float* const* __restrict__ ptab, const uint32_t* __restrict__ keep_bits,
                                                             float* __restrict__ bias_all, int L, int ww, int heads, int Hd, float scale,
                                                             uint32_t thr) {
-    __shared__ float red[4][HEADS_MAX][64];
+    constexpr int PW = 64 * PPL;                       // pairs per workgroup
+    __shared__ float red[4][HEADS_MAX][PW];
     const int blk = blockIdx.y;
     // (pointers loaded from memory are generic-address-space pointers: cast to global so that the uniform weight loads stay scalar)
     const gfloat* __restrict__ w1 = (const gfloat*)ptab[blk * 4 + 0];
@@ -220,35 +223,54 @@ __global__ __launch_bounds__(256) void cpb_fwd_multi_kernel(const float* const* 
     const gfloat* __restrict__ b2 = (const gfloat*)ptab[blk * 4 + 3];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int L2 = L * L;
-    const int p = min(blockIdx.x * 64 + lane, L2 - 1);
-    float r0, r1;
-    rel_coord(p, L, ww, r0, r1);
+    float r0[PPL], r1[PPL];
+    const uint32_t* krow[PPL];
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) {
+        const int p = min(blockIdx.x * PW + 64 * i + lane, L2 - 1);
+        rel_coord(p, L, ww, r0[i], r1[i]);
+        krow[i] = keep_bits ? keep_bits + ((size_t)blk * L2 + p) * (Hd >> 3) : nullptr;
+    }
     const int jq = Hd >> 2, j0 = wave * jq, j1 = j0 + jq;          // Hd % 32 == 0 (checked by the host): 8 units per trip
-    float acc[HEADS_MAX];
+    float acc[PPL][HEADS_MAX];
 #pragma unroll
-    for (int h = 0; h < HEADS_MAX; ++h) acc[h] = 0.f;
-    const uint32_t* krow = keep_bits ? keep_bits + ((size_t)blk * L2 + p) * (Hd >> 3) : nullptr;
+    for (int i = 0; i < PPL; ++i)
+#pragma unroll
+        for (int h = 0; h < HEADS_MAX; ++h) acc[i][h] = 0.f;
     for (int j = j0; j < j1; j += 8) {
-        const uint32_t kw = krow ? krow[j >> 3] : 0xffffffffu;
-        float hd8[8];
+        uint32_t kw[PPL];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const float hv = fmaxf(fmaf(w1[2 * (j + u)], r0, fmaf(w1[2 * (j + u) + 1], r1, b1[j + u])), 0.f);
-            hd8[u] = krow ? ((((kw >> (3 * u)) & 7u) >= thr) ? hv * scale : 0.f) : hv;
-        }
+        for (int i = 0; i < PPL; ++i) kw[i] = keep_bits ? krow[i][j >> 3] : 0xffffffffu;
+        float wa[8], wb[8], bb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { wa[u] = w1[2 * (j + u)]; wb[u] = w1[2 * (j + u) + 1]; bb[u] = b1[j + u]; }
+        float hd8[PPL][8];
+#pragma unroll
+        for (int i = 0; i < PPL; ++i)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float hv = fmaxf(fmaf(wa[u], r0[i], fmaf(wb[u], r1[i], bb[u])), 0.f);
+                hd8[i][u] = keep_bits ? ((((kw[i] >> (3 * u)) & 7u) >= thr) ? hv * scale : 0.f) : hv;
+            }
 #pragma unroll
         for (int h = 0; h < HEADS_MAX; ++h) {          // rows past `heads` re-read the last head; their sums are dropped
             const gfloat* w2h = w2 + min(h, heads - 1) * Hd + j;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc[h] = fmaf(w2h[u], hd8[u], acc[h]);
+            for (int u = 0; u < 8; ++u) {
+                const float wv = w2h[u];
+#pragma unroll
+                for (int i = 0; i < PPL; ++i) acc[i][h] = fmaf(wv, hd8[i][u], acc[i][h]);
+            }
         }
     }
 #pragma unroll
-    for (int h = 0; h < HEADS_MAX; ++h) red[wave][h][lane] = acc[h];
+    for (int i = 0; i < PPL; ++i)
+#pragma unroll
+        for (int h = 0; h < HEADS_MAX; ++h) red[wave][h][64 * i + lane] = acc[i][h];
     __syncthreads();
     float* bias = bias_all + (size_t)blk * heads * L2;
-    for (int i = threadIdx.x; i < heads * 64; i += 256) {
-        const int h = i >> 6, l = i & 63, pp = blockIdx.x * 64 + l;
+    for (int i = threadIdx.x; i < heads * PW; i += 256) {
+        const int h = i / PW, l = i % PW, pp = blockIdx.x * PW + l;
         if (pp < L2) bias[(size_t)h * L2 + pp] = red[0][h][l] + red[1][h][l] + red[2][h][l] + red[3][h][l] + b2[h];
     }
 }
@@ -259,30 +281,40 @@ __global__ __launch_bounds__(256) void cpb_fwd_multi_kernel(const float* const* 
 // The staging is the kernel's cost (nchunk = 32 at the benchmark shape: 27 MB per block, 324 MB per step): all CPB_PPB = 128 pairs of the
 // workgroup in ONE round, 16-byte loads (4 consecutive pairs of one (chunk, head) row), 8 chunk loads in flight per thread -- the first
 // version (64 pairs per round, 4-byte loads, 4 in flight: 6 KB in flight per workgroup) ran at 1.16 TB/s, 281 us per step.
-template <int HEADS_MAX, bool VEC4>
-__global__ __launch_bounds__(512) void cpb_bwd_multi_kernel(const float* __restrict__ dpart, int nchunk, const float* const* __restrict__ ptab,
+template <int HEADS_MAX, bool VEC4, int U>
+__global__ __launch_bounds__(128) void cpb_bwd_multi_kernel(const float* __restrict__ dpart, int nchunk, const float* const* __restrict__ ptab,
                                                             const uint32_t* __restrict__ keep_bits, int L, int ww, int heads, int Hd,
                                                             float scale, uint32_t thr, float* __restrict__ part) {
+    // U hidden units per thread (j = tid + 128 u): the pair-uniform values of the inner loop (d bias of the heads, the two coordinates)
+    // are LDS broadcast reads, 10 per pair and wave -- with one unit per thread (6 waves at 384 units) those reads, not the arithmetic,
+    // bounded the kernel (~250 us per step at depth 12); three units per thread share each read
     __shared__ __attribute__((aligned(16))) float dbs[HEADS_MAX + 2][CPB_PPB];   // [d bias of head 0.., r0, r1][pair]
     const int blk = blockIdx.y;
     const gfloat* __restrict__ w1 = (const gfloat*)ptab[blk * 4 + 0];
     const gfloat* __restrict__ b1 = (const gfloat*)ptab[blk * 4 + 1];
     const gfloat* __restrict__ w2 = (const gfloat*)ptab[blk * 4 + 2];
-    const int j = threadIdx.x;
-    const bool act = j < Hd;
-    const int jc = act ? j : 0;
-    const float wa = act ? w1[2 * j] : 0.f, wb = act ? w1[2 * j + 1] : 0.f, bb = act ? b1[j] : 0.f;
-    float w2r[HEADS_MAX], g2[HEADS_MAX];
+    const int tid = threadIdx.x;
+    bool act[U];
+    float wa[U], wb[U], bb[U], w2r[U][HEADS_MAX], g2[U][HEADS_MAX], ga[U], gb[U], gbias[U];
 #pragma unroll
-    for (int h = 0; h < HEADS_MAX; ++h) { w2r[h] = (act && h < heads) ? w2[h * Hd + j] : 0.f; g2[h] = 0.f; }
-    float ga = 0.f, gb = 0.f, gbias = 0.f, gb2 = 0.f;
+    for (int u = 0; u < U; ++u) {
+        const int j = tid + 128 * u;
+        act[u] = j < Hd;
+        wa[u] = act[u] ? w1[2 * j] : 0.f;
+        wb[u] = act[u] ? w1[2 * j + 1] : 0.f;
+        bb[u] = act[u] ? b1[j] : 0.f;
+        ga[u] = gb[u] = gbias[u] = 0.f;
+#pragma unroll
+        for (int h = 0; h < HEADS_MAX; ++h) { w2r[u][h] = (act[u] && h < heads) ? w2[h * Hd + j] : 0.f; g2[u][h] = 0.f; }
+    }
+    float gb2 = 0.f;
     const int L2 = L * L;
     const int p0 = blockIdx.x * CPB_PPB, p1 = min(L2, p0 + CPB_PPB);
     const float* dsrc = dpart + (size_t)blk * nchunk * heads * L2;
     const size_t cstride = (size_t)heads * L2;
-    // ---- stage: dbs[h][pp] = sum over the chunks' tables, + the pairs' two coordinates
+    // ---- stage: dbs[h][pp] = sum over the chunks' tables (16-byte loads, 8 chunk loads in flight per thread), + the pairs' coordinates
     if constexpr (VEC4) {                      // L2 % 4 == 0: every (chunk, head) row segment is 16-byte aligned
-        for (int i = threadIdx.x; i < heads * (CPB_PPB / 4); i += blockDim.x) {
+        for (int i = tid; i < heads * (CPB_PPB / 4); i += 128) {
             const int h = i / (CPB_PPB / 4), q4 = i % (CPB_PPB / 4), pp = 4 * q4;
             f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
             if (p0 + pp < p1) {                // (p1 - p0 is a multiple of 4)
@@ -291,16 +323,16 @@ __global__ __launch_bounds__(512) void cpb_bwd_multi_kernel(const float* __restr
                 for (; c + 7 < nchunk; c += 8) {
                     f32x4 v[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)(src + (size_t)(c + u) * cstride);
+                    for (int e = 0; e < 8; ++e) v[e] = *(const f32x4*)(src + (size_t)(c + e) * cstride);
 #pragma unroll
-                    for (int u = 0; u < 8; u += 2) { s0 += v[u]; s1 += v[u + 1]; }
+                    for (int e = 0; e < 8; e += 2) { s0 += v[e]; s1 += v[e + 1]; }
                 }
                 for (; c < nchunk; ++c) s0 += *(const f32x4*)(src + (size_t)c * cstride);
             }
             *(f32x4*)&dbs[h][pp] = s0 + s1;
         }
     } else {
-        for (int i = threadIdx.x; i < heads * CPB_PPB; i += blockDim.x) {
+        for (int i = tid; i < heads * CPB_PPB; i += 128) {
             const int h = i / CPB_PPB, pp = i % CPB_PPB;
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
             if (p0 + pp < p1) {
@@ -317,60 +349,73 @@ __global__ __launch_bounds__(512) void cpb_bwd_multi_kernel(const float* __restr
             dbs[h][pp] = (s0 + s1) + (s2 + s3);
         }
     }
-    if (threadIdx.x < CPB_PPB) {
+    for (int i = tid; i < CPB_PPB; i += 128) {
         float r0, r1;
-        rel_coord(min(p0 + (int)threadIdx.x, L2 - 1), L, ww, r0, r1);
-        dbs[HEADS_MAX][threadIdx.x] = r0;
-        dbs[HEADS_MAX + 1][threadIdx.x] = r1;
+        rel_coord(min(p0 + i, L2 - 1), L, ww, r0, r1);
+        dbs[HEADS_MAX][i] = r0;
+        dbs[HEADS_MAX + 1][i] = r1;
     }
-    // the pairs' keep flags of this hidden unit (in flight during the staging)
-    uint32_t kbits[CPB_PPB / 32];
+    // the pairs' keep flags of this thread's hidden units
+    uint32_t kbits[U][CPB_PPB / 32];
 #pragma unroll
-    for (int w = 0; w < CPB_PPB / 32; ++w) kbits[w] = ~0u;
-    if (keep_bits) {
-        const uint32_t* kw = keep_bits + (size_t)blk * L2 * (Hd >> 3) + (jc >> 3);
-        const int sh = 3 * (jc & 7);
+    for (int u = 0; u < U; ++u) {
+        const int jc = act[u] ? tid + 128 * u : 0;
 #pragma unroll
-        for (int w = 0; w < CPB_PPB / 32; ++w) {
-            uint32_t b = 0;
+        for (int w = 0; w < CPB_PPB / 32; ++w) kbits[u][w] = ~0u;
+        if (keep_bits) {
+            const uint32_t* kw = keep_bits + (size_t)blk * L2 * (Hd >> 3) + (jc >> 3);
+            const int sh = 3 * (jc & 7);
 #pragma unroll
-            for (int u = 0; u < 32; ++u)
-                b |= (uint32_t)(((kw[(size_t)min(p0 + 32 * w + u, L2 - 1) * (Hd >> 3)] >> sh) & 7u) >= thr) << u;
-            kbits[w] = b;
+            for (int w = 0; w < CPB_PPB / 32; ++w) {
+                uint32_t b = 0;
+#pragma unroll
+                for (int e = 0; e < 32; ++e)
+                    b |= (uint32_t)(((kw[(size_t)min(p0 + 32 * w + e, L2 - 1) * (Hd >> 3)] >> sh) & 7u) >= thr) << e;
+                kbits[u][w] = b;
+            }
         }
     }
     __syncthreads();
-#pragma unroll 4
+#pragma unroll 2
     for (int pp = 0; pp < CPB_PPB; ++pp) {          // pairs past p1 hold d bias = 0 and contribute nothing
         const float r0 = dbs[HEADS_MAX][pp], r1 = dbs[HEADS_MAX + 1][pp];
-        const float pre = fmaf(wa, r0, fmaf(wb, r1, bb));
-        const float m = keep_bits ? (((kbits[pp >> 5] >> (pp & 31)) & 1u) ? scale : 0.f) : 1.f;
-        const float hdn = fmaxf(pre, 0.f) * m;
-        float dh = 0.f;
+        float d[HEADS_MAX];
 #pragma unroll
-        for (int h = 0; h < HEADS_MAX; ++h) {
-            const float d = (h < heads) ? dbs[h][pp] : 0.f;
-            g2[h] = fmaf(d, hdn, g2[h]);
-            dh = fmaf(d, w2r[h], dh);
+        for (int h = 0; h < HEADS_MAX; ++h) d[h] = (h < heads) ? dbs[h][pp] : 0.f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float pre = fmaf(wa[u], r0, fmaf(wb[u], r1, bb[u]));
+            const float m = keep_bits ? (((kbits[u][pp >> 5] >> (pp & 31)) & 1u) ? scale : 0.f) : 1.f;
+            const float hdn = fmaxf(pre, 0.f) * m;
+            float dh = 0.f;
+#pragma unroll
+            for (int h = 0; h < HEADS_MAX; ++h) {
+                g2[u][h] = fmaf(d[h], hdn, g2[u][h]);
+                dh = fmaf(d[h], w2r[u][h], dh);
+            }
+            dh = (pre > 0.f) ? dh * m : 0.f;
+            ga[u] = fmaf(dh, r0, ga[u]);
+            gb[u] = fmaf(dh, r1, gb[u]);
+            gbias[u] += dh;
         }
-        dh = (pre > 0.f) ? dh * m : 0.f;
-        ga = fmaf(dh, r0, ga);
-        gb = fmaf(dh, r1, gb);
-        gbias += dh;
     }
-    if (j < heads)
-        for (int pp = 0; pp < CPB_PPB; ++pp) gb2 += dbs[j][pp];
+    if (tid < heads)
+        for (int pp = 0; pp < CPB_PPB; ++pp) gb2 += dbs[tid][pp];
     const int n = 3 * Hd + heads * Hd + heads;
     float* row = part + ((size_t)blk * gridDim.x + blockIdx.x) * n;
-    if (act) {
-        row[2 * j] = ga;
-        row[2 * j + 1] = gb;
-        row[2 * Hd + j] = gbias;
 #pragma unroll
-        for (int h = 0; h < HEADS_MAX; ++h)
-            if (h < heads) row[3 * Hd + h * Hd + j] = g2[h];
+    for (int u = 0; u < U; ++u) {
+        const int j = tid + 128 * u;
+        if (act[u]) {
+            row[2 * j] = ga[u];
+            row[2 * j + 1] = gb[u];
+            row[2 * Hd + j] = gbias[u];
+#pragma unroll
+            for (int h = 0; h < HEADS_MAX; ++h)
+                if (h < heads) row[3 * Hd + h * Hd + j] = g2[u][h];
+        }
     }
-    if (j < heads) row[3 * Hd + heads * Hd + j] = gb2;
+    if (tid < heads) row[3 * Hd + heads * Hd + tid] = gb2;
 }
 
 // grads[blk][i] += the sum of the block's partial rows (fixed order); layout of a row = [dw1 (2 Hd) | db1 (Hd) | dw2 (heads Hd) | db2 (heads)]
@@ -486,13 +531,13 @@ extern "C" int swv2_cpb_fwd_multi(const float* const* params_dev, int nblk, cons
     SWV2_CHECK_ARG(bias, "cpb_fwd_multi: null output");
     const int L = wh * ww, L2 = L * L;
     const float scale = 1.f / (1.f - drop_p);
-#define CPB_FWDM(HM)                                                                                                       \
-    hipLaunchKernelGGL((cpb_fwd_multi_kernel<HM>), dim3(cdiv(L2, 64), nblk), dim3(256), 0, (hipStream_t)stream, params_dev, \
+#define CPB_FWDM(HM, PPL)                                                                                                       \
+    hipLaunchKernelGGL((cpb_fwd_multi_kernel<HM, PPL>), dim3(cdiv(L2, 64 * PPL), nblk), dim3(256), 0, (hipStream_t)stream, params_dev, \
                        keep_bits, bias, L, ww, heads, hidden, scale, thr)
-    if (heads <= 4) CPB_FWDM(4);
-    else if (heads <= 8) CPB_FWDM(8);
-    else if (heads <= 16) CPB_FWDM(16);
-    else CPB_FWDM(CPB_MAX_HEADS);
+    if (heads <= 4) CPB_FWDM(4, 4);
+    else if (heads <= 8) CPB_FWDM(8, 4);
+    else if (heads <= 16) CPB_FWDM(16, 2);
+    else CPB_FWDM(CPB_MAX_HEADS, 1);
 #undef CPB_FWDM
     SWV2_CHECK_LAUNCH("swv2_cpb_fwd_multi");
     return SWV2_OK;
@@ -513,21 +558,23 @@ extern "C" int swv2_cpb_bwd_multi(const float* dbias_tables, int nchunk, const f
     SWV2_CHECK_ARG(ws && ws_bytes >= swv2_cpb_bwd_multi_ws_bytes(nblk, wh, ww, heads, hidden), "cpb_bwd_multi: workspace of %zu bytes, %zu needed",
                    ws_bytes, swv2_cpb_bwd_multi_ws_bytes(nblk, wh, ww, heads, hidden));
     const int L = wh * ww, L2 = L * L, rows = cdiv(L2, CPB_PPB), n = 3 * hidden + heads * hidden + heads;
-    const int threads = cdiv(hidden, 64) * 64;
     const float scale = 1.f / (1.f - drop_p);
+#define CPB_BWDM2(HM, V, UU)                                                                                                 \
+    hipLaunchKernelGGL((cpb_bwd_multi_kernel<HM, V, UU>), dim3(rows, nblk), dim3(128), 0, (hipStream_t)stream, dbias_tables, nchunk, \
+                       params_dev, keep_bits, L, ww, heads, hidden, scale, thr, (float*)ws)
 #define CPB_BWDM(HM)                                                                                                        \
     do {                                                                                                                    \
-        if ((L2 & 3) == 0)                                                                                                  \
-            hipLaunchKernelGGL((cpb_bwd_multi_kernel<HM, true>), dim3(rows, nblk), dim3(threads), 0, (hipStream_t)stream, dbias_tables, \
-                               nchunk, params_dev, keep_bits, L, ww, heads, hidden, scale, thr, (float*)ws);               \
-        else                                                                                                                \
-            hipLaunchKernelGGL((cpb_bwd_multi_kernel<HM, false>), dim3(rows, nblk), dim3(threads), 0, (hipStream_t)stream, dbias_tables, \
-                               nchunk, params_dev, keep_bits, L, ww, heads, hidden, scale, thr, (float*)ws);               \
+        const bool v4 = (L2 & 3) == 0;                                                                                      \
+        if (hidden <= 128) { if (v4) CPB_BWDM2(HM, true, 1); else CPB_BWDM2(HM, false, 1); }                                \
+        else if (hidden <= 256) { if (v4) CPB_BWDM2(HM, true, 2); else CPB_BWDM2(HM, false, 2); }                           \
+        else if (hidden <= 384) { if (v4) CPB_BWDM2(HM, true, 3); else CPB_BWDM2(HM, false, 3); }                           \
+        else { if (v4) CPB_BWDM2(HM, true, 4); else CPB_BWDM2(HM, false, 4); }                                              \
     } while (0)
     if (heads <= 4) CPB_BWDM(4);
     else if (heads <= 8) CPB_BWDM(8);
     else if (heads <= 16) CPB_BWDM(16);
     else CPB_BWDM(CPB_MAX_HEADS);
+#undef CPB_BWDM2
 #undef CPB_BWDM
     static_assert(CPB_PPB % 32 == 0 && CPB_PPB <= 512, "pairs per workgroup");
     hipLaunchKernelGGL(cpb_fold_multi_kernel, dim3(cdiv(n, 64), nblk), dim3(512), 0, (hipStream_t)stream, (const float*)ws, rows, n, grads);

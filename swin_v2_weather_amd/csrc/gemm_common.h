@@ -82,6 +82,19 @@ __device__ __forceinline__ uint32_t gelu_tab_off2(uint32_t w, bool& bad) {
     return __builtin_bit_cast(uint32_t, off);
 }
 
+// the same for a table that holds the POSITIVE arguments only (GT_HALF entries): offsets of |x|; the caller applies the sign symmetry
+template <int ESZ>
+__device__ __forceinline__ uint32_t gelu_tab_off2_abs(uint32_t w, bool& bad) {
+    const u16x2_t a = __builtin_bit_cast(u16x2_t, w & 0x7fff7fffu);
+    const u16x2_t lo = {(unsigned short)GT_LO, (unsigned short)GT_LO};
+    const u16x2_t mx = {(unsigned short)(GT_HALF - 1), (unsigned short)(GT_HALF - 1)};
+    const u16x2_t idx = a - lo;
+    const u16x2_t idc = __builtin_elementwise_min(idx, mx);
+    bad = bad || (__builtin_bit_cast(uint32_t, idx) != __builtin_bit_cast(uint32_t, idc));
+    const u16x2_t off = idc * (unsigned short)ESZ;
+    return __builtin_bit_cast(uint32_t, off);
+}
+
 __device__ __forceinline__ uint4 pack8(const float* v) {
     uint4 r;
     r.x = f2bf2(v[0], v[1]); r.y = f2bf2(v[2], v[3]); r.z = f2bf2(v[4], v[5]); r.w = f2bf2(v[6], v[7]);

@@ -391,9 +391,15 @@ __global__ __launch_bounds__(256, (C >= 192 && MT == 2) ? 1 : 2) void mlp_bwd_ke
     constexpr int LBASE = SBYTES + 4 * 16 * MT * PHS * 2;
     constexpr bool ONE_WG = C >= 192 && MT == 2;          // (the launch bounds of that shape: one wave per SIMD, > 256 registers)
     constexpr bool GTAB = LBASE + GT_N * 4 <= (ONE_WG ? 156 : 80) * 1024;
-    __shared__ __attribute__((aligned(16))) float ggtab[GTAB ? GT_N : 4];
+    // round 5: where the full table does not fit beside the second workgroup (192 channels: 65.5 + 18 KB) its POSITIVE half does (9 KB):
+    // GELU'(-x) = 1 - GELU'(x)  (Phi(-x) = 1 - Phi(x), x phi(x) odd), one subtraction + select per value instead of the formula
+    // (an exp, a reciprocal and a dozen fmas: 26 % of a wave's life at C = 128 before the table); |difference| to the formula <= 1 ulp of 1
+    constexpr bool GHALF = !GTAB && !ONE_WG && (LBASE + GT_HALF * 4 <= 80 * 1024);
+    __shared__ __attribute__((aligned(16))) float ggtab[GTAB ? GT_N : (GHALF ? GT_HALF : 4)];
     if (GTAB)
         for (int i = tid; i < GT_N; i += 256) ggtab[i] = gelu_grad_f(bf2f(gelu_tab_arg(i)));
+    else if (GHALF)
+        for (int i = tid; i < GT_HALF; i += 256) ggtab[i] = gelu_grad_f(bf2f(gelu_tab_arg(i)));
 
     static_assert(32 * P1 <= W2E, "the row-major fc1 chunk of the recompute mode fits the W1^T chunk's slot");
     u32x4 s1[SPT], s2[SPT];
@@ -616,9 +622,10 @@ __global__ __launch_bounds__(256, (C >= 192 && MT == 2) ? 1 : 2) void mlp_bwd_ke
                 // with gelu_grad_f, so bit-identical to the formula); the formula -- an exp, a reciprocal and a dozen
                 // fmas per value, 26 % of a wave's life -- only for the rare group with an argument outside the table
                 bool bad = false;
-                const uint32_t o0 = gelu_tab_off2<4>(w0, bad), o1 = gelu_tab_off2<4>(w1, bad);
+                const uint32_t o0 = GHALF ? gelu_tab_off2_abs<4>(w0, bad) : gelu_tab_off2<4>(w0, bad);
+                const uint32_t o1 = GHALF ? gelu_tab_off2_abs<4>(w1, bad) : gelu_tab_off2<4>(w1, bad);
                 f32x4 gg;
-                if (!GTAB || __builtin_expect(__any((int)bad), 0)) {
+                if ((!GTAB && !GHALF) || __builtin_expect(__any((int)bad), 0)) {
                     gg[0] = gelu_grad_f(__uint_as_float(w0 << 16));
                     gg[1] = gelu_grad_f(__uint_as_float(w0 & 0xffff0000u));
                     gg[2] = gelu_grad_f(__uint_as_float(w1 << 16));
@@ -629,6 +636,12 @@ __global__ __launch_bounds__(256, (C >= 192 && MT == 2) ? 1 : 2) void mlp_bwd_ke
                     gg[1] = *(const float*)(tb + (o0 >> 16));
                     gg[2] = *(const float*)(tb + (o1 & 0xffffu));
                     gg[3] = *(const float*)(tb + (o1 >> 16));
+                    if constexpr (GHALF) {
+                        gg[0] = (w0 & 0x8000u) ? 1.f - gg[0] : gg[0];
+                        gg[1] = (w0 & 0x80000000u) ? 1.f - gg[1] : gg[1];
+                        gg[2] = (w1 & 0x8000u) ? 1.f - gg[2] : gg[2];
+                        gg[3] = (w1 & 0x80000000u) ? 1.f - gg[3] : gg[3];
+                    }
                 }
                 hb[mt][ht] = f2bf4(hacc[ht][mt] * gg);
             }
@@ -795,7 +808,7 @@ int swv2_mlp_bwd_impl(const swv2_mlp_bwd_args* a, void* stream, int* deferred, f
         case 128: mt2 ? launch_mlp_bwd<128, 2>(k, st) : launch_mlp_bwd<128, 1>(k, st); break;
         case 192: {
             // measured on BASELINE configs[4] (B = 2, ms per step): one row tile per wave, two workgroups per CU, GELU' by formula (the
-            // table does not fit beside two workgroups): 35.5; the same with the table and one workgroup per CU: 38.3; two row tiles
+            // full table does not fit beside two workgroups; since round 5 its positive half does, GHALF): 35.5; the same with the table and one workgroup per CU: 38.3; two row tiles
             // per wave (302 registers, one workgroup per CU, table; SWV2_MLP_BWD192=2): 37.2
             static const int v192 = getenv("SWV2_MLP_BWD192") ? atoi(getenv("SWV2_MLP_BWD192")) : 0;
             two192 = k.hpre && mt2 && v192 == 2;

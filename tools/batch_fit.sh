@@ -6,7 +6,7 @@ O=$R/gpurun_out/batch_fit
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for B in 1 2 4; do
-  rocprofv3 --kernel-trace --stats -d $O/b$B -o t --output-format csv -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --local-batch $B > $O/b$B.log 2>&1
+  rocprofv3 --kernel-trace --stats -d $O/b$B -o t --output-format csv -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --local-batch $B > $O/b$B.log 2>&1
   find $O/b$B -type f ! -name "*kernel_stats.csv" -delete
 done
 cd $R && python3 tools/batch_fit.py $O

@@ -527,6 +527,9 @@ def main():
             pmc = None
         main_rf = roofline_entry(a.roofline_kernel, ktimes, a, pmc, B)
         main_rf["co_running"] = None
+        # (the kernel the north star names -- not the largest by time: profiles/rNN_kernel_stats.md ranks the grouped weight gradient
+        # and the fused MLP backward above it; their roofline objects are in `roofline_others`)
+        main_rf["why_this_kernel"] = "window-attention backward: the kernel BASELINE.json's north_star names; third by time per step"
         main_rf["timed"] = f"HIP event pairs on the launch stream around every {a.time_every}th launch inside the timed region"
         if alone_ms:
             main_rf["avg_ms_alone"] = alone_ms

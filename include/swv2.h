@@ -469,13 +469,16 @@ int swv2_cpb_bwd_ws(const float* dbias, const float* w1, const float* b1, const 
 /* The tables of ALL blocks of a stage in one launch each way (nothing in :240-261,274-287 depends on activations, so the model
  * computes the `nblk` tables before its first block and their parameter gradients after the first block's backward).
  *   params_dev : DEVICE array [nblk][4] of device pointers: w1 [hidden][2], b1 [hidden], w2 [heads][hidden], b2 [heads] of each block
- *   keep_bits  : u32 [nblk][L*L][hidden / 8] of uniformly random bits drawn by the caller, or NULL (eval): hidden unit j of a pair is
- *                DROPPED iff the 3-bit field (word[j / 8] >> 3 (j % 8)) & 7 is < 8 drop_p (drop_p must be a multiple of 1/8; the
- *                reference's hard-coded Dropout(0.125), :245, is 1/8); kept units are scaled by 1 / (1 - drop_p)
+ *   keep_bits  : u32 [nblk][L*L][hidden / 8] of uniformly random bits drawn by the caller (31 random bits per word are enough: only the
+ *                three low bytes are used), or NULL (eval).  Hidden unit j of a pair <-> bit (j & 7) of W | W >> 8 | W >> 16 with
+ *                W = word ((j >> 3) & 3) * (hidden / 32) + (j >> 5) of the pair: the unit is DROPPED iff that bit is clear in all three
+ *                low bytes of W -- probability 1/8, the reference's hard-coded Dropout(0.125) (:245; drop_p must be 0.125); kept units
+ *                are scaled by 1 / (1 - drop_p)
  *   bias       : out [nblk][heads][L][L]
  * backward: dbias_tables [nblk][nchunk][heads][L][L] -- d bias of a block = the SUM of its nchunk tables (the per-workgroup tables
  * swv2_attn_bwd leaves with dbias_partials; nchunk = 1: plain gradients) -- grads [nblk][3 hidden + heads hidden + heads] =
- * (dw1 | db1 | dw2 | db2) per block, ACCUMULATED; ws: swv2_cpb_bwd_multi_ws_bytes.  hidden % 32 == 0, heads <= 32.  No atomics. */
+ * (dw1 | db1 | dw2 | db2) per block, ACCUMULATED; ws: swv2_cpb_bwd_multi_ws_bytes.  heads <= 16, hidden in {64, 128, 256, 384, 512}.  No atomics;
+ * both directions run their contractions on the matrix pipe with hi + lo split bf16 operands (fp32 accuracy: ~1e-5 relative). */
 int swv2_cpb_fwd_multi(const float* const* params_dev, int nblk, const uint32_t* keep_bits, float* bias, int wh, int ww, int heads,
                        int hidden, float drop_p, void* stream);
 size_t swv2_cpb_bwd_multi_ws_bytes(int nblk, int wh, int ww, int heads, int hidden);

@@ -444,8 +444,9 @@ class _CpbMultiFn(torch.autograd.Function):
         st.ptab = st.pointer_table()
         st.keep_bits = None
         if train:
-            # Dropout(0.125) of the meta MLP (:245) for all blocks: uniformly random bits from the torch generator, 3 per hidden unit
-            # (dropped iff all three are zero); SWV2_CPB_PER_BLOCK=1 restores the reference's per-block F.dropout draws
+            # Dropout(0.125) of the meta MLP (:245) for all blocks: uniformly random words from the torch generator, one per 8 hidden
+            # units of a pair (a unit is dropped iff its bit is clear in all three low bytes of the word: probability 1/8, include/swv2.h);
+            # SWV2_CPB_PER_BLOCK=1 restores the reference's per-block F.dropout draws
             st.keep_bits = torch.empty(st.nblk, st.L * st.L, st.hidden // 8, dtype=torch.int32, device=dev).random_()
         st.bias_all = torch.empty(st.nblk, st.heads, st.L, st.L, dtype=torch.float32, device=dev)
         ops.cpb_fwd_multi(st.ptab, st.nblk, st.keep_bits, st.bias_all, st.wh, st.ww, st.heads, st.hidden, 0.125)

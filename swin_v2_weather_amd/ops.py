@@ -494,8 +494,9 @@ def cpb_bwd(dbias, w1, b1, w2, keep, dw1, db1, dw2, db2, wh, ww, heads, hidden, 
 
 
 def cpb_multi_supported(heads: int, hidden: int, drop_p: float) -> bool:
-    """shapes the one-launch-per-stage CPB kernels cover (swv2_cpb_fwd_multi): 3-bit keep fields, 8 hidden units per word"""
-    return 0 < heads <= 32 and 0 < hidden <= 512 and hidden % 32 == 0 and abs(drop_p * 8 - round(drop_p * 8)) < 1e-6 and drop_p < 1.0
+    """shapes the one-launch-per-stage CPB kernels cover (swv2_cpb_fwd_multi / _bwd_multi: MFMA tiles of 16 heads x 64-unit waves; the
+    keep words express Dropout(0.125))"""
+    return 0 < heads <= 16 and hidden in (64, 128, 256, 384, 512) and abs(drop_p - 0.125) < 1e-6
 
 
 def cpb_fwd_multi(ptab, nblk, keep_bits, bias_all, wh, ww, heads, hidden, drop_p):

@@ -421,7 +421,9 @@ def test_ddp_bucket_plan_overlaps_backward_and_isolates_pos_embed():
     model = helpers.get_model(p)
     cap = helpers.DDP_BUCKET_CAP_MB
     sizes, where = helpers.ddp_bucket_plan(model)
-    assert where >= 5, (sizes, where)                                 # first (1 MB) bucket + >= 4 block buckets before pos_embed's
+    # >= 4 block buckets before pos_embed's (an explicit bucket_cap_mb also caps the FIRST bucket: torch's 1 MB first-bucket limit
+    # applies only with the default cap -- found in round 5 by comparing this plan with the reducer's own report, ddp_observed_buckets)
+    assert where >= 4, (sizes, where)
     block_mb = sum(q.numel() for n, q in model.named_parameters() if ".blocks.0." in n) * 4 / 1e6
     assert all(s <= cap * 1.048576 + block_mb for s in sizes[:where]), sizes
     pos_mb = model.model.pos_embed.numel() * 4 / 1e6

@@ -8,7 +8,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$TAG
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline"
+B="python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary"
 rocprofv3 --kernel-trace --stats -d $O/trace -o t --output-format csv -- $B > $O/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o p --output-format csv -- $B > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $O/write -o p --output-format csv -- $B > $O/write.log 2>&1

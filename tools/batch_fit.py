@@ -10,7 +10,7 @@ for B in (1, 2, 4):
     f = glob.glob(os.path.join(root, f"b{B}", "**", "*_kernel_stats.csv"), recursive=True)[0]
     for r in csv.DictReader(open(f)):
         n = short(r["Name"])
-        data.setdefault(n, {})[B] = (int(r["Calls"]) / 21.0, float(r["AverageNs"]) / 1e3)
+        data.setdefault(n, {})[B] = (int(r["Calls"]) / 24.0, float(r["AverageNs"]) / 1e3)      # 8 settle + 3 warm-up + 10 timed + 3 roofline_others steps
 rows = []
 for n, d in data.items():
     if len(d) < 3:

@@ -561,6 +561,7 @@ RM, OF = "row_max", "operand_folded"    # forward softmax regimes (oracle.set_ro
     (8, 20, 8, 16, 2, 2, True, False, OF), (10, 17, 8, 16, 2, 2, True, False, OF),   # 160 / 170 tokens: attn2.hip's run-time-L instantiation (masked branch)
     (9, 18, 2, 16, 1, 2, True, True, OF),   # one window row: every window carries the shift mask (bias forward of attn2.hip, masked branch)
     (9, 18, 8, 16, 2, 3, False, True, OF),   # CPB table, unshifted: the fixed-maximum branch of the bias forward (reference sigma' + max bias')
+    (10, 17, 8, 16, 2, 2, True, True, OF), (8, 20, 4, 16, 2, 2, False, True, OF),   # 170 / 160 tokens with a table: the run-time-L instantiation of the bias forward
     (8, 16, 8, 16, 2, 2, True, False, RM), (10, 15, 4, 24, 2, 2, True, False, RM), (8, 16, 2, 16, 2, 2, False, True, RM),   # 128 / 150 tokens in the 176-row layout: key tiles 8 .. 10 hold padded keys only -> first generation
     (9, 18, 2, 96, 2, 2, True, False, RM),   # the reference yaml's head width (768 / 8), 128-column layout: attn_wide.hip's backward
     (9, 18, 2, 80, 1, 2, False, False, RM), (9, 18, 1, 96, 2, 2, True, True, RM),     # 80 channels in the 96-channel kernel; with bias: first generation

@@ -303,12 +303,26 @@ class _BlockFn(torch.autograd.Function):
         for name, off in zip(run.SCRATCH, run.scr_off):
             setattr(d, name, sb + off)
         params = (logit_scale, qkv_w, qkv_b, proj_w, proj_b, n1_w, n1_b, fc1_w, fc1_b, fc2_w, fc2_b, n2_w, n2_b)
-        # the views are handed out at most ONCE per backward pass: a multi-step rollout (MultiStepWrapper) runs this node
-        # n_future + 1 times per pass while p.grad is still None, and a second hand-out would zero / overwrite the gradient
+        # A multi-step rollout (MultiStepWrapper) runs this node n_future + 1 times per backward pass.  The first call of a pass hands
+        # autograd the 13 parameter gradients (bucket views under DDP, one flat buffer otherwise) and remembers WHERE they are; every later
+        # call of the same pass accumulates straight into those buffers -- every gradient kernel of the block accumulates, "caller zeroes" --
+        # and returns no parameter gradients, so autograd has nothing to add (it launched one add kernel per parameter and use: 156 tiny
+        # launches per 2-step training step, 1.1 ms of 22).  The tensors themselves stay alive in the engine's input buffers until the
+        # AccumulateGrad nodes run, which is after the last use of the pass; only their addresses are kept here (a reference would stop
+        # AccumulateGrad from taking the tensor as p.grad without a copy), and an engine callback forgets them at the end of the pass.
+        # SWV2_GRAD_ACC_INPLACE=0: the plain path (autograd sums the calls' gradients).
+        reuse = blk._pass_grad_ptrs if os.environ.get("SWV2_GRAD_ACC_INPLACE", "1") != "0" else None
+        # the views are handed out at most ONCE per backward pass: a second hand-out would zero / overwrite the gradient
         # autograd's input buffer still holds as an alias (g_last twice instead of g_1 + ... + g_k)
-        views = blk._bucket_views(params) if (blk._ddp_bucket_grads and not blk._bv_in_use) else None
+        views = blk._bucket_views(params) if (reuse is None and blk._ddp_bucket_grads and not blk._bv_in_use) else None
         dbias_view = None
-        if views is not None:
+        if reuse is not None:
+            for name, ptr in zip(run.grad_names, reuse):
+                setattr(d, name, ptr)
+            d.grad_zero, d.grad_zero_bytes = None, 0
+            if ctx.has_bias and cpb is None:                 # (a table of this call's own: its gradient is this call's alone)
+                dbias_view = torch.zeros_like(bias_c)
+        elif views is not None:
             blk._bv_in_use = True
             # DDP (gradient_as_bucket_view): write the gradients straight into the reducer's bucket memory and hand autograd
             # aliases of it, so the reducer finds them in place instead of launching one copy kernel per parameter
@@ -331,7 +345,7 @@ class _BlockFn(torch.autograd.Function):
                 dbias_view = grads[nfl:nfl + bias_c.numel()].view_as(bias_c)
             for name, off in zip(run.grad_names, run.grad_off):
                 setattr(d, name, gb + off)
-        if blk._ddp_bucket_grads:
+        if blk._ddp_bucket_grads and reuse is None:
             blk._queue_view_refresh(params)
         dbias = (dbias_view if dbias_view is not None else torch.zeros_like(bias_c)) if own_bias else None
         dx = torch.empty_like(x)
@@ -345,10 +359,13 @@ class _BlockFn(torch.autograd.Function):
         ops.block_event_pair("bwd", d)
         L.check(ops._timed("block_bwd", L.load().swv2_block_bwd, run.desc, ops._stream()), "swv2_block_bwd")
         del keep
+        if reuse is not None:
+            return (dx, dbias) + (None,) * 18
         if views is not None:
             g = [v.detach() for v in views]
         else:
             g = [grads[o // 4:o // 4 + int(torch.Size(s).numel())].view(*s) for o, s in zip(run.grad_off, run.grad_shapes)]
+        blk._remember_pass_grads(g)
         (dlogit, dqkvw, dqkvb, dprojw, dprojb, dn1w, dn1b, dfc1w, dfc1b, dfc2w, dfc2b, dn2w, dn2b) = g
         return (dx, dbias, None, None, dlogit, dqkvw, dqkvb, dprojw, dprojb, dn1w, dn1b, dfc1w, dfc1b, dfc2w, dfc2b, dn2w,
                 dn2b, None, None, None)
@@ -666,6 +683,15 @@ class SwinTransformerV2CrBlock(nn.Module):
                 return None
             views.append(bv)
         return views
+
+    _pass_grad_ptrs = None      # addresses of the 13 gradient buffers handed to autograd by this pass's first backward call
+
+    def _remember_pass_grads(self, g):
+        self._pass_grad_ptrs = [t.data_ptr() for t in g]
+
+        def forget():
+            self._pass_grad_ptrs = None
+        torch.autograd.Variable._execution_engine.queue_callback(forget)
 
     def _queue_view_refresh(self, params):
         """At the end of this backward pass p.grad IS the reducer's bucket view (gradient_as_bucket_view=True): remember it."""

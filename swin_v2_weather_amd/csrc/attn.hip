@@ -655,6 +655,48 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
             }
             const uint16_t* const Qa = (const uint16_t*)(lds + OFF_Q);
             const uint16_t* const Da = (const uint16_t*)(lds + OFF_DO);
+#ifndef SWV2_BIAS_BWD_ROLLED
+            // The two-stage software pipeline of the kernel without bias, FULLY UNROLLED so that the d bias rows are statically indexed
+            // registers, with a scheduling fence after every pair of steps: the fence keeps the scheduler from hoisting the LDS reads
+            // of all eleven steps to the top (which is what made earlier unrolled forms spill), and inside a pair stage A of the next
+            // step interleaves with stage B of the current one.  The rolled form below needs a scalar switch to pick the row; the
+            // compiler turns it into ~24 64-bit register copies per step.
+            struct St { f32x4 s, dp; bf16x4 tq, td, b4; };
+            auto stageA = [&](const int qt, St& o) {
+                const bf16x8 qa = *(const bf16x8*)(Qa + (16 * qt + fr) * QP + 8 * g);
+                const bf16x8 da = *(const bf16x8*)(Da + (16 * qt + fr) * QP + 8 * g);
+                o.td = lds_tr_read(Da + (16 * qt + 4 * g + (fr >> 2)) * QP + (fr & 3) * 4);
+                o.tq = lds_tr_read(Qa + (16 * qt + 4 * g + (fr >> 2)) * QP + (fr & 3) * 4);
+                o.b4 = *(const bf16x4*)(biasS + min(key, BROWS - 1) * DSP + 16 * qt + 4 * g);
+                o.s = mfma32(qa, kf8, (f32x4){0.f, 0.f, 0.f, 0.f});
+                o.dp = mfma32(da, vf8, (f32x4){0.f, 0.f, 0.f, 0.f});
+            };
+            auto stageB = [&](const int qt, const St& in, f32x4& dbrow) {
+                f32x4 p, ds;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    p[r] = __builtin_amdgcn_exp2f(fmaf(in.s[r], sc2, bf2f(in.b4[r])));
+                    ds[r] = p[r] * in.dp[r];
+                }
+                const bf16x4 pb = f2bf4(p), dsb = f2bf4(ds);
+                *(bf16x4*)(dSb + key * DSP + 16 * qt + 4 * g) = dsb;
+                dv[0][0] = mfma16(in.td, pb, dv[0][0]);
+                dk[0][0] = mfma16(in.tq, dsb, dk[0][0]);
+                dbrow += ds;
+                asm volatile("" : "+v"(dbrow));      // add HERE: otherwise all eleven dS rows are kept live and added behind the loop
+            };
+            St sa, sb;
+            stageA(0, sa);
+#pragma unroll
+            for (int qt = 0; qt + 1 < LT; qt += 2) {
+                stageA(qt + 1, sb);
+                stageB(qt, sa, dbr[qt]);
+                if (qt + 2 < LT) stageA(qt + 2, sa);
+                stageB(qt + 1, sb, dbr[qt + 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (LT & 1) stageB(LT - 1, sa, dbr[LT - 1]);
+#else
 #pragma unroll 1
             for (int qt = 0; qt < LT; ++qt) {
                 const bf16x8 qa = *(const bf16x8*)(Qa + (16 * qt + fr) * QP + 8 * g);
@@ -679,6 +721,7 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
                               SWV2_CASE(6) SWV2_CASE(7) SWV2_CASE(8) SWV2_CASE(9) SWV2_CASE(10) }
 #undef SWV2_CASE
             }
+#endif
         } else if constexpr (HAS_BIAS) {
             const int key = 16 * tw + fr;
             // rolled loop; the bias-gradient rows stay statically indexed registers through a (scalar, wave-uniform)

@@ -685,6 +685,8 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
                 dbrow += ds;
                 asm volatile("" : "+v"(dbrow));      // add HERE: otherwise all eleven dS rows are kept live and added behind the loop
             };
+            // (q-tiles in pairs with one K = 32 product for dV / dK, as in the kernel without bias below, needs two more stage sets: 39
+            // registers spilled around the loop per window, 240 us against 128.)
             St sa, sb;
             stageA(0, sa);
 #pragma unroll
@@ -811,16 +813,72 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
                     dk[0][dt] = mfma16(in.tq[dt], dsb, dk[0][dt]);
                 }
             };
-            St sa, sb;
-            stageA(0, sa);
+            if constexpr (DK == 1) {
+                // q-tiles in PAIRS: the dV / dK products of two tiles are one K = 32 MFMA (k-slot (g, j) = row 4g + j of the first tile for
+                // j < 4, of the second for j >= 4, on both operands) -- 6 MFMAs per pair instead of 8; the odd last tile has its own accumulators
+                auto stageB2 = [&](const int qt, const St& i0, const St& i1) {
+                    f32x4 p0, p1, ds0, ds1;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        p0[r] = __builtin_amdgcn_exp2f(i0.s[r] * sc2);
+                        p1[r] = __builtin_amdgcn_exp2f(i1.s[r] * sc2);
+                        ds0[r] = p0[r] * i0.dp[r];
+                        ds1[r] = p1[r] * i1.dp[r];
+                    }
+                    const bf16x4 pb0 = f2bf4(p0), pb1 = f2bf4(p1), dsb0 = f2bf4(ds0), dsb1 = f2bf4(ds1);
+                    *(bf16x4*)(dSb + key * DSP + 16 * qt + 4 * g) = dsb0;
+                    *(bf16x4*)(dSb + key * DSP + 16 * qt + 16 + 4 * g) = dsb1;
+                    const bf16x8 pb = __builtin_shufflevector(pb0, pb1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    const bf16x8 dsb = __builtin_shufflevector(dsb0, dsb1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    const bf16x8 td = __builtin_shufflevector(i0.td[0], i1.td[0], 0, 1, 2, 3, 4, 5, 6, 7);
+                    const bf16x8 tq = __builtin_shufflevector(i0.tq[0], i1.tq[0], 0, 1, 2, 3, 4, 5, 6, 7);
+                    dv[0][0] = mfma32(td, pb, dv[0][0]);
+                    dk[0][0] = mfma32(tq, dsb, dk[0][0]);
+                };
+                St a0, a1, b0, b1;
+                stageA(0, a0);
+                stageA(1, a1);
+#pragma unroll
+                for (int qt = 0; qt + 1 < LT; qt += 4) {
+                    if (qt + 2 < LT) stageA(qt + 2, b0);
+                    if (qt + 3 < LT) stageA(qt + 3, b1);
+                    stageB2(qt, a0, a1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (qt + 3 < LT) {
+                        if (qt + 4 < LT) stageA(qt + 4, a0);
+                        if (qt + 5 < LT) stageA(qt + 5, a1);
+                        stageB2(qt + 2, b0, b1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if (LT & 1) {
+                    // the odd last tile: its stage A went into a0 (LT % 4 == 1) or b0 (LT % 4 == 3)
+                    const St& in = ((LT & 3) == 1) ? a0 : b0;
+                    f32x4 p, ds;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        p[r] = __builtin_amdgcn_exp2f(in.s[r] * sc2);
+                        ds[r] = p[r] * in.dp[r];
+                    }
+                    const bf16x4 pb = f2bf4(p), dsb = f2bf4(ds);
+                    *(bf16x4*)(dSb + key * DSP + 16 * (LT - 1) + 4 * g) = dsb;
+                    const f32x4 tv = mfma16(in.td[0], pb, (f32x4){0.f, 0.f, 0.f, 0.f});
+                    const f32x4 tk = mfma16(in.tq[0], dsb, (f32x4){0.f, 0.f, 0.f, 0.f});
+                    dv[0][0] += tv;
+                    dk[0][0] += tk;
+                }
+            } else {
+                St sa, sb;
+                stageA(0, sa);
 #pragma unroll 1
-            for (int qt = 0; qt + 1 < LT; qt += 2) {
-                stageA(qt + 1, sb);
-                stageB(qt, sa);
-                if (qt + 2 < LT) stageA(qt + 2, sa);
-                stageB(qt + 1, sb);
+                for (int qt = 0; qt + 1 < LT; qt += 2) {
+                    stageA(qt + 1, sb);
+                    stageB(qt, sa);
+                    if (qt + 2 < LT) stageA(qt + 2, sa);
+                    stageB(qt + 1, sb);
+                }
+                if (LT & 1) stageB(LT - 1, sa);
             }
-            if (LT & 1) stageB(LT - 1, sa);
         } else if constexpr (TPW == 1) {
             // software-pipelined over the q tiles (two register sets used alternately): stage A of step qt + 1 (fragment
             // reads, S and dP MFMAs) is issued before stage B of step qt (softmax backward on the vector ALU, dV / dK

@@ -28,8 +28,9 @@ extern "C" {
 /* ABI revision: bumped whenever a struct layout or an entry point of this header changes (swv2_version() returns the value the
  * library was built with; swin_v2_weather_amd/_lib.py refuses a library whose revision differs from the one it mirrors).
  * 100 rounds 1 - 4; 105 round 5: swv2_attn_args.dbias_partials, swv2_block_desc.bias_prepacked / dbias_part, the *_multi CPB
- * entry points, swv2_attn_pack_bias_multi / swv2_attn_bias_chunks, a (max, min) part in the packed bias buffer. */
-#define SWV2_VERSION 105
+ * entry points, swv2_attn_pack_bias_multi / swv2_attn_bias_chunks, a (max, min) part in the packed bias buffer;
+ * 106: SWV2_EPI_UNPATCH_LOSS writes slot 1 of loss_part only where swv2_loss_part_reduce reads it. */
+#define SWV2_VERSION 106
 
 enum {
     SWV2_OK = 0,
@@ -174,8 +175,9 @@ enum swv2_epilogue_kind {
                                loss_tar fp32 [B][q[0]][H][W] (channels q[1] .. q[1] + Cout): per (sample, channel)
                                sum_hw qw[h] (y - tar)^2 and sum_hw qw[h] tar^2, left as per-row-group partial sums
                                loss_part[g][slot][c][2] (g = group of SWV2_LOSS_GROUP_ROWS rows of the GEMM; slot 0 = rows of the sample of the
-                               group's first row, slot 1 = rows of the following sample, zero unless the group straddles a
-                               sample boundary; plain stores, no atomics: same-address float atomics from every workgroup
+                               group's first row, slot 1 = rows of the following sample -- WRITTEN only by groups whose successor
+                               row belongs to another sample or lies past M, the only groups swv2_loss_part_reduce reads it of;
+                               zero there unless the group straddles the boundary; plain stores, no atomics: same-address float atomics from every workgroup
                                measured 8 x the whole kernel) which swv2_loss_part_reduce folds in a fixed order.  Also
                                writes loss_resid bf16 [M][N] = qw[h] (y - tar) in the GEMM's own row / column order -- the
                                operand SWV2_OP_BF16_CSCALE feeds to the head's backward, so neither the prediction nor a
@@ -197,7 +199,7 @@ typedef struct swv2_epilogue {
     /* SWV2_EPI_UNPATCH_LOSS only (ignored by every other kind) */
     const float* loss_tar;   /* target [B][q[0]][H][W] fp32 */
     const float* loss_qw;    /* quadrature row weights [H] */
-    float* loss_part;        /* [ceil(M / SWV2_LOSS_GROUP_ROWS)][2][Cout][2] fp32 per-group partial sums, overwritten */
+    float* loss_part;        /* [ceil(M / SWV2_LOSS_GROUP_ROWS)][2][Cout][2] fp32 per-group partial sums: slot 0 overwritten, slot 1 see above */
     void* loss_resid;        /* bf16 [M][N] */
     int q[2];                /* channels per sample of loss_tar, first target channel of this prediction */
 } swv2_epilogue;

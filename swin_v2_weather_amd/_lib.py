@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("SWV2_LIB") or os.path.join(HERE, "libswv2.so")     # SWV2_LIB: a privately built variant (tools/ab_macro.sh)
 SOURCES = ["capi.hip", "attn.hip", "attn2.hip", "attn_wide.hip", "gemm.hip", "gemm_tn.hip", "gemm_tn_slab.hip", "rowops.hip", "block.hip", "cpb.hip", "mlp.hip", "proj_ln.hip", "dataio.hip"]
 
-ABI_VERSION = 105          # SWV2_VERSION of the include/swv2.h these ctypes mirrors were written against (checked in load())
+ABI_VERSION = 106          # SWV2_VERSION of the include/swv2.h these ctypes mirrors were written against (checked in load())
 
 _lib = None
 _lock = threading.Lock()

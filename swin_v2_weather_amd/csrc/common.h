@@ -72,6 +72,48 @@ __device__ __forceinline__ float wave_sum_dpp63(float v) {
     return v;
 }
 
+// All-reduce sums on the vector ALU only (no LDS crossbar): every lane of a group of G consecutive lanes gets the group's sum.
+//   G <= 16: DPP (quad swaps, row_half_mirror, row_mirror);  G = 32: + v_permlane16_swap of the value with a copy of itself (rows
+//   (x0, x0, x2, x2) + (x1, x1, x3, x3));  G = 64: + v_permlane32_swap likewise.  A __shfl_xor step is a ds_bpermute (an LDS-pipe
+//   instruction + an lgkmcnt wait per step, ~100 cycles of latency each); the LayerNorm backward of a block did 160 of them per thread.
+// Inline assembly for the swaps: this toolchain compiles element 1 of __builtin_amdgcn_permlane{16,32}_swap's result as element 0
+// (see Epi<E_UNPATCH_LOSS>::wave_sum8_rows in gemm.hip); s_nop 1 = the wait the compiler itself puts between a vector write and a swap.
+#ifdef SWV2_ALLSUM_SHFL        // (A/B and bisection: the ds_bpermute forms)
+__device__ __forceinline__ float xor16_allsum(float x) { return x + __shfl_xor(x, 16); }
+__device__ __forceinline__ float xor32_allsum(float x) { return x + __shfl_xor(x, 32); }
+template <int G>
+__device__ __forceinline__ float group_allsum(float v) {
+#pragma unroll
+    for (int o = 1; o < G; o <<= 1) v += __shfl_xor(v, o);
+    return v;
+}
+#else
+__device__ __forceinline__ float xor16_allsum(float x) {
+    float y = x;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+    return x + y;
+}
+__device__ __forceinline__ float xor32_allsum(float x) {
+    float y = x;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+    return x + y;
+}
+template <int G>
+__device__ __forceinline__ float group_allsum(float v) {
+    static_assert(G == 1 || G == 2 || G == 4 || G == 8 || G == 16 || G == 32 || G == 64, "power-of-two lane groups");
+    auto dpp = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
+    };
+    if constexpr (G >= 2) v += dpp(v, std::integral_constant<int, 0xb1>{});      // quad_perm [1,0,3,2]
+    if constexpr (G >= 4) v += dpp(v, std::integral_constant<int, 0x4e>{});      // quad_perm [2,3,0,1]
+    if constexpr (G >= 8) v += dpp(v, std::integral_constant<int, 0x141>{});     // row_half_mirror
+    if constexpr (G >= 16) v += dpp(v, std::integral_constant<int, 0x140>{});    // row_mirror
+    if constexpr (G >= 32) v = xor16_allsum(v);
+    if constexpr (G >= 64) v = xor32_allsum(v);
+    return v;
+}
+#endif
+
 // ---- host side ----------------------------------------------------------------------------
 void swv2_set_error(const char* fmt, ...);
 #define SWV2_CHECK_ARG(cond, ...)                 \

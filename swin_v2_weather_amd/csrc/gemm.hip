@@ -543,12 +543,16 @@ __global__ __launch_bounds__(NTHREADS, ((EK == E_UNPATCH_LOSS || EK == E_UNPATCH
 
     f32x4 acc[RT][4];
     constexpr bool LOSS = EK == E_UNPATCH_LOSS || EK == E_UNPATCH_LOSS_SKIP;
-    [[maybe_unused]] typename std::conditional<LOSS, typename Epi<E_UNPATCH_LOSS>::Tar, int>::type ltar0, ltar1;
+    // target sets: lt[i] = this N tile's row tile i, ltn[i] = the NEXT N tile's, requested a whole N tile (two row tiles + one MFMA
+    // phase) ahead: one row tile ahead the wave had 4 KB of target loads in flight -- 32 KB per CU, ~16 GB/s per CU at 2 us
+    typedef typename std::conditional<LOSS, typename Epi<E_UNPATCH_LOSS>::Tar, int>::type TarT;
+    [[maybe_unused]] TarT lt[RT], ltn[RT];
     [[maybe_unused]] typename std::conditional<LOSS, typename Epi<E_UNPATCH_LOSS>::Row, int>::type lrow[RT];
     if constexpr (LOSS) {
 #pragma unroll
         for (int i = 0; i < RT; ++i) lrow[i] = ep.row_of(m_base + wr * 16 * RT + 16 * i, lane);
-        ep.load_tar(lrow[0], wc * 64, ltar0);
+#pragma unroll
+        for (int i = 0; i < RT; ++i) ep.load_tar(lrow[i], wc * 64, lt[i]);
     }
     issue(0);
     if constexpr (LOSS) commit(0);
@@ -601,15 +605,15 @@ __global__ __launch_bounds__(NTHREADS, ((EK == E_UNPATCH_LOSS || EK == E_UNPATCH
 #pragma unroll
                     for (int ii = 0; ii < 2; ++ii) {
                         const int i = 2 * grp + ii;
-                        // request the NEXT tile's targets (next row tile, or the first row tile of the next N tile) before this
-                        // tile's stores; ltar0 serves the even, ltar1 the odd row tiles
-                        if (i + 1 < RT) ep.load_tar(lrow[i + 1 < RT ? i + 1 : 0], n_w, (i & 1) ? ltar0 : ltar1);
-                        else ep.load_tar(lrow[0], n_w + BN, ltar0);           // (clamped inside: unconditional also behind the last N tile)
-                        ep.template tile_loss_t<EK == E_UNPATCH_LOSS_SKIP>(acc[i], (uint16_t*)st, lrow[i], m_w + 16 * i, n_w, lane, ls, ls2, b0,
-                                                                           (i & 1) ? ltar1 : ltar0);
+                        // request this row tile's targets of the NEXT N tile before this tile's stores (channels clamped inside:
+                        // unconditional also behind the last N tile)
+                        ep.load_tar(lrow[i], n_w + BN, ltn[i]);
+                        ep.template tile_loss_t<EK == E_UNPATCH_LOSS_SKIP>(acc[i], (uint16_t*)st, lrow[i], m_w + 16 * i, n_w, lane, ls, ls2, b0, lt[i]);
                     }
                     ep.template flush<32>(ls, ls2, edge, m_g, n_w, lane);
                 }
+#pragma unroll
+                for (int i = 0; i < RT; ++i) lt[i] = ltn[i];
                 if (s + 1 < steps) commit(s + 1);
             } else {
 #pragma unroll

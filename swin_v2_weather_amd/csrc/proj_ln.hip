@@ -138,16 +138,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void proj_ln_fwd_kernel(c
 #pragma unroll
             for (int e = 0; e < 4; ++e) { yacc[mt][tn][e] = bf2f(ar[e]); s += yacc[mt][tn][e]; }
         }
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
+        s = xor32_allsum(xor16_allsum(s));
         const float mu = s * (1.f / C);
         float q = 0.f;
 #pragma unroll
         for (int tn = 0; tn < NTC; ++tn)
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const float d = yacc[mt][tn][e] - mu; q = fmaf(d, d, q); }
-        q += __shfl_xor(q, 16);
-        q += __shfl_xor(q, 32);
+        q = xor32_allsum(xor16_allsum(q));
         const float rs = rsqrtf(q * (1.f / C) + a.eps);
         if (g == 0) {
             const int m = min(row0 + 16 * mt + fr, a.Mw - 1);
@@ -289,8 +287,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void proj_ln_bwd_kernel(c
                     t1 += gg[e];
                     t2 = fmaf(gg[e], xh[e], t2);
                 }
-#pragma unroll
-                for (int o = 1; o < LPR; o <<= 1) { t1 += __shfl_xor(t1, o); t2 += __shfl_xor(t2, o); }
+                t1 = group_allsum<LPR>(t1); t2 = group_allsum<LPR>(t2);        // (vector ALU only: common.h)
                 t1 *= (1.f / C); t2 *= (1.f / C);
                 f32x4 o4;
 #pragma unroll

@@ -21,11 +21,7 @@ __device__ __forceinline__ uint4 pack8f(const float* v) {
     return r;
 }
 template <int G>
-__device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+__device__ __forceinline__ float group_sum(float v) { return group_allsum<G>(v); }       // (vector ALU only: common.h)
 
 // ------------------------------------------------------------------------------------------------
 // y[dst] = res[rsrc] + scale[b] * (LN(a[m]) * gamma + beta)

@@ -78,7 +78,7 @@ blocks = [b for b in m.modules() if isinstance(b, N.SwinTransformerV2CrBlock)]
 used = sum(1 for b in blocks if all(hasattr(p, "_swv2_bv") for p in b.mlp.parameters()))
 stuck = sum(1 for b in blocks if b._bv_in_use)
 if rank == 0:
-    torch.save({"losses": losses, "params": [p.detach().cpu() for p in m.parameters()], "used": used, "stuck": stuck,
+    torch.save({"losses": losses, "params": [p.detach().cpu() for p in m.parameters()], "names": [n for n, _ in m.named_parameters()], "used": used, "stuck": stuck,
                 "nranks": dist.get_world_size() if mode != "plain" else 1,
                 # what the reducer reports after its bucket rebuild vs the plan the cap was chosen with (helpers.ddp_bucket_plan)
                 "buckets_observed": ddp_observed_buckets(net) if mode != "plain" else None,

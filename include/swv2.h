@@ -29,8 +29,9 @@ extern "C" {
  * library was built with; swin_v2_weather_amd/_lib.py refuses a library whose revision differs from the one it mirrors).
  * 100 rounds 1 - 4; 105 round 5: swv2_attn_args.dbias_partials, swv2_block_desc.bias_prepacked / dbias_part, the *_multi CPB
  * entry points, swv2_attn_pack_bias_multi / swv2_attn_bias_chunks, a (max, min) part in the packed bias buffer;
- * 106: SWV2_EPI_UNPATCH_LOSS writes slot 1 of loss_part only where swv2_loss_part_reduce reads it. */
-#define SWV2_VERSION 106
+ * 106: SWV2_EPI_UNPATCH_LOSS writes slot 1 of loss_part only where swv2_loss_part_reduce reads it; 107: swv2_epilogue.q[3], the loss
+ * epilogue with the rollout destinations. */
+#define SWV2_VERSION 107
 
 enum {
     SWV2_OK = 0,
@@ -184,7 +185,9 @@ enum swv2_epilogue_kind {
                                materialised gradient is read again.  A operand: SWV2_OP_F32 only; at least
                                SWV2_LOSS_GROUP_ROWS rows per sample; every tensor below 2^32 elements; `out` and loss_resid must be
                                followed by SWV2_LOSS_DUMP_BYTES of write-only scratch (masked lanes store there, so that the
-                               epilogue is branch-free)                                                 */
+                               epilogue is branch-free).  Rollouts (107): p[4] = channels per sample of the tensor `out` points into
+                               (with q[2]), aux_out / ld = a second destination [B][ld][H][W] for the same prediction (the next
+                               step's input, also followed by SWV2_LOSS_DUMP_BYTES), as SWV2_EPI_UNPATCH has them  */
 };
 
 typedef struct swv2_epilogue {
@@ -201,7 +204,9 @@ typedef struct swv2_epilogue {
     const float* loss_qw;    /* quadrature row weights [H] */
     float* loss_part;        /* [ceil(M / SWV2_LOSS_GROUP_ROWS)][2][Cout][2] fp32 per-group partial sums: slot 0 overwritten, slot 1 see above */
     void* loss_resid;        /* bf16 [M][N] */
-    int q[2];                /* channels per sample of loss_tar, first target channel of this prediction */
+    int q[3];                /* channels per sample of loss_tar, first target channel of this prediction, and (rollouts: p[4] != 0, `out`
+                                points into a [B][p[4]][H][W] tensor) the offset in floats from `out` to that tensor's dump area; 0 = behind
+                                the dense [B][Cout][H][W] prediction */
 } swv2_epilogue;
 
 int swv2_linear(const swv2_operand* a, const void* w_bf16, const swv2_epilogue* e, int N, void* stream);
@@ -321,6 +326,12 @@ int swv2_loss_grad(const float* prd, const float* tar, const float* quad_w, cons
  * g % SWV2_LOSS_PART_SLICES == j of (slot 0 of g if g's first row lies in sample b) + (slot 1 of g if it lies in sample b - 1),
  * ascending g; T rows per sample (T >= SWV2_LOSS_GROUP_ROWS).  sums: [SWV2_LOSS_PART_SLICES][B][Ct][2], overwritten for the Cout channels from coff. */
 int swv2_loss_part_reduce(const float* part, int M, int T, int B, int Cout, int Ct, int coff, float* sums, void* stream);
+/* The loss epilogue's residual (loss_resid, bf16 [M][Cout * 16], rows = patches (b, i, j), columns c * 16 + p * 4 + q) back in image layout and
+ * scaled: out[b][c][4i + p][4j + q] = coef[b][c] * resid (+ add[b][c][..] when add != NULL; add: [B][Cadd][H][W], out: the first Cout channels of
+ * [B][Cs][H][W]) -- d loss / d prediction where a consumer wants it as an image (the skip connection of a rollout step,
+ * swinv2_global.py:799-801).  coef as for swv2_loss_grad.  (107) */
+int swv2_loss_resid_to_image(const void* resid, const float* coef, const float* add, float* out, int B, int Cout, int H, int W, int Cs, int Cadd,
+                             void* stream);
 int swv2_loss_finalize(const float* sums, int layers, const float* chw, int BC, int C, int absolute, int squared, float* loss, float* coef,
                        void* stream);
 

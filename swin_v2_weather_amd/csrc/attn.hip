@@ -492,8 +492,7 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
                 }
             }
             if constexpr (CPR_P2) {
-#pragma unroll
-                for (int o = 1; o < CPR; o <<= 1) dl += __shfl_xor(dl, o);
+                dl = group_allsum<CPR>(dl);             // (vector ALU only: common.h)
             } else {
                 if (c < CH) DLp[c] = dl;            // summed per row by finish_delta() behind the barrier (a row's chunks straddle lane groups)
             }
@@ -966,8 +965,7 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
             for (int dt = 0; dt < DK; ++dt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dot = fmaf(dk[i][dt][r], bf2f(kf[i][dt][r]), dot);
-            dot += __shfl_xor(dot, 16);
-            dot += __shfl_xor(dot, 32);
+            dot = xor32_allsum(xor16_allsum(dot));
             // d logit_scale: sigma sum_{q,k} dS cos = sigma sum_k (sum_q dS[q][k] q^[q]) . k^[k] = sigma sum_k dot_k -- the same dot
             // product the normalisation backward needs, so the per-element accumulation in the step loop is gone
             if (g == 0) dsig += dot;
@@ -1045,8 +1043,7 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dot = fmaf(dq[i][dt][r], bf2f(qn[dt][r]), dot);
                 }
-                dot += __shfl_xor(dot, 16);
-                dot += __shfl_xor(dot, 32);
+                dot = xor32_allsum(xor16_allsum(dot));
 #pragma unroll
                 for (int dt = 0; dt < DK; ++dt) {
                     f32x4 v;

@@ -180,7 +180,7 @@ enum swv2_epilogue_kind {
                                row belongs to another sample or lies past M, the only groups swv2_loss_part_reduce reads it of;
                                zero there unless the group straddles the boundary; plain stores, no atomics: same-address float atomics from every workgroup
                                measured 8 x the whole kernel) which swv2_loss_part_reduce folds in a fixed order.  Also
-                               writes loss_resid bf16 [M][N] = qw[h] (y - tar) in the GEMM's own row / column order -- the
+                               writes loss_resid bf16 [M][SWV2_LOSS_RESID_PITCH(N)] = qw[h] (y - tar) in the GEMM's own row / column order -- the
                                operand SWV2_OP_BF16_CSCALE feeds to the head's backward, so neither the prediction nor a
                                materialised gradient is read again.  A operand: SWV2_OP_F32 only; at least
                                SWV2_LOSS_GROUP_ROWS rows per sample; every tensor below 2^32 elements; `out` and loss_resid must be
@@ -203,7 +203,7 @@ typedef struct swv2_epilogue {
     const float* loss_tar;   /* target [B][q[0]][H][W] fp32 */
     const float* loss_qw;    /* quadrature row weights [H] */
     float* loss_part;        /* [ceil(M / SWV2_LOSS_GROUP_ROWS)][2][Cout][2] fp32 per-group partial sums: slot 0 overwritten, slot 1 see above */
-    void* loss_resid;        /* bf16 [M][N] */
+    void* loss_resid;        /* bf16 [M][SWV2_LOSS_RESID_PITCH(N)], columns 0 .. N - 1 written */
     int q[3];                /* channels per sample of loss_tar, first target channel of this prediction, and (rollouts: p[4] != 0, `out`
                                 points into a [B][p[4]][H][W] tensor) the offset in floats from `out` to that tensor's dump area; 0 = behind
                                 the dense [B][Cout][H][W] prediction */
@@ -322,11 +322,14 @@ int swv2_loss_grad(const float* prd, const float* tar, const float* quad_w, cons
 #define SWV2_LOSS_PART_SLICES 8
 #define SWV2_LOSS_GROUP_ROWS 32
 #define SWV2_LOSS_DUMP_BYTES 2048
+/* row pitch (elements) of loss_resid for N = Cout * 16 columns: whole 128-byte lines per row, so that the 64-column pieces the epilogue
+ * writes and the head's backward products read never straddle a line (107) */
+#define SWV2_LOSS_RESID_PITCH(N) (((N) + 63) / 64 * 64)
 /* Folds the loss epilogue's per-group partial sums: sums[j][b][coff + c][k] = sum over the SWV2_LOSS_GROUP_ROWS-row groups g with
  * g % SWV2_LOSS_PART_SLICES == j of (slot 0 of g if g's first row lies in sample b) + (slot 1 of g if it lies in sample b - 1),
  * ascending g; T rows per sample (T >= SWV2_LOSS_GROUP_ROWS).  sums: [SWV2_LOSS_PART_SLICES][B][Ct][2], overwritten for the Cout channels from coff. */
 int swv2_loss_part_reduce(const float* part, int M, int T, int B, int Cout, int Ct, int coff, float* sums, void* stream);
-/* The loss epilogue's residual (loss_resid, bf16 [M][Cout * 16], rows = patches (b, i, j), columns c * 16 + p * 4 + q) back in image layout and
+/* The loss epilogue's residual (loss_resid, bf16 [M][SWV2_LOSS_RESID_PITCH(Cout * 16)], rows = patches (b, i, j), columns c * 16 + p * 4 + q) back in image layout and
  * scaled: out[b][c][4i + p][4j + q] = coef[b][c] * resid (+ add[b][c][..] when add != NULL; add: [B][Cadd][H][W], out: the first Cout channels of
  * [B][Cs][H][W]) -- d loss / d prediction where a consumer wants it as an image (the skip connection of a rollout step,
  * swinv2_global.py:799-801).  coef as for swv2_loss_grad.  (107) */

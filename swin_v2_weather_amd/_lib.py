@@ -134,6 +134,11 @@ ATTN_FIRST_GEN, ATTN_PLAIN_STATS = 16, 8192      # swv2_attn_args.dbg switches (
 LOSS_PART_SLICES = 8          # SWV2_LOSS_PART_SLICES
 LOSS_GROUP_ROWS = 32          # SWV2_LOSS_GROUP_ROWS
 LOSS_DUMP_BYTES = 2048        # SWV2_LOSS_DUMP_BYTES
+
+
+def loss_resid_pitch(n: int) -> int:
+    """SWV2_LOSS_RESID_PITCH: row pitch (elements) of the loss epilogue's residual for n columns"""
+    return (n + 63) // 64 * 64
 class BlockDesc(C.Structure):
     _fields_ = ([(n, C.c_int) for n in ("B", "T", "C", "heads", "head_dim", "hidden", "L", "Lp", "DP", "nwh", "nww", "mask_thr")] +
                 [(n, C.c_void_p) for n in (

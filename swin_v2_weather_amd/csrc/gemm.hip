@@ -380,7 +380,10 @@ template <> struct Epi<E_UNPATCH_LOSS> {
         const uint32_t plane = (uint32_t)(d.p1 * d.p2);
         const float q = in.q;
         float* outp = (float*)d.out;
-        const uint32_t ydump = (uint32_t)d.q2 + lane * 4, ndump = (uint32_t)d.q3 + lane * 4, rdump = (uint32_t)d.M * d.N + lane * 16;
+        // residual rows have a pitch of whole 128-byte lines (SWV2_LOSS_RESID_PITCH): with N = 1168 elements per row every 128-byte
+        // piece straddled two lines and the head's two backward products fetched 644 / 708 MB for 368 / 335 MB (profiles/r05_pmc_hbm.json)
+        const uint32_t RPITCH = (uint32_t)SWV2_LOSS_RESID_PITCH(d.N);
+        const uint32_t ydump = (uint32_t)d.q2 + lane * 4, ndump = (uint32_t)d.q3 + lane * 4, rdump = (uint32_t)d.M * RPITCH + lane * 16;
         const bool same = (rw.b == b0);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -407,7 +410,7 @@ template <> struct Epi<E_UNPATCH_LOSS> {
         // residual rows out as bf16, row-major: lane -> (row lane / 4, 16 columns), 128 contiguous bytes per row
         const int r2 = lane >> 2, c0 = (lane & 3) * 16, m2 = m0 + r2, n = n0 + c0;
         const uint4 w0 = *(const uint4*)(st16 + r2 * RP + c0), w1 = *(const uint4*)(st16 + r2 * RP + c0 + 8);
-        uint16_t* o = d.loss_resid + ((m2 < d.M && n < d.N) ? (uint32_t)m2 * d.N + n : rdump);
+        uint16_t* o = d.loss_resid + ((m2 < d.M && n < d.N) ? (uint32_t)m2 * RPITCH + n : rdump);
 #ifndef SWV2_HEAD_ABL_NO_RESID
         *(uint4*)o = w0;
         *(uint4*)(o + 8) = w1;
@@ -453,7 +456,7 @@ template <> struct Epi<E_UNPATCH_LOSS> {
     // stores the same instruction into the dump area behind the residual, so the common path has no branch around memory operations.
     template <int GR> __device__ __forceinline__ void flush(float (&ls)[8], float (&ls2)[8], bool edge, int m_first, int n0, int lane) const {
         const int c0 = n0 >> 4, qr = lane >> 4, vi = ((qr & 1) << 1) | (qr >> 1);
-        float* const dump = (float*)(d.loss_resid + (size_t)d.M * d.N) + 2 * lane;
+        float* const dump = (float*)(d.loss_resid + (size_t)d.M * SWV2_LOSS_RESID_PITCH(d.N)) + 2 * lane;
         float* const sp = d.loss_part + ((long)(m_first / GR) * 2 * d.p0 + c0) * 2;
         const bool lead = (lane & 15) == 0 && m_first < d.M;
         const bool ok0 = lead && c0 + (vi >> 1) < d.p0, ok1 = lead && c0 + 2 + (vi >> 1) < d.p0;
@@ -1625,7 +1628,7 @@ extern "C" int swv2_linear(const swv2_operand* a, const void* w_bf16, const swv2
         const double plane_ = (double)e->p[1] * e->p[2], nb_ = (double)a->rows / ((e->p[1] / 4) * (e->p[2] / 4));
         SWV2_CHECK_ARG((e->p[1] / 4) * (e->p[2] / 4) >= SWV2_LOSS_GROUP_ROWS, "swv2_linear: the loss epilogue needs at least %d patches per sample", SWV2_LOSS_GROUP_ROWS);
         const double cmax_ = fmax(fmax((double)e->p[3], (double)e->p[0]), fmax((double)e->p[4], e->aux_out ? (double)e->ld : 0.0));
-        SWV2_CHECK_ARG(nb_ * e->q[0] * plane_ < 4.29e9 && nb_ * cmax_ * plane_ + 1024 < 4.29e9 && (double)a->rows * N < 4.29e9 && (double)e->q[2] < 4.29e9,
+        SWV2_CHECK_ARG(nb_ * e->q[0] * plane_ < 4.29e9 && nb_ * cmax_ * plane_ + 1024 < 4.29e9 && (double)a->rows * SWV2_LOSS_RESID_PITCH(N) + 2048 < 4.29e9 && (double)e->q[2] < 4.29e9,
                        "swv2_linear: the loss epilogue indexes its tensors with 32-bit element offsets (tensor too large)");
     }
     const int M = a->rows, K = a->cols;

@@ -752,6 +752,7 @@ __global__ __launch_bounds__(256) void resid_to_image_kernel(const uint16_t* __r
                                                              int W, int Cs, int Cadd, int gw) {
     extern __shared__ __attribute__((aligned(16))) uint16_t rs[];
     const int N = Cout * 16, P = N + 8;                    // LDS pitch
+    const int RP = SWV2_LOSS_RESID_PITCH(N);               // row pitch of the residual in memory
     const int tid = threadIdx.x;
     const int j0 = blockIdx.x * TOK, i = blockIdx.y, b = blockIdx.z;
     const int gh = H >> 2;
@@ -760,7 +761,7 @@ __global__ __launch_bounds__(256) void resid_to_image_kernel(const uint16_t* __r
     const int cpr = N / 8;                                 // 16-byte chunks per row
     for (int u = tid; u < ntok * cpr; u += 256) {
         const int t = u / cpr, ch = u - t * cpr;
-        *(uint4*)(rs + t * P + 8 * ch) = *(const uint4*)(resid + (m0 + t) * N + 8 * ch);
+        *(uint4*)(rs + t * P + 8 * ch) = *(const uint4*)(resid + (m0 + t) * RP + 8 * ch);
     }
     __syncthreads();
     const int t = tid & (TOK - 1);

@@ -904,8 +904,9 @@ class _HeadFn(torch.autograd.Function):
             y = ybuf[:B * Cout * H * W].view(B, Cout, H, W)
             sums = torch.empty(L.LOSS_PART_SLICES, B, Cout, 2, dtype=torch.float32, device=dev)
             part = torch.empty((M + GRP - 1) // GRP, 2, Cout, 2, dtype=torch.float32, device=dev)
-            rbuf = torch.empty(M * Cout * 16 + L.LOSS_DUMP_BYTES // 2, dtype=ops.BF16, device=dev)
-            resid = rbuf[:M * Cout * 16].view(M, Cout * 16)
+            RP = L.loss_resid_pitch(Cout * 16)                   # rows padded to whole 128-byte lines
+            rbuf = torch.empty(M * RP + L.LOSS_DUMP_BYTES // 2, dtype=ops.BF16, device=dev)
+            resid = rbuf[:M * RP].view(M, RP)
             ops.linear(ops.op_f32(e2d), wb, ops.epilogue(L.EPI_UNPATCH_LOSS, y, aux=skip, p=(Cout, H, W, Cs, 0),
                                                          loss=(tar, qw, part, resid, 0)), Cout * 16, tag="head_fwd")
             ops.loss_part_reduce(part, M, gh * gw, B, Cout, 0, sums)
@@ -930,8 +931,9 @@ class _HeadFn(torch.autograd.Function):
                 M, GRP = B * gh * gw, L.LOSS_GROUP_ROWS
                 sums = torch.empty(L.LOSS_PART_SLICES, B, Cout, 2, dtype=torch.float32, device=dev)
                 part = torch.empty((M + GRP - 1) // GRP, 2, Cout, 2, dtype=torch.float32, device=dev)
-                rbuf = torch.empty(M * Cout * 16 + L.LOSS_DUMP_BYTES // 2, dtype=ops.BF16, device=dev)
-                resid = rbuf[:M * Cout * 16].view(M, Cout * 16)
+                RP = L.loss_resid_pitch(Cout * 16)
+                rbuf = torch.empty(M * RP + L.LOSS_DUMP_BYTES // 2, dtype=ops.BF16, device=dev)
+                resid = rbuf[:M * RP].view(M, RP)
                 ep = ops.epilogue(L.EPI_UNPATCH_LOSS, y, aux=skip, aux_out=nxt, ld=(nxt.shape[1] if nxt is not None else 0),
                                   p=(Cout, H, W, Cs, Ct), loss=(tar, qw, part, resid, coff, result))
                 ops.linear(ops.op_f32(e2d), wb, ep, Cout * 16, tag="head_fwd")
@@ -975,7 +977,7 @@ class _HeadFn(torch.autograd.Function):
             # d loss / d y = coef[b, c] q[h] (y - tar) with coef = 2 d loss / d S0: the stored residual scaled on load
             coef = (2.0 * dsums[0, :, :Cout, 0]).contiguous().float()
             coef16 = coef
-            g = lambda: ops.op_bf16_cscale(resid, coef16, T)     # noqa: E731
+            g = lambda: ops.op_bf16_cscale(resid, coef16, T, cols=Cout * 16)     # noqa: E731
             ops.linear_wgrad(g(), ops.op_f32(e2d), dw, None, nmap=perm)
             de = torch.empty(B * T, Cc, **f32)
             ops.linear(g(), wt, ops.epilogue(L.EPI_F32, de, ld=Cc), Cc, tag="head_dx")

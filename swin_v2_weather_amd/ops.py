@@ -149,12 +149,14 @@ def op_bf16(x2d: torch.Tensor, rows=None, rowidx=None, gelu=False):
                    x2d.shape[1], x2d.shape[1], rowidx)
 
 
-def op_bf16_cscale(x2d: torch.Tensor, coef: torch.Tensor, rows_per_sample: int):
-    """bf16 rows scaled on load by coef[row // rows_per_sample][col // 16] (fp32 [B, cols / 16])"""
+def op_bf16_cscale(x2d: torch.Tensor, coef: torch.Tensor, rows_per_sample: int, cols: int = 0):
+    """bf16 rows scaled on load by coef[row // rows_per_sample][col // 16] (fp32 [B, cols / 16]); `cols` < x2d.shape[1]: only the first
+    `cols` columns of every row are the operand (the loss epilogue's residual: rows padded to whole cache lines)"""
     _chk(x2d, BF16, "op_bf16_cscale"); _chk(coef, torch.float32, "op_bf16_cscale coef")
-    if coef.dim() != 2 or coef.shape[1] * 16 != x2d.shape[1] or coef.shape[0] * rows_per_sample != x2d.shape[0]:
-        raise L.Swv2Error(f"op_bf16_cscale: coef {tuple(coef.shape)} does not match rows {x2d.shape[0]} / {rows_per_sample}, cols {x2d.shape[1]}")
-    return operand(L.OP_BF16_CSCALE, x2d, x2d.shape[0], x2d.shape[1], x2d.shape[1], aux=(coef, None, None, None),
+    cols = cols or x2d.shape[1]
+    if coef.dim() != 2 or coef.shape[1] * 16 != cols or coef.shape[0] * rows_per_sample != x2d.shape[0] or cols > x2d.shape[1]:
+        raise L.Swv2Error(f"op_bf16_cscale: coef {tuple(coef.shape)} does not match rows {x2d.shape[0]} / {rows_per_sample}, cols {cols}")
+    return operand(L.OP_BF16_CSCALE, x2d, x2d.shape[0], cols, x2d.shape[1], aux=(coef, None, None, None),
                    p=(rows_per_sample, 0, coef.shape[1], 0))
 
 
@@ -188,6 +190,8 @@ def epilogue(kind, out, ld=0, bias=None, aux=None, aux_out=None, rowidx=None, p=
         base = loss[5] if len(loss) > 5 else None
         _chk(tar, torch.float32, "loss target"); _chk(qw, torch.float32, "quadrature weights")
         _chk(resid, BF16, "loss residual"); _chk(part, torch.float32, "loss partial sums")
+        if resid.dim() != 2 or resid.shape[1] % 64:
+            raise L.Swv2Error(f"loss epilogue: residual rows must be padded to whole 128-byte lines (ops._lib.loss_resid_pitch), got {tuple(resid.shape)}")
         behind = [(out if base is None else base, "out"), (resid, "residual")] + ([(aux_out, "second destination")] if aux_out is not None else [])
         for t_, nm in behind:      # room behind the tensors for the masked lanes' stores
             room = t_.untyped_storage().nbytes() - (t_.storage_offset() + t_.numel()) * t_.element_size()
@@ -388,6 +392,8 @@ def loss_resid_to_image(resid, coef, out, Cout: int, add=None):
     add fp32 [B, Cadd, H, W] contiguous or None"""
     _chk(resid, BF16, "loss residual"); _chk(coef, torch.float32, "coef"); _chk(out, torch.float32, "out")
     B, Cs, H, W = out.shape
+    if resid.shape[1] != L.loss_resid_pitch(Cout * 16):
+        raise L.Swv2Error(f"loss_resid_to_image: residual rows of {resid.shape[1]} elements, expected the padded pitch {L.loss_resid_pitch(Cout * 16)}")
     if add is not None:
         _chk(add, torch.float32, "add")
     L.check(L.load().swv2_loss_resid_to_image(_p(resid), _p(coef), _p(add), _p(out), B, Cout, H, W, Cs, add.shape[1] if add is not None else 0,

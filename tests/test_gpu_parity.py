@@ -1259,7 +1259,9 @@ def test_head_epilogue_loss_sums_and_scaled_residual_operand(dev, K):
     y1 = torch.full((B * Cout * H * W + L.LOSS_DUMP_BYTES // 4,), float("nan"), device=dev)[:B * Cout * H * W].view(B, Cout, H, W)
     sums_l = torch.zeros(L.LOSS_PART_SLICES, B, Cout + 2, 2, device=dev)
     part = torch.full(((M + L.LOSS_GROUP_ROWS - 1) // L.LOSS_GROUP_ROWS, 2, Cout, 2), float("nan"), device=dev)
-    resid = torch.full((M * Nn + L.LOSS_DUMP_BYTES // 2,), float("nan"), dtype=BF, device=dev)[:M * Nn].view(M, Nn)
+    RP = L.loss_resid_pitch(Nn)                     # residual rows are padded to whole 128-byte lines (here 80 -> 128 columns)
+    resid_p = torch.full((M * RP + L.LOSS_DUMP_BYTES // 2,), float("nan"), dtype=BF, device=dev)[:M * RP].view(M, RP)
+    resid = resid_p
     ops.linear(ops.op_f32(e2d), wb, ops.epilogue(L.EPI_UNPATCH_LOSS, y1, aux=skip, p=(Cout, H, W, Cs, 0),
                                                  loss=(tar, qw, part, resid, 1)), Nn)
     ops.loss_part_reduce(part, M, T, B, Cout, 1, sums_l)
@@ -1285,6 +1287,8 @@ def test_head_epilogue_loss_sums_and_scaled_residual_operand(dev, K):
     # residual in the GEMM's layout: row (b, i, j), column c*16 + p*4 + q
     r_img = (q * (y0.double() - t)).float()                                                     # [B, Cout, H, W]
     r_mat = r_img.view(B, Cout, gh, 4, gw, 4).permute(0, 2, 4, 1, 3, 5).reshape(M, Nn)
+    assert bool(torch.isnan(resid_p[:, Nn:]).all())                                             # the pad columns are never written
+    resid = resid_p[:, :Nn]
     assert torch.equal(resid.float(), rb(r_mat)) or rel(resid.float(), rb(r_mat)) < 2e-3        # (bf16 ties of fp32 vs fp64 diffs)
     # backward operand: coef[b, c] * residual against the materialised gradient through the patch loader
     coef = (torch.randn(B, Cout, device=dev) * 0.3).contiguous()
@@ -1292,11 +1296,11 @@ def test_head_epilogue_loss_sums_and_scaled_residual_operand(dev, K):
     wt = ops.prep_weight(w, transpose=True)
     de_ref, de = torch.empty(M, Cc, device=dev), torch.empty(M, Cc, device=dev)
     ops.linear(ops.operand(L.OP_PATCH, grad, M, Nn, 0, p=(Cout, H, W, 0)), wt, ops.epilogue(L.EPI_F32, de_ref, ld=Cc), Cc)
-    ops.linear(ops.op_bf16_cscale(resid, coef, T), wt, ops.epilogue(L.EPI_F32, de, ld=Cc), Cc)
+    ops.linear(ops.op_bf16_cscale(resid_p, coef, T, cols=Nn), wt, ops.epilogue(L.EPI_F32, de, ld=Cc), Cc)
     assert rel(de, de_ref) < 6e-3                                                               # one extra bf16 rounding of the operand
     dw_ref, dw = torch.zeros(Nn, Cc, device=dev), torch.zeros(Nn, Cc, device=dev)
     ops.linear_wgrad(ops.operand(L.OP_PATCH, grad, M, Nn, 0, p=(Cout, H, W, 0)), ops.op_f32(e2d), dw_ref, None)
-    ops.linear_wgrad(ops.op_bf16_cscale(resid, coef, T), ops.op_f32(e2d), dw, None)
+    ops.linear_wgrad(ops.op_bf16_cscale(resid_p, coef, T, cols=Nn), ops.op_f32(e2d), dw, None)
     assert rel(dw, dw_ref) < 6e-3
     exact = (coef.view(B, 1, 1, Cout, 1, 1).double() * r_mat.view(B, gh, gw, Cout, 4, 4).double().to(dev)).reshape(M, Nn)
     assert rel(dw, exact.float().T @ e2d) < 6e-3

@@ -21,7 +21,8 @@ tar = torch.randn(B, Cout, H, W, device=dev)
 qw = torch.rand(H, device=dev)
 y = torch.empty(B * Cout * H * W + 512, device=dev)[:B * Cout * H * W].view(B, Cout, H, W)
 part = torch.empty((M + 31) // 32, 2, Cout, 2, device=dev)
-resid = torch.empty(M * Nn + 1024, dtype=torch.bfloat16, device=dev)[:M * Nn].view(M, Nn)
+RP = L.loss_resid_pitch(Nn)
+resid = torch.empty(M * RP + 1024, dtype=torch.bfloat16, device=dev)[:M * RP].view(M, RP)
 print("plain un-patchify:", round(timeit(lambda: ops.linear(ops.op_f32(e2d), wb, ops.epilogue(L.EPI_UNPATCH, y, p=(Cout, H, W, 0, 0)), Nn)), 1), "us")
 f = lambda: ops.linear(ops.op_f32(e2d), wb, ops.epilogue(L.EPI_UNPATCH_LOSS, y, p=(Cout, H, W, 0, 0), loss=(tar, qw, part, resid, 0)), Nn)
 print("loss epilogue:", round(timeit(f), 1), "us")
@@ -29,5 +30,5 @@ coef = torch.rand(B, Cout, device=dev)
 wt = ops.prep_weight((torch.randn(Nn, Cc) * 0.1).to(dev), transpose=True)
 de = torch.empty(M, Cc, device=dev)
 dw = torch.zeros(Nn, Cc, device=dev)
-print("dx from scaled residual:", round(timeit(lambda: ops.linear(ops.op_bf16_cscale(resid, coef, T), wt, ops.epilogue(L.EPI_F32, de, ld=Cc), Cc)), 1), "us")
-print("dW from scaled residual:", round(timeit(lambda: ops.linear_wgrad(ops.op_bf16_cscale(resid, coef, T), ops.op_f32(e2d), dw, None)), 1), "us")
+print("dx from scaled residual:", round(timeit(lambda: ops.linear(ops.op_bf16_cscale(resid, coef, T, cols=Nn), wt, ops.epilogue(L.EPI_F32, de, ld=Cc), Cc)), 1), "us")
+print("dW from scaled residual:", round(timeit(lambda: ops.linear_wgrad(ops.op_bf16_cscale(resid, coef, T, cols=Nn), ops.op_f32(e2d), dw, None)), 1), "us")

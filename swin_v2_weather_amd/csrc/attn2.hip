@@ -501,16 +501,23 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn_fwd3b_kernel(
     const bool bounded = 2.f * sc2 + (bmax - bmin) <= 80.f;
 
     // bias rows of this wave's q-tiles: bq[i][t] = keys 16t + 4g .. + 3 of query 16 (wave + i WAVES) + fr, packed bf16, log2 domain
-    uint32_t bq[NQ][LT][2];
-#pragma unroll
-    for (int i = 0; i < NQ; ++i) {
+    // STREAM: only the CURRENT q-tile's rows are held (22 registers instead of 66): they are re-requested from L2 for the next q-tile the
+    // moment the identity products have consumed them and land while the rest of the tile runs -- three workgroups per CU
+    constexpr bool STREAM = OCC >= 3;
+    uint32_t bq[STREAM ? 1 : NQ][LT][2];
+    auto load_rows = [&](int i, uint32_t (&dst)[LT][2]) {
         const int qt = min(wave + i * WAVES, LT - 1);
         const uint32_t* src = bpack + (((size_t)hd * LT + qt) * LT) * 128 + lane;
 #pragma unroll
         for (int t = 0; t < LT; ++t) {
-            bq[i][t][0] = src[t * 128];
-            bq[i][t][1] = src[t * 128 + 64];
+            dst[t][0] = src[t * 128];
+            dst[t][1] = src[t * 128 + 64];
         }
+    };
+    if constexpr (STREAM) load_rows(0, bq[0]);
+    else {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) load_rows(i, bq[i]);
     }
     // identity A operand of the 16 x 16 x 16 MFMA: A[i = fr][k = 4g + j]
     bf16x4 idA;
@@ -612,7 +619,18 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn_fwd3b_kernel(
             }                                                                            \
         }                                                                                \
         break;
+            if constexpr (STREAM) {
+#pragma unroll
+                for (int t = 0; t < LT; ++t) {
+                    const uint32_t bw2[2] = {bq[0][t][0], bq[0][t][1]};
+                    acc[t] = mfma16(idA, __builtin_bit_cast(bf16x4, bw2), cinit);
+                }
+                // the next q-tile of this wave (the first one of the next item behind the last): same registers, requested now
+                const bool more = (i + 1 < NQ) && (wave + (i + 1) * WAVES < LT);
+                load_rows(more ? i + 1 : 0, bq[0]);
+            } else {
             switch (i) { SWV2_BIAS_TILES(0) SWV2_BIAS_TILES(1) SWV2_BIAS_TILES(2) SWV2_BIAS_TILES(3) default: break; }
+            }
 #undef SWV2_BIAS_TILES
 #pragma unroll
             for (int t = 0; t < LT; ++t) {
@@ -728,6 +746,8 @@ int swv2_attn2_fwd(const swv2_attn_args* a, int Lp, int DP, void* stream) {
         const float* brange = (const float*)((const char*)a->bias_pack + swv2_attn_bias_range_offset(a->heads, a->L));
         static const int kreg = getenv("SWV2_ATTN_FWD3B_KREG") ? atoi(getenv("SWV2_ATTN_FWD3B_KREG")) : 0;
         if (kreg) return a->L == 162 ? launch_fwd3b<11, 162, 4, 2, true>(a, bpack, brange, st) : launch_fwd3b<11, 0, 4, 2, true>(a, bpack, brange, st);
+        static const int stream = getenv("SWV2_ATTN_FWD3B_STREAM") ? atoi(getenv("SWV2_ATTN_FWD3B_STREAM")) : 1;
+        if (stream && a->L == 162) return launch_fwd3b<11, 162, 4, 3, false>(a, bpack, brange, st);
         return a->L == 162 ? launch_fwd3b<11, 162, 4, 2, false>(a, bpack, brange, st) : launch_fwd3b<11, 0, 4, 2, false>(a, bpack, brange, st);
     }
     if (DP == 32) {

@@ -313,15 +313,19 @@ template <> struct Epi<E_UNPATCH> {
 
 // un-patchify (+ skip) that also evaluates the geometric l2 loss of the prediction while it is in registers
 // (losses.py:188-206: sum_hw q[h] (prd - tar)^2 and sum_hw q[h] tar^2 per (sample, channel); grids.py:115-117) and leaves the
-// quadrature-weighted residual q[h] (prd - tar) as a bf16 [M][N] matrix in the GEMM's own layout for the head's backward.
+// quadrature-weighted residual q[h] (prd - tar) as a bf16 [M][SWV2_LOSS_RESID_PITCH(N)] matrix in the GEMM's own layout for the head's backward.
 // The reference (and rounds 1 - 2 here) read the 303 MB / sample prediction back twice (loss, loss gradient) and wrote a
 // gradient of the same size that both backward GEMMs of the head re-read through the 4 x 4 patch gather.
-//   tile_loss: one 16 x 64 staged sub-tile; item k of a lane = (row it & 15, channel n0/16 + k, image row p = lane >> 4),
-//              so the lane's four items are four different channels: ls[2k], ls[2k + 1] = that channel's partial sums
-//   flush    : per (N tile, wave) wave-reduce the sums and STORE them as the partial sums of the wave's 64-row group
-//              (swv2_loss_part_reduce adds the groups of a sample in a fixed order: the loss value is bit-reproducible).  The
-//              first version added them to the (sample, channel) sums with atomics: 146 addresses hit by 80 K wave-level
-//              atomics made the kernel 1071 us instead of 138 us.
+//   row_of      : what a lane has to know about its row of a 16-row tile (sample, image position, quadrature weight), once per kernel
+//   load_tar    : the lane's four target float4 of one 16 x 64 tile (four channels), requested a whole N tile ahead
+//   tile_loss_t : one 16 x 64 tile on the accumulators of the TRANSPOSED product: lane = (token fr, image row p = g), register r = q, one
+//                 channel per 16 x 16 tile; ls[2k], ls[2k + 1] = channel k's partial sums; only the bf16 residual is staged through LDS
+//   flush       : per (N tile, 32-row group) wave-reduce the sums (lane swaps + DPP) and STORE them as the group's partial sums
+//                 (swv2_loss_part_reduce adds the groups of a sample in a fixed order: the loss value is bit-reproducible).  The
+//                 first version added them to the (sample, channel) sums with atomics: 146 addresses hit by 80 K wave-level
+//                 atomics made the kernel 1071 us instead of 138 us.
+// Rollouts (round 5): `out` may be a channel block of a larger tensor (p4 channels per sample, dump offset q2) and aux_out a second
+// destination (the next step's input) written from the same registers.
 template <> struct Epi<E_UNPATCH_LOSS> {
     EpiDesc d;
     __device__ __forceinline__ void tile(const float*, int, int, int) const {}

@@ -1540,16 +1540,11 @@ int launch_nt2(const swv2_operand* a, const void* w, const swv2_epilogue* e, int
                                (const uint16_t*)w, ep, M, N, K);
     }
     if constexpr (EK == E_UNPATCH_LOSS || EK == E_UNPATCH_LOSS_SKIP) {
-        // 64-row workgroups (one 32-row partial-sum group per wave); SWV2_HEAD_BM=128: two groups per wave -- measured equal (422.8 vs
-        // 420.9 us) and 23 registers spilled
-        static const int bm = getenv("SWV2_HEAD_BM") ? atoi(getenv("SWV2_HEAD_BM")) : 64;
+        // 64-row workgroups (one 32-row partial-sum group per wave).  128-row workgroups (two groups per wave) measured equal -- 422.8 vs
+        // 420.9 us -- with 23 registers spilled: not instantiated
         half = true;
-        if (bm == 64)
-            hipLaunchKernelGGL((gemm_nt_kernel<AK, EK, BM / 2>), dim3(cdiv(M, BM / 2)), dim3(NTHREADS), 0, st, make_loader<AK>(a),
-                               (const uint16_t*)w, ep, M, N, K);
-        else
-            hipLaunchKernelGGL((gemm_nt_kernel<AK, EK, BM>), dim3(cdiv(M, BM)), dim3(NTHREADS), 0, st, make_loader<AK>(a),
-                               (const uint16_t*)w, ep, M, N, K);
+        hipLaunchKernelGGL((gemm_nt_kernel<AK, EK, BM / 2>), dim3(cdiv(M, BM / 2)), dim3(NTHREADS), 0, st, make_loader<AK>(a),
+                           (const uint16_t*)w, ep, M, N, K);
     }
     if constexpr (EK != E_UNPATCH_LOSS && EK != E_UNPATCH_LOSS_SKIP)
     if (!half)

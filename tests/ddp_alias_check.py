@@ -63,10 +63,25 @@ y = torch.randn(GB, 5 * (n_future + 1), 96, 144, generator=g)
 lb = GB // world if mode != "plain" else GB
 lo = rank * lb if mode != "plain" else 0
 x, y = x[lo:lo + lb].to(dev), y[lo:lo + lb].to(dev)
+# SWV2_DDP_LOSS=handler: the trainer's loss path -- LossHandler('l2') with its sums in the head epilogue(s) (LossHandler.fused_with; every
+# step's head in a rollout); the handler SUMS over the batch (losses.py:196-201), so it is divided by the local batch to keep the DDP
+# average equal to the 1-process whole-batch gradient
+lh = None
+if os.environ.get("SWV2_DDP_LOSS", "mse") == "handler":
+    from swin_v2_weather_amd.utils.losses import LossHandler
+    lh = LossHandler(SimpleNamespace(n_future=n_future, img_shape_x=96, img_shape_y=144, loss="l2", channel_weights="none", n_out_channels=5,
+                                     model_grid_type="equiangular")).to(dev).train()
 losses = []
+took = 0
 for i in range(steps):
     net.zero_grad()
-    loss = ((net(x) - y) ** 2).mean()
+    if lh is not None:
+        with lh.fused_with(net, y):
+            gen = net(x)
+        took += int(lh._fused is not None and (lh._fused.sums is not None or bool(lh._fused.steps)))
+        loss = lh(gen, y, x) / lb
+    else:
+        loss = ((net(x) - y) ** 2).mean()
     loss.backward()
     opt.step()
     if mode != "plain" and world > 1:
@@ -78,7 +93,7 @@ blocks = [b for b in m.modules() if isinstance(b, N.SwinTransformerV2CrBlock)]
 used = sum(1 for b in blocks if all(hasattr(p, "_swv2_bv") for p in b.mlp.parameters()))
 stuck = sum(1 for b in blocks if b._bv_in_use)
 if rank == 0:
-    torch.save({"losses": losses, "params": [p.detach().cpu() for p in m.parameters()], "names": [n for n, _ in m.named_parameters()], "used": used, "stuck": stuck,
+    torch.save({"losses": losses, "params": [p.detach().cpu() for p in m.parameters()], "names": [n for n, _ in m.named_parameters()], "used": used, "stuck": stuck, "fused_steps": took,
                 "nranks": dist.get_world_size() if mode != "plain" else 1,
                 # what the reducer reports after its bucket rebuild vs the plan the cap was chosen with (helpers.ddp_bucket_plan)
                 "buckets_observed": ddp_observed_buckets(net) if mode != "plain" else None,

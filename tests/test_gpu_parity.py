@@ -2078,7 +2078,7 @@ def test_grouped_weight_gradients_match_separate_launches(dev, K, monkeypatch, g
         assert float((g1 - g0).abs().max()) <= 2e-5 * float(g0.abs().max()) + 1e-12, n_
 
 
-def _ddp_run(tmp_path, tag, world, backend, mode, n_future, port, opt="sgd", cap_mb=25.0):
+def _ddp_run(tmp_path, tag, world, backend, mode, n_future, port, opt="sgd", cap_mb=25.0, extra_env=None):
     """spawn `world` worker processes (tests/ddp_alias_check.py), all on cuda:0; returns rank 0's record"""
     import subprocess
     out = os.path.join(str(tmp_path), f"{tag}.pt")
@@ -2090,7 +2090,8 @@ def _ddp_run(tmp_path, tag, world, backend, mode, n_future, port, opt="sgd", cap
         for r in range(world):
             env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port + 100 * attempt), RANK=str(r), WORLD_SIZE=str(world),
                        LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0", SWV2_DDP_BACKEND=backend, SWV2_DDP_MODE=mode,
-                       SWV2_DDP_NFUTURE=str(n_future), SWV2_DDP_STEPS="3", SWV2_DDP_OUT=out, SWV2_DDP_OPT=opt, SWV2_DDP_CAP_MB=str(cap_mb))
+                       SWV2_DDP_NFUTURE=str(n_future), SWV2_DDP_STEPS="3", SWV2_DDP_OUT=out, SWV2_DDP_OPT=opt, SWV2_DDP_CAP_MB=str(cap_mb),
+                       **(extra_env or {}))
             procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ddp_alias_check.py")], env=env,
                                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
         logs = [p_.communicate(timeout=900)[0].decode() for p_ in procs]
@@ -2135,6 +2136,13 @@ def test_ddp_two_ranks_hip_model(dev, K, tmp_path):
         assert two["nranks"] == 2 and two["stuck"] == 0
         # (two ranks sum the weight-gradient partial tiles in another order than one process on the whole batch: rounding level)
         _ddp_close(two, ref)
+    # the trainer's loss path under 2-rank DDP: LossHandler with its sums in the head epilogue -- every step's head in the 2-step rollout (skip
+    # connection: the model is residual) -- against ONE process on the whole batch with the two-pass loss kernels
+    for nf in (0, 1):
+        refh = _ddp_run(tmp_path, f"plainh{nf}", 1, "gloo", "plain", nf, 29561 + nf, extra_env={"SWV2_DDP_LOSS": "handler", "SWV2_LOSS_IN_HEAD": "0"})
+        twoh = _ddp_run(tmp_path, f"twoh{nf}", 2, "gloo", "alias", nf, 29565 + nf, extra_env={"SWV2_DDP_LOSS": "handler"})
+        assert refh["fused_steps"] == 0 and twoh["fused_steps"] == 3 and twoh["stuck"] == 0
+        _ddp_close(twoh, refh)
     stock = _ddp_run(tmp_path, "stock0", 2, "gloo", "ddp", 0, 29547)
     plain0 = _ddp_run(tmp_path, "plain0b", 1, "gloo", "plain", 0, 29549)
     _ddp_close(stock, plain0)

@@ -459,3 +459,34 @@ def test_dma_kernels_with_hand_counted_waits_use_no_scratch(tmp_path):
     assert len(slab) == 2, sorted(seen)
     for k, v in slab.items():
         assert v.get("ScratchSize [bytes/lane]") == 0 and v.get("VGPRs Spill") == 0, (k, v)
+
+
+def test_rollout_loss_hand_over_bookkeeping():
+    """host logic of LossHandler.fused_with for rollouts (utils/losses.py::_LossCtx): the per-step sums are concatenated in channel order only
+    when EVERY channel block of the concatenated prediction was offered exactly once for this result buffer; anything else falls back to the
+    two-pass kernels (returns None).  Also: the residual pitch helper mirrors SWV2_LOSS_RESID_PITCH of the header."""
+    from swin_v2_weather_amd.utils.losses import _LossCtx
+    from swin_v2_weather_amd import _lib as L
+    hdr = open(os.path.join(ROOT, "include", "swv2.h")).read()
+    assert "#define SWV2_LOSS_RESID_PITCH(N) (((N) + 63) / 64 * 64)" in hdr
+    assert [L.loss_resid_pitch(n) for n in (64, 80, 1168, 1216)] == [64, 128, 1216, 1216]
+    B, Cout, S = 2, 3, 3
+    result = torch.zeros(B, S * Cout, 4, 8)
+    tar = torch.zeros(B, S * Cout, 4, 8)
+    sums = [torch.full((8, B, Cout, 2), float(s)) for s in range(S)]
+    lc = _LossCtx(tar, torch.ones(4))
+    assert lc.rollout_sums(result, Cout) is None                      # nothing offered
+    for s in (2, 0, 1):                                                  # any order
+        lc.offer_step(result, s * Cout, sums[s])
+    got = lc.rollout_sums(result, Cout)
+    assert got is not None and tuple(got.shape) == (8, B, S * Cout, 2)
+    assert [float(got[0, 0, c, 0]) for c in range(S * Cout)] == [0.0] * 3 + [1.0] * 3 + [2.0] * 3
+    assert lc.rollout_sums(result.clone(), Cout) is None                # another buffer
+    lc.offer_step(result, 0, sums[0])                                    # a block offered twice (e.g. a recomputed forward)
+    assert lc.rollout_sums(result, Cout) is None
+    lc2 = _LossCtx(tar, torch.ones(4))
+    lc2.offer_step(result, 0, sums[0]); lc2.offer_step(result, 2 * Cout, sums[2])     # a step declined
+    assert lc2.rollout_sums(result, Cout) is None
+    other = torch.zeros_like(result)
+    lc2.offer_step(other, 0, sums[0])                                    # a new result buffer starts a new collection
+    assert lc2.result_ptr == other.data_ptr() and len(lc2.steps) == 1

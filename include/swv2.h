@@ -64,6 +64,7 @@ int swv2_attn_fwd_regime(int L, int head_dim, int has_bias, int dbg);
 
 #define SWV2_ATTN_FIRST_GEN 16
 #define SWV2_ATTN_PLAIN_STATS 8192
+#define SWV2_ATTN_BWD_TWO_PHASE 32
 
 typedef struct swv2_attn_args {
     const void* qkvh;         /* in  */
@@ -90,7 +91,9 @@ typedef struct swv2_attn_args {
                                  also the product path of other shapes): SWV2_ATTN_FIRST_GEN = the first-generation kernels of
                                  csrc/attn.hip instead of the small-workgroup forward of csrc/attn2.hip; SWV2_ATTN_PLAIN_STATS =
                                  the two-phase backward with the softmax statistics read from LDS instead of riding in the
-                                 MFMA operands */
+                                 MFMA operands; SWV2_ATTN_BWD_TWO_PHASE = the barrier-separated two-phase backward of csrc/attn.hip
+                                 (statistics in the operands) where csrc/attn_bwd_stream.hip would run (176-row layout, 16-wide
+                                 head slots, no table): same arithmetic, bit-identical d(qkv) */
     void* dbias_ws;           /* bwd, optional scratch of dbias_ws_bytes >= swv2_attn_dbias_ws_bytes(heads, L, max_chunks): the
                                  workgroups store their d bias tables there and one more launch sums them into dbias (in a
                                  fixed order); NULL / too small = 31 K float atomics per workgroup instead */

@@ -13,7 +13,7 @@ import threading
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("SWV2_LIB") or os.path.join(HERE, "libswv2.so")     # SWV2_LIB: a privately built variant (tools/ab_macro.sh)
-SOURCES = ["capi.hip", "attn.hip", "attn2.hip", "attn_wide.hip", "gemm.hip", "gemm_tn.hip", "gemm_tn_slab.hip", "rowops.hip", "block.hip", "cpb.hip", "mlp.hip", "proj_ln.hip", "dataio.hip"]
+SOURCES = ["capi.hip", "attn.hip", "attn2.hip", "attn_bwd_stream.hip", "attn_wide.hip", "gemm.hip", "gemm_tn.hip", "gemm_tn_slab.hip", "rowops.hip", "block.hip", "cpb.hip", "mlp.hip", "proj_ln.hip", "dataio.hip"]
 
 ABI_VERSION = 107          # SWV2_VERSION of the include/swv2.h these ctypes mirrors were written against (checked in load())
 
@@ -130,7 +130,7 @@ class LnArgs(C.Structure):
 
 
 LN_BWD_MAX_BLOCKS = 512
-ATTN_FIRST_GEN, ATTN_PLAIN_STATS = 16, 8192      # swv2_attn_args.dbg switches (SWV2_ATTN_FIRST_GEN / _PLAIN_STATS)
+ATTN_FIRST_GEN, ATTN_PLAIN_STATS, ATTN_BWD_TWO_PHASE = 16, 8192, 32      # swv2_attn_args.dbg switches (SWV2_ATTN_FIRST_GEN / _PLAIN_STATS)
 LOSS_PART_SLICES = 8          # SWV2_LOSS_PART_SLICES
 LOSS_GROUP_ROWS = 32          # SWV2_LOSS_GROUP_ROWS
 LOSS_DUMP_BYTES = 2048        # SWV2_LOSS_DUMP_BYTES

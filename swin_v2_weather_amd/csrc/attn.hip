@@ -275,6 +275,7 @@ __global__ __launch_bounds__(64 * LT) void attn_fwd_kernel(
 
 #ifdef SWV2_ATTN1_STAMPS          // diagnostic build (tools/probe_attn1_stamps.py): per-phase s_memtime sums of every wave 0
 __device__ unsigned long long attn1_stamps[512 * 8];
+__device__ unsigned long long attn1_win[64 * 128];        // wave 8 of the first 64 workgroups of head 0: s_memtime at the end of every window
 #define GSTAMP_DECL unsigned long long st_prev = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define GSTAMP_START() do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev) : : "memory"); } while (0)
 #define GSTAMP(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : : "memory"); \
@@ -550,6 +551,9 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
     const int Lc = LFIX > 0 ? LFIX : L;
     GSTAMP_DECL
     GSTAMP_START();
+#ifdef SWV2_ATTN1_STAMPS
+    const unsigned long long st_first = st_prev;
+#endif
     for (; bw < Bw; bw += gridDim.x) {
         const size_t slab0 = ((size_t)bw * h + hd) * 3 * SLAB;
         const int bw_next = bw + gridDim.x;
@@ -1061,6 +1065,12 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
         __syncthreads();
         if (bw_next < Bw) finish_delta();
         GSTAMP(7);                      // barrier 3
+#ifdef SWV2_ATTN1_STAMPS
+        if (lane == 0 && tw == 8 && blockIdx.y == 0 && blockIdx.x < 64) {
+            const int it_ = (bw - (int)blockIdx.x) / (int)gridDim.x;
+            if (it_ < 128) attn1_win[blockIdx.x * 128 + it_] = st_prev - st_first;
+        }
+#endif
     }
 #ifdef SWV2_ATTN1_STAMPS
     if (lane == 0 && blockIdx.y == 0 && blockIdx.x * WAVES + tw < 512)        // every wave of the first workgroups of head 0
@@ -1231,6 +1241,9 @@ extern "C" int swv2_attn_geometry(int L, int head_dim, int* Lp, int* DP) {
     return SWV2_ERR_UNSUPPORTED;
 
 #ifdef SWV2_ATTN1_STAMPS
+extern "C" int swv2_debug_attn1_win(void* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(attn1_win), sizeof(unsigned long long) * 64 * 128) == hipSuccess ? 0 : -3;
+}
 extern "C" int swv2_debug_attn1_stamps(void* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(attn1_stamps), sizeof(unsigned long long) * 512 * 8) == hipSuccess ? 0 : -3;
 }
@@ -1275,6 +1288,9 @@ int swv2_attn2_fwd(const swv2_attn_args* a, int Lp, int DP, void* stream);
 int swv2_attn_fwd_wide(const swv2_attn_args* a, int Lp, int DP, void* stream);
 int swv2_attn_bwd_wide(const swv2_attn_args* a, int Lp, int DP, void* stream);
 
+// the streamed-dQ backward of attn_bwd_stream.hip (176-row layout, 16-wide head slots, no table): 0 / negative = handled, 1 = not covered
+int swv2_attn_bwd_stream(const swv2_attn_args* a, int Lp, int DP, void* stream);
+
 // which forward kernel family serves a geometry (pure host function, no launch): 1 = the operand-folded softmax of attn2.hip, 0 = row
 // maximum + exact sum (attn.hip, attn_wide.hip); negative: geometry not covered.  The parity tests declare the regime their oracle
 // emulates and check it against this.
@@ -1311,6 +1327,8 @@ extern "C" int swv2_attn_bwd(const swv2_attn_args* a, void* stream) {
         int rc2 = swv2_attn_geometry(a->L, a->head_dim, &Lp2, &DP2);
         if (rc2) return rc2;
         rc2 = swv2_attn_bwd_wide(a, Lp2, DP2, stream);
+        if (rc2 <= 0) return rc2;
+        rc2 = swv2_attn_bwd_stream(a, Lp2, DP2, stream);
         if (rc2 <= 0) return rc2;
     }
     SWV2_ATTN_DISPATCH(launch_bwd)

@@ -1,0 +1,434 @@
+// Cosine window attention backward at the benchmark head geometry (176-row layout, 16-wide heads, no CPB table): the dQ phase
+// STREAMS behind the dK / dV phase through LDS counters -- one workgroup barrier per window instead of three (gfx950 / CDNA4).
+//
+// Same semantics, data layout and arithmetic as attn_bwd_kernel<11, 1, false, *, 1, true> of attn.hip (reference
+// networks/swinv2_global.py:298-318 under autograd): per (window, head)
+//   S' = Q_aug K_aug^T, dP' = dO_aug V_aug^T (statistics / padded keys / shift mask inside the K = 32 operands),
+//   P = exp2(S' sigma log2 e), dS = P dP', dV^T += dO^T P, dK^T += Q^T dS, dQ^T = K^T dS^T, then the L2-normalisation backward.
+//
+// Why a second kernel.  The two-phase kernel is paced by barriers (tools/probe_attn1_stamps.py, LABNOTES round 4 / 5): 11 waves sit
+// 3 + 3 + 3 + 2 on the four SIMDs, the SIMD serves its oldest wave first, so waves 0 - 3 end phase 1 a third earlier than waves 8 - 10
+// and wait (28 % of their time); then every wave runs a short, latency-bound phase 2 (transposed reads -> a dependent MFMA chain) with
+// nothing to overlap it (20 %), then the commit of the next window's slabs between two more barriers (7 %).  Here:
+//   * phase 1 is unchanged (wave = key tile, q-tiles in pairs, software-pipelined, fully unrolled with fences); after the dS tiles
+//     of a q-tile pair are written, lane 0 of the wave adds 1 to the pair's LDS counter (LDS executes a wave's instructions in order:
+//     the add is behind the tile writes);
+//   * phase 2 (all 11 q-tiles) belongs to waves 3 and 7 -- the two waves that share a SIMD with no third one (a workgroup's waves go
+//     to the SIMDs cyclically: {w, w + 4, w + 8} share one), i.e. the SIMD that idles a third of phase 1 in the two-phase kernel: they
+//     run their own phase 1 first (at 2 waves per SIMD they are done at ~60 % of the window), then wave 3 takes q-tile pairs 0, 1 and
+//     wave 7 pairs 2, 3, spinning on the pair's counter until it shows all 11 waves, then reading the dS image transposed (K^T fragments
+//     once per pair, two interleaved accumulation chains).  The last pair and the odd tile go to waves 1 and 0, the oldest waves of two
+//     other SIMDs, which are done first and would otherwise wait at the barrier.  (All 11 tiles on waves 3 / 7, one tile at a time:
+//     128 us against 112 -- a tile's chain of transposed reads -> 6 dependent MFMAs -> row sum -> store is ~400 cycles of latency;
+//     one tile per wave inside every wave's own loop: 110, the old waves' dQ + commit then sit behind the last signal);
+//   * the q | dO | k | v slabs (and the 1 / |q|, 1 / |k| rows) are double-buffered in LDS, so the next window's slabs are committed
+//     from the prefetch registers before the window's ONE barrier; the dS image is single (every reader has passed the barrier
+//     before the next window's first tile is written).
+// LDS: 2 x 40 832 (slabs) + 63 360 (dS image) + counters = 145 KB, one persistent workgroup per CU as before.
+#include <stdlib.h>
+
+#include "attn_common.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) unsigned lds_u32;
+
+#ifdef SWV2_ATTNS_STAMPS          // diagnostic build (tools/probe_attn_stream_stamps.py): per-phase s_memtime sums of every wave
+__device__ unsigned long long attns_stamps[512 * 8];
+__device__ unsigned long long attns_win[64 * 128];        // wave 8 of the first 64 workgroups of head 0: s_memtime at the end of every window
+__device__ unsigned long long attns_clock[512 * 2];       // per wave: s_memtime span, s_memrealtime span (100 MHz) of the window loop
+#define SSTAMP_DECL unsigned long long st_prev = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define SSTAMP_START() do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev) : : "memory"); } while (0)
+#define SSTAMP(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : : "memory"); \
+                       st_acc[k] += t_ - st_prev; st_prev = t_; } while (0)
+#else
+#define SSTAMP_DECL
+#define SSTAMP_START() do {} while (0)
+#define SSTAMP(k) do {} while (0)
+#endif
+
+template <int LFIX>
+__global__ __launch_bounds__(704) void attn_bwd_stream_kernel(
+    const uint16_t* __restrict__ qkvh, const float* __restrict__ logit_scale, const uint16_t* __restrict__ oh,
+    const uint16_t* __restrict__ doh, const float* __restrict__ lse,
+    const float* __restrict__ rnorm,       // [Bw][h][2][Lp]  1/max(|q|,eps), 1/max(|k|,eps)
+    uint16_t* __restrict__ dqkvh,          // [Bw][h][3][Lp][DP]  grads w.r.t. the UN-normalised q, k and v
+    float* __restrict__ dlogit,            // [h]      (atomically accumulated)
+    int Bw, int h, int L, int nW, int nww, int nwh, int mask_thr) {
+    constexpr int LT = 11, Lp = 16 * LT, DP = 16, SLAB = Lp * DP, WAVES = LT, NT = 64 * WAVES;
+    constexpr int DSP = Lp + 4;                              // row pitch (elements) of the [key][q] bf16 dS image
+    constexpr int QP = 40, QSTAT = 16;                       // 80-byte q / dO rows: 16 channels, 8 statistics slots, 16 bytes of padding (bank spread)
+    constexpr int CH = SLAB / 8, CPR = 2;                    // 16-byte chunks per slab / per row
+    constexpr int NPAIR = (LT + 1) / 2;                      // q-tile pairs (the odd last tile is a "pair" of its own)
+    // one buffer: q rows | dO rows | k | v | 1/|q|, 1/|k|
+    constexpr int B_Q = 0, B_DO = B_Q + Lp * QP * 2, B_K = B_DO + Lp * QP * 2, B_V = B_K + SLAB * 2, B_RN = B_V + SLAB * 2,
+                  BUFB = B_RN + 2 * Lp * 4;
+    constexpr int OFF_DS = 2 * BUFB, OFF_CNT = OFF_DS + Lp * DSP * 2, OFF_RED = OFF_CNT + 32, LDS_BYTES = OFF_RED + ((WAVES * 4 + 15) / 16) * 16;
+    static_assert(BUFB % 16 == 0 && OFF_DS % 16 == 0 && OFF_CNT % 16 == 0, "16-byte aligned sub-arrays");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+    uint16_t* const dSb = (uint16_t*)(lds + OFF_DS);
+    float* const red = (float*)(lds + OFF_RED);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int tw = __builtin_amdgcn_readfirstlane(tid >> 6);   // key tile of this wave in phase 1
+    const int fr = lane & 15, g = lane >> 4;
+    const int hd = blockIdx.y;
+    const bool p2wave = (tw == 3) || (tw == 7);               // the dQ waves (they share a SIMD with no third wave)
+
+    const float tau = logit_scale[hd];
+    const float sigma = __expf(fminf(tau, SWV2_LN100));
+    const float sc2 = sigma * SWV2_LOG2E;
+    const float inv_sc2 = 1.f / sc2;
+    const int Lc = LFIX > 0 ? LFIX : L;
+
+    if (tid < 8) ((unsigned*)(lds + OFF_CNT))[tid] = 0u;
+    const unsigned cnt_addr = (unsigned)(uintptr_t)(lds_u32*)(lds + OFF_CNT);           // the counters' LDS address (for the inline ds_add / ds_read)
+
+    // ---- staging registers (waves 0, 1, 2, 4, 5, 6 = 384 threads: chunk c of the q, k, v, dO, o slabs; lse of the chunk's row; one 1/|.| value)
+    uint4 sq, sk, sv, sdo, so;
+    float slse_row = 0.f, srn = 0.f;
+    const bool stager = !p2wave && tw < 7;                     // wave-uniform
+    const int craw = (tw < 3 ? tw : tw - 1) * 64 + lane;      // (stagers; the last 32 lanes of wave 6 repeat the last chunk, unused)
+    const int c = min(craw, CH - 1);
+    // 32-bit, loop-invariant lane offsets against wave-uniform bases: the loads take the (SGPR base + VGPR offset) form.  With 64-bit
+    // per-lane addresses the compiler builds them in the loads' own destination registers and guards that overwrite with s_waitcnt
+    // vmcnt(..) -- which, the counter being in order, also waits for the previous window's d(qkv) STORES (ISA, attn2.hip round 2)
+    const unsigned off16 = (unsigned)c * 16u, offl = (unsigned)(c / CPR) * 4u, offr = (unsigned)c * 4u;
+    auto issue = [&](int bw) {
+        if (stager) {
+            const size_t item = (size_t)__builtin_amdgcn_readfirstlane(bw) * h + hd;
+            const char* const qb = (const char*)(qkvh + item * 3 * SLAB);
+            // k / v bases of their own: 5 632 / 11 264 do not fit the loads' offset field, and as known constants they are split into a
+            // per-lane 64-bit add + a small offset
+            unsigned kofs = SLAB * 2, vofs = 2 * SLAB * 2;
+            asm volatile("" : "+s"(kofs), "+s"(vofs));
+            const char* const kb_ = qb + kofs;
+            const char* const vb_ = qb + vofs;
+            const char* const dob = (const char*)(doh + item * SLAB);
+            const char* const ob = (const char*)(oh + item * SLAB);
+            // (opaque per call: otherwise loop-invariant code motion folds the lane offsets into 64-bit per-lane pointers outside the window loop)
+            unsigned o16 = off16, ol = offl, orn = offr;
+            asm volatile("" : "+v"(o16), "+v"(ol), "+v"(orn));
+            sq = *(const uint4*)(qb + o16);
+            sk = *(const uint4*)(kb_ + o16);
+            sv = *(const uint4*)(vb_ + o16);
+            sdo = *(const uint4*)(dob + o16);
+            so = *(const uint4*)(ob + o16);
+            slse_row = *(const float*)((const char*)(lse + item * Lp) + ol);
+            srn = *(const float*)((const char*)(rnorm + item * 2 * Lp) + orn);
+        }
+    };
+    auto commit = [&](int buf) {
+        if (stager) {
+            unsigned char* const B = lds + buf * BUFB;
+            const int row = c / CPR, half = c % CPR;
+            // delta partial over this chunk's 8 channels, reduced over the 2 chunks of the row (adjacent lanes; vector ALU only)
+            float dl = 0.f;
+            {
+                const uint32_t a[4] = {sdo.x, sdo.y, sdo.z, sdo.w}, b[4] = {so.x, so.y, so.z, so.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    dl = fmaf(__uint_as_float(a[e] << 16), __uint_as_float(b[e] << 16), dl);
+                    dl = fmaf(__uint_as_float(a[e] & 0xffff0000u), __uint_as_float(b[e] & 0xffff0000u), dl);
+                }
+            }
+            dl = group_allsum<CPR>(dl);
+            // slots 16..23 of the row (the even chunk's thread): lse / (sigma log2 e) in three bf16 parts, a constant 1 (padded-key
+            // flag), the query's mask-region flags -- and delta in three parts for the dO row; slots 24..31 (odd chunk): zeros
+            uint4 aq = make_uint4(0, 0, 0, 0), ad = make_uint4(0, 0, 0, 0);
+            if (half == 0) {
+                const bool q_ok = row < L;
+                const float lq = q_ok ? slse_row * inv_sc2 : 1.0e30f;            // padded query rows: P = 0
+                uint16_t l0 = f2bf(lq);
+                const float r1 = lq - bf2f(l0);
+                uint16_t l1 = f2bf(r1), l2 = f2bf(r1 - bf2f(l1));
+                if (!q_ok) l1 = l2 = 0;
+                const uint16_t d0 = f2bf(dl);
+                const float e1 = dl - bf2f(d0);
+                const uint16_t d1 = f2bf(e1), d2 = f2bf(e1 - bf2f(d1));
+                const uint32_t one = 0x3f80u, rqf = (row >= mask_thr) ? 0x3f80u : 0u;
+                aq = make_uint4(l0 | ((uint32_t)l1 << 16), l2 | (one << 16), rqf | ((one - rqf) << 16), 0);
+                ad = make_uint4(d0 | ((uint32_t)d1 << 16), d2, 0, 0);
+            }
+            if (craw < CH) {
+                *(uint4*)((uint16_t*)(B + B_Q) + row * QP + half * 8) = sq;
+                *(uint4*)((uint16_t*)(B + B_DO) + row * QP + half * 8) = sdo;
+                *(uint4*)((uint16_t*)(B + B_K) + c * 8) = sk;
+                *(uint4*)((uint16_t*)(B + B_V) + c * 8) = sv;
+                *(uint4*)((uint16_t*)(B + B_Q) + row * QP + QSTAT + half * 8) = aq;
+                *(uint4*)((uint16_t*)(B + B_DO) + row * QP + QSTAT + half * 8) = ad;
+                ((float*)(B + B_RN))[c] = srn;
+            }
+        }
+    };
+
+    int bw = blockIdx.x;
+    if (bw >= Bw) return;
+    issue(bw);
+    commit(0);
+    __syncthreads();
+
+    float dsig = 0.f;
+    SSTAMP_DECL
+    SSTAMP_START();
+#ifdef SWV2_ATTNS_STAMPS
+    const unsigned long long ck0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    for (int it = 0; bw < Bw; bw += gridDim.x, ++it) {
+        const int buf = it & 1;
+        const size_t slab0 = ((size_t)bw * h + hd) * 3 * SLAB;
+        const int bw_next = bw + gridDim.x;
+        if (bw_next < Bw) issue(bw_next);
+        const unsigned char* const B = lds + buf * BUFB;
+        const uint16_t* const Qa = (const uint16_t*)(B + B_Q);
+        const uint16_t* const Da = (const uint16_t*)(B + B_DO);
+        const uint16_t* const Ks = (const uint16_t*)(B + B_K);
+        const uint16_t* const Vs = (const uint16_t*)(B + B_V);
+        const float* const RN = (const float*)(B + B_RN);
+        const unsigned target = (unsigned)(WAVES * (it + 1));
+        SSTAMP(0);                      // prefetch issue of the next window
+
+        // ================= phase 1: wave = key tile =================
+        const int key = 16 * tw + fr;
+        const bool do_mask = (mask_thr > 0) && (((bw % nW) / nww) == nwh - 1);
+        const float cmask = do_mask ? fmaxf(-100.f * SWV2_LOG2E * inv_sc2, -1.0e30f) : 0.f;
+        const bf16x4 kf = *(const bf16x4*)(Ks + key * DP + 4 * g);          // (the normalisation backward's copy of k^)
+        bf16x8 kf8, vf8;
+        {
+            const uint32_t m1 = 0xbf80u;                                       // -1
+            const uint32_t padk = (key < Lc) ? 0u : (uint32_t)f2bf(-1.0e30f);
+            const bool kreg = key >= mask_thr;
+            const uint32_t mk0 = f2bf(kreg ? 0.f : cmask), mk1 = f2bf(kreg ? cmask : 0.f);
+            const uint4 augk = make_uint4(m1 | (m1 << 16), m1 | (padk << 16), mk0 | (mk1 << 16), 0);
+            const uint4 augv = make_uint4(m1 | (m1 << 16), m1, 0, 0);
+            const uint4 z = make_uint4(0, 0, 0, 0);
+            const uint4 rk = *(const uint4*)(Ks + key * DP + (g & 1) * 8), rv = *(const uint4*)(Vs + key * DP + (g & 1) * 8);
+            kf8 = __builtin_bit_cast(bf16x8, g < 2 ? rk : (g == 2 ? augk : z));
+            vf8 = __builtin_bit_cast(bf16x8, g < 2 ? rv : (g == 2 ? augv : z));
+        }
+        f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+
+        struct St { f32x4 s, dp; bf16x4 tq, td; };
+        auto stageA = [&](const int qt, St& o) {
+            const bf16x8 qa = *(const bf16x8*)(Qa + (16 * qt + fr) * QP + 8 * g);
+            const bf16x8 da = *(const bf16x8*)(Da + (16 * qt + fr) * QP + 8 * g);
+            o.td = lds_tr_read(Da + (16 * qt + 4 * g + (fr >> 2)) * QP + (fr & 3) * 4);
+            o.tq = lds_tr_read(Qa + (16 * qt + 4 * g + (fr >> 2)) * QP + (fr & 3) * 4);
+            o.s = mfma32(qa, kf8, (f32x4){0.f, 0.f, 0.f, 0.f});
+            o.dp = mfma32(da, vf8, (f32x4){0.f, 0.f, 0.f, 0.f});
+        };
+        // the dS tiles of q-tile pair `p` of this wave are in the image: tell the dQ side (the LDS runs a wave's instructions in order)
+        auto signal = [&](const int p) {
+            if (lane == 0) asm volatile("ds_add_u32 %0, %1" : : "v"(cnt_addr + 4u * (unsigned)p), "v"(1u) : "memory");
+        };
+        // q-tiles in PAIRS: the dV / dK products of two tiles are one K = 32 MFMA (k-slot (g, j) = row 4g + j of the first tile for
+        // j < 4, of the second for j >= 4, on both operands) -- 6 MFMAs per pair instead of 8; the odd last tile has its own accumulators
+        auto stageB2 = [&](const int qt, const St& i0, const St& i1) {
+            f32x4 p0, p1, ds0, ds1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                p0[r] = __builtin_amdgcn_exp2f(i0.s[r] * sc2);
+                p1[r] = __builtin_amdgcn_exp2f(i1.s[r] * sc2);
+                ds0[r] = p0[r] * i0.dp[r];
+                ds1[r] = p1[r] * i1.dp[r];
+            }
+            const bf16x4 pb0 = f2bf4(p0), pb1 = f2bf4(p1), dsb0 = f2bf4(ds0), dsb1 = f2bf4(ds1);
+            *(bf16x4*)(dSb + key * DSP + 16 * qt + 4 * g) = dsb0;
+            *(bf16x4*)(dSb + key * DSP + 16 * qt + 16 + 4 * g) = dsb1;
+            const bf16x8 pb = __builtin_shufflevector(pb0, pb1, 0, 1, 2, 3, 4, 5, 6, 7);
+            const bf16x8 dsb = __builtin_shufflevector(dsb0, dsb1, 0, 1, 2, 3, 4, 5, 6, 7);
+            const bf16x8 td = __builtin_shufflevector(i0.td, i1.td, 0, 1, 2, 3, 4, 5, 6, 7);
+            const bf16x8 tq = __builtin_shufflevector(i0.tq, i1.tq, 0, 1, 2, 3, 4, 5, 6, 7);
+            dv = mfma32(td, pb, dv);
+            dk = mfma32(tq, dsb, dk);
+        };
+
+        // ================= phase 2: dQ of the q-tiles of pair `pr` (NQ = 2) or of the odd last tile (NQ = 1) =================
+        // dQ^T = sum_t K_t^T dS_t^T, key tiles in pairs (one K = 32 product per pair), both operands as transposed reads -- the K^T
+        // fragments are read once for both q-tiles, whose accumulation chains interleave; one chain per q-tile in key order + the odd
+        // key tile on its own accumulator: the summation order of the two-phase kernel (bit-identical d q)
+        auto phase2 = [&](const int pr, auto nq_c) {
+            constexpr int NQ = decltype(nq_c)::value;
+            {
+                const unsigned a = cnt_addr + 4u * (unsigned)pr;
+                while (true) {
+                    unsigned v;
+                    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+                    if ((unsigned)__builtin_amdgcn_readfirstlane(v) >= target) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            SSTAMP(2);
+            f32x4 dq[NQ];
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) dq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const uint16_t* const kb = Ks + (4 * g + (fr >> 2)) * DP + (fr & 3) * 4;
+            const uint16_t* const db = dSb + (4 * g + (fr >> 2)) * DSP + 32 * pr + (fr & 3) * 4;
+#pragma unroll
+            for (int t = 0; t + 1 < LT; t += 2) {
+                const bf16x4 k0 = lds_tr_read(kb + 16 * t * DP), k1 = lds_tr_read(kb + 16 * (t + 1) * DP);
+                const bf16x8 ka = __builtin_shufflevector(k0, k1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) {
+                    const bf16x4 d0 = lds_tr_read(db + 16 * t * DSP + 16 * i), d1 = lds_tr_read(db + 16 * (t + 1) * DSP + 16 * i);
+                    dq[i] = mfma32(ka, __builtin_shufflevector(d0, d1, 0, 1, 2, 3, 4, 5, 6, 7), dq[i]);
+                }
+            }
+            {
+                // own accumulator: a K = 16 MFMA chained directly onto a K = 32 accumulator gave wrong sums (attn.hip)
+                const bf16x4 k0 = lds_tr_read(kb + 16 * (LT - 1) * DP);
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) {
+                    const bf16x4 d0 = lds_tr_read(db + 16 * (LT - 1) * DSP + 16 * i);
+                    const f32x4 tail = mfma16(k0, d0, (f32x4){0.f, 0.f, 0.f, 0.f});
+                    dq[i] += tail;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const int q = 32 * pr + 16 * i + fr;
+                const float rq = RN[q] * sigma;
+                const bf16x4 qn = *(const bf16x4*)(Qa + q * QP + 4 * g);
+                float dot = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dot = fmaf(dq[i][r], bf2f(qn[r]), dot);
+                dot = xor32_allsum(xor16_allsum(dot));
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = rq * (dq[i][r] - bf2f(qn[r]) * dot);
+                *(bf16x4*)(dqkvh + slab0 + (size_t)q * DP + 4 * g) = f2bf4(v);
+            }
+            SSTAMP(3);
+        };
+
+        St a0, a1, b0, b1;
+        stageA(0, a0);
+        stageA(1, a1);
+#pragma unroll
+        for (int qt = 0; qt + 1 < LT; qt += 4) {
+            if (qt + 2 < LT) stageA(qt + 2, b0);
+            if (qt + 3 < LT) stageA(qt + 3, b1);
+            stageB2(qt, a0, a1);
+            signal(qt >> 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (qt + 3 < LT) {
+                if (qt + 4 < LT) stageA(qt + 4, a0);
+                if (qt + 5 < LT) stageA(qt + 5, a1);
+                stageB2(qt + 2, b0, b1);
+                signal((qt >> 1) + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        static_assert((LT & 3) == 3, "the odd last tile's stage A went into b0");
+        {
+            const St& in = b0;
+            f32x4 p, ds;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                p[r] = __builtin_amdgcn_exp2f(in.s[r] * sc2);
+                ds[r] = p[r] * in.dp[r];
+            }
+            const bf16x4 pb = f2bf4(p), dsb = f2bf4(ds);
+            *(bf16x4*)(dSb + key * DSP + 16 * (LT - 1) + 4 * g) = dsb;
+            const f32x4 tv = mfma16(in.td, pb, (f32x4){0.f, 0.f, 0.f, 0.f});
+            const f32x4 tk = mfma16(in.tq, dsb, (f32x4){0.f, 0.f, 0.f, 0.f});
+            dv += tv;
+            dk += tk;
+            signal(NPAIR - 1);
+        }
+        SSTAMP(1);                      // phase 1 loop
+        // ---- dK (through the L2-normalisation) and dV of this wave's key tile
+        {
+            const float rk = RN[Lp + key];
+            float dot = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dot = fmaf(dk[r], bf2f(kf[r]), dot);
+            dot = xor32_allsum(xor16_allsum(dot));
+            // d logit_scale: sigma sum_{q,k} dS cos = sigma sum_k (sum_q dS[q][k] q^[q]) . k^[k] = sigma sum_k dot_k
+            if (g == 0) dsig += dot;
+            const float rks = rk * sigma;                     // the accumulators hold sum_q q^ dS: d(cos) = sigma dS
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = rks * (dk[r] - bf2f(kf[r]) * dot);
+            *(bf16x4*)(dqkvh + slab0 + SLAB + (size_t)key * DP + 4 * g) = f2bf4(v);
+            *(bf16x4*)(dqkvh + slab0 + 2 * SLAB + (size_t)key * DP + 4 * g) = f2bf4(dv);
+        }
+        SSTAMP(4);                      // dK / dV normalisation backward + stores
+        if (bw_next < Bw) commit(buf ^ 1);
+        SSTAMP(5);                      // commit (wait for the prefetch + LDS writes + delta)
+        // who computes which dQ tiles, all behind the wave's own phase 1: waves 3 and 7 (a SIMD of their own) the pairs that are complete
+        // early, the two oldest waves of the other SIMDs (done first, otherwise waiting at the barrier) the last pair and the odd tile
+        if (tw == 3) {
+            phase2(0, std::integral_constant<int, 2>{});
+            phase2(1, std::integral_constant<int, 2>{});
+        } else if (tw == 7) {
+            phase2(2, std::integral_constant<int, 2>{});
+            phase2(3, std::integral_constant<int, 2>{});
+        } else if (tw == 1) {
+            phase2(4, std::integral_constant<int, 2>{});
+        } else if (tw == 0) {
+            phase2(NPAIR - 1, std::integral_constant<int, 1>{});
+        }
+        __syncthreads();
+        SSTAMP(6);                      // the window's barrier
+#ifdef SWV2_ATTNS_STAMPS
+        if (lane == 0 && tw == 8 && blockIdx.y == 0 && blockIdx.x < 64 && it < 128) attns_win[blockIdx.x * 128 + it] = st_prev - ck0;
+#endif
+    }
+#ifdef SWV2_ATTNS_STAMPS
+    if (lane == 0 && blockIdx.y == 0 && blockIdx.x * WAVES + tw < 512) {      // every wave of the first workgroups of head 0
+        for (int k = 0; k < 8; ++k) attns_stamps[(blockIdx.x * WAVES + tw) * 8 + k] = st_acc[k];
+        attns_clock[(blockIdx.x * WAVES + tw) * 2] = __builtin_amdgcn_s_memtime() - ck0;
+        attns_clock[(blockIdx.x * WAVES + tw) * 2 + 1] = __builtin_amdgcn_s_memrealtime() - rt0;
+    }
+#endif
+
+    // ---- flush the per-workgroup reduction: one atomic per workgroup for the logit scale
+    dsig = wave_sum(dsig);
+    if (lane == 0) red[tw] = dsig;
+    __syncthreads();
+    if (tid == 0 && tau <= SWV2_LN100) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < WAVES; ++i) t += red[i];
+        atomicAdd(dlogit + hd, t * sigma);
+    }
+}
+
+}  // namespace
+
+#ifdef SWV2_ATTNS_STAMPS
+extern "C" int swv2_debug_attns_stamps(void* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(attns_stamps), sizeof(unsigned long long) * 512 * 8) == hipSuccess ? 0 : -3;
+}
+extern "C" int swv2_debug_attns_win(void* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(attns_win), sizeof(unsigned long long) * 64 * 128) == hipSuccess ? 0 : -3;
+}
+extern "C" int swv2_debug_attns_clock(void* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(attns_clock), sizeof(unsigned long long) * 512 * 2) == hipSuccess ? 0 : -3;
+}
+#endif
+
+// called by swv2_attn_bwd (attn.hip); returns 1 when this kernel does not cover the shape or is switched off (the caller then runs
+// the two-phase kernel): the 176-row layout with 16-wide head slots, no CPB table.  Window areas: any L <= 176 of the layout (padded
+// keys are switched off inside the operand, padded query rows carry lse = 1e30).
+int swv2_attn_bwd_stream(const swv2_attn_args* a, int Lp, int DP, void* stream) {
+    static const int on = getenv("SWV2_ATTN_BWD_STREAM") ? atoi(getenv("SWV2_ATTN_BWD_STREAM")) : 1;
+    if (!on || Lp != 176 || DP != 16 || a->bias || (a->dbg & (SWV2_ATTN_PLAIN_STATS | SWV2_ATTN_BWD_TWO_PHASE))) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    const int nchunk = a->Bw < a->max_chunks ? a->Bw : a->max_chunks;
+    dim3 grid(nchunk, a->heads), block(704);
+    const int nW = a->nwh * a->nww;
+    if (a->L == 162)
+        hipLaunchKernelGGL((attn_bwd_stream_kernel<162>), grid, block, 0, st, (const uint16_t*)a->qkvh, a->logit_scale, (const uint16_t*)a->oh,
+                           (const uint16_t*)a->doh, a->lse, a->rnorm, (uint16_t*)a->dqkvh, a->dlogit_scale, a->Bw, a->heads, a->L, nW, a->nww,
+                           a->nwh, a->mask_thr);
+    else
+        hipLaunchKernelGGL((attn_bwd_stream_kernel<0>), grid, block, 0, st, (const uint16_t*)a->qkvh, a->logit_scale, (const uint16_t*)a->oh,
+                           (const uint16_t*)a->doh, a->lse, a->rnorm, (uint16_t*)a->dqkvh, a->dlogit_scale, a->Bw, a->heads, a->L, nW, a->nww,
+                           a->nwh, a->mask_thr);
+    SWV2_CHECK_LAUNCH("swv2_attn_bwd");
+    return SWV2_OK;
+}

@@ -717,7 +717,7 @@ def test_attention_kernel_generations_agree(dev, K, shifted):
     assert float((res[0][1][:, :, :Lw] - res[L.ATTN_FIRST_GEN][1][:, :, :Lw]).abs().max()) < 2e-2
     oh, lse = res[L.ATTN_FIRST_GEN]
     grads = {}
-    for dbg in (0, L.ATTN_PLAIN_STATS):
+    for dbg in (0, L.ATTN_PLAIN_STATS, L.ATTN_BWD_TWO_PHASE):
         dq = torch.zeros(Bw, h, 3, Lp, DP, dtype=BF, device=dev)
         dls = torch.zeros(h, device=dev)
         a = ops.attn_args(qkvh, ls, None, oh, lse, Bw, h, Lw, d, nwh, nww, mask_thr, doh=doh, rnorm=rnorm, dqkvh=dq, dlogit=dls)
@@ -726,6 +726,17 @@ def test_attention_kernel_generations_agree(dev, K, shifted):
         grads[dbg] = (dq, dls)
     assert rel(grads[0][0], grads[L.ATTN_PLAIN_STATS][0]) < 1e-2
     assert float(grads[0][1][-1]) == 0.0 and rel(grads[0][1], grads[L.ATTN_PLAIN_STATS][1]) < 5e-2
+    # the streamed-dQ backward (csrc/attn_bwd_stream.hip, the default at this geometry) against the barrier-separated two-phase kernel
+    # with the same operand-carried statistics: the same products in the same order -> d(qkv) bit for bit; d logit_scale up to the
+    # order of the workgroups' atomics.  Several max_chunks: 1 .. 6 windows per workgroup (odd / even window counts: both LDS buffers,
+    # a workgroup's last window without a successor to prefetch)
+    assert torch.equal(grads[0][0], grads[L.ATTN_BWD_TWO_PHASE][0])
+    assert rel(grads[0][1], grads[L.ATTN_BWD_TWO_PHASE][1]) < 1e-5
+    for mc in (1, 2, 5, 12):
+        dq = torch.full((Bw, h, 3, Lp, DP), float("nan"), dtype=BF, device=dev)
+        dls = torch.zeros(h, device=dev)
+        ops.attn_bwd(ops.attn_args(qkvh, ls, None, oh, lse, Bw, h, Lw, d, nwh, nww, mask_thr, doh=doh, rnorm=rnorm, dqkvh=dq, dlogit=dls, max_chunks=mc))
+        assert torch.equal(dq, grads[L.ATTN_BWD_TWO_PHASE][0]) and rel(dls, grads[L.ATTN_BWD_TWO_PHASE][1]) < 1e-5, mc
 
 
 # ---------------------------------------------------------------------------------------------------------------

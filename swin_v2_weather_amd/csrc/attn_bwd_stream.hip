@@ -48,18 +48,21 @@ __device__ unsigned long long attns_clock[512 * 2];       // per wave: s_memtime
 #endif
 
 template <int LFIX>
-__global__ __launch_bounds__(704) void attn_bwd_stream_kernel(
+__global__ __launch_bounds__(1024) void attn_bwd_stream_kernel(
     const uint16_t* __restrict__ qkvh, const float* __restrict__ logit_scale, const uint16_t* __restrict__ oh,
     const uint16_t* __restrict__ doh, const float* __restrict__ lse,
     const float* __restrict__ rnorm,       // [Bw][h][2][Lp]  1/max(|q|,eps), 1/max(|k|,eps)
     uint16_t* __restrict__ dqkvh,          // [Bw][h][3][Lp][DP]  grads w.r.t. the UN-normalised q, k and v
     float* __restrict__ dlogit,            // [h]      (atomically accumulated)
     int Bw, int h, int L, int nW, int nww, int nwh, int mask_thr) {
-    constexpr int LT = 11, Lp = 16 * LT, DP = 16, SLAB = Lp * DP, WAVES = LT, NT = 64 * WAVES;
+    constexpr int LT = 11, Lp = 16 * LT, DP = 16, SLAB = Lp * DP;
+    constexpr int PW = LT, HW = 5, WAVES = PW + HW;          // 11 phase-1 waves (wave = key tile) + 5 helper waves (staging, commit, dQ): 4 per SIMD
     constexpr int DSP = Lp + 4;                              // row pitch (elements) of the [key][q] bf16 dS image
     constexpr int QP = 40, QSTAT = 16;                       // 80-byte q / dO rows: 16 channels, 8 statistics slots, 16 bytes of padding (bank spread)
     constexpr int CH = SLAB / 8, CPR = 2;                    // 16-byte chunks per slab / per row
     constexpr int NPAIR = (LT + 1) / 2;                      // q-tile pairs (the odd last tile is a "pair" of its own)
+    constexpr int HT = 64 * HW;                              // helper threads (320): chunk c = their index, the first 32 of the last helper also chunk 320 + lane
+    static_assert(CH > HT && CH <= HT + 32, "second chunks on the first half of one helper wave");
     // one buffer: q rows | dO rows | k | v | 1/|q|, 1/|k|
     constexpr int B_Q = 0, B_DO = B_Q + Lp * QP * 2, B_K = B_DO + Lp * QP * 2, B_V = B_K + SLAB * 2, B_RN = B_V + SLAB * 2,
                   BUFB = B_RN + 2 * Lp * 4;
@@ -72,10 +75,10 @@ __global__ __launch_bounds__(704) void attn_bwd_stream_kernel(
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int tw = __builtin_amdgcn_readfirstlane(tid >> 6);   // key tile of this wave in phase 1
-    const int fr = lane & 15, g = lane >> 4;
+    const int tw = __builtin_amdgcn_readfirstlane(tid >> 6);   // phase-1 waves: the key tile; helpers: PW + helper index
     const int hd = blockIdx.y;
-    const bool p2wave = (tw == 3) || (tw == 7);               // the dQ waves (they share a SIMD with no third wave)
+    const bool helper = tw >= PW;                              // wave-uniform
+    const int hw = tw - PW;
 
     const float tau = logit_scale[hd];
     const float sigma = __expf(fminf(tau, SWV2_LN100));
@@ -84,50 +87,58 @@ __global__ __launch_bounds__(704) void attn_bwd_stream_kernel(
     const int Lc = LFIX > 0 ? LFIX : L;
 
     if (tid < 8) ((unsigned*)(lds + OFF_CNT))[tid] = 0u;
-    const unsigned cnt_addr = (unsigned)(uintptr_t)(lds_u32*)(lds + OFF_CNT);           // the counters' LDS address (for the inline ds_add / ds_read)
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_u32*)lds;
+    const unsigned cnt_addr = lds_base + OFF_CNT;           // the counters' LDS address (for the inline ds_add / ds_read)
 
-    // ---- staging registers (waves 0, 1, 2, 4, 5, 6 = 384 threads: chunk c of the q, k, v, dO, o slabs; lse of the chunk's row; one 1/|.| value)
-    uint4 sq, sk, sv, sdo, so;
-    float slse_row = 0.f, srn = 0.f;
-    const bool stager = !p2wave && tw < 7;                     // wave-uniform
-    const int craw = (tw < 3 ? tw : tw - 1) * 64 + lane;      // (stagers; the last 32 lanes of wave 6 repeat the last chunk, unused)
-    const int c = min(craw, CH - 1);
+    // ---- staging (helper waves): one 16-byte chunk of the q, k, v, dO, o slabs; lse of the chunk's row; one 1/|.| value -- twice on helper 0
+    // (k and v go straight to LDS by DMA: 44 staging registers beside the dQ pair did not fit the 128 of a 16-wave workgroup)
+    struct Stg { uint4 q, dO, o; float lse, rn; };
+    Stg s0, s1;
+    const bool two = helper && hw == HW - 1;                   // wave-uniform: this wave stages a second chunk (its lanes 0 .. 31); it commits BEFORE its dQ pair
     // 32-bit, loop-invariant lane offsets against wave-uniform bases: the loads take the (SGPR base + VGPR offset) form.  With 64-bit
     // per-lane addresses the compiler builds them in the loads' own destination registers and guards that overwrite with s_waitcnt
-    // vmcnt(..) -- which, the counter being in order, also waits for the previous window's d(qkv) STORES (ISA, attn2.hip round 2)
-    const unsigned off16 = (unsigned)c * 16u, offl = (unsigned)(c / CPR) * 4u, offr = (unsigned)c * 4u;
-    auto issue = [&](int bw) {
-        if (stager) {
-            const size_t item = (size_t)__builtin_amdgcn_readfirstlane(bw) * h + hd;
-            const char* const qb = (const char*)(qkvh + item * 3 * SLAB);
-            // k / v bases of their own: 5 632 / 11 264 do not fit the loads' offset field, and as known constants they are split into a
-            // per-lane 64-bit add + a small offset
-            unsigned kofs = SLAB * 2, vofs = 2 * SLAB * 2;
-            asm volatile("" : "+s"(kofs), "+s"(vofs));
-            const char* const kb_ = qb + kofs;
-            const char* const vb_ = qb + vofs;
-            const char* const dob = (const char*)(doh + item * SLAB);
-            const char* const ob = (const char*)(oh + item * SLAB);
+    // vmcnt(..) -- which, the counter being in order, also waits for earlier d(qkv) STORES (ISA, attn2.hip round 2)
+    auto issue = [&](int bw, int nbuf, int hidx) {      // nbuf: the LDS buffer the window will be committed to; hidx: the helper thread's index
+        const size_t item = (size_t)__builtin_amdgcn_readfirstlane(bw) * h + hd;
+        const char* const qb = (const char*)(qkvh + item * 3 * SLAB);
+        // k / v bases of their own: 5 632 / 11 264 do not fit the loads' offset field, and as known constants they are split into a
+        // per-lane 64-bit add + a small offset
+        unsigned kofs = SLAB * 2, vofs = 2 * SLAB * 2;
+        asm volatile("" : "+s"(kofs), "+s"(vofs));
+        const char* const kb_ = qb + kofs;
+        const char* const vb_ = qb + vofs;
+        const char* const dob = (const char*)(doh + item * SLAB);
+        const char* const ob = (const char*)(oh + item * SLAB);
+        auto one = [&](Stg& st, const int craw, const unsigned lds_k) {
+            const int c = min(craw, CH - 1);
             // (opaque per call: otherwise loop-invariant code motion folds the lane offsets into 64-bit per-lane pointers outside the window loop)
-            unsigned o16 = off16, ol = offl, orn = offr;
+            unsigned o16 = (unsigned)c * 16u, ol = (unsigned)(c / CPR) * 4u, orn = (unsigned)c * 4u;
             asm volatile("" : "+v"(o16), "+v"(ol), "+v"(orn));
-            sq = *(const uint4*)(qb + o16);
-            sk = *(const uint4*)(kb_ + o16);
-            sv = *(const uint4*)(vb_ + o16);
-            sdo = *(const uint4*)(dob + o16);
-            so = *(const uint4*)(ob + o16);
-            slse_row = *(const float*)((const char*)(lse + item * Lp) + ol);
-            srn = *(const float*)((const char*)(rnorm + item * 2 * Lp) + orn);
-        }
+            // k, v: LDS-DMA (M0 = the LDS address of the wave's first chunk, lane l lands 16 l bytes behind it), issued BEFORE the register
+            // loads: the counter is in order, so the compiler's own wait for a younger register load covers them
+            if (craw < CH) {
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(o16), "s"(kb_), "s"(lds_k) : "memory");
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(o16), "s"(vb_), "s"(lds_k + SLAB * 2) : "memory");
+            }
+            st.q = *(const uint4*)(qb + o16);
+            st.dO = *(const uint4*)(dob + o16);
+            st.o = *(const uint4*)(ob + o16);
+            st.lse = *(const float*)((const char*)(lse + item * Lp) + ol);
+            st.rn = *(const float*)((const char*)(rnorm + item * 2 * Lp) + orn);
+        };
+        const unsigned lds_k0 = lds_base + (unsigned)(nbuf * BUFB + B_K);
+        one(s0, hidx, lds_k0 + (unsigned)hw * 1024u);
+        if (two) one(s1, HT + (hidx & 63), lds_k0 + (unsigned)HT * 16u);
     };
-    auto commit = [&](int buf) {
-        if (stager) {
-            unsigned char* const B = lds + buf * BUFB;
+    auto commit = [&](int buf, int hidx) {
+        unsigned char* const B = lds + buf * BUFB;
+        auto one = [&](const Stg& st, const int craw) {
+            const int c = min(craw, CH - 1);
             const int row = c / CPR, half = c % CPR;
             // delta partial over this chunk's 8 channels, reduced over the 2 chunks of the row (adjacent lanes; vector ALU only)
             float dl = 0.f;
             {
-                const uint32_t a[4] = {sdo.x, sdo.y, sdo.z, sdo.w}, b[4] = {so.x, so.y, so.z, so.w};
+                const uint32_t a[4] = {st.dO.x, st.dO.y, st.dO.z, st.dO.w}, b[4] = {st.o.x, st.o.y, st.o.z, st.o.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     dl = fmaf(__uint_as_float(a[e] << 16), __uint_as_float(b[e] << 16), dl);
@@ -140,7 +151,7 @@ __global__ __launch_bounds__(704) void attn_bwd_stream_kernel(
             uint4 aq = make_uint4(0, 0, 0, 0), ad = make_uint4(0, 0, 0, 0);
             if (half == 0) {
                 const bool q_ok = row < L;
-                const float lq = q_ok ? slse_row * inv_sc2 : 1.0e30f;            // padded query rows: P = 0
+                const float lq = q_ok ? st.lse * inv_sc2 : 1.0e30f;            // padded query rows: P = 0
                 uint16_t l0 = f2bf(lq);
                 const float r1 = lq - bf2f(l0);
                 uint16_t l1 = f2bf(r1), l2 = f2bf(r1 - bf2f(l1));
@@ -148,26 +159,28 @@ __global__ __launch_bounds__(704) void attn_bwd_stream_kernel(
                 const uint16_t d0 = f2bf(dl);
                 const float e1 = dl - bf2f(d0);
                 const uint16_t d1 = f2bf(e1), d2 = f2bf(e1 - bf2f(d1));
-                const uint32_t one = 0x3f80u, rqf = (row >= mask_thr) ? 0x3f80u : 0u;
-                aq = make_uint4(l0 | ((uint32_t)l1 << 16), l2 | (one << 16), rqf | ((one - rqf) << 16), 0);
+                const uint32_t one_ = 0x3f80u, rqf = (row >= mask_thr) ? 0x3f80u : 0u;
+                aq = make_uint4(l0 | ((uint32_t)l1 << 16), l2 | (one_ << 16), rqf | ((one_ - rqf) << 16), 0);
                 ad = make_uint4(d0 | ((uint32_t)d1 << 16), d2, 0, 0);
             }
             if (craw < CH) {
-                *(uint4*)((uint16_t*)(B + B_Q) + row * QP + half * 8) = sq;
-                *(uint4*)((uint16_t*)(B + B_DO) + row * QP + half * 8) = sdo;
-                *(uint4*)((uint16_t*)(B + B_K) + c * 8) = sk;
-                *(uint4*)((uint16_t*)(B + B_V) + c * 8) = sv;
+                *(uint4*)((uint16_t*)(B + B_Q) + row * QP + half * 8) = st.q;
+                *(uint4*)((uint16_t*)(B + B_DO) + row * QP + half * 8) = st.dO;
                 *(uint4*)((uint16_t*)(B + B_Q) + row * QP + QSTAT + half * 8) = aq;
                 *(uint4*)((uint16_t*)(B + B_DO) + row * QP + QSTAT + half * 8) = ad;
-                ((float*)(B + B_RN))[c] = srn;
+                ((float*)(B + B_RN))[c] = st.rn;
             }
-        }
+        };
+        one(s0, hidx);
+        if (two) one(s1, HT + (hidx & 63));
     };
 
     int bw = blockIdx.x;
     if (bw >= Bw) return;
-    issue(bw);
-    commit(0);
+    if (helper) {
+        issue(bw, 0, hw * 64 + lane);
+        commit(0, hw * 64 + lane);
+    }
     __syncthreads();
 
     float dsig = 0.f;
@@ -180,196 +193,212 @@ __global__ __launch_bounds__(704) void attn_bwd_stream_kernel(
         const int buf = it & 1;
         const size_t slab0 = ((size_t)bw * h + hd) * 3 * SLAB;
         const int bw_next = bw + gridDim.x;
-        if (bw_next < Bw) issue(bw_next);
         const unsigned char* const B = lds + buf * BUFB;
         const uint16_t* const Qa = (const uint16_t*)(B + B_Q);
         const uint16_t* const Da = (const uint16_t*)(B + B_DO);
         const uint16_t* const Ks = (const uint16_t*)(B + B_K);
         const uint16_t* const Vs = (const uint16_t*)(B + B_V);
         const float* const RN = (const float*)(B + B_RN);
-        const unsigned target = (unsigned)(WAVES * (it + 1));
-        SSTAMP(0);                      // prefetch issue of the next window
+        const unsigned target = (unsigned)(PW * (it + 1));
 
-        // ================= phase 1: wave = key tile =================
-        const int key = 16 * tw + fr;
-        const bool do_mask = (mask_thr > 0) && (((bw % nW) / nww) == nwh - 1);
-        const float cmask = do_mask ? fmaxf(-100.f * SWV2_LOG2E * inv_sc2, -1.0e30f) : 0.f;
-        const bf16x4 kf = *(const bf16x4*)(Ks + key * DP + 4 * g);          // (the normalisation backward's copy of k^)
-        bf16x8 kf8, vf8;
-        {
-            const uint32_t m1 = 0xbf80u;                                       // -1
-            const uint32_t padk = (key < Lc) ? 0u : (uint32_t)f2bf(-1.0e30f);
-            const bool kreg = key >= mask_thr;
-            const uint32_t mk0 = f2bf(kreg ? 0.f : cmask), mk1 = f2bf(kreg ? cmask : 0.f);
-            const uint4 augk = make_uint4(m1 | (m1 << 16), m1 | (padk << 16), mk0 | (mk1 << 16), 0);
-            const uint4 augv = make_uint4(m1 | (m1 << 16), m1, 0, 0);
-            const uint4 z = make_uint4(0, 0, 0, 0);
-            const uint4 rk = *(const uint4*)(Ks + key * DP + (g & 1) * 8), rv = *(const uint4*)(Vs + key * DP + (g & 1) * 8);
-            kf8 = __builtin_bit_cast(bf16x8, g < 2 ? rk : (g == 2 ? augk : z));
-            vf8 = __builtin_bit_cast(bf16x8, g < 2 ? rv : (g == 2 ? augv : z));
-        }
-        f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
-
-        struct St { f32x4 s, dp; bf16x4 tq, td; };
-        auto stageA = [&](const int qt, St& o) {
-            const bf16x8 qa = *(const bf16x8*)(Qa + (16 * qt + fr) * QP + 8 * g);
-            const bf16x8 da = *(const bf16x8*)(Da + (16 * qt + fr) * QP + 8 * g);
-            o.td = lds_tr_read(Da + (16 * qt + 4 * g + (fr >> 2)) * QP + (fr & 3) * 4);
-            o.tq = lds_tr_read(Qa + (16 * qt + 4 * g + (fr >> 2)) * QP + (fr & 3) * 4);
-            o.s = mfma32(qa, kf8, (f32x4){0.f, 0.f, 0.f, 0.f});
-            o.dp = mfma32(da, vf8, (f32x4){0.f, 0.f, 0.f, 0.f});
-        };
-        // the dS tiles of q-tile pair `p` of this wave are in the image: tell the dQ side (the LDS runs a wave's instructions in order)
-        auto signal = [&](const int p) {
-            if (lane == 0) asm volatile("ds_add_u32 %0, %1" : : "v"(cnt_addr + 4u * (unsigned)p), "v"(1u) : "memory");
-        };
-        // q-tiles in PAIRS: the dV / dK products of two tiles are one K = 32 MFMA (k-slot (g, j) = row 4g + j of the first tile for
-        // j < 4, of the second for j >= 4, on both operands) -- 6 MFMAs per pair instead of 8; the odd last tile has its own accumulators
-        auto stageB2 = [&](const int qt, const St& i0, const St& i1) {
-            f32x4 p0, p1, ds0, ds1;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                p0[r] = __builtin_amdgcn_exp2f(i0.s[r] * sc2);
-                p1[r] = __builtin_amdgcn_exp2f(i1.s[r] * sc2);
-                ds0[r] = p0[r] * i0.dp[r];
-                ds1[r] = p1[r] * i1.dp[r];
-            }
-            const bf16x4 pb0 = f2bf4(p0), pb1 = f2bf4(p1), dsb0 = f2bf4(ds0), dsb1 = f2bf4(ds1);
-            *(bf16x4*)(dSb + key * DSP + 16 * qt + 4 * g) = dsb0;
-            *(bf16x4*)(dSb + key * DSP + 16 * qt + 16 + 4 * g) = dsb1;
-            const bf16x8 pb = __builtin_shufflevector(pb0, pb1, 0, 1, 2, 3, 4, 5, 6, 7);
-            const bf16x8 dsb = __builtin_shufflevector(dsb0, dsb1, 0, 1, 2, 3, 4, 5, 6, 7);
-            const bf16x8 td = __builtin_shufflevector(i0.td, i1.td, 0, 1, 2, 3, 4, 5, 6, 7);
-            const bf16x8 tq = __builtin_shufflevector(i0.tq, i1.tq, 0, 1, 2, 3, 4, 5, 6, 7);
-            dv = mfma32(td, pb, dv);
-            dk = mfma32(tq, dsb, dk);
-        };
-
-        // ================= phase 2: dQ of the q-tiles of pair `pr` (NQ = 2) or of the odd last tile (NQ = 1) =================
-        // dQ^T = sum_t K_t^T dS_t^T, key tiles in pairs (one K = 32 product per pair), both operands as transposed reads -- the K^T
-        // fragments are read once for both q-tiles, whose accumulation chains interleave; one chain per q-tile in key order + the odd
-        // key tile on its own accumulator: the summation order of the two-phase kernel (bit-identical d q)
-        auto phase2 = [&](const int pr, auto nq_c) {
-            constexpr int NQ = decltype(nq_c)::value;
+        // (the lane id is re-derived behind an opaque asm in each role's branch: otherwise loop-invariant code motion hoists every
+        // lane-dependent address of BOTH roles in front of the window loop and spills them -- 53 registers, reloaded by VMEM operations)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int fr = ln & 15, g = ln >> 4;
+        if (!helper) {
+            // ================= phase 1: wave = key tile =================
+            const int key = 16 * tw + fr;
+            const bool do_mask = (mask_thr > 0) && (((bw % nW) / nww) == nwh - 1);
+            const float cmask = do_mask ? fmaxf(-100.f * SWV2_LOG2E * inv_sc2, -1.0e30f) : 0.f;
+            const bf16x4 kf = *(const bf16x4*)(Ks + key * DP + 4 * g);          // (the normalisation backward's copy of k^)
+            bf16x8 kf8, vf8;
             {
-                const unsigned a = cnt_addr + 4u * (unsigned)pr;
-                while (true) {
-                    unsigned v;
-                    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
-                    if ((unsigned)__builtin_amdgcn_readfirstlane(v) >= target) break;
-                    __builtin_amdgcn_s_sleep(2);
+                const uint32_t m1 = 0xbf80u;                                       // -1
+                const uint32_t padk = (key < Lc) ? 0u : (uint32_t)f2bf(-1.0e30f);
+                const bool kreg = key >= mask_thr;
+                const uint32_t mk0 = f2bf(kreg ? 0.f : cmask), mk1 = f2bf(kreg ? cmask : 0.f);
+                const uint4 augk = make_uint4(m1 | (m1 << 16), m1 | (padk << 16), mk0 | (mk1 << 16), 0);
+                const uint4 augv = make_uint4(m1 | (m1 << 16), m1, 0, 0);
+                const uint4 z = make_uint4(0, 0, 0, 0);
+                const uint4 rk = *(const uint4*)(Ks + key * DP + (g & 1) * 8), rv = *(const uint4*)(Vs + key * DP + (g & 1) * 8);
+                kf8 = __builtin_bit_cast(bf16x8, g < 2 ? rk : (g == 2 ? augk : z));
+                vf8 = __builtin_bit_cast(bf16x8, g < 2 ? rv : (g == 2 ? augv : z));
+            }
+            f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+
+            struct St { f32x4 s, dp; bf16x4 tq, td; };
+            auto stageA = [&](const int qt, St& o) {
+                const bf16x8 qa = *(const bf16x8*)(Qa + (16 * qt + fr) * QP + 8 * g);
+                const bf16x8 da = *(const bf16x8*)(Da + (16 * qt + fr) * QP + 8 * g);
+                o.td = lds_tr_read(Da + (16 * qt + 4 * g + (fr >> 2)) * QP + (fr & 3) * 4);
+                o.tq = lds_tr_read(Qa + (16 * qt + 4 * g + (fr >> 2)) * QP + (fr & 3) * 4);
+                o.s = mfma32(qa, kf8, (f32x4){0.f, 0.f, 0.f, 0.f});
+                o.dp = mfma32(da, vf8, (f32x4){0.f, 0.f, 0.f, 0.f});
+            };
+            // the dS tiles of q-tile pair `p` of this wave are in the image: tell the dQ side (the LDS runs a wave's instructions in order)
+            auto signal = [&](const int p) {
+                if (ln == 0) asm volatile("ds_add_u32 %0, %1" : : "v"(cnt_addr + 4u * (unsigned)p), "v"(1u) : "memory");
+            };
+            // q-tiles in PAIRS: the dV / dK products of two tiles are one K = 32 MFMA (k-slot (g, j) = row 4g + j of the first tile for
+            // j < 4, of the second for j >= 4, on both operands) -- 6 MFMAs per pair instead of 8; the odd last tile has its own accumulators
+            auto stageB2 = [&](const int qt, const St& i0, const St& i1) {
+                f32x4 p0, p1, ds0, ds1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    p0[r] = __builtin_amdgcn_exp2f(i0.s[r] * sc2);
+                    p1[r] = __builtin_amdgcn_exp2f(i1.s[r] * sc2);
+                    ds0[r] = p0[r] * i0.dp[r];
+                    ds1[r] = p1[r] * i1.dp[r];
+                }
+                const bf16x4 pb0 = f2bf4(p0), pb1 = f2bf4(p1), dsb0 = f2bf4(ds0), dsb1 = f2bf4(ds1);
+                *(bf16x4*)(dSb + key * DSP + 16 * qt + 4 * g) = dsb0;
+                *(bf16x4*)(dSb + key * DSP + 16 * qt + 16 + 4 * g) = dsb1;
+                const bf16x8 pb = __builtin_shufflevector(pb0, pb1, 0, 1, 2, 3, 4, 5, 6, 7);
+                const bf16x8 dsb = __builtin_shufflevector(dsb0, dsb1, 0, 1, 2, 3, 4, 5, 6, 7);
+                const bf16x8 td = __builtin_shufflevector(i0.td, i1.td, 0, 1, 2, 3, 4, 5, 6, 7);
+                const bf16x8 tq = __builtin_shufflevector(i0.tq, i1.tq, 0, 1, 2, 3, 4, 5, 6, 7);
+                dv = mfma32(td, pb, dv);
+                dk = mfma32(tq, dsb, dk);
+            };
+            // Issue priority falls with the wave's own progress (3 at the start of the window, 0 behind the fourth pair): the SIMD arbiter serves
+            // the oldest wave of the highest priority first, so without this the oldest wave of a SIMD runs ahead, ends at ~60 % of the window,
+            // and the youngest finishes alone with nothing to cover its latencies.  A wave that is behind now outranks one that is ahead.
+#ifndef SWV2_ATTNS_NO_PRIO
+#define SWV2_PRIO(n) __builtin_amdgcn_s_setprio(n)
+#else
+#define SWV2_PRIO(n) do {} while (0)
+#endif
+            SWV2_PRIO(3);
+            St a0, a1, b0, b1;
+            stageA(0, a0);
+            stageA(1, a1);
+#pragma unroll
+            for (int qt = 0; qt + 1 < LT; qt += 4) {
+                if (qt + 2 < LT) stageA(qt + 2, b0);
+                if (qt + 3 < LT) stageA(qt + 3, b1);
+                stageB2(qt, a0, a1);
+                signal(qt >> 1);
+                if (qt == 0) SWV2_PRIO(3); else if (qt == 4) SWV2_PRIO(1); else SWV2_PRIO(0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (qt + 3 < LT) {
+                    if (qt + 4 < LT) stageA(qt + 4, a0);
+                    if (qt + 5 < LT) stageA(qt + 5, a1);
+                    stageB2(qt + 2, b0, b1);
+                    signal((qt >> 1) + 1);
+                    if (qt == 0) SWV2_PRIO(2); else SWV2_PRIO(1);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            SSTAMP(2);
-            f32x4 dq[NQ];
-#pragma unroll
-            for (int i = 0; i < NQ; ++i) dq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const uint16_t* const kb = Ks + (4 * g + (fr >> 2)) * DP + (fr & 3) * 4;
-            const uint16_t* const db = dSb + (4 * g + (fr >> 2)) * DSP + 32 * pr + (fr & 3) * 4;
-#pragma unroll
-            for (int t = 0; t + 1 < LT; t += 2) {
-                const bf16x4 k0 = lds_tr_read(kb + 16 * t * DP), k1 = lds_tr_read(kb + 16 * (t + 1) * DP);
-                const bf16x8 ka = __builtin_shufflevector(k0, k1, 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-                for (int i = 0; i < NQ; ++i) {
-                    const bf16x4 d0 = lds_tr_read(db + 16 * t * DSP + 16 * i), d1 = lds_tr_read(db + 16 * (t + 1) * DSP + 16 * i);
-                    dq[i] = mfma32(ka, __builtin_shufflevector(d0, d1, 0, 1, 2, 3, 4, 5, 6, 7), dq[i]);
-                }
-            }
+            static_assert((LT & 3) == 3, "the odd last tile's stage A went into b0");
             {
-                // own accumulator: a K = 16 MFMA chained directly onto a K = 32 accumulator gave wrong sums (attn.hip)
-                const bf16x4 k0 = lds_tr_read(kb + 16 * (LT - 1) * DP);
+                const St& in = b0;
+                f32x4 p, ds;
 #pragma unroll
-                for (int i = 0; i < NQ; ++i) {
-                    const bf16x4 d0 = lds_tr_read(db + 16 * (LT - 1) * DSP + 16 * i);
-                    const f32x4 tail = mfma16(k0, d0, (f32x4){0.f, 0.f, 0.f, 0.f});
-                    dq[i] += tail;
+                for (int r = 0; r < 4; ++r) {
+                    p[r] = __builtin_amdgcn_exp2f(in.s[r] * sc2);
+                    ds[r] = p[r] * in.dp[r];
                 }
+                const bf16x4 pb = f2bf4(p), dsb = f2bf4(ds);
+                *(bf16x4*)(dSb + key * DSP + 16 * (LT - 1) + 4 * g) = dsb;
+                const f32x4 tv = mfma16(in.td, pb, (f32x4){0.f, 0.f, 0.f, 0.f});
+                const f32x4 tk = mfma16(in.tq, dsb, (f32x4){0.f, 0.f, 0.f, 0.f});
+                dv += tv;
+                dk += tk;
+                signal(NPAIR - 1);
             }
-#pragma unroll
-            for (int i = 0; i < NQ; ++i) {
-                const int q = 32 * pr + 16 * i + fr;
-                const float rq = RN[q] * sigma;
-                const bf16x4 qn = *(const bf16x4*)(Qa + q * QP + 4 * g);
+            SSTAMP(1);                      // phase 1 loop
+            // ---- dK (through the L2-normalisation) and dV of this wave's key tile
+            {
+                const float rk = RN[Lp + key];
                 float dot = 0.f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dot = fmaf(dq[i][r], bf2f(qn[r]), dot);
+                for (int r = 0; r < 4; ++r) dot = fmaf(dk[r], bf2f(kf[r]), dot);
                 dot = xor32_allsum(xor16_allsum(dot));
+                // d logit_scale: sigma sum_{q,k} dS cos = sigma sum_k (sum_q dS[q][k] q^[q]) . k^[k] = sigma sum_k dot_k
+                if (g == 0) dsig += dot;
+                const float rks = rk * sigma;                     // the accumulators hold sum_q q^ dS: d(cos) = sigma dS
                 f32x4 v;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = rq * (dq[i][r] - bf2f(qn[r]) * dot);
-                *(bf16x4*)(dqkvh + slab0 + (size_t)q * DP + 4 * g) = f2bf4(v);
+                for (int r = 0; r < 4; ++r) v[r] = rks * (dk[r] - bf2f(kf[r]) * dot);
+                *(bf16x4*)(dqkvh + slab0 + SLAB + (size_t)key * DP + 4 * g) = f2bf4(v);
+                *(bf16x4*)(dqkvh + slab0 + 2 * SLAB + (size_t)key * DP + 4 * g) = f2bf4(dv);
             }
-            SSTAMP(3);
-        };
-
-        St a0, a1, b0, b1;
-        stageA(0, a0);
-        stageA(1, a1);
+            SSTAMP(4);                      // dK / dV normalisation backward + stores
+        } else {
+            // ================= helper waves: the next window's prefetch, phase 2 (dQ), the commit =================
+            const int hidx = hw * 64 + ln;
+            if (bw_next < Bw) issue(bw_next, buf ^ 1, hidx);
+            SSTAMP(0);
+            // dQ of the q-tiles of pair `pr` (NQ = 2) or of the odd last tile (NQ = 1): dQ^T = sum_t K_t^T dS_t^T, key tiles in pairs (one
+            // K = 32 product per pair), both operands as transposed reads -- the K^T fragments are read once for both q-tiles, whose
+            // accumulation chains interleave; one chain per q-tile in key order + the odd key tile on its own accumulator: the summation
+            // order of the two-phase kernel (bit-identical d q)
+            auto phase2 = [&](const int pr, auto nq_c) {
+                constexpr int NQ = decltype(nq_c)::value;
+                {
+                    const unsigned a = cnt_addr + 4u * (unsigned)pr;
+                    while (true) {
+                        unsigned v;
+                        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+                        if ((unsigned)__builtin_amdgcn_readfirstlane(v) >= target) break;
+                        __builtin_amdgcn_s_sleep(4);
+                    }
+                }
+                SSTAMP(2);
+                f32x4 dq[NQ];
 #pragma unroll
-        for (int qt = 0; qt + 1 < LT; qt += 4) {
-            if (qt + 2 < LT) stageA(qt + 2, b0);
-            if (qt + 3 < LT) stageA(qt + 3, b1);
-            stageB2(qt, a0, a1);
-            signal(qt >> 1);
-            __builtin_amdgcn_sched_barrier(0);
-            if (qt + 3 < LT) {
-                if (qt + 4 < LT) stageA(qt + 4, a0);
-                if (qt + 5 < LT) stageA(qt + 5, a1);
-                stageB2(qt + 2, b0, b1);
-                signal((qt >> 1) + 1);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int i = 0; i < NQ; ++i) dq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const uint16_t* const kb = Ks + (4 * g + (fr >> 2)) * DP + (fr & 3) * 4;
+                const uint16_t* const db = dSb + (4 * g + (fr >> 2)) * DSP + 32 * pr + (fr & 3) * 4;
+#pragma unroll
+                for (int t = 0; t + 1 < LT; t += 2) {
+                    const bf16x4 k0 = lds_tr_read(kb + 16 * t * DP), k1 = lds_tr_read(kb + 16 * (t + 1) * DP);
+                    const bf16x8 ka = __builtin_shufflevector(k0, k1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                    for (int i = 0; i < NQ; ++i) {
+                        const bf16x4 d0 = lds_tr_read(db + 16 * t * DSP + 16 * i), d1 = lds_tr_read(db + 16 * (t + 1) * DSP + 16 * i);
+                        dq[i] = mfma32(ka, __builtin_shufflevector(d0, d1, 0, 1, 2, 3, 4, 5, 6, 7), dq[i]);
+                    }
+                }
+                {
+                    // own accumulator: a K = 16 MFMA chained directly onto a K = 32 accumulator gave wrong sums (attn.hip)
+                    const bf16x4 k0 = lds_tr_read(kb + 16 * (LT - 1) * DP);
+#pragma unroll
+                    for (int i = 0; i < NQ; ++i) {
+                        const bf16x4 d0 = lds_tr_read(db + 16 * (LT - 1) * DSP + 16 * i);
+                        const f32x4 tail = mfma16(k0, d0, (f32x4){0.f, 0.f, 0.f, 0.f});
+                        dq[i] += tail;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) {
+                    const int q = 32 * pr + 16 * i + fr;
+                    const float rq = RN[q] * sigma;
+                    const bf16x4 qn = *(const bf16x4*)(Qa + q * QP + 4 * g);
+                    float dot = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dot = fmaf(dq[i][r], bf2f(qn[r]), dot);
+                    dot = xor32_allsum(xor16_allsum(dot));
+                    f32x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = rq * (dq[i][r] - bf2f(qn[r]) * dot);
+                    *(bf16x4*)(dqkvh + slab0 + (size_t)q * DP + 4 * g) = f2bf4(v);
+                }
+                SSTAMP(3);
+            };
+            // helper hw: pair hw; the commit behind it (the prefetch has landed by then) -- except helper 4 (the last pair) which commits
+            // first; helper 0 ends with the odd last tile
+            if (hw == HW - 1) {
+                if (bw_next < Bw) commit(buf ^ 1, hidx);
+                SSTAMP(5);
+                phase2(NPAIR - 2, std::integral_constant<int, 2>{});
+            } else {
+                phase2(hw, std::integral_constant<int, 2>{});
+                if (bw_next < Bw) commit(buf ^ 1, hidx);
+                SSTAMP(5);
+                if (hw == 0) phase2(NPAIR - 1, std::integral_constant<int, 1>{});
             }
-        }
-        static_assert((LT & 3) == 3, "the odd last tile's stage A went into b0");
-        {
-            const St& in = b0;
-            f32x4 p, ds;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                p[r] = __builtin_amdgcn_exp2f(in.s[r] * sc2);
-                ds[r] = p[r] * in.dp[r];
-            }
-            const bf16x4 pb = f2bf4(p), dsb = f2bf4(ds);
-            *(bf16x4*)(dSb + key * DSP + 16 * (LT - 1) + 4 * g) = dsb;
-            const f32x4 tv = mfma16(in.td, pb, (f32x4){0.f, 0.f, 0.f, 0.f});
-            const f32x4 tk = mfma16(in.tq, dsb, (f32x4){0.f, 0.f, 0.f, 0.f});
-            dv += tv;
-            dk += tk;
-            signal(NPAIR - 1);
-        }
-        SSTAMP(1);                      // phase 1 loop
-        // ---- dK (through the L2-normalisation) and dV of this wave's key tile
-        {
-            const float rk = RN[Lp + key];
-            float dot = 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dot = fmaf(dk[r], bf2f(kf[r]), dot);
-            dot = xor32_allsum(xor16_allsum(dot));
-            // d logit_scale: sigma sum_{q,k} dS cos = sigma sum_k (sum_q dS[q][k] q^[q]) . k^[k] = sigma sum_k dot_k
-            if (g == 0) dsig += dot;
-            const float rks = rk * sigma;                     // the accumulators hold sum_q q^ dS: d(cos) = sigma dS
-            f32x4 v;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = rks * (dk[r] - bf2f(kf[r]) * dot);
-            *(bf16x4*)(dqkvh + slab0 + SLAB + (size_t)key * DP + 4 * g) = f2bf4(v);
-            *(bf16x4*)(dqkvh + slab0 + 2 * SLAB + (size_t)key * DP + 4 * g) = f2bf4(dv);
-        }
-        SSTAMP(4);                      // dK / dV normalisation backward + stores
-        if (bw_next < Bw) commit(buf ^ 1);
-        SSTAMP(5);                      // commit (wait for the prefetch + LDS writes + delta)
-        // who computes which dQ tiles, all behind the wave's own phase 1: waves 3 and 7 (a SIMD of their own) the pairs that are complete
-        // early, the two oldest waves of the other SIMDs (done first, otherwise waiting at the barrier) the last pair and the odd tile
-        if (tw == 3) {
-            phase2(0, std::integral_constant<int, 2>{});
-            phase2(1, std::integral_constant<int, 2>{});
-        } else if (tw == 7) {
-            phase2(2, std::integral_constant<int, 2>{});
-            phase2(3, std::integral_constant<int, 2>{});
-        } else if (tw == 1) {
-            phase2(4, std::integral_constant<int, 2>{});
-        } else if (tw == 0) {
-            phase2(NPAIR - 1, std::integral_constant<int, 1>{});
         }
         __syncthreads();
         SSTAMP(6);                      // the window's barrier
@@ -392,7 +421,7 @@ __global__ __launch_bounds__(704) void attn_bwd_stream_kernel(
     if (tid == 0 && tau <= SWV2_LN100) {
         float t = 0.f;
 #pragma unroll
-        for (int i = 0; i < WAVES; ++i) t += red[i];
+        for (int i = 0; i < PW; ++i) t += red[i];
         atomicAdd(dlogit + hd, t * sigma);
     }
 }
@@ -419,7 +448,7 @@ int swv2_attn_bwd_stream(const swv2_attn_args* a, int Lp, int DP, void* stream) 
     if (!on || Lp != 176 || DP != 16 || a->bias || (a->dbg & (SWV2_ATTN_PLAIN_STATS | SWV2_ATTN_BWD_TWO_PHASE))) return 1;
     hipStream_t st = (hipStream_t)stream;
     const int nchunk = a->Bw < a->max_chunks ? a->Bw : a->max_chunks;
-    dim3 grid(nchunk, a->heads), block(704);
+    dim3 grid(nchunk, a->heads), block(1024);
     const int nW = a->nwh * a->nww;
     if (a->L == 162)
         hipLaunchKernelGGL((attn_bwd_stream_kernel<162>), grid, block, 0, st, (const uint16_t*)a->qkvh, a->logit_scale, (const uint16_t*)a->oh,

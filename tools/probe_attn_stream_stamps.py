@@ -34,10 +34,11 @@ buf = torch.zeros(512 * 8, dtype=torch.int64)
 assert ctypes.CDLL(so).swv2_debug_attns_stamps(ctypes.c_void_p(buf.data_ptr())) == 0
 ck = torch.zeros(512 * 2, dtype=torch.int64)
 assert ctypes.CDLL(so).swv2_debug_attns_clock(ctypes.c_void_p(ck.data_ptr())) == 0
-ck = ck.view(512, 2).double()[:44]
+ck = ck.view(512, 2).double()[:64]
 print(f"window loop: {ck[:, 1].mean() / 100:.1f} us by s_memrealtime, in-kernel clock {ck[:, 0].mean() / ck[:, 1].mean() * 100:.0f} MHz, B = {B}")
-nwg = 512 // 11
-pw = buf.view(512, 8).double()[:nwg * 11].view(nwg, 11, 8)
+NW = 16          # 11 phase-1 waves + 5 helpers
+nwg = 512 // NW
+pw = buf.view(512, 8).double()[:nwg * NW].view(nwg, NW, 8)
 names = ["issue next window's prefetch", "phase 1 loop", "phase 2: spin on the pair counter", "phase 2: dQ + normalisation + store",
          "dK / dV normalisation + stores", "commit (prefetch wait, LDS, delta)", "the window's barrier"]
 tot = pw.sum(2).mean()
@@ -45,6 +46,6 @@ print(f"attn_bwd (streamed dQ, with stamps): {e0.elapsed_time(e1) * 100:.1f} us;
 for i, n in enumerate(names):
     print(f"  {n:40s} {100 * pw[:, :, i].mean() / tot:5.1f} %")
 print("per wave (mean ticks): issue | phase 1 | p2 spin | p2 | dK/dV | commit | barrier")
-for w in range(11):
+for w in range(NW):
     m = pw[:, w, :].mean(0)
     print(f"  wave {w:2d}: " + " ".join(f"{m[i]:8.0f}" for i in range(7)))

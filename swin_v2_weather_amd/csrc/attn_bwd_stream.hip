@@ -9,21 +9,27 @@
 // Why a second kernel.  The two-phase kernel is paced by barriers (tools/probe_attn1_stamps.py, LABNOTES round 4 / 5): 11 waves sit
 // 3 + 3 + 3 + 2 on the four SIMDs, the SIMD serves its oldest wave first, so waves 0 - 3 end phase 1 a third earlier than waves 8 - 10
 // and wait (28 % of their time); then every wave runs a short, latency-bound phase 2 (transposed reads -> a dependent MFMA chain) with
-// nothing to overlap it (20 %), then the commit of the next window's slabs between two more barriers (7 %).  Here:
-//   * phase 1 is unchanged (wave = key tile, q-tiles in pairs, software-pipelined, fully unrolled with fences); after the dS tiles
-//     of a q-tile pair are written, lane 0 of the wave adds 1 to the pair's LDS counter (LDS executes a wave's instructions in order:
-//     the add is behind the tile writes);
-//   * phase 2 (all 11 q-tiles) belongs to waves 3 and 7 -- the two waves that share a SIMD with no third one (a workgroup's waves go
-//     to the SIMDs cyclically: {w, w + 4, w + 8} share one), i.e. the SIMD that idles a third of phase 1 in the two-phase kernel: they
-//     run their own phase 1 first (at 2 waves per SIMD they are done at ~60 % of the window), then wave 3 takes q-tile pairs 0, 1 and
-//     wave 7 pairs 2, 3, spinning on the pair's counter until it shows all 11 waves, then reading the dS image transposed (K^T fragments
-//     once per pair, two interleaved accumulation chains).  The last pair and the odd tile go to waves 1 and 0, the oldest waves of two
-//     other SIMDs, which are done first and would otherwise wait at the barrier.  (All 11 tiles on waves 3 / 7, one tile at a time:
-//     128 us against 112 -- a tile's chain of transposed reads -> 6 dependent MFMAs -> row sum -> store is ~400 cycles of latency;
-//     one tile per wave inside every wave's own loop: 110, the old waves' dQ + commit then sit behind the last signal);
-//   * the q | dO | k | v slabs (and the 1 / |q|, 1 / |k| rows) are double-buffered in LDS, so the next window's slabs are committed
-//     from the prefetch registers before the window's ONE barrier; the dS image is single (every reader has passed the barrier
-//     before the next window's first tile is written).
+// nothing to overlap it (20 %), then the commit of the next window's slabs between two more barriers (7 %).  Here a workgroup is 16
+// waves (4 per SIMD, 128 registers):
+//   * waves 0 .. 10, phase 1, unchanged arithmetic (wave = key tile, q-tiles in pairs, software-pipelined, fully unrolled with fences);
+//     behind the dS tiles of a q-tile pair, lane 0 of the wave adds 1 to the pair's LDS counter (the LDS executes a wave's
+//     instructions in order: the add is behind the tile writes).  No staging registers, no dQ work: ~100 registers;
+//   * waves 11 .. 15, helpers: each prefetches a fifth of the next window's slabs (v by LDS-DMA, the rest through registers), computes
+//     the dQ of one q-tile pair -- spinning on the pair's counter until it shows all 11 phase-1 waves, then reading the dS image
+//     transposed (K^T fragments once per pair, two interleaved accumulation chains, the two-phase kernel's summation order) -- and
+//     commits its slab chunks (with delta = rowsum(dO O) and the statistics slots) to the OTHER LDS buffer;
+//   * the q | dO | k | v slabs (and the 1 / |q|, 1 / |k| rows) are double-buffered in LDS, so the commit needs no barrier of its own;
+//     the dS image is single (every reader has passed the window's ONE barrier before the next window's first tile is written);
+//   * issue priority (s_setprio) falls with a phase-1 wave's own progress, so the three phase-1 waves of a SIMD advance together
+//     instead of oldest first.
+// Measured with tools/probe_attn_bwd_windows.py (s_memtime at every window's end, same box): 8 740 cycles per window for the two-phase
+// kernel, 7 480 - 7 520 here, the same at 25 and at 100 windows per workgroup; d(qkv) bit-identical.  What was built on the way and
+// lost (LABNOTES round 6): 11 waves with the dQ tiles inside every wave's own loop (8 560) or on the two waves of the short SIMD (one
+// tile at a time: slower than two-phase -- a tile's chain of transposed reads -> 6 dependent MFMAs -> row sum -> store is ~400 cycles of
+// latency); the last three q-tiles' dQ deferred into the next window through a second tail image (tools/experiments/
+// attn_bwd_stream_deferred.hip: 7 620, the commits then wait for those tiles); helpers at priority 2 / 3 (7 620 - 7 670).
+// The phase-1 loop is ~270 issue cycles per q-tile pair by the instruction costs of MI355X_MICROARCH (8 exp, 8 + 4 multiplies, 8 packs,
+// 6 MFMAs, 9 LDS instructions, the signal): ~5 000 per window and SIMD -- the kernel runs at two thirds of its own issue bound.
 // LDS: 2 x 40 832 (slabs) + 63 360 (dS image) + counters = 145 KB, one persistent workgroup per CU as before.
 #include <stdlib.h>
 
@@ -45,6 +51,15 @@ __device__ unsigned long long attns_clock[512 * 2];       // per wave: s_memtime
 #define SSTAMP_DECL
 #define SSTAMP_START() do {} while (0)
 #define SSTAMP(k) do {} while (0)
+#endif
+
+#ifndef SWV2_ATTNS_NO_PRIO          // (A/B builds)
+#define SWV2_PRIO(n) __builtin_amdgcn_s_setprio(n)
+#else
+#define SWV2_PRIO(n) do {} while (0)
+#endif
+#ifndef SWV2_ATTNS_COMMIT_FIRST     // helpers from this index on commit before their dQ pair (A/B builds: 99 = none)
+#define SWV2_ATTNS_COMMIT_FIRST 2
 #endif
 
 template <int LFIX>
@@ -263,12 +278,8 @@ __global__ __launch_bounds__(1024) void attn_bwd_stream_kernel(
             };
             // Issue priority falls with the wave's own progress (3 at the start of the window, 0 behind the fourth pair): the SIMD arbiter serves
             // the oldest wave of the highest priority first, so without this the oldest wave of a SIMD runs ahead, ends at ~60 % of the window,
-            // and the youngest finishes alone with nothing to cover its latencies.  A wave that is behind now outranks one that is ahead.
-#ifndef SWV2_ATTNS_NO_PRIO
-#define SWV2_PRIO(n) __builtin_amdgcn_s_setprio(n)
-#else
-#define SWV2_PRIO(n) do {} while (0)
-#endif
+            // and the youngest finishes alone with nothing to cover its latencies.  A wave that is behind now outranks one that is ahead
+            // (same box, cycles per window: 8 099 without, 7 716 with; helpers at priority 2 / 3 on top: 7 620 - 7 670 against 7 473 - 7 516).
             SWV2_PRIO(3);
             St a0, a1, b0, b1;
             stageA(0, a0);
@@ -387,15 +398,18 @@ __global__ __launch_bounds__(1024) void attn_bwd_stream_kernel(
                 }
                 SSTAMP(3);
             };
-            // helper hw: pair hw; the commit behind it (the prefetch has landed by then) -- except helper 4 (the last pair) which commits
-            // first; helper 0 ends with the odd last tile
+            // helper hw: pair hw and the commit; helper 4 (the last pair) commits first; helper 0 ends with the odd last tile
             if (hw == HW - 1) {
                 if (bw_next < Bw) commit(buf ^ 1, hidx);
                 SSTAMP(5);
                 phase2(NPAIR - 2, std::integral_constant<int, 2>{});
             } else {
+                // helpers 2, 3 commit BEFORE their pair: it completes at 55 / 73 % of the window, the prefetch has landed by then, and behind the
+                // pair's signal only the dQ pass is left (commit behind it: the window ended with that commit; 7 716 -> 7 473 cycles per window)
+                const bool cf = hw >= SWV2_ATTNS_COMMIT_FIRST;
+                if (cf && bw_next < Bw) commit(buf ^ 1, hidx);
                 phase2(hw, std::integral_constant<int, 2>{});
-                if (bw_next < Bw) commit(buf ^ 1, hidx);
+                if (!cf && bw_next < Bw) commit(buf ^ 1, hidx);
                 SSTAMP(5);
                 if (hw == 0) phase2(NPAIR - 1, std::integral_constant<int, 1>{});
             }

@@ -5,9 +5,10 @@ usage: PROBE_B=2 tools/probe_attn_bwd_windows.py"""
 import ctypes, os, subprocess, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from swin_v2_weather_amd import _lib as L
-so = "/tmp/libswv2_wstamps.so"
+so = os.environ.get("PROBE_SO") or "/tmp/libswv2_wstamps.so"        # PROBE_SO: a stamped library built beforehand (tools/r06/build_stamped.sh)
 srcs = [os.path.join(L.CSRC, s) for s in L.SOURCES]
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DSWV2_ATTNS_STAMPS", "-DSWV2_ATTN1_STAMPS",
+if not os.environ.get("PROBE_SO"):
+  subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DSWV2_ATTNS_STAMPS", "-DSWV2_ATTN1_STAMPS",
                        "-o", so] + srcs, stderr=subprocess.DEVNULL)
 L.LIB_PATH = so
 from swin_v2_weather_amd import ops
@@ -27,7 +28,10 @@ doh = torch.randn(Bw, h, Lp, DP, device=dev).to(BF); doh[:, :, Lw:] = 0
 rnorm = torch.rand(Bw, h, 2, Lp, device=dev) + 0.5
 lib = ctypes.CDLL(so)
 nwin = Bw // (256 // h)
-for name, dbg, sym in (("two-phase", L.ATTN_BWD_TWO_PHASE, "swv2_debug_attn1_win"), ("streamed", 0, "swv2_debug_attns_win")):
+kernels = (("two-phase", L.ATTN_BWD_TWO_PHASE, "swv2_debug_attn1_win"), ("streamed", 0, "swv2_debug_attns_win"))
+if os.environ.get("PROBE_ONLY_STREAMED"):
+    kernels = kernels[1:]
+for name, dbg, sym in kernels:
     dq, dls = torch.empty_like(qkvh), torch.zeros(h, device=dev)
     a = ops.attn_args(qkvh, ls, None, oh, lse, Bw, h, Lw, 16, plan.nwh, plan.nww, plan.mask_thr, doh=doh, rnorm=rnorm, dqkvh=dq, dlogit=dls, max_chunks=256 // h)
     a.dbg = dbg

@@ -12,6 +12,7 @@
 // any occupancy; v_fma 2.0 at >= 3 waves per SIMD; K = 16 and K = 32 MFMAs both 16 cycles.
 // The other members of this generation (a bias-capable forward and a backward in the same 4-wave shape) lost their A/B against
 // the first-generation kernels and live in tools/experiments/attn2_experiments.hip, outside the shipped library.
+#include <atomic>
 #include <type_traits>
 
 #include "attn_common.h"
@@ -56,10 +57,14 @@ __device__ unsigned long long fwd3_span[2048 * 2];
 // loop-invariant reads back into the row loop, where -- double-buffered in 8 registers -- every QK MFMA waits a full LDS
 // round trip: 11 x ~80 cycles per row against 11 x 16 for back-to-back MFMAs; measured on one wave per SIMD: ~2000 cycles
 // per row of pure compute).
-template <int LT, int LFIX, int WAVES, int OCC, bool KREG>
+// DYN: the (window, head) items are handed out by an atomic counter instead of a fixed stride (first two items of a workgroup static).
+// 6 400 items on 768 resident workgroups are 8 or 9 each, and of the three workgroups of a CU the oldest is served first: measured spans
+// of the item loop (s_memtime, tools/probe_attn_fwd.py) mean 78 K cycles, max 104 K -- the launch ends with the slowest.  `sched`: two
+// zero-initialised words (work counter, finished workgroups); the last workgroup to finish zeroes them again for the next launch.
+template <int LT, int LFIX, int WAVES, int OCC, bool KREG, bool DYN = false>
 __global__ __launch_bounds__(64 * WAVES, OCC) void attn_fwd3_kernel(
     const uint16_t* __restrict__ qkvh, const float* __restrict__ logit_scale, uint16_t* __restrict__ oh, float* __restrict__ lse,
-    int Bw, int h, int L, int nW, int nww, int nwh, int mask_thr, int dbg) {
+    int Bw, int h, int L, int nW, int nww, int nwh, int mask_thr, int dbg, unsigned* __restrict__ sched) {
     constexpr int DP = 16, Lp = 16 * LT, SLAB = Lp * DP;
     constexpr int NT = 64 * WAVES;
     constexpr int CH = 2 * SLAB / 8;                  // 16-byte chunks of the K | V slabs (a multiple of 64)
@@ -76,32 +81,56 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn_fwd3_kernel(
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, g = lane >> 4;
-    const int hd = blockIdx.y;
+    int hd = DYN ? 0 : blockIdx.y;
     const bool last_chunk_ok = (wave * 64 + (CPT - 1) * NT) < CH;          // wave-uniform
     const int Lc = LFIX > 0 ? LFIX : L;
 
-    const float sc2 = __expf(fminf(logit_scale[hd], SWV2_LN100)) * SWV2_LOG2E;
-    const bool bounded = sc2 <= 40.f;
+    float sc2 = __expf(fminf(logit_scale[hd], SWV2_LN100)) * SWV2_LOG2E;
+    bool bounded = sc2 <= 40.f;
+    // DYN: items are flat ids (window-major: id = bw * h + head); the scales of all heads sit in LDS, the id after next is fetched
+    // one item ahead by thread 0 and handed over through LDS behind the item's barrier
+    [[maybe_unused]] __shared__ float sc2s[DYN ? 64 : 1];
+    [[maybe_unused]] __shared__ int nxt_s[2];
+    const int total = Bw * h, nwg = gridDim.x * gridDim.y;
+    if constexpr (DYN) {
+        if (tid < h && tid < 64) sc2s[tid] = __expf(fminf(logit_scale[tid], SWV2_LN100)) * SWV2_LOG2E;
+    }
 
     u32x4 stage[CPT], stageq[QPT];
     // 32-bit, loop-invariant lane offsets against a wave-uniform base: the loads then take the (SGPR base + VGPR offset)
     // form.  With 64-bit per-lane addresses the compiler built them in the loads' own destination registers, guarded that
     // overwrite with s_waitcnt vmcnt(..0) -- and with the in-order counter that wait also covered the previous item's
     // output STORES, once per (window, head) item in front of the prefetch (ISA, round 2).
-    unsigned soff[CPT], qoff[QPT];
+    // (recomputed per item from an opaque copy of the thread id: kept live across the item they were three spilled registers, reloaded by
+    // VMEM operations in front of the commit)
+    auto issue_loads = [&](int bw) {          // (DYN: bw is the flat item id)
+        unsigned t_ = (unsigned)tid;
+        asm volatile("" : "+v"(t_));
+        unsigned soff[CPT], qoff[QPT];            // (unsigned + min: provably small, so the element -> byte shift stays 32-bit and the loads keep the SGPR-base form)
 #pragma unroll
-    for (int j = 0; j < CPT; ++j) soff[j] = (unsigned)(SLAB + min(tid + j * NT, CH - 1) * 8);
+        for (int j = 0; j < CPT; ++j) soff[j] = min(t_ + (unsigned)(j * NT), (unsigned)(CH - 1)) * 8u;
 #pragma unroll
-    for (int j = 0; j < QPT; ++j) qoff[j] = (unsigned)(min(tid + j * NT, QCH - 1) * 8);
-    auto issue_loads = [&](int bw) {
-        const uint16_t* base = qkvh + ((size_t)bw * h + hd) * 3 * SLAB;
+        for (int j = 0; j < QPT; ++j) qoff[j] = min(t_ + (unsigned)(j * NT), (unsigned)(QCH - 1)) * 8u;
+        const uint16_t* base = qkvh + (DYN ? (size_t)bw : ((size_t)bw * h + hd)) * 3 * SLAB;
+        // the K | V slabs from a base of their own: the slab offset (5 632 bytes) does not fit the loads' immediate, and as a known constant
+        // it is split into a per-lane 64-bit add (built in the loads' destination registers, behind a wait) + a small immediate
+        unsigned kvo = SLAB;
+        asm volatile("" : "+s"(kvo));
+        const uint16_t* const base_kv = base + kvo;
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) stage[j] = *(const u32x4*)(base + soff[j]);
+        for (int j = 0; j < CPT; ++j) stage[j] = *(const u32x4*)(base_kv + soff[j]);
 #pragma unroll
         for (int j = 0; j < QPT; ++j) stageq[j] = *(const u32x4*)(base + qoff[j]);
     };
     auto write_stage = [&](int buf) {
         uint16_t* dst = smem + buf * BUF;
+        // (opaque here: the register copies that build the duplicated K image are invariant in the row loop, and hoisted in front of it they
+        // wait for the whole prefetch at the START of the item -- seen in the ISA of the dynamically scheduled instantiation, 22 K cycles
+        // per item instead of 9.3 K)
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) asm volatile("" : "+v"(stage[j]));
+        int tid = threadIdx.x;                                     // (re-derived: its LDS offsets are not worth registers across the item)
+        asm volatile("" : "+v"(tid));
 #pragma unroll
         for (int j = 0; j < CPT; ++j)
             if (j < CPT - 1 || last_chunk_ok) {
@@ -120,9 +149,10 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn_fwd3_kernel(
             if (tid + j * NT < QCH) *(u32x4*)(dst + KIMG + SLAB + (size_t)(tid + j * NT) * 8) = stageq[j];
     };
 
-    int bw = blockIdx.x;
-    if (bw >= Bw) return;
-    const int bw_first = bw;
+    int bw = DYN ? (int)(blockIdx.y * gridDim.x + blockIdx.x) : (int)blockIdx.x;
+    if (bw >= (DYN ? total : Bw)) return;
+    [[maybe_unused]] const int bw_first = bw;
+    [[maybe_unused]] int dyn_next = bw + nwg;                    // DYN: the workgroup's second item is static too
     STAMP_DECL
     issue_loads(bw);
     write_stage(0);
@@ -138,16 +168,46 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn_fwd3_kernel(
     const unsigned long long span_r0 = __builtin_amdgcn_s_memrealtime(), span_c0 = __builtin_amdgcn_s_memtime();
 #endif
 
-    for (int it = 0; bw < Bw; bw += gridDim.x, ++it) {
+    const int bw_end = DYN ? total : Bw;
+    for (int it = 0; bw < bw_end; ++it) {
         const int buf = it & 1;
-        const int bw_next = bw + gridDim.x;
+        const int bw_next = DYN ? dyn_next : bw + (int)gridDim.x;
+        const int Bw_ = bw_end;                                        // (loop bound of the item index in either mode)
+        size_t item;
+        int win;
+        if constexpr (DYN) {
+            item = (size_t)bw;
+            win = bw / h;
+            hd = bw - win * h;
+            // (through readfirstlane: a value read from LDS is per-lane to the compiler, `fixed` below would be a divergent condition and BOTH
+            // softmax paths would run under exec masks -- 22 K cycles per item instead of 9.3 K, measured)
+            sc2 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sc2s[hd])));
+            bounded = sc2 <= 40.f;
+        } else {
+            item = (size_t)bw * h + hd;
+            win = bw;
+        }
+        [[maybe_unused]] int n2 = bw_end;
         // the next item's K / V are requested AFTER this item's first row fragment has been waited for (a wait for a younger
         // load would otherwise drain this prefetch too: in-order vmcnt)
         const uint16_t* Ki = smem + buf * BUF;
         const uint16_t* Vs = Ki + KIMG;
         const uint16_t* Qs = Vs + SLAB;
-        if (bw_next < Bw) issue_loads(bw_next);      // consumed by write_stage at the top of the wave's last row
-        const bool do_mask = (mask_thr > 0) && (((bw % nW) / nww) == nwh - 1);
+        // Unconditional (the workgroup's last item re-requests itself, from L2, and commits it to the idle buffer): under `if (next item)` here
+        // and again at the commit, the compiler sees a path "requested but never consumed" around the item loop and guards every register it
+        // reuses for the lane offsets with a wait that, the counter being in order, also covers the previous item's output STORES.
+        issue_loads(bw_next < Bw_ ? bw_next : bw);      // consumed by write_stage in front of the wave's last row
+        if constexpr (DYN) {
+            // the id after next (behind the prefetch in the in-order counter: waited for at the end of the item, when the prefetch has landed anyway)
+            // Inline assembly: the wait for the returned value is placed by hand at the end of the item (the compiler's own would be a
+            // vmcnt(0) where the value is merged with the other path of this divergent `if`).
+#ifdef SWV2_FWD3_DYN_NOATOMIC          // (ablation: flat ids with a fixed stride)
+            n2 = bw_next + nwg - 2 * nwg;
+#else
+            if (tid == 0 && bw_next < Bw_) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(n2) : "v"(sched), "v"(1u) : "memory");
+#endif
+        }
+        const bool do_mask = (mask_thr > 0) && (((win % nW) / nww) == nwh - 1);
         const bool fixed = bounded && !do_mask;                       // wave-uniform
         const float c0 = fixed ? -sc2 : 0.f;
         // accumulator start of the last key tile: padded keys (rows of S^T = registers) get -1e30, so P = 0 there
@@ -175,20 +235,14 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn_fwd3_kernel(
         }
 
         STAMP(5, cpad[0]);
-#pragma unroll 1
-        for (int qt = wave; qt < LT; qt += WAVES) {                   // wave-uniform trip count
+        auto row = [&](const int qt) {
             const int q = 16 * qt + fr;
-#ifndef SWV2_FWD3_NO_PRIO
-            // Issue priority falls with the wave's progress through its item.  The three waves of a SIMD belong to the CU's three workgroups and
-            // the arbiter serves the oldest first: spans of the item loop (s_memtime, -DSWV2_FWD3_SPAN, tools/probe_attn_fwd.py) mean 78 K cycles,
-            // max 104 K without this, 80.5 K / 96 K with it -- the launch ends with the slowest workgroup.
+#ifdef SWV2_FWD3_PRIO
+            // issue priority falls with the wave's progress through its item (the three waves of a SIMD belong to three workgroups)
             if (qt < WAVES) __builtin_amdgcn_s_setprio(2);
             else if (qt < 2 * WAVES) __builtin_amdgcn_s_setprio(1);
             else __builtin_amdgcn_s_setprio(0);
 #endif
-            // the next item's slabs go to the other LDS buffer before the LAST row's stores are issued: its wait (in-order
-            // vmcnt) then covers only loads issued rows ago and the earlier rows' stores
-            if (qt + WAVES >= LT && bw_next < Bw) write_stage(buf ^ 1);
             const bf16x4 qraw = *(const bf16x4*)(Qs + (size_t)q * DP + 4 * g);
 
             // B operand of S^T = K Q^T over k = (part, d): (hi | lo) bf16 split of sigma' q^[4g .. 4g + 3] (exact to ~2^-17)
@@ -276,21 +330,60 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn_fwd3_kernel(
             const float sum = rs[0];                                  // every row of the ones product holds the column sums
             STAMP(3, sum);
             const float inv = (q < L) ? __builtin_amdgcn_rcpf(sum) : 0.f;
-            uint16_t* orow = oh + ((size_t)bw * h + hd) * SLAB + (size_t)q * DP;
+            uint16_t* orow = oh + item * SLAB + (size_t)q * DP;
             f32x4 v = o;
             v[0] *= inv; v[1] *= inv; v[2] *= inv; v[3] *= inv;
             {
                 *(bf16x4*)(orow + 4 * g) = f2bf4(v);
-                if (g == 0) lse[((size_t)bw * h + hd) * Lp + q] = (q < L) ? mx + __log2f(sum) : 0.f;
+                if (g == 0) lse[item * Lp + q] = (q < L) ? mx + __log2f(sum) : 0.f;
             }
             STAMP(4, v[0]);
+        };
+        // The wave's LAST row is peeled out of the loop, with the next item's slabs committed to the other LDS buffer in front of it.  Inside
+        // the loop that commit made the loop "stores, no loads, and a use of registers loaded outside": the compiler's wait-count pass then
+        // flushes vmcnt(0) in the loop's preheader -- every item waited for its own prefetch before its first row (ISA of rounds 2 - 5:
+        // s_waitcnt vmcnt(0) right behind the prefetch), the prefetch overlapped nothing.  The loop now touches no prefetch register; the
+        // commit's own wait covers loads issued rows ago and the earlier rows' stores.
+        int qt_ = wave;
+#pragma unroll 1
+        for (; qt_ + WAVES < LT; qt_ += WAVES) row(qt_);              // wave-uniform trip count
+        write_stage(buf ^ 1);
+        row(qt_);
+        if constexpr (DYN) {
+            if (tid == 0) {
+                const bool got = bw_next < Bw_;
+                // counted: wave 0 has issued its rows' O / lse stores since (2 per row); vmcnt(0) would wait for THEM (a store round trip per
+                // item) -- the atomic itself returned long ago, in front of the prefetch's wait
+                constexpr int NST = 2 * ((LT + WAVES - 1) / WAVES);
+#ifndef SWV2_FWD3_DYN_NOATOMIC
+                asm volatile("s_waitcnt vmcnt(%1)" : "+v"(n2) : "n"(NST) : "memory");
+#endif
+                nxt_s[it & 1] = got ? 2 * nwg + n2 : bw_end;
+            }
         }
         __syncthreads();
         STAMP(6, stage[0][0]);
+        if constexpr (DYN) {
+            bw = dyn_next;
+            dyn_next = __builtin_amdgcn_readfirstlane(nxt_s[it & 1]);        // (scalar: the prefetch addresses stay SGPR base + lane offset)
+        } else {
+            bw += gridDim.x;
+        }
+    }
+    if constexpr (DYN) {
+        // the last workgroup to finish re-arms the counters for the next launch (same stream: launches do not overlap)
+        if (tid == 0) {
+            __threadfence();
+            if (atomicAdd(sched + 1, 1u) == (unsigned)nwg - 1u) {
+                sched[0] = 0u;
+                sched[1] = 0u;
+                __threadfence();
+            }
+        }
     }
 #ifdef SWV2_ATTN_STAMPS
     if (tid == 0 && Lp - L >= 14) {
-        unsigned long long* dst = (unsigned long long*)(lse + ((size_t)bw_first * h + hd) * Lp + L);
+        unsigned long long* dst = (unsigned long long*)(lse + (DYN ? (size_t)bw_first : ((size_t)bw_first * h + blockIdx.y)) * Lp + L);
 #pragma unroll
         for (int k_ = 0; k_ < 7; ++k_) dst[k_] = st_acc[k_];
         (void)rt0; (void)ct0;
@@ -737,14 +830,38 @@ int launch_fwd3w(const swv2_attn_args* a, hipStream_t st) {
     return SWV2_OK;
 }
 
+// work counters of the dynamically scheduled forward: a pool of zero-initialised slots, one per launch in rotation (a launch leaves its slot
+// zeroed; 64 launches of this kernel in flight at once would be needed to collide).  Device globals: one copy per device.
+__device__ unsigned fwd3_sched[64][2];
+
 template <int LT, int LFIX, int WAVES, int OCC, bool KREG>
 int launch_fwd3(const swv2_attn_args* a, hipStream_t st) {
     // OCC workgroups per CU on 256 CUs, every workgroup loops over windows
     int nchunk = (OCC * 256 + a->heads - 1) / a->heads;
     if (nchunk > a->Bw) nchunk = a->Bw;
     dim3 grid(nchunk, a->heads), block(64 * WAVES);
-    hipLaunchKernelGGL((attn_fwd3_kernel<LT, LFIX, WAVES, OCC, KREG>), grid, block, 0, st, (const uint16_t*)a->qkvh, a->logit_scale,
-                       (uint16_t*)a->oh, a->lse, a->Bw, a->heads, a->L, a->nwh * a->nww, a->nww, a->nwh, a->mask_thr, a->dbg);
+    static const int dyn = getenv("SWV2_ATTN_FWD_DYN") ? atoi(getenv("SWV2_ATTN_FWD_DYN")) : 1;
+    // (dynamic hand-out needs at least two items per workgroup to have anything to balance, and the head scales fit its LDS table)
+    if (dyn && !KREG && a->heads <= 64 && (long)a->Bw * a->heads >= 2L * nchunk * a->heads) {
+        static std::atomic<unsigned> seq{0};
+        static std::atomic<unsigned*> base[16];                 // per device (one process per GPU is the normal case)
+        int devi = 0;
+        (void)hipGetDevice(&devi);
+        unsigned* sched = base[devi & 15].load();
+        if (!sched) {
+            if (hipGetSymbolAddress((void**)&sched, HIP_SYMBOL(fwd3_sched)) != hipSuccess) {
+                swv2_set_error("swv2_attn_fwd: no address for the scheduling counters");
+                return SWV2_ERR_LAUNCH;
+            }
+            base[devi & 15].store(sched);
+        }
+        sched += 2 * (seq.fetch_add(1) % 64u);
+        hipLaunchKernelGGL((attn_fwd3_kernel<LT, LFIX, WAVES, OCC, false, true>), grid, block, 0, st, (const uint16_t*)a->qkvh, a->logit_scale,
+                           (uint16_t*)a->oh, a->lse, a->Bw, a->heads, a->L, a->nwh * a->nww, a->nww, a->nwh, a->mask_thr, a->dbg, sched);
+    } else {
+        hipLaunchKernelGGL((attn_fwd3_kernel<LT, LFIX, WAVES, OCC, KREG, false>), grid, block, 0, st, (const uint16_t*)a->qkvh, a->logit_scale,
+                           (uint16_t*)a->oh, a->lse, a->Bw, a->heads, a->L, a->nwh * a->nww, a->nww, a->nwh, a->mask_thr, a->dbg, (unsigned*)nullptr);
+    }
     SWV2_CHECK_LAUNCH("swv2_attn_fwd");
     return SWV2_OK;
 }

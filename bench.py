@@ -113,7 +113,7 @@ def cpu_baseline(a):
 # kernels timed with HIP events inside the timed region (round robin over the 12 blocks of every step):
 #   name -> (rocprof kernel-name fragment, bound, algorithmic bytes per token-channel and sample, MFMA flops per T*L*C*B)
 ROOFLINE_KERNELS = {
-    "attn_bwd": ("attn_bwd_kernel", "hbm", 16.0, 8.0),      # bf16 q, k, v, o, do in; dq, dk, dv out
+    "attn_bwd": ("attn_bwd_", "hbm", 16.0, 8.0),            # bf16 q, k, v, o, do in; dq, dk, dv out; attn_bwd_stream_kernel or attn_bwd_kernel
     "attn_fwd": ("attn_fwd3_kernel", "hbm", 8.0, 4.0),      # bf16 q, k, v in; o out
     "mlp_bwd": ("mlp_bwd_kernel", "hbm", 28.0, 0.0),        # dx2, x-stats, a2, hpre in; da2, dh, dx1 out
     "mlp_fwd": ("mlp_fwd_kernel", "hbm", 18.0, 0.0),
@@ -128,6 +128,13 @@ ROOFLINE_KERNELS = {
     "dx": ("gemm_rw_kernel<3, 1", "hbm", 14.0, 0.0),
 }
 ATTENTION_MODULE = ("qkv", "attn_fwd", "proj_ln_fwd", "proj_ln_bwd", "attn_bwd", "dx")
+# SURVEY 8d's bytes for a FUSED module (bf16 x in, y out: 4 B per token-channel forward; x, dy in, dx out (+ y): 8 B backward) -- what the
+# module would have to move if nothing were materialised between its kernels.  The per-kernel figures above are this DESIGN's bytes (they
+# include the materialised q / k / v, hpre, dh ...): `frac` says how well a kernel moves what it moves, `frac_8d` how far the design is
+# from what the module needs to move.  Kernels that are one piece of a module carry the module's name instead.
+BYTES_8D = {"mlp_fwd": 4.0, "mlp_bwd": 8.0, "attn_fwd": 8.0, "attn_bwd": 16.0}
+MODULE_OF = {"qkv": "attention_module", "proj_ln_fwd": "attention_module", "proj_ln_bwd": "attention_module", "dx": "attention_module",
+             "wgrad_group": "weight gradients (SURVEY 8d gives no byte figure: dW = dY^T X streams both operands once, the design's 36 B)"}
 
 
 def roofline_entry(name, ktimes, a, pmc, B):
@@ -152,7 +159,14 @@ def roofline_entry(name, ktimes, a, pmc, B):
         else:
             traffic, src = pmc[1][hits[0]]["hbm_bytes_per_launch"], f"{pmc[0]}: {hits[0]}"
     e = {"kernel": name, "bound": bound, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-         "traffic": traffic, "traffic_source": src, "launches_timed": n_l, "avg_ms": k_ms, "algorithmic_bytes_per_launch": alg}
+         "traffic": traffic, "traffic_source": src, "launches_timed": n_l, "avg_ms": k_ms, "algorithmic_bytes_per_launch": alg,
+         "design_bytes": alg}
+    if name in BYTES_8D:
+        a8 = BYTES_8D[name] * T * a.embed_dim * B
+        e["algorithmic_bytes_8d"] = a8
+        e["frac_8d"] = a8 / (k_ms * 1e-3) / 1e9 / 8000.0 if k_ms > 0 else 0.0
+    else:
+        e["algorithmic_bytes_8d"], e["frac_8d"], e["part_of"] = None, None, MODULE_OF.get(name)
     if fpe:
         fl = fpe * T * Lw * a.embed_dim * B
         e["flops_per_launch"] = fl
@@ -195,8 +209,12 @@ def attention_module(ktimes, a, B):
         return None
     # data path only: forward 8 C^2 + 4 L C per token, backward the same again for dX (dW excluded) -> x2
     flops = 2.0 * T * (8.0 * C * C + 4.0 * Lw * C) * B
+    # SURVEY 8d, fused module: forward 4 T C, backward 8 T C bytes (bf16 x -> y; x, dy -> dx)
+    a8 = 12.0 * T * C * B
     out = {"kernels": list(ATTENTION_MODULE), "ms_per_block": t_ms, "data_path_flops_per_block": flops,
-           "mfma_frac_by_flops": flops / (t_ms * 1e-3) / 2.5e15, "mfma_pipe_busy_frac": None, "counter_source": None}
+           "mfma_frac_by_flops": flops / (t_ms * 1e-3) / 2.5e15, "mfma_pipe_busy_frac": None, "counter_source": None,
+           "algorithmic_bytes_8d": a8, "frac_8d": a8 / (t_ms * 1e-3) / 1e9 / 8000.0,
+           "design_bytes": sum(ROOFLINE_KERNELS[k][2] for k in ATTENTION_MODULE) * T * C * B}
     try:
         import glob
         from swin_v2_weather_amd import _lib as L_
@@ -296,6 +314,64 @@ def secondary_legs(a, dev, rank):
     return out
 
 
+def ddp_extra_legs(a, net, step, fence, dev, rank, world, B, make_pool, loss_obj, opt):
+    """After the timed region of an N > 1 run (never part of `value`):
+    (1) `exposed_comm`: K more steps inside `net.no_sync()` -- same kernels, no gradient all-reduce; ms_per_step(DDP) - ms_per_step(no_sync) is
+        the communication that backward did not hide (the reference overlaps bucketed all-reduces with backward: train.py:186-190);
+    (2) BASELINE configs[2]: the same model under the same DDP wrapper at local batch 8 (global batch 64 at 8 GPUs), timed like the headline
+        (barrier + synchronize on both sides, max over ranks).  The headline stays local batch 2 at every N, so that the N = 1 point of a
+        scaling run is the BENCH line and per-GPU work is fixed (weak scaling); this leg is the same measurement at configs[2]'s load."""
+    K = max(4, min(a.steps, 10))
+
+    def timed(fn, n):
+        fence()
+        t0 = time.perf_counter()
+        for i in range(n):
+            fn(i)
+        fence()
+        t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        ts = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(ts, t)
+        return max(float(x) for x in ts) / n, min(float(x) for x in ts) / n
+    for i in range(2):
+        step(i)
+    t_ddp, _ = timed(step, K)
+    with net.no_sync():
+        for i in range(2):
+            step(i)
+        t_ns, _ = timed(step, K)
+    out = {"exposed_comm": {"ms_per_step_ddp": 1e3 * t_ddp, "ms_per_step_no_sync": 1e3 * t_ns, "exposed_ms": 1e3 * max(0.0, t_ddp - t_ns),
+                            "steps": K, "method": "same steps under DistributedDataParallel.no_sync(), max over ranks"}}
+    B2 = 8
+    if B != B2 and not a.no_secondary:
+        try:
+            pool2 = make_pool(B2)
+
+            def step2(i):
+                inp, tar = pool2[i % len(pool2)]
+                net.zero_grad()
+                with loss_obj.fused_with(net, tar):
+                    gen = net(inp)
+                loss = loss_obj(gen, tar, inp)
+                loss.backward()
+                opt.step()
+            for i in range(4):
+                step2(i)
+            t2, t2min = timed(step2, K)
+            with net.no_sync():
+                for i in range(2):
+                    step2(i)
+                t2ns, _ = timed(step2, K)
+            out["secondary"] = [{"workload": f"BASELINE configs[2]: swin_73var depth{a.depth} embed{a.embed_dim}, DDP over {world} ranks ({a.backend}), "
+                                             f"local batch {B2} (global {B2 * world})", "local_batch": B2, "global_batch": B2 * world,
+                                 "value": world * B2 / t2, "unit": "samples/sec", "ms_per_step": 1e3 * t2,
+                                 "rank_ms_per_step": {"min": 1e3 * t2min, "max": 1e3 * t2}, "steps": K,
+                                 "exposed_comm_ms": 1e3 * max(0.0, t2 - t2ns), "ms_per_step_no_sync": 1e3 * t2ns}]
+        except Exception as e:                      # noqa: BLE001
+            out["secondary"] = [{"workload": "configs[2] leg failed", "error": f"{type(e).__name__}: {e}"[:300]}]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -391,8 +467,10 @@ def main():
             enable_ddp_bucket_grads(net)
     g = torch.Generator(device=dev).manual_seed(333 + rank)
     B = a.local_batch
-    pool = [(torch.randn(B, 73, a.height, a.width, device=dev, generator=g),
-             torch.randn(B, 73, a.height, a.width, device=dev, generator=g)) for _ in range(a.pool)]
+    def make_pool(b):
+        return [(torch.randn(b, 73, a.height, a.width, device=dev, generator=g),
+                 torch.randn(b, 73, a.height, a.width, device=dev, generator=g)) for _ in range(a.pool)]
+    pool = make_pool(B)
 
     def step(i):
         inp, tar = pool[i % len(pool)]
@@ -491,9 +569,11 @@ def main():
             del pipe, src
     final_loss = float(loss.detach())
     ddp_observed = None
+    ddp_legs = None
     if use_ddp:
         from swin_v2_weather_amd.networks.helpers import ddp_observed_buckets
         ddp_observed = ddp_observed_buckets(net)
+        ddp_legs = ddp_extra_legs(a, net, step, fence, dev, rank, world, B, make_pool, loss_obj, opt)
     secondary = None
     if world == 1 and not use_ddp and not a.no_secondary:
         # the main model / pool are no longer needed: free them before the secondary configurations allocate theirs
@@ -555,7 +635,10 @@ def main():
             # GPU-side duration of every timed step of rank 0 (HIP events at the step boundaries): spread of the K steps behind `value`
             "step_ms": {"min": step_ms[0], "p50": step_ms[len(step_ms) // 2], "p90": step_ms[min(len(step_ms) - 1, int(0.9 * len(step_ms)))],
                         "max": step_ms[-1], "n": len(step_ms), "sequence": [round(v, 3) for v in step_seq]},
-            "secondary": secondary,
+            "secondary": secondary if secondary is not None else (ddp_legs or {}).get("secondary"),
+            # N > 1 only: the same step with the gradient all-reduce switched off (DistributedDataParallel.no_sync) -- the difference is the
+            # communication the backward did NOT hide (+ the reducer's own bookkeeping)
+            "exposed_comm": (ddp_legs or {}).get("exposed_comm"),
             "weak_scaling_local_batch": B,      # fixed per GPU at every N (BASELINE cfg 2's batch; cfg 3's 8 per GPU: --local-batch 8)
             "roofline": main_rf,
             "roofline_others": [dict(roofline_entry(k, ktimes, a, pmc, B), timed="every launch of 3 extra steps AFTER the timed region")

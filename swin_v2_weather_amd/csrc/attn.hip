@@ -1151,6 +1151,8 @@ int launch_bwd(const swv2_attn_args* a, hipStream_t st) {
         // benchmark shape)
         const size_t need = (size_t)nchunk * a->heads * a->L * a->L * sizeof(float);
         float* dbws = (a->dbias_ws && a->dbias_ws_bytes >= need) ? (float*)a->dbias_ws : nullptr;
+        // (in FRONT of the launch: with dbias == NULL and a too small workspace the kernel would add into address 0 -- ADVICE r5)
+        if (a->dbias_partials) SWV2_CHECK_ARG(dbws != nullptr, "attn_bwd: dbias_partials needs a workspace of %zu bytes", need);
         // 16-wide heads with the bias image in LDS: statistics / mask inside the MFMA operands here too
         if (DK == 1 && !(a->dbg & SWV2_ATTN_PLAIN_STATS))
             hipLaunchKernelGGL((attn_bwd_kernel<LT, DK, true, LFIX, 1, true>), grid, block, 0, st, (const uint16_t*)a->qkvh, a->logit_scale,
@@ -1162,7 +1164,6 @@ int launch_bwd(const swv2_attn_args* a, hipStream_t st) {
                            a->bias, bimg, (const uint16_t*)a->oh, (const uint16_t*)a->doh, a->lse, a->rnorm,
                            (uint16_t*)a->dqkvh, a->dlogit_scale, a->dbias, a->Bw, a->heads, a->L, nW, a->nww, a->nwh,
                            a->mask_thr, dbws);
-        if (a->dbias_partials) SWV2_CHECK_ARG(dbws != nullptr, "attn_bwd: dbias_partials needs a workspace of %zu bytes", need);
         if (dbws && !a->dbias_partials) {
             const int n = a->heads * a->L * a->L;
             hipLaunchKernelGGL(dbias_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)dbws, a->dbias, n, nchunk);

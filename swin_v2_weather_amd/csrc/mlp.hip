@@ -321,6 +321,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(const MlpFwd a) {
 
 template <int C, int MT>
 void launch_mlp_fwd(const MlpFwd& k, hipStream_t st) {
+    // (<192, 1> holds an fc1-bias table of 1 024 entries, mlp_fwd_kernel::B1N: swv2_mlp_fwd selects <192, 2> for wider hidden layers)
     hipLaunchKernelGGL((mlp_fwd_kernel<C, MT>), dim3(cdiv(k.M, 64 * MT)), dim3(256), 0, st, k);
 }
 
@@ -775,7 +776,9 @@ extern "C" int swv2_mlp_fwd(const swv2_mlp_args* a, void* stream) {
             // <192, 2>: 94 KB of LDS and 359 registers, ONE 4-wave workgroup per CU (cfg 4: 47.8 -> 45.7 ms/step against <192, 1> at one
             // workgroup per CU); <192, 1> with its fc1-bias table trimmed fits twice (SWV2_MLP_FWD192=2 restores two row tiles)
             static const int v192 = getenv("SWV2_MLP_FWD192") ? atoi(getenv("SWV2_MLP_FWD192")) : 1;
-            (mt2 && (v192 == 2 || a->hidden > 1024)) ? launch_mlp_fwd<192, 2>(k, st) : launch_mlp_fwd<192, 1>(k, st);
+            // <192, 1> holds an fc1-bias table of 1 024 entries (mlp_fwd_kernel::B1N): wider hidden layers run <192, 2> whatever the row
+            // count (selected on `mt2 &&` the small-M case wrote past the table)
+            (a->hidden > 1024 || (mt2 && v192 == 2)) ? launch_mlp_fwd<192, 2>(k, st) : launch_mlp_fwd<192, 1>(k, st);
             break;
         }
         case 256: launch_mlp_fwd<256, 1>(k, st); break;

@@ -106,6 +106,15 @@ def ddp_bucket_plan(model, cap_mb=DDP_BUCKET_CAP_MB):
         item = order.pop(pe[0])
         first_embed = next((i for i, (n, _) in enumerate(order) if ".patch_embed." in n or n.startswith("patch_embed.")), len(order))
         order.insert(first_embed, item)
+    # rel_pos=True with the stage-level CPB pipeline (swinv2_global._CpbStage, the default): the meta-MLP gradients of ALL blocks of a stage
+    # arrive together, from _CpbMultiFn.backward, which runs after the stage's first block -- move them behind block 0's parameters
+    import os
+    if os.environ.get("SWV2_CPB_PER_BLOCK", "0") == "0" and any(".attn.meta_mlp." in n for n, _ in order):
+        meta = [it for it in order if ".attn.meta_mlp." in it[0]]
+        order = [it for it in order if ".attn.meta_mlp." not in it[0]]
+        b0 = [i for i, (n, _) in enumerate(order) if ".blocks.0." in n]
+        at = (b0[-1] + 1) if b0 else len(order)
+        order[at:at] = meta
     tensors = [p for _, p in order]
     # an EXPLICIT bucket_cap_mb (every caller here passes one) also caps the first bucket: torch applies
     # dist._DEFAULT_FIRST_BUCKET_BYTES (1 MB) only with the default 25 MB cap (DistributedDataParallel.__init__: `bucket_bytes_cap_default`).

@@ -311,7 +311,13 @@ class _BlockFn(torch.autograd.Function):
         # AccumulateGrad nodes run, which is after the last use of the pass; only their addresses are kept here (a reference would stop
         # AccumulateGrad from taking the tensor as p.grad without a copy), and an engine callback forgets them at the end of the pass.
         # SWV2_GRAD_ACC_INPLACE=0: the plain path (autograd sums the calls' gradients).
-        reuse = blk._pass_grad_ptrs if os.environ.get("SWV2_GRAD_ACC_INPLACE", "1") != "0" else None
+        # The cached addresses are valid only (a) inside the backward pass that stored them -- they carry the engine's graph-task id, so a pass
+        # that died in an exception (its end-of-pass callback never ran) cannot leak its addresses into the next one -- and (b) while somebody
+        # holds the memory: the cache keeps a reference to the buffer itself, and is only filled when autograd actually takes the parameter
+        # gradients (a frozen trunk, or torch.autograd.grad w.r.t. the input only, drops the returned views at once: ADVICE r5).
+        wants_param_grads = any(ctx.needs_input_grad[4:17])
+        reuse = blk._pass_grads_of(torch._C._current_graph_task_id()) \
+            if (wants_param_grads and os.environ.get("SWV2_GRAD_ACC_INPLACE", "1") != "0") else None
         # the views are handed out at most ONCE per backward pass: a second hand-out would zero / overwrite the gradient
         # autograd's input buffer still holds as an alias (g_last twice instead of g_1 + ... + g_k)
         views = blk._bucket_views(params) if (reuse is None and blk._ddp_bucket_grads and not blk._bv_in_use) else None
@@ -365,7 +371,8 @@ class _BlockFn(torch.autograd.Function):
             g = [v.detach() for v in views]
         else:
             g = [grads[o // 4:o // 4 + int(torch.Size(s).numel())].view(*s) for o, s in zip(run.grad_off, run.grad_shapes)]
-        blk._remember_pass_grads(g)
+        if wants_param_grads:
+            blk._remember_pass_grads(g, None if views is not None else grads, torch._C._current_graph_task_id())
         (dlogit, dqkvw, dqkvb, dprojw, dprojb, dn1w, dn1b, dfc1w, dfc1b, dfc2w, dfc2b, dn2w, dn2b) = g
         return (dx, dbias, None, None, dlogit, dqkvw, dqkvb, dprojw, dprojb, dn1w, dn1b, dfc1w, dfc1b, dfc2w, dfc2b, dn2w,
                 dn2b, None, None, None)
@@ -684,13 +691,25 @@ class SwinTransformerV2CrBlock(nn.Module):
             views.append(bv)
         return views
 
-    _pass_grad_ptrs = None      # addresses of the 13 gradient buffers handed to autograd by this pass's first backward call
+    # (graph-task id, addresses of the 13 gradient buffers handed to autograd by that pass's first backward call, the buffer behind them)
+    _pass_grads = None
 
-    def _remember_pass_grads(self, g):
-        self._pass_grad_ptrs = [t.data_ptr() for t in g]
+    def _pass_grads_of(self, task_id):
+        c = self._pass_grads
+        if c is None:
+            return None
+        if c[0] != task_id or task_id < 0:        # another pass's leftovers (its callback never ran) or no engine pass at all
+            self._pass_grads = None
+            return None
+        return c[1]
+
+    def _remember_pass_grads(self, g, base, task_id):
+        # `base`: the flat buffer the 13 views live in (None for the reducer's bucket views, which the reducer owns).  The VIEWS are not kept:
+        # a second reference to them would stop AccumulateGrad from taking them as p.grad without a copy.
+        self._pass_grads = (task_id, [t.data_ptr() for t in g], base)
 
         def forget():
-            self._pass_grad_ptrs = None
+            self._pass_grads = None
         torch.autograd.Variable._execution_engine.queue_callback(forget)
 
     def _queue_view_refresh(self, params):

@@ -102,7 +102,17 @@ class _LossCtx:
         return (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and not t.requires_grad and t.dim() == 4 and
                 t.shape[0] == x.shape[0] and t.shape[1] == result.shape[1] and coff + net.out_chans <= t.shape[1] and
                 tuple(t.shape[2:]) == tuple(x.shape[2:]) and self.qw.numel() == t.shape[2] and t.shape[3] % 4 == 0 and
-                (t.shape[2] // 4) * (t.shape[3] // 4) >= 32 and t.numel() < 2 ** 32 - 1024 and x.numel() < 2 ** 32 - 1024)
+                (t.shape[2] // 4) * (t.shape[3] // 4) >= 32 and t.numel() < 2 ** 32 - 1024 and x.numel() < 2 ** 32 - 1024 and
+                # what the fused rollout path itself needs (else the two-pass loss, as before -- ADVICE r5): the dump offset is a C int,
+                # swv2_loss_resid_to_image stages 16 rows of Cout * 16 (+ 8) bf16 in 64 KB of LDS, and the concatenated prediction must
+                # carry the epilogue's scratch behind it
+                result.numel() < 2 ** 31 - 1024 and 16 * (net.out_chans * 16 + 8) * 2 <= 65536 and self._slack_behind(result) >= ops.L.LOSS_DUMP_BYTES)
+
+    @staticmethod
+    def _slack_behind(t):
+        """allocated bytes behind the last element of a (view of a) tensor"""
+        base = t._base if t._base is not None else t
+        return base.data_ptr() + base.numel() * base.element_size() - (t.data_ptr() + t.numel() * t.element_size())
 
     def offer_step(self, result, coff, sums):
         if self.steps is None or self.result_ptr != result.data_ptr():

@@ -273,6 +273,13 @@ __global__ __launch_bounds__(64 * LT) void attn_fwd_kernel(
     }
 }
 
+// Issue priority that falls with a wave's progress through phase 1 (see attn_bwd_stream.hip: the SIMD arbiter serves its oldest wave first, the
+// youngest then finishes the phase alone with nothing to cover its latencies); reset to 0 behind the phase.  -DSWV2_ATTN1_NO_PRIO: A/B builds.
+#ifndef SWV2_ATTN1_NO_PRIO
+#define SWV2_P1PRIO(n) __builtin_amdgcn_s_setprio(n)
+#else
+#define SWV2_P1PRIO(n) do {} while (0)
+#endif
 #ifdef SWV2_ATTN1_STAMPS          // diagnostic build (tools/probe_attn1_stamps.py): per-phase s_memtime sums of every wave 0
 __device__ unsigned long long attn1_stamps[512 * 8];
 __device__ unsigned long long attn1_win[64 * 128];        // wave 8 of the first 64 workgroups of head 0: s_memtime at the end of every window
@@ -691,6 +698,7 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
             // (q-tiles in pairs with one K = 32 product for dV / dK, as in the kernel without bias below, needs two more stage sets: 39
             // registers spilled around the loop per window, 240 us against 128.)
             St sa, sb;
+            SWV2_P1PRIO(3);
             stageA(0, sa);
 #pragma unroll
             for (int qt = 0; qt + 1 < LT; qt += 2) {
@@ -698,9 +706,11 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
                 stageB(qt, sa, dbr[qt]);
                 if (qt + 2 < LT) stageA(qt + 2, sa);
                 stageB(qt + 1, sb, dbr[qt + 1]);
+                if (qt == 2) SWV2_P1PRIO(2); else if (qt == 4) SWV2_P1PRIO(1); else if (qt == 8) SWV2_P1PRIO(0);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (LT & 1) stageB(LT - 1, sa, dbr[LT - 1]);
+            SWV2_P1PRIO(0);
 #else
 #pragma unroll 1
             for (int qt = 0; qt < LT; ++qt) {
@@ -839,6 +849,7 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
                     dk[0][0] = mfma32(tq, dsb, dk[0][0]);
                 };
                 St a0, a1, b0, b1;
+                SWV2_P1PRIO(3);
                 stageA(0, a0);
                 stageA(1, a1);
 #pragma unroll
@@ -846,11 +857,13 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
                     if (qt + 2 < LT) stageA(qt + 2, b0);
                     if (qt + 3 < LT) stageA(qt + 3, b1);
                     stageB2(qt, a0, a1);
+                    if (qt == 4) SWV2_P1PRIO(1); else if (qt == 8) SWV2_P1PRIO(0);
                     __builtin_amdgcn_sched_barrier(0);
                     if (qt + 3 < LT) {
                         if (qt + 4 < LT) stageA(qt + 4, a0);
                         if (qt + 5 < LT) stageA(qt + 5, a1);
                         stageB2(qt + 2, b0, b1);
+                        if (qt == 0) SWV2_P1PRIO(2);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -872,6 +885,7 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
                 }
             } else {
                 St sa, sb;
+                SWV2_P1PRIO(3);
                 stageA(0, sa);
 #pragma unroll 1         // (32-wide head slots: unrolled with fences measured equal, 35.0 ms per configs[3] step either way)
                 for (int qt = 0; qt + 1 < LT; qt += 2) {
@@ -879,8 +893,10 @@ __global__ __launch_bounds__(64 * ((LT + TPW - 1) / TPW)) void attn_bwd_kernel(
                     stageB(qt, sa);
                     if (qt + 2 < LT) stageA(qt + 2, sa);
                     stageB(qt + 1, sb);
+                    if (4 * qt >= LT) { if (4 * qt >= 3 * LT) SWV2_P1PRIO(0); else if (2 * qt >= LT) SWV2_P1PRIO(1); else SWV2_P1PRIO(2); }
                 }
                 if (LT & 1) stageB(LT - 1, sa);
+                SWV2_P1PRIO(0);
             }
         } else if constexpr (TPW == 1) {
             // software-pipelined over the q tiles (two register sets used alternately): stage A of step qt + 1 (fragment

@@ -490,3 +490,16 @@ def test_rollout_loss_hand_over_bookkeeping():
     other = torch.zeros_like(result)
     lc2.offer_step(other, 0, sums[0])                                    # a new result buffer starts a new collection
     assert lc2.result_ptr == other.data_ptr() and len(lc2.steps) == 1
+
+
+@pytest.mark.skipif(os.environ.get("SWV2_TEST_SANITIZERS", "0") == "0",
+                    reason="opt-in (SWV2_TEST_SANITIZERS=1): rebuilds every source with host-side ASAN + UBSAN, ~3 minutes on 8 cores; "
+                           "profiles/r06_sanitize_host.txt is the committed run")
+def test_host_halves_under_address_and_ub_sanitizers():
+    """The host halves of the C ABI (argument checks, workspace arithmetic, block orchestration, error strings) under AddressSanitizer +
+    UndefinedBehaviorSanitizer: tools/sanitize_host.sh builds csrc/*.hip with -Xarch_host -fsanitize=address,undefined and runs the
+    host-side tests of this file against that library (SWV2_LIB).  CPU only: the GPU pool refuses sanitizer runs."""
+    import subprocess
+    r = subprocess.run([os.path.join(ROOT, "tools", "sanitize_host.sh")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1800)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and " passed" in out and "ERROR: AddressSanitizer" not in out and "runtime error" not in out, out[-3000:]

@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: same-box A/B of the training step with environment switches.  usage: tools/r06/ab_env.sh "ENV_A=.." "ENV_B=.." [bench flags]
+# GPU box: same-box A/B of the training step with environment switches.  usage: tools/ab_env.sh "ENV_A=.." "ENV_B=.." [bench flags]
 A="$1"; B="$2"; shift 2
 for rep in 1 2; do
   for E in "$A" "$B"; do

@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: same-box A/B of library variants on a probe.  usage: tools/r06/ab_lib.sh "<probe command>" libA.so libB.so ...   ("" = the shipped library)
+# GPU box: same-box A/B of library variants on a probe.  usage: tools/ab_lib.sh "<probe command>" libA.so libB.so ...   ("" = the shipped library)
 PROBE="$1"; shift
 for rep in 1 2; do
   for SO in "$@"; do

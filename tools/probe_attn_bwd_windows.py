@@ -5,7 +5,7 @@ usage: PROBE_B=2 tools/probe_attn_bwd_windows.py"""
 import ctypes, os, subprocess, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from swin_v2_weather_amd import _lib as L
-so = os.environ.get("PROBE_SO") or "/tmp/libswv2_wstamps.so"        # PROBE_SO: a stamped library built beforehand (tools/r06/build_stamped.sh)
+so = os.environ.get("PROBE_SO") or "/tmp/libswv2_wstamps.so"        # PROBE_SO: a stamped library built beforehand (tools/build_stamped.sh)
 srcs = [os.path.join(L.CSRC, s) for s in L.SOURCES]
 if not os.environ.get("PROBE_SO"):
   subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DSWV2_ATTNS_STAMPS", "-DSWV2_ATTN1_STAMPS",

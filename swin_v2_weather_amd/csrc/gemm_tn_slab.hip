@@ -30,6 +30,15 @@
 
 namespace {
 
+// Partial tiles in bf16 (default) or fp32 (-DSWV2_SLAB_PART_F32, A/B builds).  Every workgroup leaves its whole N x K accumulator tile for the
+// reduction launch -- 56 MB written and read again per block whatever the batch (24 + 12 us of the two launches, round 5's ablations).  In bf16
+// that is half; a partial is a sum over >= 1 000 rows rounded once to 8 bits, the fold over the ~64 - 80 slices stays fp32 and in a fixed order
+// (bit-deterministic as before), and the reference's own weight gradients under autocast are bf16 GEMM outputs.
+#ifdef SWV2_SLAB_PART_F32
+typedef float sl_part_t;
+#else
+typedef uint16_t sl_part_t;
+#endif
 constexpr int SL_TH = 512;
 constexpr int SL_SMEM = 160 * 1024;           // the whole LDS of a CU: one workgroup per CU
 constexpr int SL_IDX_CAP = 4096;              // gather index table in LDS: a ring of two halves (2 x 2048 rows), refilled while the other half is in use
@@ -88,7 +97,7 @@ struct SlOp {                 // one operand (plain data)
 };
 struct SlProd {
     SlOp y, x;
-    float* part;              // [tile][chunk][slice][256] partial outputs, chunks in accumulator layout (see the epilogue)
+    sl_part_t* part;          // [tile][chunk][slice][256] partial outputs, chunks in accumulator layout (see the epilogue)
     float* dbpart;            // [slices][N] partial bias gradients (null: none)
     int M, N, K;
     int first, wgs, ntile;    // workgroups first .. first + wgs - 1; job j -> (tile j % ntile, slice j / ntile)
@@ -426,11 +435,17 @@ __device__ __forceinline__ void slab_job(const SlProd& P, const int j, unsigned 
 #endif
     {
         constexpr int CPT = 8 * IA * JB;             // chunks per tile
-        float* out = P.part + ((size_t)(tile * CPT + wave * IA * JB) * S + slice) * 256 + lane * 4;
+        sl_part_t* out = P.part + ((size_t)(tile * CPT + wave * IA * JB) * S + slice) * 256 + lane * 4;
 #pragma unroll
         for (int i = 0; i < IA; ++i)
 #pragma unroll
-            for (int jj = 0; jj < JB; ++jj) *(f32x4*)(out + (size_t)(i * JB + jj) * S * 256) = acc[i][jj];
+            for (int jj = 0; jj < JB; ++jj) {
+#ifdef SWV2_SLAB_PART_F32
+                *(f32x4*)(out + (size_t)(i * JB + jj) * S * 256) = acc[i][jj];
+#else
+                *(bf16x4*)(out + (size_t)(i * JB + jj) * S * 256) = f2bf4(acc[i][jj]);
+#endif
+            }
     }
 #ifdef SWV2_SLAB_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -479,7 +494,7 @@ __global__ __launch_bounds__(SL_TH) void gemm_tn_slab_c192_kernel(SlArgs a) {
 // optional rider of the reduction launch: d gamma / d beta of the block's two LayerNorms from the partial rows their backward kernels
 // left (rowops.hip: ln_partials_reduce_kernel as its own launch otherwise): [nblocks][2][C] per set
 struct SlLnRed { const float* ws[2]; float* dg[2]; float* db[2]; int n[2]; int C; };
-struct SlRed { float* dW; float* db; const int32_t* nmap; const int32_t* kmap; const float* part; const float* dbpart;
+struct SlRed { float* dW; float* db; const int32_t* nmap; const int32_t* kmap; const sl_part_t* part; const float* dbpart;
                int ldw, N, K, TN, TK, WGK, IA, JB, ntk, S, first, dbfirst; };
 struct SlRedArgs { SlRed p[4]; int total, dbtotal; SlLnRed ln; int cpw; };      // cpw: 1 KB chunks per workgroup (1: 8 slice groups per chunk; 2: 4 each)
 __global__ __launch_bounds__(512) void tn_slab_reduce_kernel(SlRedArgs a) {
@@ -556,19 +571,27 @@ __global__ __launch_bounds__(512) void tn_slab_reduce_kernel(SlRedArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) old[r] = p.dW[(long)max(nn[r], 0) * p.ldw + max(kk, 0)];
     }
-    const float* src = p.part + (size_t)cg * p.S * 256 + lane * 4;
+    const sl_part_t* src = p.part + (size_t)cg * p.S * 256 + lane * 4;
+#ifdef SWV2_SLAB_PART_F32
+    auto ld = [](const sl_part_t* q) -> f32x4 { return *(const f32x4*)q; };
+#else
+    auto ld = [](const sl_part_t* q) -> f32x4 {
+        const bf16x4 v = *(const bf16x4*)q;
+        return (f32x4){bf2f(v[0]), bf2f(v[1]), bf2f(v[2]), bf2f(v[3])};
+    };
+#endif
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
     int s = sl0;
 #if defined(SWV2_SLAB_ABL) && (SWV2_SLAB_ABL & 8)      // timing ablation: one slice only (fixed cost of the reduction launch)
     s = p.S;
 #endif
     for (; s + 3 * NG < p.S; s += 4 * NG) {
-        s0 += *(const f32x4*)(src + (size_t)s * 256);
-        s1 += *(const f32x4*)(src + (size_t)(s + NG) * 256);
-        s2 += *(const f32x4*)(src + (size_t)(s + 2 * NG) * 256);
-        s3 += *(const f32x4*)(src + (size_t)(s + 3 * NG) * 256);
+        s0 += ld(src + (size_t)s * 256);
+        s1 += ld(src + (size_t)(s + NG) * 256);
+        s2 += ld(src + (size_t)(s + 2 * NG) * 256);
+        s3 += ld(src + (size_t)(s + 3 * NG) * 256);
     }
-    for (; s < p.S; s += NG) s0 += *(const f32x4*)(src + (size_t)s * 256);
+    for (; s < p.S; s += NG) s0 += ld(src + (size_t)s * 256);
     red[sg][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (sl0 == 0 && kk >= 0) {
@@ -723,7 +746,7 @@ int swv2_tn_slab_launch(const swv2_wgrad_item* it, void* ws, size_t ws_bytes, co
     for (int i = 0; i < 4; ++i) {
         SlProd& p = a.p[i];
         p.y = sl_op(it[i].dy); p.x = sl_op(it[i].x);
-        p.part = (float*)((char*)ws + pl.part_off[i]);
+        p.part = (sl_part_t*)((char*)ws + pl.part_off[i]);
         p.dbpart = it[i].db ? (float*)((char*)ws + pl.db_off[i]) : nullptr;
         p.M = it[i].dy.rows; p.N = it[i].dy.cols; p.K = it[i].x.cols;
         p.first = first; p.wgs = pl.wgs[i]; p.ntile = pl.ntile[i];

@@ -2084,7 +2084,7 @@ def test_block_wide_heads_against_oracle(dev, K, gh, gw, wh, ww, sh, sw, Cc, h, 
 def test_grouped_weight_gradients_match_separate_launches(dev, K, monkeypatch, gh, gw, wh, ww, sh, sw, Cc, h):
     """swv2_block_wgrad (the block's four weight gradients + bias gradients as one launch) against the four swv2_linear_wgrad_ws
     launches on the same block backward: same products, only the order in which the row slices are summed differs (fp32) -> 2e-5
-    of each gradient's largest element.  C = 128 / 8 heads and C = 192 / 8 heads (BASELINE cfg 2 and cfg 4 blocks) run the slab kernel
+    of each gradient's largest element (5e-3 for the slab kernel's weight gradients, whose partial tiles are bf16 since round 6).  C = 128 / 8 heads and C = 192 / 8 heads (BASELINE cfg 2 and cfg 4 blocks) run the slab kernel
     (gemm_tn_slab.hip: operands by LDS-DMA; the 27 x 54 grid has a row count that is not a multiple of the 32-row stage: ragged last
     stage), the other shapes the 128 x 128 tile kernel."""
     N = K["N"]
@@ -2105,9 +2105,16 @@ def test_grouped_weight_gradients_match_separate_launches(dev, K, monkeypatch, g
         blk(x).backward(gy0.to(dev))
         assert blk._runner(B, x.device).desc.wgrad_group == int(grp)
         grads[grp] = {n_: p_.grad.detach().cpu() for n_, p_ in blk.named_parameters()} | {"x": x.grad.cpu()}
+    # round 6: the slab kernel hands its per-workgroup partial tiles to the fold in bf16 (half the 56 MB a block wrote and re-read whatever the
+    # batch): a partial is rounded once to 8 bits, the fold over the slices stays fp32 in a fixed order.  On this test's random data the
+    # partial sums of ~55 rows are incoherent (a random walk: |partial| ~ |total| / 9), so the rounding of ~80 partials adds up to 1 - 2e-3
+    # of the largest gradient element (measured 2.2e-3 on fc1 at 27 x 54; bar 5e-3) -- the size of the ONE bf16 rounding the reference's own
+    # autocast weight gradients carry on every element (2^-9 = 2e-3); coherent gradients sit well below.  Tile-kernel shapes: fp32, 2e-5.
+    slab = Cc in (128, 192) and h == 8
     for n_, g1 in grads["1"].items():
         g0 = grads["0"][n_]
-        assert float((g1 - g0).abs().max()) <= 2e-5 * float(g0.abs().max()) + 1e-12, n_
+        bar = 5e-3 if (slab and n_.endswith("weight") and g0.dim() == 2) else 2e-5
+        assert float((g1 - g0).abs().max()) <= bar * float(g0.abs().max()) + 1e-12, (n_, float((g1 - g0).abs().max()) / float(g0.abs().max()))
 
 
 def _ddp_run(tmp_path, tag, world, backend, mode, n_future, port, opt="sgd", cap_mb=25.0, extra_env=None):

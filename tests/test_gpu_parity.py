@@ -961,7 +961,10 @@ def test_full_size_block_at_local_batch_8(dev, K, rel_pos):
         scale = float(g8[n_].abs().max())
         if n_.endswith("meta_mlp.fc2.bias"):
             scale = float(g8[n_[:-4] + "weight"].abs().max())
-        assert float((g8[n_] - p_.grad).abs().max()) <= 2e-3 * scale + 1e-9, n_
+        # (weight matrices: the slab kernel's bf16 partial tiles, round 6 -- five launches with different row slices, random data: see
+        # test_grouped_weight_gradients_match_separate_launches for the arithmetic behind 5e-3)
+        bar = 5e-3 if (g8[n_].dim() == 2 and n_.endswith("weight")) else 2e-3
+        assert float((g8[n_] - p_.grad).abs().max()) <= bar * scale + 1e-9, (n_, float((g8[n_] - p_.grad).abs().max()) / scale)
     # (2) samples 0 and 7 against the oracle in the kernels' rounding mode
     sel = [0, 7]
     xo = x[sel].clone().requires_grad_(True)

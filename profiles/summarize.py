@@ -70,7 +70,7 @@ def source_hash():
 
 
 # the kernels bench.py reports roofline objects for (name fragments)
-ROOFLINE_FRAGMENTS = ("attn_bwd_kernel", "attn_fwd3_kernel", "mlp_bwd_kernel", "mlp_fwd_kernel", "gemm_tn_slab_c128_kernel")
+ROOFLINE_FRAGMENTS = ("attn_bwd_", "attn_fwd3_kernel", "mlp_bwd_kernel", "mlp_fwd_kernel", "gemm_tn_slab_c128_kernel")
 
 
 def check(stats_md, hbm_json, mfma_json):

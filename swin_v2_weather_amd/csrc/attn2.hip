@@ -146,6 +146,10 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn_fwd3_kernel(
         const uint16_t* Ki = smem + buf * BUF;
         const uint16_t* Vs = Ki + KIMG;
         const uint16_t* Qs = Vs + SLAB;
+        // (What the ISA does with this prefetch, rounds 2 - 6: the row loop below stores, does not load, and uses these registers in the wave's
+        // last row, so the compiler's wait-count pass flushes vmcnt(0) in the loop's PREHEADER -- the workgroup waits for its own prefetch before
+        // its first row, and it is the CU's other two workgroups that cover the latency.  Peeling the last row removes the flush and measured
+        // slower, 9 843 against 9 310 cycles per item: LABNOTES round 6.)
         if (bw_next < Bw) issue_loads(bw_next);      // consumed by write_stage at the top of the wave's last row
         const bool do_mask = (mask_thr > 0) && (((bw % nW) / nww) == nwh - 1);
         const bool fixed = bounded && !do_mask;                       // wave-uniform

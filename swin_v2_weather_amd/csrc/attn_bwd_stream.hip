@@ -253,6 +253,8 @@ __global__ __launch_bounds__(1024) void attn_bwd_stream_kernel(
             };
             // the dS tiles of q-tile pair `p` of this wave are in the image: tell the dQ side (the LDS runs a wave's instructions in order)
             auto signal = [&](const int p) {
+                // (EXEC narrowed to lane 0 inside the asm -- three instructions instead of the compare / saveexec / branch / restore -- measured equal:
+                // 7 555 - 7 575 against 7 529 - 7 614 cycles per window)
                 if (ln == 0) asm volatile("ds_add_u32 %0, %1" : : "v"(cnt_addr + 4u * (unsigned)p), "v"(1u) : "memory");
             };
             // q-tiles in PAIRS: the dV / dK products of two tiles are one K = 32 MFMA (k-slot (g, j) = row 4g + j of the first tile for

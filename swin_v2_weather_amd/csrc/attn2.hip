@@ -399,6 +399,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn_fwd3w_kernel(
 #pragma unroll 1
         for (int qt = wave; qt < LT; qt += WAVES) {                   // wave-uniform trip count
             const int q = 16 * qt + fr;
+            // (no progress priority here: at two workgroups per CU it measured 34.1 / 34.6 against 34.0 / 33.9 ms per configs[3] step)
             if (NBUF == 2 && qt + WAVES >= LT && bw_next < Bw) write_stage(buf ^ 1);
             const bf16x8 qraw = *(const bf16x8*)(Qs + (size_t)q * DP + 8 * g);
             // B operands of S^T = K Q^T: hi and lo bf16 parts of sigma' q^[8g .. 8g + 7] (sum exact to ~2^-17)
@@ -617,6 +618,12 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void attn_fwd3b_kernel(
             const int qt = wave + i * WAVES;
             if (qt >= LT) break;                                      // wave-uniform
             const int q = 16 * qt + fr;
+#ifndef SWV2_FWD3_NO_PRIO
+            // (issue priority falls with the wave's progress through its item, see attn_fwd3_kernel: 62.4 -> 57.7 - 58.0 us in situ, same box)
+            if (i == 0) __builtin_amdgcn_s_setprio(2);
+            else if (i == 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+#endif
             if (qt + WAVES >= LT && bw_next < Bw) write_stage(buf ^ 1);
             const bf16x4 qraw = *(const bf16x4*)(Qs + (size_t)q * DP + 4 * g);
             bf16x8 qB;

@@ -739,6 +739,48 @@ def test_attention_kernel_generations_agree(dev, K, shifted):
         assert torch.equal(dq, grads[L.ATTN_BWD_TWO_PHASE][0]) and rel(dls, grads[L.ATTN_BWD_TWO_PHASE][1]) < 1e-5, mc
 
 
+def test_streamed_attention_backward_is_deterministic_under_load(dev, K):
+    """The streamed-dQ backward hands dS tiles from its phase-1 waves to its helper waves through LDS counters and lands k / v by LDS-DMA
+    beside register-staged loads: a race there would show as an occasional wrong tile, not as a wrong formula.  Full-size launch geometry
+    (800 windows x 8 heads = 25 windows per persistent workgroup, both LDS buffers, every counter wrapping 25 times), 60 launches back to
+    back with other kernels in between: every result bit-identical to the first and to the barrier-separated two-phase kernel; and the
+    same at 3 200 windows (100 per workgroup)."""
+    ops, L = K["ops"], K["L"]
+    torch.manual_seed(7)
+    for B, reps in ((2, 60), (8, 12)):
+        plan = ops.window_plan(B, 180, 360, 9, 18, 4, 9, 8, 16, 0)
+        Bw, h, Lp, DP, Lw = plan.Bw, 8, plan.Lp, plan.DP, plan.L
+        qkvh = torch.randn(Bw, h, 3, Lp, DP, device=dev)
+        qkvh[:, :, :2] = torch.nn.functional.normalize(qkvh[:, :, :2], dim=-1)
+        qkvh[:, :, :, Lw:] = 0
+        qkvh = qkvh.to(BF).contiguous()
+        ls = torch.log(torch.tensor([3.0, 8.0, 10.0, 12.0, 20.0, 27.0, 30.0, 60.0], device=dev))
+        oh = torch.empty(Bw, h, Lp, DP, dtype=BF, device=dev)
+        lse = torch.zeros(Bw, h, Lp, device=dev)
+        ops.attn_fwd(ops.attn_args(qkvh, ls, None, oh, lse, Bw, h, Lw, 16, plan.nwh, plan.nww, plan.mask_thr))
+        doh = torch.randn(Bw, h, Lp, DP, device=dev).to(BF)
+        doh[:, :, Lw:] = 0
+        rnorm = torch.rand(Bw, h, 2, Lp, device=dev) + 0.5
+
+        def run(dbg):
+            dq = torch.full((Bw, h, 3, Lp, DP), float("nan"), dtype=BF, device=dev)
+            dls = torch.zeros(h, device=dev)
+            a = ops.attn_args(qkvh, ls, None, oh, lse, Bw, h, Lw, 16, plan.nwh, plan.nww, plan.mask_thr, doh=doh, rnorm=rnorm, dqkvh=dq, dlogit=dls,
+                              max_chunks=256 // h)
+            a.dbg = dbg
+            ops.attn_bwd(a)
+            return dq, dls
+        ref, dls_ref = run(L.ATTN_BWD_TWO_PHASE)
+        assert not torch.isnan(ref.float()).any()
+        scratch = torch.empty(64 << 20, device=dev)
+        for i in range(reps):
+            if i % 3 == 1:
+                scratch.normal_()                       # other kernels in between: other LDS contents, other cache state
+            dq, dls = run(0)
+            assert torch.equal(dq, ref), (B, i, int((dq != ref).sum()))
+            assert rel(dls, dls_ref) < 1e-5
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # modules against the golden vectors of the real reference
 # ---------------------------------------------------------------------------------------------------------------

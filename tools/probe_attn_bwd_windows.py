@@ -31,6 +31,7 @@ nwin = Bw // (256 // h)
 kernels = (("two-phase", L.ATTN_BWD_TWO_PHASE, "swv2_debug_attn1_win"), ("streamed", 0, "swv2_debug_attns_win"))
 if os.environ.get("PROBE_ONLY_STREAMED"):
     kernels = kernels[1:]
+outs = {}
 for name, dbg, sym in kernels:
     dq, dls = torch.empty_like(qkvh), torch.zeros(h, device=dev)
     a = ops.attn_args(qkvh, ls, None, oh, lse, Bw, h, Lw, 16, plan.nwh, plan.nww, plan.mask_thr, doh=doh, rnorm=rnorm, dqkvh=dq, dlogit=dls, max_chunks=256 // h)
@@ -43,6 +44,7 @@ for name, dbg, sym in kernels:
     for _ in range(10):
         ops.attn_bwd(a)
     e1.record(); torch.cuda.synchronize()
+    outs[name] = (dq.float(), dls.clone())
     buf = torch.zeros(64 * 128, dtype=torch.int64)
     assert getattr(lib, sym)(ctypes.c_void_p(buf.data_ptr())) == 0
     w = buf.view(64, 128)[:32, :min(nwin, 128)].double()
@@ -50,3 +52,9 @@ for name, dbg, sym in kernels:
     m = d.mean(0)
     print(f"{name}: {e0.elapsed_time(e1) * 100:.1f} us per launch (stamped build), {nwin} windows per workgroup; ticks per window (mean over 32 workgroups):")
     print("   first 8:", " ".join(f"{x:6.0f}" for x in m[:8]), "| last 4:", " ".join(f"{x:6.0f}" for x in m[-4:]), f"| mean {m.mean():.0f}, total {w[:, -1].mean():.0f} (min {w[:, -1].min():.0f} max {w[:, -1].max():.0f})")
+if len(outs) == 2:
+    (a, la), (b, lb) = outs["two-phase"], outs["streamed"]
+    for part, nm in enumerate(("dq", "dk", "dv")):
+        x, y = a[:, :, part], b[:, :, part]
+        print(f"streamed vs two-phase {nm}: max |diff| {float((x - y).abs().max()):.3e} of max {float(x.abs().max()):.3e}; equal {bool(torch.equal(x, y))}; padded rows max {float(y[:, :, Lw:].abs().max()):.1e}")
+    print("d logit_scale rel diff", float(((la - lb).abs() / la.abs().clamp_min(1e-9)).max()))

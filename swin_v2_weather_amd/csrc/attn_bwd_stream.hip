@@ -14,20 +14,25 @@
 //   * waves 0 .. 10, phase 1, unchanged arithmetic (wave = key tile, q-tiles in pairs, software-pipelined, fully unrolled with fences);
 //     behind the dS tiles of a q-tile pair, lane 0 of the wave adds 1 to the pair's LDS counter (the LDS executes a wave's
 //     instructions in order: the add is behind the tile writes).  No staging registers, no dQ work: ~100 registers;
-//   * waves 11 .. 15, helpers: each prefetches a fifth of the next window's slabs (v by LDS-DMA, the rest through registers), computes
-//     the dQ of one q-tile pair -- spinning on the pair's counter until it shows all 11 phase-1 waves, then reading the dS image
-//     transposed (K^T fragments once per pair, two interleaved accumulation chains, the two-phase kernel's summation order) -- and
-//     commits its slab chunks (with delta = rowsum(dO O) and the statistics slots) to the OTHER LDS buffer;
+//   * waves 11 .. 15, helpers: each prefetches a fifth of the next window's slabs (k, v by LDS-DMA, the rest through registers), commits
+//     its chunks (with delta = rowsum(dO O) and the statistics slots) to the OTHER LDS buffer, and computes the dQ of the first q-tiles
+//     (helper 0 the first pair, helpers 1 .. 3 tiles 2 .. 4) -- spinning on the pair's counter until it shows all 11 phase-1 waves,
+//     then reading the dS image transposed, every fragment before the first product (the two-phase kernel's summation order);
+//   * the dQ of the last six q-tiles is computed by the phase-1 waves that finish their key tile first (one single-tile pass each
+//     behind their dK / dV stores): with every dQ pass on the helpers the window's barrier waited ~1 000 cycles for the last pair's
+//     pass while the phase-1 waves idled (tools/probe_attn_bwd_arrive.py);
 //   * the q | dO | k | v slabs (and the 1 / |q|, 1 / |k| rows) are double-buffered in LDS, so the commit needs no barrier of its own;
 //     the dS image is single (every reader has passed the window's ONE barrier before the next window's first tile is written);
-//   * issue priority (s_setprio) falls with a phase-1 wave's own progress, so the three phase-1 waves of a SIMD advance together
-//     instead of oldest first.
+//   * issue priority (s_setprio) falls with a phase-1 wave's own progress (the older waves of a SIMD one stage earlier), so the three
+//     phase-1 waves of a SIMD advance together instead of oldest first.
 // Measured with tools/probe_attn_bwd_windows.py (s_memtime at every window's end, same box): 8 740 cycles per window for the two-phase
-// kernel, 7 480 - 7 520 here, the same at 25 and at 100 windows per workgroup; d(qkv) bit-identical.  What was built on the way and
+// kernel, 7 480 - 7 520 with all dQ passes on the helpers, the same at 25 and at 100 windows per workgroup; barrier to barrier in a
+// production build (tools/probe_attn_bwd_arrive.py) 6 960 -> 6 620 with the last tiles on the phase-1 waves; d(qkv) bit-identical.  What was built on the way and
 // lost (LABNOTES round 6): 11 waves with the dQ tiles inside every wave's own loop (8 560) or on the two waves of the short SIMD (one
 // tile at a time: slower than two-phase -- a tile's chain of transposed reads -> 6 dependent MFMAs -> row sum -> store is ~400 cycles of
 // latency); the last three q-tiles' dQ deferred into the next window through a second tail image (tools/experiments/
-// attn_bwd_stream_deferred.hip: 7 620, the commits then wait for those tiles); helpers at priority 2 / 3 (7 620 - 7 670).
+// attn_bwd_stream_deferred.hip: 7 620, the commits then wait for those tiles); helpers at priority 2 / 3 (7 620 - 7 670); scale and statistics
+// through the MFMA's C operand, prefetch distance two, no barrier at all (tools/experiments/attn_bwd_stream_nobar.hip, LABNOTES "second pass").
 // The phase-1 loop is ~270 issue cycles per q-tile pair by the instruction costs of MI355X_MICROARCH (8 exp, 8 + 4 multiplies, 8 packs,
 // 6 MFMAs, 9 LDS instructions, the signal): ~5 000 per window and SIMD -- the kernel runs at two thirds of its own issue bound.
 // LDS: 2 x 40 832 (slabs) + 63 360 (dS image) + counters = 145 KB, one persistent workgroup per CU as before.
@@ -38,6 +43,10 @@
 namespace {
 
 typedef __attribute__((address_space(3))) unsigned lds_u32;
+
+#ifdef SWV2_ATTNS_ARRIVE          // diagnostic build (tools/probe_attn_bwd_arrive.py): when each wave of ONE workgroup reaches the window's barrier and when it opens
+__device__ unsigned long long attns_arr[17 * 8];      // (8 windows; nothing else is instrumented: the kernel runs as in production)
+#endif
 
 #ifdef SWV2_ATTNS_STAMPS          // diagnostic build (tools/probe_attn_stream_stamps.py): per-phase s_memtime sums of every wave
 __device__ unsigned long long attns_stamps[512 * 8];
@@ -57,9 +66,6 @@ __device__ unsigned long long attns_clock[512 * 2];       // per wave: s_memtime
 #define SWV2_PRIO(n) __builtin_amdgcn_s_setprio(n)
 #else
 #define SWV2_PRIO(n) do {} while (0)
-#endif
-#ifndef SWV2_ATTNS_COMMIT_FIRST     // helpers from this index on commit before their dQ pair (A/B builds: 99 = none)
-#define SWV2_ATTNS_COMMIT_FIRST 2
 #endif
 
 template <int LFIX>
@@ -221,6 +227,64 @@ __global__ __launch_bounds__(1024) void attn_bwd_stream_kernel(
         int ln = lane;
         asm volatile("" : "+v"(ln));
         const int fr = ln & 15, g = ln >> 4;
+        // dQ of q-tiles qt0 .. qt0 + NQ - 1 (NQ = 2: a pair, the K^T fragments are read once for both): dQ^T = sum_t K_t^T dS_t^T, key tiles in pairs (one
+        // K = 32 product per pair), both operands as transposed reads; one accumulation chain per q-tile in key order + the odd key tile on its own
+        // accumulator: the summation order of the two-phase kernel (bit-identical d q).  EVERY fragment is read before the first product: a pass is one
+        // wave's chain, and with the reads interleaved it paid an LDS round trip per product (~970 -> ~620 cycles for one tile behind the last signals)
+        auto phase2 = [&](const int qt0, auto nq_c, auto sleep_c) {
+            constexpr int NQ = decltype(nq_c)::value;
+            {
+                const unsigned a = cnt_addr + 4u * (unsigned)(qt0 >> 1);
+                while (true) {
+                    unsigned v;
+                    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+                    if ((unsigned)__builtin_amdgcn_readfirstlane(v) >= target) break;
+                    __builtin_amdgcn_s_sleep(decltype(sleep_c)::value);
+                }
+            }
+            SSTAMP(2);
+            f32x4 dq[NQ];
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) dq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const uint16_t* const kb = Ks + (4 * g + (fr >> 2)) * DP + (fr & 3) * 4;
+            const uint16_t* const db = dSb + (4 * g + (fr >> 2)) * DSP + 16 * qt0 + (fr & 3) * 4;
+            bf16x4 kk[LT], dd[NQ][LT];
+#pragma unroll
+            for (int t = 0; t < LT; ++t) {
+                kk[t] = lds_tr_read(kb + 16 * t * DP);
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) dd[i][t] = lds_tr_read(db + 16 * t * DSP + 16 * i);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t + 1 < LT; t += 2) {
+                const bf16x8 ka = __builtin_shufflevector(kk[t], kk[t + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int i = 0; i < NQ; ++i)
+                    dq[i] = mfma32(ka, __builtin_shufflevector(dd[i][t], dd[i][t + 1], 0, 1, 2, 3, 4, 5, 6, 7), dq[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                // own accumulator: a K = 16 MFMA chained directly onto a K = 32 accumulator gave wrong sums (attn.hip)
+                const f32x4 tail = mfma16(kk[LT - 1], dd[i][LT - 1], (f32x4){0.f, 0.f, 0.f, 0.f});
+                dq[i] += tail;
+            }
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const int q = 16 * qt0 + 16 * i + fr;
+                const float rq = RN[q] * sigma;
+                const bf16x4 qn = *(const bf16x4*)(Qa + q * QP + 4 * g);
+                float dot = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dot = fmaf(dq[i][r], bf2f(qn[r]), dot);
+                dot = xor32_allsum(xor16_allsum(dot));
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = rq * (dq[i][r] - bf2f(qn[r]) * dot);
+                *(bf16x4*)(dqkvh + slab0 + (size_t)q * DP + 4 * g) = f2bf4(v);
+            }
+            SSTAMP(3);
+        };
         if (!helper) {
             // ================= phase 1: wave = key tile =================
             const int key = 16 * tw + fr;
@@ -282,7 +346,15 @@ __global__ __launch_bounds__(1024) void attn_bwd_stream_kernel(
             // the oldest wave of the highest priority first, so without this the oldest wave of a SIMD runs ahead, ends at ~60 % of the window,
             // and the youngest finishes alone with nothing to cover its latencies.  A wave that is behind now outranks one that is ahead
             // (same box, cycles per window: 8 099 without, 7 716 with; helpers at priority 2 / 3 on top: 7 620 - 7 670 against 7 473 - 7 516).
-            SWV2_PRIO(3);
+            // The older waves of a SIMD -- served first at equal priority -- step down one stage earlier than the younger ones (stage = pairs signalled;
+            // waves 8 .. 10: 3 3 2 1 1 0, waves 4 .. 7: 3 2 2 1 0 0, waves 0 .. 3: 3 2 1 1 0 0; in situ 86.3 / 86.7 -> 85.5 / 85.4 us)
+            const int cls = tw >> 2;
+            auto setp = [&](auto s_c) {
+                constexpr int sg = decltype(s_c)::value;
+                constexpr int p2 = 3 - (2 * sg) / 3, p1 = 3 - (2 * sg + 1) / 3, p0 = (3 - (2 * sg + 2) / 3) < 0 ? 0 : 3 - (2 * sg + 2) / 3;
+                if (cls == 2) SWV2_PRIO(p2); else if (cls == 1) SWV2_PRIO(p1); else SWV2_PRIO(p0);
+            };
+            setp(std::integral_constant<int, 0>{});
             St a0, a1, b0, b1;
             stageA(0, a0);
             stageA(1, a1);
@@ -292,14 +364,14 @@ __global__ __launch_bounds__(1024) void attn_bwd_stream_kernel(
                 if (qt + 3 < LT) stageA(qt + 3, b1);
                 stageB2(qt, a0, a1);
                 signal(qt >> 1);
-                if (qt == 0) SWV2_PRIO(3); else if (qt == 4) SWV2_PRIO(1); else SWV2_PRIO(0);
+                if (qt == 0) setp(std::integral_constant<int, 1>{}); else if (qt == 4) setp(std::integral_constant<int, 3>{}); else setp(std::integral_constant<int, 5>{});
                 __builtin_amdgcn_sched_barrier(0);
                 if (qt + 3 < LT) {
                     if (qt + 4 < LT) stageA(qt + 4, a0);
                     if (qt + 5 < LT) stageA(qt + 5, a1);
                     stageB2(qt + 2, b0, b1);
                     signal((qt >> 1) + 1);
-                    if (qt == 0) SWV2_PRIO(2); else SWV2_PRIO(1);
+                    if (qt == 0) setp(std::integral_constant<int, 2>{}); else setp(std::integral_constant<int, 4>{});
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -338,85 +410,39 @@ __global__ __launch_bounds__(1024) void attn_bwd_stream_kernel(
                 *(bf16x4*)(dqkvh + slab0 + 2 * SLAB + (size_t)key * DP + 4 * g) = f2bf4(dv);
             }
             SSTAMP(4);                      // dK / dV normalisation backward + stores
+            // The dQ of the last six q-tiles, one single-tile pass each on the phase-1 waves that finish their key tile first (the four oldest + wave 7; wave 3,
+            // alone with wave 7 and two helpers on its SIMD, takes two).  Which waves the window's barrier waits for, production build with one s_memtime per
+            // wave and window (-DSWV2_ATTNS_ARRIVE, tools/probe_attn_bwd_arrive.py): with all dQ on the helpers the phase-1 waves arrived 900 - 2 600 cycles
+            // before it opened and helper 4 (the last pair, behind the last signals: a ~1 700-cycle pair pass) 114; now every wave arrives within ~900.
+            // 6 960 -> 6 620 cycles per window, in situ 89.3 -> 86.5 us.
+            {
+                const int tt = tw == 3 ? 6 : tw == 7 ? 7 : tw == 0 ? 8 : tw == 2 ? 9 : tw == 1 ? 10 : -1;
+                if (tt >= 0) {
+                    SWV2_PRIO(2);
+                    if (tw == 3) phase2(5, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+                    phase2(tt, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+                }
+            }
         } else {
             // ================= helper waves: the next window's prefetch, phase 2 (dQ), the commit =================
             const int hidx = hw * 64 + ln;
             if (bw_next < Bw) issue(bw_next, buf ^ 1, hidx);
             SSTAMP(0);
-            // dQ of the q-tiles of pair `pr` (NQ = 2) or of the odd last tile (NQ = 1): dQ^T = sum_t K_t^T dS_t^T, key tiles in pairs (one
-            // K = 32 product per pair), both operands as transposed reads -- the K^T fragments are read once for both q-tiles, whose
-            // accumulation chains interleave; one chain per q-tile in key order + the odd key tile on its own accumulator: the summation
-            // order of the two-phase kernel (bit-identical d q)
-            auto phase2 = [&](const int pr, auto nq_c) {
-                constexpr int NQ = decltype(nq_c)::value;
-                {
-                    const unsigned a = cnt_addr + 4u * (unsigned)pr;
-                    while (true) {
-                        unsigned v;
-                        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
-                        if ((unsigned)__builtin_amdgcn_readfirstlane(v) >= target) break;
-                        __builtin_amdgcn_s_sleep(4);
-                    }
-                }
-                SSTAMP(2);
-                f32x4 dq[NQ];
-#pragma unroll
-                for (int i = 0; i < NQ; ++i) dq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                const uint16_t* const kb = Ks + (4 * g + (fr >> 2)) * DP + (fr & 3) * 4;
-                const uint16_t* const db = dSb + (4 * g + (fr >> 2)) * DSP + 32 * pr + (fr & 3) * 4;
-#pragma unroll
-                for (int t = 0; t + 1 < LT; t += 2) {
-                    const bf16x4 k0 = lds_tr_read(kb + 16 * t * DP), k1 = lds_tr_read(kb + 16 * (t + 1) * DP);
-                    const bf16x8 ka = __builtin_shufflevector(k0, k1, 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-                    for (int i = 0; i < NQ; ++i) {
-                        const bf16x4 d0 = lds_tr_read(db + 16 * t * DSP + 16 * i), d1 = lds_tr_read(db + 16 * (t + 1) * DSP + 16 * i);
-                        dq[i] = mfma32(ka, __builtin_shufflevector(d0, d1, 0, 1, 2, 3, 4, 5, 6, 7), dq[i]);
-                    }
-                }
-                {
-                    // own accumulator: a K = 16 MFMA chained directly onto a K = 32 accumulator gave wrong sums (attn.hip)
-                    const bf16x4 k0 = lds_tr_read(kb + 16 * (LT - 1) * DP);
-#pragma unroll
-                    for (int i = 0; i < NQ; ++i) {
-                        const bf16x4 d0 = lds_tr_read(db + 16 * (LT - 1) * DSP + 16 * i);
-                        const f32x4 tail = mfma16(k0, d0, (f32x4){0.f, 0.f, 0.f, 0.f});
-                        dq[i] += tail;
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < NQ; ++i) {
-                    const int q = 32 * pr + 16 * i + fr;
-                    const float rq = RN[q] * sigma;
-                    const bf16x4 qn = *(const bf16x4*)(Qa + q * QP + 4 * g);
-                    float dot = 0.f;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) dot = fmaf(dq[i][r], bf2f(qn[r]), dot);
-                    dot = xor32_allsum(xor16_allsum(dot));
-                    f32x4 v;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = rq * (dq[i][r] - bf2f(qn[r]) * dot);
-                    *(bf16x4*)(dqkvh + slab0 + (size_t)q * DP + 4 * g) = f2bf4(v);
-                }
-                SSTAMP(3);
-            };
-            // helper hw: pair hw and the commit; helper 4 (the last pair) commits first; helper 0 ends with the odd last tile
-            if (hw == HW - 1) {
-                if (bw_next < Bw) commit(buf ^ 1, hidx);
-                SSTAMP(5);
-                phase2(NPAIR - 2, std::integral_constant<int, 2>{});
-            } else {
-                // helpers 2, 3 commit BEFORE their pair: it completes at 55 / 73 % of the window, the prefetch has landed by then, and behind the
-                // pair's signal only the dQ pass is left (commit behind it: the window ended with that commit; 7 716 -> 7 473 cycles per window)
-                const bool cf = hw >= SWV2_ATTNS_COMMIT_FIRST;
-                if (cf && bw_next < Bw) commit(buf ^ 1, hidx);
-                phase2(hw, std::integral_constant<int, 2>{});
-                if (!cf && bw_next < Bw) commit(buf ^ 1, hidx);
-                SSTAMP(5);
-                if (hw == 0) phase2(NPAIR - 1, std::integral_constant<int, 1>{});
-            }
+            // every helper commits first (its loads were issued at the window's start), then helper 0: the first pair, helpers 1 .. 3: q-tiles 2 .. 4
+            // (all complete by ~55 % of the window); helper 4 stages and commits two chunks per thread and takes no tile
+            if (bw_next < Bw) commit(buf ^ 1, hidx);
+            SSTAMP(5);
+            if (hw == 0) phase2(0, std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
+            else if (hw < HW - 1) phase2(hw + 1, std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{});
         }
+#ifdef SWV2_ATTNS_ARRIVE
+        const bool arr_on = blockIdx.x == 3 && blockIdx.y == 0 && it >= 8 && it < 16;
+        if (arr_on && lane == 0) attns_arr[tw * 8 + it - 8] = __builtin_amdgcn_s_memtime();
+#endif
         __syncthreads();
+#ifdef SWV2_ATTNS_ARRIVE
+        if (arr_on && tid == 0) attns_arr[16 * 8 + it - 8] = __builtin_amdgcn_s_memtime();
+#endif
         SSTAMP(6);                      // the window's barrier
 #ifdef SWV2_ATTNS_STAMPS
         if (lane == 0 && tw == 8 && blockIdx.y == 0 && blockIdx.x < 64 && it < 128) attns_win[blockIdx.x * 128 + it] = st_prev - ck0;
@@ -444,6 +470,11 @@ __global__ __launch_bounds__(1024) void attn_bwd_stream_kernel(
 
 }  // namespace
 
+#ifdef SWV2_ATTNS_ARRIVE
+extern "C" int swv2_debug_attns_arrive(void* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(attns_arr), sizeof(unsigned long long) * 17 * 8) == hipSuccess ? 0 : -3;
+}
+#endif
 #ifdef SWV2_ATTNS_STAMPS
 extern "C" int swv2_debug_attns_stamps(void* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(attns_stamps), sizeof(unsigned long long) * 512 * 8) == hipSuccess ? 0 : -3;

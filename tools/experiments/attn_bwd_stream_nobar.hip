@@ -38,6 +38,9 @@
 namespace {
 
 typedef __attribute__((address_space(3))) unsigned lds_u32;
+#ifdef SWV2_ATTNS_ARRIVE          // diagnostic: when each wave of ONE workgroup reaches the window's barrier (8 windows), and when the barrier opens
+__device__ unsigned long long attns_arr[17 * 8];
+#endif
 typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const volatile u32x4s lds_cv4;      // (a generic volatile pointer compiled to flat loads + vmcnt(0) waits)
 
@@ -616,7 +619,14 @@ __global__ __launch_bounds__(1024) void attn_bwd_stream_kernel(
                 const int tt = tw == 3 ? 6 : tw == 7 ? 7 : tw == 0 ? 8 : tw == 2 ? 9 : tw == 1 ? 10 : -1;
 #endif
                 if (tt >= 0) {
+#ifdef SWV2_ATTNS_TAILPRIO
+                    SWV2_PRIO(SWV2_ATTNS_TAILPRIO);
+#else
                     SWV2_PRIO(2);
+#endif
+#if SWV2_ATTNS_TAIL == 5
+                    if (tw == 3) phase2(5, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});     // (helper 4 commits two chunks: its tile)
+#endif
                     phase2(tt, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
                 }
             }
@@ -693,9 +703,9 @@ __global__ __launch_bounds__(1024) void attn_bwd_stream_kernel(
             SSTAMP(5);
             if (SWV2_ATTNS_TAIL == 2) {
                 if (hw < 3) phase2(2 * hw, std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
-            } else {      // 3: pair 0 on helper 0, q-tiles 2 .. 5 on helpers 1 .. 4
+            } else {      // 3: pair 0 on helper 0, q-tiles 2 .. 5 on helpers 1 .. 4 (5: helper 4 none)
                 if (hw == 0) phase2(0, std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
-                else phase2(hw + 1, std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{});
+                else if (SWV2_ATTNS_TAIL != 5 || hw < 4) phase2(hw + 1, std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{});
             }
 #else
             if (hw < 2) phase2(2 * hw, std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
@@ -722,8 +732,15 @@ __global__ __launch_bounds__(1024) void attn_bwd_stream_kernel(
 #endif
         }
 #endif
+#ifdef SWV2_ATTNS_ARRIVE
+        const bool arr_on = blockIdx.x == 3 && blockIdx.y == 0 && it >= 8 && it < 16;
+        if (arr_on && lane == 0) attns_arr[tw * 8 + it - 8] = __builtin_amdgcn_s_memtime();
+#endif
 #if !SWV2_ATTNS_NOBAR
         __syncthreads();
+#endif
+#ifdef SWV2_ATTNS_ARRIVE
+        if (arr_on && tid == 0) attns_arr[16 * 8 + it - 8] = __builtin_amdgcn_s_memtime();
 #endif
 #if SWV2_ATTNS_PF2
         kv = kv == 2 ? 0 : kv + 1;
@@ -766,6 +783,11 @@ __global__ __launch_bounds__(1024) void attn_bwd_stream_kernel(
 
 }  // namespace
 
+#ifdef SWV2_ATTNS_ARRIVE
+extern "C" int swv2_debug_attns_arrive(void* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(attns_arr), sizeof(unsigned long long) * 17 * 8) == hipSuccess ? 0 : -3;
+}
+#endif
 #ifdef SWV2_ATTNS_STAMPS
 extern "C" int swv2_debug_attns_stamps(void* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(attns_stamps), sizeof(unsigned long long) * 512 * 8) == hipSuccess ? 0 : -3;

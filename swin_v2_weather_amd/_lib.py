@@ -231,6 +231,10 @@ def load() -> C.CDLL:
             if not os.path.exists(LIB_PATH):
                 raise Swv2Error(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                 "(the HIP library is required; there is no fallback path)")
+            # torch first: the library then binds to the HIP runtime torch ships (same soname, already loaded).  Loaded the other way round the
+            # process holds two runtimes and every launch of this library fails with "no ROCm-capable device is detected" (seen with build() and
+            # smoke() in one process on a GPU box)
+            import torch  # noqa: F401
             lib = C.CDLL(LIB_PATH)
             for name, (res, args) in SYMBOLS.items():
                 fn = getattr(lib, name)            # AttributeError if a declared symbol is missing

@@ -27,14 +27,28 @@ if os.environ.get("STEP_OPS_DDP", "0") == "1":          # one-rank RCCL group: w
     net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], broadcast_buffers=False, gradient_as_bucket_view=True, bucket_cap_mb=12)
     enable_ddp_bucket_grads(net)
 x, y = torch.randn(2, 73, 720, 1440, device=dev), torch.randn(2, 73, 720, 1440, device=dev)
-def step():
-    net.zero_grad(); l = loss_obj(net(x), y, x); l.backward(); opt.step()
+def step():                     # bench.py's step: the loss rides in the head's epilogue
+    net.zero_grad()
+    with loss_obj.fused_with(model, y):
+        g = net(x)
+    l = loss_obj(g, y, x); l.backward(); opt.step()
 for _ in range(4): step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
     step(); torch.cuda.synchronize()
 rows = [e for e in prof.key_averages() if e.device_time_total > 0 or e.self_device_time_total > 0]
 rows.sort(key=lambda e: -e.self_device_time_total)
 for e in rows[:70]:
     if not any(k in e.key for k in ("gemm_", "mlp_", "attn_", "proj_ln", "tn_reduce", "ln_")):
         print(f"{e.key[:90]:90s} n={e.count:4d} self_dev={e.self_device_time_total:9.1f} us")
+
+# where the small aten launches come from: python call sites of the ops that launch fill / copy / elementwise kernels
+import collections
+sites = collections.Counter()
+for ev in prof.events():
+    if ev.key in ("aten::fill_", "aten::zero_", "aten::copy_", "aten::mul", "aten::add_", "aten::div_", "aten::bernoulli_") and ev.stack:
+        fr = [f for f in ev.stack if "swin_v2_weather_amd" in f or "bench.py" in f or "step_ops" in f]
+        sites[(ev.key, fr[0] if fr else ev.stack[0])] += 1
+print("call sites of the small aten ops (one step):")
+for (k, f), n in sites.most_common(30):
+    print(f"  {n:3d} x {k:16s} {f}")
